@@ -1,0 +1,79 @@
+"""ctypes mirror of include/drloco_hip.h (POD descriptors + constants).
+
+Kept byte-compatible with the C header; tests/test_abi.py checks sizeof() against the
+library's own view (dl_abi_sizeof) and that every declared symbol is exported.
+"""
+import ctypes as C
+
+DL_ABI_VERSION = 1
+DL_MAX_BODY, DL_MAX_DOF, DL_MAX_GEOM, DL_MAX_SITE, DL_MAX_ACT = 12, 20, 12, 8, 16
+DL_JNT_SLIDE, DL_JNT_HINGE = 0, 1
+DL_GEOM_CAPSULE, DL_GEOM_BOX = 0, 1
+(DL_CUR_I_STEP, DL_CUR_POS, DL_CUR_RSI_STEP, DL_CUR_COUNT, DL_CUR_EP_DUR, DL_CUR_HAS_DIST,
+ DL_CUR_EPISODE, DL_CUR_READ_STEP) = range(8)
+DL_CUR_WORDS = 8
+DL_OK, DL_E_INVAL, DL_E_NODEVICE, DL_E_HIP, DL_E_NOMEM = 0, -1, -2, -3, -4
+
+_d, _i = C.c_double, C.c_int32
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ('nbody', _i), ('nv', _i), ('nu', _i), ('ngeom', _i), ('nsite', _i), ('frame_skip', _i),
+        ('timestep', _d), ('gravity', _d * 3), ('solref', _d * 2), ('solimp', _d * 5),
+        ('tolerance', _d), ('ls_tolerance', _d), ('iterations', _i), ('ls_iterations', _i),
+        ('body_parent', _i * DL_MAX_BODY), ('body_pos', (_d * 3) * DL_MAX_BODY),
+        ('body_mass', _d * DL_MAX_BODY), ('body_ipos', (_d * 3) * DL_MAX_BODY),
+        ('body_inertia', (_d * 3) * DL_MAX_BODY),
+        ('jnt_type', _i * DL_MAX_DOF), ('jnt_body', _i * DL_MAX_DOF),
+        ('jnt_axis', (_d * 3) * DL_MAX_DOF), ('jnt_pos', (_d * 3) * DL_MAX_DOF),
+        ('jnt_qpos0', _d * DL_MAX_DOF), ('jnt_limited', _i * DL_MAX_DOF),
+        ('jnt_range', (_d * 2) * DL_MAX_DOF), ('jnt_damping', _d * DL_MAX_DOF),
+        ('jnt_armature', _d * DL_MAX_DOF),
+        ('geom_type', _i * DL_MAX_GEOM), ('geom_body', _i * DL_MAX_GEOM),
+        ('geom_pos', (_d * 3) * DL_MAX_GEOM), ('geom_mat', (_d * 9) * DL_MAX_GEOM),
+        ('geom_size', (_d * 3) * DL_MAX_GEOM), ('geom_friction', _d * DL_MAX_GEOM),
+        ('floor_friction', _d),
+        ('site_body', _i * DL_MAX_SITE), ('site_pos', (_d * 3) * DL_MAX_SITE),
+        ('act_dof', _i * DL_MAX_ACT), ('act_gear', _d * DL_MAX_ACT),
+        ('act_ctrlrange', (_d * 2) * DL_MAX_ACT), ('act_forcerange', (_d * 2) * DL_MAX_ACT),
+        ('body_invweight0', (_d * 2) * DL_MAX_BODY), ('dof_invweight0', _d * DL_MAX_DOF),
+        ('meaninertia', _d),
+    ]
+
+
+class RefsDesc(C.Structure):
+    _fields_ = [
+        ('n_steps', _i), ('n_rows', _i), ('total_len', _i), ('stride', _i),
+        ('table', C.POINTER(_d)), ('step_off', C.POINTER(_i)), ('step_is_left', C.POINTER(_i)),
+        ('step_vel', C.POINTER(_d)),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ('rew_weights', _d * 3), ('rew_scale', _d), ('alive_bonus', _d), ('com_z_min', _d),
+        ('ctrl_freq', _d), ('ep_dur_max', _i), ('mirror_policy', _i), ('precision', _i),
+        ('env_index_base', _i), ('seed', C.c_uint64),
+    ]
+
+
+def default_config(**kw):
+    """Constants of drloco/config/hypers.py:48-58 and config.py:20 (reference defaults)."""
+    c = Config()
+    c.rew_weights[:] = [0.8, 0.2, 0.0]
+    c.rew_scale = 1.0
+    c.alive_bonus = 0.2
+    c.com_z_min = 0.5
+    c.ctrl_freq = 200.0
+    c.ep_dur_max = 3000
+    c.mirror_policy = 1
+    c.precision = 32
+    c.env_index_base = 0
+    c.seed = 1234
+    for k, v in kw.items():
+        if k == 'rew_weights':
+            c.rew_weights[:] = list(v)
+        else:
+            setattr(c, k, v)
+    return c

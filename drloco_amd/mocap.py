@@ -1,0 +1,101 @@
+"""Mocap ingestion: the reference's step-segmented MATLAB file -> flat table.
+
+Restates StraightWalkingTrajectories' load-time processing
+(drloco/ref_trajecs/straight_walk_trajecs.py):
+  _load_ref_trajecs          :304-320   data['Data'].flatten() -> per-step (rows, len) arrays
+  _calculate_walking_speed   :393-415   mean COM-x velocity per step, exp. smoothing alpha = 0.2
+                                        (smooth_exponential, drloco/common/utils.py:264-268)
+  _determine_left_steps_indices :221-230 max knee velocity L > R
+and the walker's row selection (drloco/mujoco/mimic_walker3d.py:11-23).
+"""
+import os
+
+import numpy as np
+
+from . import abi
+
+# row indices of the constant-speed file (38 rows): straight_walk_trajecs.py:59-91
+_QPOS_ROWS = [0, 1, 2, 35, 36, 37, 8, 7, 9, 10, 12, 11, 13, 14]
+_QVEL_ROWS = [15, 16, 17, 18, 19, 20, 22, 21, 23, 24, 26, 25, 27, 28]
+_KNEE_VEL_R, _KNEE_VEL_L, _COM_VEL_X = 23, 27, 15
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+DEFAULT_TABLE = os.path.join(DATA_DIR, 'straight_walk_const400.npz')
+
+
+class RefTable:
+    """Flat reference table: table[2*nv, total_len] (qpos rows then qvel rows, model order)."""
+
+    def __init__(self, table, step_off, step_is_left, step_vel, stride):
+        self.table = np.ascontiguousarray(table, dtype=np.float64)
+        self.step_off = np.ascontiguousarray(step_off, dtype=np.int32)
+        self.step_is_left = np.ascontiguousarray(step_is_left, dtype=np.int32)
+        self.step_vel = np.ascontiguousarray(step_vel, dtype=np.float64)
+        self.stride = int(stride)
+        assert self.table.shape[1] == self.step_off[-1]
+
+    @property
+    def n_steps(self):
+        return len(self.step_off) - 1
+
+    @property
+    def step_len(self):
+        return np.diff(self.step_off)
+
+    def as_desc(self):
+        import ctypes as C
+        d = abi.RefsDesc()
+        d.n_steps, d.n_rows, d.total_len, d.stride = self.n_steps, self.table.shape[0], self.table.shape[1], self.stride
+        d.table = self.table.ctypes.data_as(C.POINTER(C.c_double))
+        d.step_off = self.step_off.ctypes.data_as(C.POINTER(C.c_int32))
+        d.step_is_left = self.step_is_left.ctypes.data_as(C.POINTER(C.c_int32))
+        d.step_vel = self.step_vel.ctypes.data_as(C.POINTER(C.c_double))
+        d._keepalive = self
+        return d
+
+    def save(self, path):
+        np.savez_compressed(path, table=self.table, step_off=self.step_off, step_is_left=self.step_is_left,
+                            step_vel=self.step_vel, stride=np.int32(self.stride))
+
+    @classmethod
+    def load(cls, path=DEFAULT_TABLE):
+        z = np.load(path)
+        return cls(z['table'], z['step_off'], z['step_is_left'], z['step_vel'], int(z['stride']))
+
+
+def _sequential_mean(row):
+    acc = 0.0
+    for x in row.tolist():
+        acc = acc + x
+    return acc / len(row)
+
+
+def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200):
+    """Trajecs_Constant_Speed_400Hz.mat -> RefTable."""
+    import scipy.io as spio
+    steps = spio.loadmat(mat_path, squeeze_me=True)['Data'].flatten()
+    if steps[0].shape[0] != 38:
+        raise ValueError('only the 38-row constant-speed layout is supported')
+    stride = sample_freq / control_freq
+    if stride != int(stride):
+        raise ValueError('sample frequency must be an integer multiple of the control frequency')
+    steps = [np.asarray(s, dtype=np.float64) for s in steps]
+    lens = [s.shape[1] for s in steps]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    table = np.concatenate([s[_QPOS_ROWS + _QVEL_ROWS, :] for s in steps], axis=1)
+    is_left = [int(np.max(s[_KNEE_VEL_L]) > np.max(s[_KNEE_VEL_R])) for s in steps]
+    # the reference's arrays are dtype=object, so its np.mean adds left to right: do the same
+    vel = np.array([_sequential_mean(s[_COM_VEL_X]) for s in steps])
+    for t in range(1, len(vel)):
+        vel[t] = 0.2 * vel[t] + 0.8 * vel[t - 1]
+    for s in steps:
+        if not s[0, 0] < 0.005:
+            raise ValueError('COM-x of every step must start at 0 (straight_walk_trajecs.py:343)')
+    return RefTable(table, off, is_left, vel, int(stride))
+
+
+if __name__ == '__main__':
+    import sys
+    src = sys.argv[1] if len(sys.argv) > 1 else '/root/reference/mocaps/straight_walking/Trajecs_Constant_Speed_400Hz.mat'
+    convert_straight_walk_mat(src).save(DEFAULT_TABLE)
+    print('wrote', DEFAULT_TABLE)

@@ -1,0 +1,236 @@
+/*
+ * drloco_hip.h -- C-ABI of the MI355X-native DRLoco hot path.
+ *
+ * The library (drloco_amd/csrc/libdrloco_hip.so) replaces, for N walkers at once,
+ * the reference's per-process environment stack
+ *
+ *     VecNormalize( SubprocVecEnv( Monitor( MimicEnv ) ) )      drloco/common/utils.py:97-134
+ *
+ * and SB3's RolloutBuffer return/advantage scan.  Every entry point cites the reference
+ * interface it stands in for.  Conventions:
+ *
+ *   - plain C, no exceptions/longjmp across the boundary; every function returns 0 on
+ *     success or a negative DL_E_* code, and dl_last_error() returns the text of the last
+ *     failure on the calling thread;
+ *   - unless stated otherwise every array pointer is a DEVICE pointer owned by the caller
+ *     (e.g. torch tensors); work is enqueued on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream) and nothing synchronises with the host;
+ *   - per-walker state lives inside the handle as structure-of-arrays [field][N];
+ *   - a handle is not thread-safe; one host thread per GPU process.
+ *
+ * There is no CPU fallback behind these symbols: dl_create() fails with DL_E_NODEVICE when
+ * no HIP device is present.
+ */
+#ifndef DRLOCO_HIP_H
+#define DRLOCO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL_ABI_VERSION 1
+
+/* static capacities of the POD descriptors */
+#define DL_MAX_BODY 12
+#define DL_MAX_DOF 20
+#define DL_MAX_GEOM 12
+#define DL_MAX_SITE 8
+#define DL_MAX_ACT 16
+
+/* error codes */
+#define DL_OK 0
+#define DL_E_INVAL (-1)     /* bad argument / unsupported model topology */
+#define DL_E_NODEVICE (-2)  /* no HIP device */
+#define DL_E_HIP (-3)       /* a HIP runtime call failed */
+#define DL_E_NOMEM (-4)
+
+/* joint / geom type codes (subset of MJCF used by the MJCF files under drloco/mujoco/xml) */
+#define DL_JNT_SLIDE 0
+#define DL_JNT_HINGE 1
+#define DL_GEOM_CAPSULE 0
+#define DL_GEOM_BOX 1
+
+/* words of the per-walker cursor/episode record (dl_get_state / dl_set_state), int32 each.
+ * They restate the python attributes of StraightWalkingTrajectories / MimicEnv:
+ *   drloco/ref_trajecs/straight_walk_trajecs.py:98-126,141-170  and  drloco/mujoco/mimic_env.py:38-45 */
+#define DL_CUR_I_STEP 0     /* refs._i_step */
+#define DL_CUR_POS 1        /* refs._pos */
+#define DL_CUR_RSI_STEP 2   /* index of refs._step (bound at reset only, quirk Q1) */
+#define DL_CUR_COUNT 3      /* refs.count_steps_same_vel (never reset, quirk Q2) */
+#define DL_CUR_EP_DUR 4     /* env.ep_dur */
+#define DL_CUR_HAS_DIST 5   /* 1 once the cursor rolled into a later step (COM-x offset active) */
+#define DL_CUR_EPISODE 6    /* number of resets so far (RSI random-stream counter) */
+#define DL_CUR_READ_STEP 7  /* step whose table the cursor reads (differs from I_STEP only after an eval init, quirk Q3) */
+#define DL_CUR_WORDS 8
+
+/* compiled model: the subset of an MJCF model the path needs.  One degree of freedom per
+ * joint (slide/hinge only, nq == nv) as in walker3d_flat_feet.xml / walker_165cm_65kg.xml. */
+typedef struct dl_model_desc {
+    int32_t nbody;      /* including the world body 0 */
+    int32_t nv;         /* = nq */
+    int32_t nu;
+    int32_t ngeom;      /* collision geoms attached to bodies (the floor plane is implicit: z = 0) */
+    int32_t nsite;
+    int32_t frame_skip; /* sim_freq / CTRL_FREQ, mimic_env.py:194-207 */
+    double timestep;    /* <option timestep>, integrator is RK4 */
+    double gravity[3];
+    double solref[2];   /* MuJoCo defaults (0.02, 1) */
+    double solimp[5];   /* (0.9, 0.95, 0.001, 0.5, 2) */
+    double tolerance;   /* solver tolerance, 1e-8 */
+    double ls_tolerance; /* 0.01 */
+    int32_t iterations;  /* 100 */
+    int32_t ls_iterations; /* 50 */
+    /* bodies */
+    int32_t body_parent[DL_MAX_BODY];
+    double body_pos[DL_MAX_BODY][3];
+    double body_mass[DL_MAX_BODY];
+    double body_ipos[DL_MAX_BODY][3];
+    double body_inertia[DL_MAX_BODY][3]; /* diagonal, aligned with the body frame */
+    /* joints == dofs, in qpos order; a body's joints are contiguous */
+    int32_t jnt_type[DL_MAX_DOF];
+    int32_t jnt_body[DL_MAX_DOF];
+    double jnt_axis[DL_MAX_DOF][3];  /* body-local unit axis */
+    double jnt_pos[DL_MAX_DOF][3];   /* body-local anchor */
+    double jnt_qpos0[DL_MAX_DOF];    /* `ref` */
+    int32_t jnt_limited[DL_MAX_DOF];
+    double jnt_range[DL_MAX_DOF][2];
+    double jnt_damping[DL_MAX_DOF];
+    double jnt_armature[DL_MAX_DOF];
+    /* geoms */
+    int32_t geom_type[DL_MAX_GEOM];
+    int32_t geom_body[DL_MAX_GEOM];
+    double geom_pos[DL_MAX_GEOM][3];   /* body-local centre */
+    double geom_mat[DL_MAX_GEOM][9];   /* body-local orientation, row-major; capsule axis = column 2 */
+    double geom_size[DL_MAX_GEOM][3];  /* capsule: radius, half-length; box: half extents */
+    double geom_friction[DL_MAX_GEOM]; /* sliding friction */
+    double floor_friction;
+    /* sites (foot corners used by reset_model, mimic_env.py:547-559) */
+    int32_t site_body[DL_MAX_SITE];
+    double site_pos[DL_MAX_SITE][3];
+    /* motors */
+    int32_t act_dof[DL_MAX_ACT];
+    double act_gear[DL_MAX_ACT];
+    double act_ctrlrange[DL_MAX_ACT][2];
+    double act_forcerange[DL_MAX_ACT][2];
+    /* compile-time constants MuJoCo derives at qpos0 (mj_setConst) */
+    double body_invweight0[DL_MAX_BODY][2];
+    double dof_invweight0[DL_MAX_DOF];
+    double meaninertia;
+} dl_model_desc;
+
+/* Mocap table: the used rows of the step-segmented .mat, flattened.
+ * drloco/ref_trajecs/straight_walk_trajecs.py:304-320 (loading), mimic_walker3d.py:11-23 (rows).
+ * HOST pointers; copied at dl_create. */
+typedef struct dl_refs_desc {
+    int32_t n_steps;         /* 30 for Trajecs_Constant_Speed_400Hz.mat */
+    int32_t n_rows;          /* 2*nv: qpos rows then qvel rows, in model order */
+    int32_t total_len;       /* sum of step lengths */
+    int32_t stride;          /* sample_freq / control_freq (2) */
+    const double* table;     /* [n_rows][total_len] */
+    const int32_t* step_off; /* [n_steps+1] */
+    const int32_t* step_is_left; /* [n_steps], straight_walk_trajecs.py:221-234 */
+    const double* step_vel;  /* [n_steps] smoothed mean COM-x velocity, :393-415 */
+} dl_refs_desc;
+
+/* Constants the reference keeps in drloco/config/{config,hypers}.py */
+typedef struct dl_config {
+    double rew_weights[3];  /* pose, vel, com: hypers.py:48 */
+    double rew_scale;       /* hypers.py:51 */
+    double alive_bonus;     /* hypers.py:55 */
+    double com_z_min;       /* 0.5, mimic_env.py:120 */
+    double ctrl_freq;       /* 200, config.py:20 */
+    int32_t ep_dur_max;     /* 3000, hypers.py:58 */
+    int32_t mirror_policy;  /* is_mod(MOD_MIRR_POLICY), hypers.py:23 */
+    int32_t precision;      /* 32 (default) or 64: arithmetic type of the dynamics kernels */
+    int32_t env_index_base; /* global index of walker 0 of this shard (multi-GPU) */
+    uint64_t seed;          /* RSI random stream seed */
+} dl_config;
+
+typedef struct dl_env_s* dl_handle;
+
+const char* dl_last_error(void);
+int dl_abi_version(void);
+
+/* MimicWalker3dEnv.__init__ x N  (mimic_walker3d.py:33-40, mimic_env.py:19-57).
+ * device: HIP device ordinal. */
+int dl_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_config* cfg,
+              int32_t n_envs, int32_t device, dl_handle* out);
+int dl_destroy(dl_handle h);
+int32_t dl_num_envs(dl_handle h);
+int32_t dl_obs_dim(dl_handle h);
+int32_t dl_act_dim(dl_handle h);
+int32_t dl_real_size(dl_handle h); /* 4 or 8: element size of state arrays */
+
+/* MujocoEnv.reset -> MimicEnv.reset_model (mimic_env.py:526-572) for the walkers whose
+ * mask byte is non-zero (NULL = all).  init_step/init_pos (int32[N], NULL = draw from the
+ * counter-based RSI stream) inject the two random draws of get_random_init_state
+ * (straight_walk_trajecs.py:460-474).  obs_out: float[N, obs_dim], rows of unmasked walkers
+ * are left untouched. */
+int dl_reset(dl_handle h, const uint8_t* mask, const int32_t* init_step, const int32_t* init_pos,
+             float* obs_out, void* stream);
+
+/* One control step of every walker: MimicEnv.step (mimic_env.py:60-126) followed by the
+ * vec-env auto-reset (SubprocVecEnv worker: terminal_observation + reset).
+ *   actions   float[N, nu]   policy outputs (unclipped)
+ *   obs       float[N, obs]  next observation (post-reset row for finished walkers)
+ *   rew       float[N]
+ *   done      uint8[N]
+ *   term_obs  float[N, obs]  or NULL: info['terminal_observation'] rows for finished walkers
+ *   rew_terms float[N, 3]    or NULL: pos_rew, vel_rew, com_rew (mimic_env.py:645) */
+int dl_step(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* done,
+            float* term_obs, float* rew_terms, void* stream);
+
+/* T control steps with pre-generated actions (synthetic fixed-length rollout; no policy):
+ *   actions float[T, N, nu]; obs float[T, N, obs]; rew float[T, N]; done uint8[T, N]. */
+int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, float* rew,
+                     uint8_t* done, void* stream);
+
+/* Parity hooks: SoA state in the handle's real type (dl_real_size):
+ * qpos[nv,N], qvel[nv,N], qacc_warmstart[nv,N], cursor int32[DL_CUR_WORDS,N].  NULL = skip. */
+int dl_get_state(dl_handle h, void* qpos, void* qvel, void* qacc_warm, int32_t* cursor,
+                 double* walked, void* stream);
+int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qacc_warm,
+                 const int32_t* cursor, const double* walked, void* stream);
+
+/* Forward dynamics only (mj_forward) at the current state with the given ctrl (real[nu,N],
+ * already in torque units): writes qacc real[nv,N]; ncon/nefc/niter int32[N] may be NULL. */
+int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc,
+               int32_t* niter, void* stream);
+
+/* Monitor attributes (drloco/mujoco/monitor_wrapper.py:88-133) kept per walker on device.
+ * name: one of ep_len_smoothed, ep_ret_smoothed, mean_reward_smoothed, moved_distance,
+ * mean_ep_pos_rew_smoothed, mean_ep_vel_rew_smoothed, mean_ep_com_rew_smoothed,
+ * mean_abs_ep_torque_smoothed.  out: double[N] device. */
+int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream);
+
+/* ---- reductions of the SB3 layer (stable-baselines3==1.0, docs/conda_env.yml:30) ---- */
+
+/* RunningMeanStd.update (VecNormalize): Chan parallel update of (mean[D], var[D], count[1])
+ * (double, device) with the batch x float[B, D]. */
+int dl_moments_update(double* mean, double* var, double* count, const float* x, int32_t B,
+                      int32_t D, void* stream);
+/* VecNormalize.normalize_obs in place: clip((x - mean)/sqrt(var + eps), +-clip). */
+int dl_normalize_obs(float* x, const double* mean, const double* var, int32_t B, int32_t D,
+                     double eps, double clip, void* stream);
+/* VecNormalize.step_wait reward branch: ret = ret*gamma + r; ret_rms.update(ret);
+ * r = clip(r/sqrt(var+eps), +-clip); ret[done] = 0.  ret: double[B] device. */
+int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* ret_mean,
+                        double* ret_var, double* ret_count, int32_t B, double gamma, double eps,
+                        double clip, void* stream);
+/* RolloutBuffer.compute_returns_and_advantage: arrays are [T, N] time-major float;
+ * ep_start[t] = "obs_t starts an episode"; last_val float[N]; last_done uint8[N]. */
+int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val,
+           const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv,
+           float* ret, void* stream);
+/* sums for PPO advantage normalisation: out[0] = sum(a), out[1] = sum(a^2), out[2] = n
+ * (double[3] device; all-reduced over ranks by the caller before dl_adv_normalize). */
+int dl_adv_stats(const float* adv, int64_t n, double* out3, void* stream);
+/* a = (a - mean)/(std_unbiased + 1e-8) from the (all-reduced) sums. */
+int dl_adv_normalize(float* adv, int64_t n, const double* sums3, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRLOCO_HIP_H */

@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the *reference*
+Python (read-only, /root/reference) in the build container.
+
+This script only runs where /root/reference exists (never on the GPU box, never
+from tests).  It injects dummy third-party modules (gym, mujoco_py, wandb,
+seaborn, stable_baselines3 are not installed), selects the constant-speed mocap
+file (the default ramp file is a missing blob, .MISSING_LARGE_BLOBS:2), builds a
+MimicWalker3dEnv without MuJoCo (a fake `sim.data` and an injected
+`do_simulation`), drives the reference's own methods and stores inputs and
+outputs as .npz.  No reference source text is written anywhere.
+
+Fixtures:
+  G1_mocap_table.npz     converted table + lengths + left steps + step velocities
+  G2_cursor_traces.npz   StraightWalkingTrajectories.next() traces
+  G3_reward_obs.npz      reward terms and observations (+ mirroring)
+  G4_step_traces.npz     MimicEnv.step() sequencing with injected dynamics
+  G5_actions.npz         _rescale_actions + mirror_action
+  G6_terminate_early.npz do_terminate_early truth table
+  G7_monitor.npz         Monitor smoothing traces
+
+Usage:  python tests/golden/make_golden.py
+"""
+import collections
+import collections.abc
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# stub environment for importing the reference
+# --------------------------------------------------------------------------
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+    def __getattr__(self, name):
+        return _Dummy()
+
+
+class _StubModule(types.ModuleType):
+    """Module whose Capitalised attributes are dummy classes (so that
+    `class MimicEnv(MujocoEnv, gym.utils.EzPickle)` can be built) and whose other
+    attributes are sub-stubs."""
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        if name[:1].isupper():
+            obj = type(name, (object,), {'__init__': lambda self, *a, **k: None})
+        else:
+            obj = _StubModule(self.__name__ + '.' + name)
+            sys.modules[obj.__name__] = obj
+        setattr(self, name, obj)
+        return obj
+
+
+def _install_stubs():
+    for name in ['gym', 'gym.utils', 'gym.envs', 'gym.envs.mujoco', 'gym.envs.mujoco.mujoco_env',
+                 'mujoco_py', 'mujoco_py.builder', 'wandb', 'seaborn',
+                 'stable_baselines3', 'stable_baselines3.common',
+                 'stable_baselines3.common.vec_env']:
+        sys.modules[name] = _StubModule(name)
+    # gym.Wrapper needs to behave like the real thing for Monitor
+    class Wrapper:
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            return getattr(self.env, name)
+    sys.modules['gym'].Wrapper = Wrapper
+    sys.modules['seaborn'].set = lambda *a, **k: None
+    sys.modules['seaborn'].set_style = lambda *a, **k: None
+    sys.modules['seaborn'].set_context = lambda *a, **k: None
+
+    class MujocoException(Exception):
+        pass
+    sys.modules['mujoco_py.builder'].MujocoException = MujocoException
+    sys.modules['mujoco_py'].builder = sys.modules['mujoco_py.builder']
+    # `from collections import Iterable` (base_ref_trajecs.py:2) was removed in py3.10
+    collections.Iterable = collections.abc.Iterable
+    import matplotlib
+    matplotlib.use('Agg', force=True)
+    _use = matplotlib.use
+    matplotlib.use = lambda *a, **k: None
+    return MujocoException
+
+
+def _import_reference():
+    MujocoException = _install_stubs()
+    sys.path.insert(0, REF)
+    import importlib.util
+    # straight_walk_trajecs computes its row constants at import time from which
+    # file is selected (:24-27, :85-91); select the file that is present.
+    path = os.path.join(REF, 'drloco/ref_trajecs/straight_walk_trajecs.py')
+    src = open(path).read()
+    assert 'PATH_REF_TRAJECS = PATH_SPEED_RAMP' in src
+    src = src.replace('PATH_REF_TRAJECS = PATH_SPEED_RAMP', 'PATH_REF_TRAJECS = PATH_CONSTANT_SPEED')
+    import drloco.ref_trajecs  # noqa: F401  (package)
+    name = 'drloco.ref_trajecs.straight_walk_trajecs'
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    sys.modules[name] = mod
+    exec(compile(src, path, 'exec'), mod.__dict__)
+    sys.modules['drloco.ref_trajecs'].straight_walk_trajecs = mod
+    from drloco.mujoco import mimic_walker3d
+    from drloco.mujoco import monitor_wrapper
+    from drloco.common import utils
+    from drloco.config import hypers
+    return mod, mimic_walker3d, monitor_wrapper, utils, hypers, MujocoException
+
+
+def make_env(walker_mod, refs_mod):
+    """Build a MimicWalker3dEnv without MuJoCo."""
+    Env = walker_mod.MimicWalker3dEnv
+    env = Env.__new__(Env)
+    env.refs = refs_mod.StraightWalkingTrajectories(walker_mod.qpos_indices, walker_mod.qvel_indices)
+    env.finished_init = True
+    env._EVAL_MODEL = False
+    env._FOLLOW_DESIRED_SPEED_PROFILE = False
+    env._PLAYBACK_REF_TRAJECS = False
+    env.pos_rew, env.vel_rew, env.com_rew = 0, 0, 0
+    env.ep_dur = 0
+    env.ep_rews = []
+    env.mean_epret_smoothed = 0
+    env.walked_distance = 0
+    env.control_freq = 200
+    env._frame_skip = 5
+    data = types.SimpleNamespace(qpos=np.zeros(14), qvel=np.zeros(14),
+                                 actuator_force=np.zeros(8), site_xpos=np.zeros((8, 3)))
+    env.sim = types.SimpleNamespace(data=data)
+    env.data = data
+    env.action_space = types.SimpleNamespace(high=np.full(8, 300.0), low=np.full(8, -300.0))
+    return env
+
+
+def set_refs_cursor(refs, i_step, pos):
+    """What get_random_init_state does (straight_walk_trajecs.py:460-474) with the
+    two random draws replaced by the injected values."""
+    refs._ep_dur = 0
+    refs.dist = 0
+    refs._i_step = i_step
+    refs._step = refs.data[i_step]
+    refs._qpos_full = refs._step
+    refs._qvel_full = refs._step
+    refs._trajec_len = refs._step.shape[1]
+    refs._pos = pos
+
+
+def main():
+    refs_mod, walker_mod, monitor_mod, utils, hypers, MujocoException = _import_reference()
+    import drloco.mujoco.mimic_env as mimic_env_mod
+    mimic_env_mod.pause_mujoco_viewer_on_start = False
+    rng = np.random.default_rng(20261001)
+    qpos_rows = list(walker_mod.qpos_indices)
+    qvel_rows = list(walker_mod.qvel_indices)
+
+    # ---------------- G1: mocap table ----------------
+    refs = refs_mod.StraightWalkingTrajectories(qpos_rows, qvel_rows)
+    data = refs.data
+    lens = np.array([s.shape[1] for s in data], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = qpos_rows + qvel_rows
+    table = np.concatenate([np.asarray(s[rows, :], dtype=np.float64) for s in data], axis=1)
+    np.savez_compressed(os.path.join(OUT, 'G1_mocap_table.npz'),
+                        table=table, step_len=lens, step_off=offs,
+                        qpos_rows=np.array(qpos_rows), qvel_rows=np.array(qvel_rows),
+                        left_step_indices=np.array(refs.left_step_indices, dtype=np.int32),
+                        step_velocities=np.asarray(refs.step_velocities, dtype=np.float64))
+
+    # ---------------- G2: cursor traces ----------------
+    starts = [(29, 270), (0, 0), (13, 100), (28, 10), (29, 0), (7, 254), (4, 248), (27, 278)]
+    n_next = 3200
+    tr = {k: np.zeros((len(starts), n_next), dtype=np.float64) for k in
+          ['i_step', 'pos', 'len', 'dist', 'count_same_vel', 'phase', 'desvel', 'is_left', 'ref_ep_dur']}
+    n_full = 400   # full 14+14 reference vectors for the first n_full calls, COM-x for all
+    tr_q = np.zeros((len(starts), n_full, 14))
+    tr_v = np.zeros((len(starts), n_full, 14))
+    tr_comx = np.zeros((len(starts), n_next))
+    count_in = np.zeros(len(starts), dtype=np.int32)
+    for k, (i0, p0) in enumerate(starts):
+        refs = refs_mod.StraightWalkingTrajectories(qpos_rows, qvel_rows)
+        # exercise Q2: count_steps_same_vel persists; start some traces with a larger count
+        refs.count_steps_same_vel = 1 + 3 * (k % 3)
+        count_in[k] = refs.count_steps_same_vel
+        set_refs_cursor(refs, i0, p0)
+        for t in range(n_next):
+            refs.next()
+            tr['i_step'][k, t] = refs._i_step
+            tr['pos'][k, t] = refs._pos
+            tr['len'][k, t] = refs._trajec_len
+            tr['dist'][k, t] = refs.dist
+            tr['count_same_vel'][k, t] = refs.count_steps_same_vel
+            tr['phase'][k, t] = refs.get_phase_variable()
+            tr['desvel'][k, t] = refs.get_desired_walking_velocity_vector(False)[0]
+            tr['is_left'][k, t] = refs.is_step_left()
+            tr['ref_ep_dur'][k, t] = refs._ep_dur
+            tr_comx[k, t] = float(refs.get_qpos()[0])
+            if t < n_full:
+                tr_q[k, t] = np.asarray(refs.get_qpos(), dtype=np.float64)
+                tr_v[k, t] = np.asarray(refs.get_qvel(), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'G2_cursor_traces.npz'), starts=np.array(starts),
+                        count_in=count_in, ref_qpos=tr_q, ref_qvel=tr_v, ref_comx=tr_comx, **tr)
+
+    # ---------------- G3: reward / obs ----------------
+    env = make_env(walker_mod, refs_mod)
+    n = 256
+    g3 = dict(i_step=np.zeros(n, np.int32), pos=np.zeros(n, np.int32), count=np.zeros(n, np.int32),
+              qpos=np.zeros((n, 14)), qvel=np.zeros((n, 14)),
+              pose=np.zeros(n), vel=np.zeros(n), com=np.zeros(n), imit=np.zeros(n),
+              obs=np.zeros((n, 29)), obs_nomirr=np.zeros((n, 29)), is_left=np.zeros(n, np.int32))
+    for k in range(n):
+        i0 = int(rng.integers(0, 30))
+        p0 = int(rng.integers(0, lens[i0]))
+        set_refs_cursor(env.refs, i0, p0)
+        env.refs.count_steps_same_vel = int(rng.integers(1, 6))
+        scale = [0.0, 0.01, 0.1, 0.5][k % 4]
+        q = np.asarray(env.refs.get_qpos(), dtype=np.float64) + scale * rng.standard_normal(14)
+        v = np.asarray(env.refs.get_qvel(), dtype=np.float64) + 10 * scale * rng.standard_normal(14)
+        env.sim.data.qpos[:] = q
+        env.sim.data.qvel[:] = v
+        g3['i_step'][k], g3['pos'][k], g3['count'][k] = i0, p0, env.refs.count_steps_same_vel
+        g3['qpos'][k], g3['qvel'][k] = q, v
+        g3['imit'][k] = env.get_imitation_reward()
+        g3['pose'][k], g3['vel'][k], g3['com'][k] = env.pos_rew, env.vel_rew, env.com_rew
+        g3['obs'][k] = env._get_obs()
+        g3['is_left'][k] = env.refs.is_step_left()
+        # un-mirrored observation (MOD_MIRR_POLICY off)
+        saved = hypers.modification
+        hypers.modification = hypers.MOD_CUSTOM_POLICY
+        g3['obs_nomirr'][k] = env._get_obs()
+        hypers.modification = saved
+    np.savez_compressed(os.path.join(OUT, 'G3_reward_obs.npz'), **g3)
+
+    # ---------------- G5: actions ----------------
+    acts = np.concatenate([rng.uniform(-2, 2, size=(60, 8)),
+                           np.array([[0.1, -0.2, -0.3, 0.4, 0.5, 0.2, 1.0, -1.0]]),
+                           np.zeros((1, 8)), np.array([[1.5, -1.5, 1, -1, 0.999, -0.999, 1e-9, -1e-9]])])
+    resc = np.array([env._rescale_actions(a) for a in acts])
+    mirr = np.array([env.mirror_action(r.copy()) for r in resc])
+    np.savez_compressed(os.path.join(OUT, 'G5_actions.npz'), actions=acts, rescaled=resc, mirrored=mirr)
+
+    # ---------------- G4: step() traces with injected dynamics ----------------
+    # The "dynamics" are injected: do_simulation copies the next row of a prepared
+    # (qpos, qvel) stream into sim.data; an exception can be raised at a chosen step.
+    def run_trace(i0, p0, count0, T, fall_at=None, exc_at=None, ep_dur0=0, seed=0, rsi_after_exc=(3, 17)):
+        r = np.random.default_rng(seed)
+        env = make_env(walker_mod, refs_mod)
+        set_refs_cursor(env.refs, i0, p0)
+        env.refs.count_steps_same_vel = count0
+        env.ep_dur = ep_dur0
+        # state stream: reference + noise (so that rewards are non-trivial)
+        stream_q = np.zeros((T, 14))
+        stream_v = np.zeros((T, 14))
+        shadow = refs_mod.StraightWalkingTrajectories(qpos_rows, qvel_rows)
+        set_refs_cursor(shadow, i0, p0)
+        for t in range(T):
+            shadow.next()
+            stream_q[t] = np.asarray(shadow.get_qpos(), float) + 0.05 * r.standard_normal(14)
+            stream_v[t] = np.asarray(shadow.get_qvel(), float) + 0.5 * r.standard_normal(14)
+            if fall_at is not None and t == fall_at:
+                stream_q[t, 2] = 0.49
+        # large velocities to exercise the 5.5 clip in update_walked_distance
+        stream_v[T // 2, 0] = 7.0
+        stream_v[T // 2, 1] = -6.0
+        state = {'t': 0}
+        ctrls = []
+
+        def do_simulation(ctrl, n_frames):
+            ctrls.append(np.array(ctrl, dtype=np.float64))
+            if exc_at is not None and state['t'] == exc_at:
+                raise MujocoException('injected')
+            env.sim.data.qpos[:] = stream_q[state['t']]
+            env.sim.data.qvel[:] = stream_v[state['t']]
+            state['t'] += 1
+        env.do_simulation = do_simulation
+
+        def reset():
+            # stands in for MujocoEnv.reset() -> reset_model() with injected RSI draw and
+            # FK replaced by "no shift" (FK is MuJoCo's; covered by the build's own tests)
+            env.ep_dur = 0
+            env.walked_distance = 0
+            set_refs_cursor(env.refs, *rsi_after_exc)
+            env.sim.data.qpos[:] = np.asarray(env.refs.get_qpos(), float)
+            env.sim.data.qvel[:] = np.asarray(env.refs.get_qvel(), float)
+            env.refs.next()
+            return env._get_obs()
+        env.reset = reset
+        actions = r.uniform(-1.3, 1.3, size=(T, 8))
+        out = dict(actions=actions, stream_q=stream_q, stream_v=stream_v,
+                   obs=np.zeros((T, 29)), rew=np.zeros(T), done=np.zeros(T, np.int32),
+                   walked=np.zeros(T), ep_dur=np.zeros(T, np.int32), ctrl=np.zeros((T, 8)),
+                   pos_rew=np.zeros(T), vel_rew=np.zeros(T), com_rew=np.zeros(T),
+                   i_step=np.zeros(T, np.int32), pos=np.zeros(T, np.int32), nsteps=0)
+        for t in range(T):
+            o, rew, done, info = env.step(actions[t])
+            out['obs'][t], out['rew'][t], out['done'][t] = o, rew, done
+            out['walked'][t], out['ep_dur'][t] = env.walked_distance, env.ep_dur
+            out['ctrl'][t] = ctrls[-1]
+            out['pos_rew'][t], out['vel_rew'][t], out['com_rew'][t] = env.pos_rew, env.vel_rew, env.com_rew
+            out['i_step'][t], out['pos'][t] = env.refs._i_step, env.refs._pos
+            out['nsteps'] = t + 1
+            if done:
+                break
+        out['start'] = np.array([i0, p0, count0, ep_dur0])
+        out['rsi_after_exc'] = np.array(rsi_after_exc)
+        out['rew_signbit'] = np.signbit(out['rew']).astype(np.int32)
+        return out
+
+    g4 = {}
+    cases = dict(fall=run_trace(5, 40, 1, 60, fall_at=37, seed=1),
+                 timeout=run_trace(28, 200, 4, 80, ep_dur0=2950, seed=2),
+                 exception=run_trace(12, 3, 2, 40, exc_at=21, seed=3),
+                 rollover=run_trace(29, 250, 1, 300, seed=4))
+    for cname, c in cases.items():
+        for k, v in c.items():
+            g4[f'{cname}__{k}'] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, 'G4_step_traces.npz'), **g4)
+
+    # ---------------- G6: do_terminate_early truth table ----------------
+    env = make_env(walker_mod, refs_mod)
+    n = 128
+    g6 = dict(i_step=np.zeros(n, np.int32), pos=np.zeros(n, np.int32), qpos=np.zeros((n, 14)),
+              flags=np.zeros((n, 4), np.int32))
+    for k in range(n):
+        i0 = int(rng.integers(0, 30))
+        p0 = int(rng.integers(0, lens[i0]))
+        set_refs_cursor(env.refs, i0, p0)
+        q = np.asarray(env.refs.get_qpos(), dtype=np.float64)
+        mode = k % 8
+        if mode == 1: q[2] = 0.74
+        if mode == 2: q[1] = 0.21 * (1 if k % 16 < 8 else -1)
+        if mode == 3: q[4] = 0.31
+        if mode == 4: q[4] = -0.06
+        if mode == 5: q[3] += 0.21
+        if mode == 6: q[5] += 0.6      # axial deviation is ignored
+        if mode == 7: q += 0.05 * rng.standard_normal(14)
+        env.sim.data.qpos[:] = q
+        g6['i_step'][k], g6['pos'][k], g6['qpos'][k] = i0, p0, q
+        g6['flags'][k] = [int(bool(x)) for x in env.do_terminate_early()]
+    np.savez_compressed(os.path.join(OUT, 'G6_terminate_early.npz'), **g6)
+
+    # ---------------- G7: Monitor smoothing traces ----------------
+    utils._exp_weighted_averages.clear()
+
+    class FakeEnv:
+        """Feeds prepared (reward, done, components, torque) streams into Monitor.step."""
+        def __init__(self, T, seed):
+            r = np.random.default_rng(seed)
+            self.rew = r.uniform(0.2, 1.2, T)
+            self.done = np.zeros(T, bool)
+            t = 0
+            while True:
+                t += int(r.integers(3, 40))
+                if t >= T:
+                    break
+                self.done[t] = True
+            self.rew[self.done] = 0.0
+            self.comp = r.uniform(0, 1, (T, 3))
+            self.tor = r.uniform(0, 300, T)
+            self.cursor = r.integers(0, 270, T)
+            self.walked = np.cumsum(r.uniform(0, 0.01, T))
+            self.t = -1
+            self.refs = types.SimpleNamespace(_pos=0, get_kinematics_labels=lambda: ['x'] * 28)
+            self.action_space = types.SimpleNamespace(high=np.zeros(8))
+            self.pos_rew = self.vel_rew = self.com_rew = 0
+
+        def step(self, a):
+            self.t += 1
+            t = self.t
+            self.refs._pos = int(self.cursor[t])
+            self.pos_rew, self.vel_rew, self.com_rew = self.comp[t]
+            return None, self.rew[t], bool(self.done[t]), {}
+
+        def get_actuator_torques(self, abs_mean=False):
+            return self.tor[self.t]
+
+        def get_walked_distance(self):
+            return self.walked[self.t]
+
+    T = 600
+    fe = FakeEnv(T, 77)
+    mon = monitor_mod.Monitor.__new__(monitor_mod.Monitor)
+    mon.env = fe
+    mon.setup_containers = types.MethodType(monitor_mod.Monitor.setup_containers, mon)
+    mon.num_dofs, mon.num_actions = 28, 8
+    mon.setup_containers()
+    names = ['ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance',
+             'mean_ep_pos_rew_smoothed', 'mean_ep_vel_rew_smoothed', 'mean_ep_com_rew_smoothed',
+             'mean_abs_ep_torque_smoothed', 'median_abs_torque_smoothed']
+    g7 = {k: np.zeros(T) for k in names}
+    for t in range(T):
+        mon.step(None)
+        for k in names:
+            g7[k][t] = getattr(mon, k)
+    g7.update(rew=fe.rew, done=fe.done.astype(np.int32), comp=fe.comp, tor=fe.tor, cursor=fe.cursor,
+              walked=fe.walked, ep_lens=np.array(mon.ep_lens), rsi_positions=np.array(mon.rsi_positions),
+              et_positions=np.array(mon.et_positions),
+              difficult_rsi_phases=np.array(mon.difficult_rsi_phases))
+    np.savez_compressed(os.path.join(OUT, 'G7_monitor.npz'), **g7)
+    print('golden fixtures written to', OUT)
+
+
+if __name__ == '__main__':
+    main()
