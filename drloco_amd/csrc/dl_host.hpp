@@ -1,0 +1,88 @@
+// dl_host.hpp -- host-side helpers: descriptor validation and conversion into the kernels'
+// parameter blocks.  Shared by the C-ABI (dl_api.hip) and the host-emulation test build.
+#pragma once
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "dl_env.hpp"
+
+namespace dl {
+
+// the compiled kernels are specialised for one kinematic tree; refuse anything else loudly
+template <typename TP> inline bool check_topology(const dl_model_desc& d, std::string& why) {
+    char buf[256];
+    auto fail = [&](const char* what, int idx) { snprintf(buf, sizeof buf, "unsupported model topology: %s[%d]", what, idx); why = buf; return false; };
+    if (d.nbody != TP::NB || d.nv != TP::NV || d.nu != TP::NU || d.ngeom != TP::NG || d.nsite != TP::NS) { why = "unsupported model topology: sizes"; return false; }
+    for (int b = 0; b < TP::NB; b++) if (d.body_parent[b] != TP::body_parent(b)) return fail("body_parent", b);
+    for (int j = 0; j < TP::NV; j++) {
+        if (d.jnt_body[j] != TP::dof_body(j)) return fail("jnt_body", j);
+        if (d.jnt_type[j] != TP::dof_type(j)) return fail("jnt_type", j);
+        if (d.jnt_limited[j] != TP::dof_limited(j)) return fail("jnt_limited", j);
+        for (int k = 0; k < 3; k++) {
+            const double want = (k == TP::dof_axis(j)) ? (double)TP::dof_sign(j) : 0.0;
+            if (std::fabs(d.jnt_axis[j][k] - want) > 1e-12) return fail("jnt_axis", j);
+            if (d.jnt_type[j] == DL_JNT_HINGE && d.jnt_pos[j][k] != 0.0) return fail("jnt_pos (hinge anchors must be the body origin)", j);
+        }
+        if (d.jnt_type[j] == DL_JNT_SLIDE && d.jnt_body[j] != 1) return fail("slide joints must belong to the root body", j);
+    }
+    for (int g = 0; g < TP::NG; g++) {
+        if (d.geom_body[g] != TP::geom_body(g)) return fail("geom_body", g);
+        if (d.geom_type[g] != TP::geom_type(g)) return fail("geom_type", g);
+    }
+    for (int s = 0; s < TP::NS; s++) if (d.site_body[s] != TP::site_body(s)) return fail("site_body", s);
+    for (int a = 0; a < TP::NU; a++) if (d.act_dof[a] != TP::act_dof(a)) return fail("act_dof", a);
+    if (d.body_pos[1][0] != 0 || d.body_pos[1][1] != 0) { why = "root body must sit above the origin"; return false; }
+    return true;
+}
+
+template <typename T, typename TP> inline void fill_dev_model(const dl_model_desc& d, DevModel<T, TP>& m) {
+    std::memset(&m, 0, sizeof m);
+    for (int b = 0; b < TP::NB; b++) {
+        for (int k = 0; k < 3; k++) { m.body_pos[b][k] = (T)d.body_pos[b][k]; m.body_ipos[b][k] = (T)d.body_ipos[b][k]; m.body_inertia[b][k] = (T)d.body_inertia[b][k]; }
+        m.body_mass[b] = (T)d.body_mass[b];
+        m.body_invw[b] = (T)d.body_invweight0[b][0];
+    }
+    for (int j = 0; j < TP::NV; j++) {
+        m.qpos0[j] = (T)d.jnt_qpos0[j]; m.range[j][0] = (T)d.jnt_range[j][0]; m.range[j][1] = (T)d.jnt_range[j][1];
+        m.damping[j] = (T)d.jnt_damping[j]; m.armature[j] = (T)d.jnt_armature[j]; m.dof_invw[j] = (T)d.dof_invweight0[j];
+    }
+    for (int g = 0; g < TP::NG; g++) {
+        for (int k = 0; k < 3; k++) { m.geom_pos[g][k] = (T)d.geom_pos[g][k]; m.geom_size[g][k] = (T)d.geom_size[g][k]; }
+        for (int k = 0; k < 9; k++) m.geom_mat[g][k] = (T)d.geom_mat[g][k];
+        m.geom_mu[g] = (T)(d.geom_friction[g] > d.floor_friction ? d.geom_friction[g] : d.floor_friction);
+    }
+    for (int s = 0; s < TP::NS; s++) for (int k = 0; k < 3; k++) m.site_pos[s][k] = (T)d.site_pos[s][k];
+    for (int a = 0; a < TP::NU; a++) {
+        m.ctrl_lo[a] = (T)d.act_ctrlrange[a][0]; m.ctrl_hi[a] = (T)d.act_ctrlrange[a][1];
+        m.force_lo[a] = (T)d.act_forcerange[a][0]; m.force_hi[a] = (T)d.act_forcerange[a][1];
+        m.gear[a] = (T)d.act_gear[a];
+    }
+    m.timestep = (T)d.timestep;
+    m.gravity_z = (T)d.gravity[2];
+    double tc = d.solref[0], dr = d.solref[1], dmax = d.solimp[1];
+    if (tc < 2 * d.timestep) tc = 2 * d.timestep;   // refsafe
+    m.solK = (T)(1.0 / std::fmax(1e-15, dmax * dmax * tc * tc * dr * dr));
+    m.solB = (T)(2.0 / std::fmax(1e-15, dmax * tc));
+    for (int k = 0; k < 5; k++) m.solimp[k] = (T)d.solimp[k];
+    m.meaninertia = (T)d.meaninertia;
+    m.tolerance = (T)d.tolerance;
+    m.ls_tolerance = (T)d.ls_tolerance;
+    // float32 cannot resolve MuJoCo's 1e-8 tolerances: stop the solver / line search at its own resolution
+    if (sizeof(T) == 4) { m.tolerance = (T)std::fmax(d.tolerance, 1e-6); m.ls_reltol = (T)1e-5; }
+    else m.ls_reltol = (T)0;
+    m.iterations = d.iterations; m.ls_iterations = d.ls_iterations; m.frame_skip = d.frame_skip;
+}
+
+template <typename T> inline void fill_dev_cfg(const dl_config& c, const dl_refs_desc& r, DevCfg<T>& o) {
+    std::memset(&o, 0, sizeof o);
+    for (int k = 0; k < 3; k++) o.rew_w[k] = (T)c.rew_weights[k];
+    o.rew_scale = (T)c.rew_scale; o.alive_bonus = (T)c.alive_bonus; o.com_z_min = (T)c.com_z_min;
+    o.inv_ctrl_freq = (T)(1.0 / c.ctrl_freq);
+    o.ep_dur_max = c.ep_dur_max; o.mirror_policy = c.mirror_policy; o.env_index_base = c.env_index_base; o.seed = c.seed;
+    o.n_steps = r.n_steps; o.total_len = r.total_len; o.stride = r.stride;
+}
+
+}  // namespace dl

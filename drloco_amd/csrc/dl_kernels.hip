@@ -1,0 +1,443 @@
+// dl_kernels.hip -- gfx950 kernels + the C-ABI of include/drloco_hip.h.
+//
+// Launch geometry of the environment kernels: one walker per lane, one 64-lane wave per
+// workgroup (f64: 32 lanes) so that a workgroup's dynamic constraint storage ([slot][lane],
+// conflict-free) fits a CU's LDS; with the benchmark's 4096 walkers that is 64 workgroups, each
+// on its own CU.  All per-walker state is SoA [field][N] in HBM: every load/store of a wave is
+// one coalesced 256-byte (f32) segment.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dl_host.hpp"
+
+using namespace dl;
+using TP = TopoStraight;
+
+// ------------------------------------------------------------------------------------------
+template <typename T> struct KernelGeom { static constexpr int BLOCK = sizeof(T) == 4 ? 64 : 32; };
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP> m, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
+                                                    float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
+                                                    const T* inj_q, const T* inj_v, const int32_t* inj_flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= st.n) return;
+    LaneMem<T> mem{reinterpret_cast<T*>(smem) + threadIdx.x, BLOCK};
+    env_step_lane<T, TP>(m, c, mem, st, i, actions, obs, rew, done, term_obs, rew_terms, inj_q, inj_v, inj_flags);
+}
+
+// mode 0: reset walkers whose need_reset > 0 (auto reset after a step); mode 1: reset walkers
+// selected by mask (NULL = all)
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP> m, const DevCfg<T> c, const DevState<T> st, int mode, const uint8_t* mask,
+                                                     const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= st.n) return;
+    int nrep;
+    if (mode == 0) nrep = st.need_reset[i];
+    else nrep = (mask == nullptr || mask[i]) ? 1 : 0;
+    if (nrep == 0) return;
+    LaneMem<T> mem{reinterpret_cast<T*>(smem) + threadIdx.x, BLOCK};
+    env_reset_lane<T, TP>(m, c, mem, st, i, nrep, init_step, init_pos, obs, term_obs);
+}
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP> m, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int i = blockIdx.x * BLOCK + threadIdx.x, n = st.n;
+    if (i >= n) return;
+    LaneMem<T> mem{reinterpret_cast<T*>(smem) + threadIdx.x, BLOCK};
+    T q[TP::NV], v[TP::NV], w[TP::NV], u[TP::NU], a[TP::NV];
+    static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; q[j] = st.qpos[(size_t)j * n + i]; v[j] = st.qvel[(size_t)j * n + i]; w[j] = st.warm[(size_t)j * n + i]; });
+    static_for<TP::NU>([&](auto ai) { constexpr int k = ai.value; u[k] = ctrl ? ctrl[(size_t)k * n + i] : T(0); });
+    EfcInfo<TP> e;
+    int it;
+    forward<T, TP>(m, mem, q, v, u, w, a, e, it);
+    static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; qacc[(size_t)j * n + i] = a[j]; });
+    if (ncon) ncon[i] = e.ncon;
+    if (nefc) nefc[i] = e.nefc;
+    if (niter) niter[i] = it;
+}
+
+template <typename T> __global__ void k_fill(T* p, T val, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = val;
+}
+template <typename T> __global__ void k_copy_cast(T* dst, const double* src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (T)src[i];
+}
+__global__ void k_mon_snapshot(const double* mon, int word, double* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mon[(size_t)word * n + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// SB3-layer reductions
+
+// block reduction of a double over a workgroup (blockDim.x multiple of 64, <= 1024)
+__device__ __forceinline__ double block_sum(double x, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = x;
+    __syncthreads();
+    double r = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 0; k < nw; k++) r += sh[k];
+    return r;
+}
+
+// RunningMeanStd.update for column k = blockIdx.x of x[B, D]: batch mean / population variance
+// in float64, Chan merge with (mean, var, count).  count is updated by k_count_add afterwards.
+template <typename X>
+__global__ __launch_bounds__(256) void k_moments(double* mean, double* var, const double* count, const X* __restrict__ x, int B, int D) {
+    __shared__ double sh[4];
+    const int k = blockIdx.x;
+    double s = 0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) s += (double)x[(size_t)i * D + k];
+    const double bm = block_sum(s, sh) / B;
+    double s2 = 0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { const double d = (double)x[(size_t)i * D + k] - bm; s2 += d * d; }
+    const double bv = block_sum(s2, sh) / B;
+    if (threadIdx.x == 0) {
+        const double cnt = *count, tot = cnt + B, delta = bm - mean[k];
+        const double M2 = var[k] * cnt + bv * B + delta * delta * cnt * B / tot;
+        mean[k] = mean[k] + delta * B / tot;
+        var[k] = M2 / tot;
+    }
+}
+__global__ void k_count_add(double* count, double b) { *count += b; }
+
+__global__ void k_normalize_obs(float* x, const double* mean, const double* var, int B, int D, double eps, double clip) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * D) return;
+    const int k = (int)(idx % D);
+    double y = ((double)x[idx] - mean[k]) / sqrt(var[k] + eps);
+    y = y < -clip ? -clip : (y > clip ? clip : y);
+    x[idx] = (float)y;
+}
+__global__ void k_ret_accumulate(double* ret, const float* rew, int B, double gamma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) ret[i] = ret[i] * gamma + (double)rew[i];
+}
+__global__ void k_reward_finish(float* rew, double* ret, const uint8_t* done, const double* ret_var, int B, double eps, double clip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double y = (double)rew[i] / sqrt(*ret_var + eps);
+    y = y < -clip ? -clip : (y > clip ? clip : y);
+    rew[i] = (float)y;
+    if (done[i]) ret[i] = 0;
+}
+
+// RolloutBuffer.compute_returns_and_advantage: one lane per walker, reverse scan over T
+__global__ void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const float* __restrict__ last_val,
+                      const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N, float* adv, float* ret) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float last = 0.f, nnt = 1.0f - (float)last_done[i], nv = last_val[i];
+    for (int t = T - 1; t >= 0; t--) {
+        const size_t o = (size_t)t * N + i;
+        const float vt = val[o];
+        const float delta = rew[o] + gamma * nv * nnt - vt;
+        last = delta + gamma * lam * nnt * last;
+        adv[o] = last;
+        ret[o] = last + vt;
+        nnt = 1.0f - (float)ep_start[o];
+        nv = vt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adv_stats(const float* __restrict__ a, long long n, double* out3) {
+    __shared__ double sh[4];
+    double s = 0, s2 = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { const double x = a[i]; s += x; s2 += x * x; }
+    s = block_sum(s, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { atomicAdd(&out3[0], s); atomicAdd(&out3[1], s2); if (blockIdx.x == 0) atomicAdd(&out3[2], (double)n); }
+}
+__global__ void k_adv_normalize(float* a, long long n, const double* s3) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double cnt = s3[2], mean = s3[0] / cnt;
+    double var = (s3[1] - cnt * mean * mean) / (cnt - 1);      // torch.std: Bessel corrected
+    if (var < 0) var = 0;
+    a[i] = (float)(((double)a[i] - mean) / (sqrt(var) + 1e-8));
+}
+
+// ------------------------------------------------------------------------------------------
+// handle
+static thread_local std::string g_err;
+static int fail(int code, const std::string& what) { g_err = what; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(DL_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct dl_env_s {
+    virtual ~dl_env_s() {}
+    int n = 0, device = 0, real_size = 4;
+    virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
+    virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
+    virtual int step(const float*, float*, float*, uint8_t*, float*, float*, hipStream_t) = 0;
+    virtual int get_state(void*, void*, void*, int32_t*, double*, hipStream_t) = 0;
+    virtual int set_state(const void*, const void*, const void*, const int32_t*, const double*, hipStream_t) = 0;
+    virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
+    virtual int snapshot(int word, double* out, hipStream_t) = 0;
+    virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
+};
+
+template <typename T> struct EnvImpl final : dl_env_s {
+    static constexpr int BLOCK = KernelGeom<T>::BLOCK;
+    static constexpr size_t LDS = (size_t)MemLayout<TP>::TOTAL * BLOCK * sizeof(T);
+    DevModel<T, TP> m;
+    DevCfg<T> c;
+    DevState<T> st;
+    std::vector<void*> allocs;
+    T *inj_q = nullptr, *inj_v = nullptr;
+    int32_t* inj_flags = nullptr;
+    bool inj_armed = false;
+    float* scratch_obs = nullptr;
+
+    ~EnvImpl() override { for (void* p : allocs) (void)hipFree(p); }
+    template <typename U> int dalloc(U** p, size_t count) {
+        HIPCHK(hipMalloc((void**)p, count * sizeof(U)));
+        allocs.push_back(*p);
+        HIPCHK(hipMemset(*p, 0, count * sizeof(U)));
+        return DL_OK;
+    }
+    int grid() const { return (n + BLOCK - 1) / BLOCK; }
+
+    int init(const dl_model_desc& d, const dl_refs_desc& r, const dl_config& cfg, int n_, int device_) override {
+        n = n_; device = device_; real_size = sizeof(T);
+        HIPCHK(hipSetDevice(device));
+        fill_dev_model<T, TP>(d, m);
+        fill_dev_cfg<T>(cfg, r, c);
+        if (r.n_rows != 2 * TP::NV) return fail(DL_E_INVAL, "refs.n_rows must be 2*nv");
+        int rc;
+        // reference table -> device, in the arithmetic type of the kernels
+        const size_t tn = (size_t)r.n_rows * r.total_len;
+        T* table; double* stage; T* svel; int32_t *soff, *sleft;
+        if ((rc = dalloc(&table, tn))) return rc;
+        if ((rc = dalloc(&stage, tn))) return rc;
+        HIPCHK(hipMemcpy(stage, r.table, tn * sizeof(double), hipMemcpyHostToDevice));
+        k_copy_cast<T><<<(unsigned)((tn + 255) / 256), 256>>>(table, stage, tn);
+        if ((rc = dalloc(&svel, r.n_steps))) return rc;
+        HIPCHK(hipMemcpy(stage, r.step_vel, r.n_steps * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipDeviceSynchronize());
+        k_copy_cast<T><<<1, 256>>>(svel, stage, r.n_steps);
+        if ((rc = dalloc(&soff, r.n_steps + 1))) return rc;
+        if ((rc = dalloc(&sleft, r.n_steps))) return rc;
+        HIPCHK(hipMemcpy(soff, r.step_off, (r.n_steps + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sleft, r.step_is_left, r.n_steps * sizeof(int32_t), hipMemcpyHostToDevice));
+        c.table = table; c.step_off = soff; c.step_is_left = sleft; c.step_vel = svel;
+        // per-walker state
+        st.n = n;
+        if ((rc = dalloc(&st.qpos, (size_t)TP::NV * n))) return rc;
+        if ((rc = dalloc(&st.qvel, (size_t)TP::NV * n))) return rc;
+        if ((rc = dalloc(&st.warm, (size_t)TP::NV * n))) return rc;
+        if ((rc = dalloc(&st.comz_off, n))) return rc;
+        if ((rc = dalloc(&st.cur, (size_t)DL_CUR_WORDS * n))) return rc;
+        if ((rc = dalloc(&st.walked, n))) return rc;
+        if ((rc = dalloc(&st.mon, (size_t)MON_WORDS * n))) return rc;
+        if ((rc = dalloc(&st.need_reset, n))) return rc;
+        if ((rc = dalloc(&st.inj_rsi, (size_t)2 * n))) return rc;
+        if ((rc = dalloc(&inj_q, (size_t)TP::NV * n))) return rc;
+        if ((rc = dalloc(&inj_v, (size_t)TP::NV * n))) return rc;
+        if ((rc = dalloc(&inj_flags, n))) return rc;
+        if ((rc = dalloc(&scratch_obs, (size_t)TP::OBS * n))) return rc;
+        const unsigned g256 = (unsigned)((n + 255) / 256);
+        for (int j = 0; j < TP::NV; j++) k_fill<T><<<g256, 256>>>(st.qpos + (size_t)j * n, (T)d.jnt_qpos0[j], (size_t)n);
+        k_fill<int32_t><<<g256, 256>>>(st.cur + (size_t)DL_CUR_COUNT * n, 1, (size_t)n);   // count_steps_same_vel = 1
+        k_fill<int32_t><<<(unsigned)((2 * n + 255) / 256), 256>>>(st.inj_rsi, -1, (size_t)2 * n);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step<T, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_reset<T, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward<T, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(stage));
+        allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)stage));
+        return DL_OK;
+    }
+    int reset(const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs, hipStream_t s) override {
+        if ((is == nullptr) != (ip == nullptr)) return fail(DL_E_INVAL, "init_step and init_pos must be given together");
+        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr);
+        HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
+        if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
+        hipLaunchKernelGGL((k_env_step<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, act, obs, rew, done, term, terms,
+                           (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
+        HIPCHK(hipGetLastError());
+        if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
+        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term);
+        HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    int get_state(void* q, void* v, void* w, int32_t* cur, double* walked, hipStream_t s) override {
+        const size_t b = (size_t)TP::NV * n * sizeof(T);
+        if (q) HIPCHK(hipMemcpyAsync(q, st.qpos, b, hipMemcpyDeviceToDevice, s));
+        if (v) HIPCHK(hipMemcpyAsync(v, st.qvel, b, hipMemcpyDeviceToDevice, s));
+        if (w) HIPCHK(hipMemcpyAsync(w, st.warm, b, hipMemcpyDeviceToDevice, s));
+        if (cur) HIPCHK(hipMemcpyAsync(cur, st.cur, (size_t)DL_CUR_WORDS * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (walked) HIPCHK(hipMemcpyAsync(walked, st.walked, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
+    }
+    int set_state(const void* q, const void* v, const void* w, const int32_t* cur, const double* walked, hipStream_t s) override {
+        const size_t b = (size_t)TP::NV * n * sizeof(T);
+        if (q) HIPCHK(hipMemcpyAsync(st.qpos, q, b, hipMemcpyDeviceToDevice, s));
+        if (v) HIPCHK(hipMemcpyAsync(st.qvel, v, b, hipMemcpyDeviceToDevice, s));
+        if (w) HIPCHK(hipMemcpyAsync(st.warm, w, b, hipMemcpyDeviceToDevice, s));
+        if (cur) HIPCHK(hipMemcpyAsync(st.cur, cur, (size_t)DL_CUR_WORDS * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (walked) HIPCHK(hipMemcpyAsync(st.walked, walked, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
+    }
+    int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
+        if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
+        hipLaunchKernelGGL((k_forward<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+        HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    int snapshot(int word, double* out, hipStream_t s) override {
+        hipLaunchKernelGGL(k_mon_snapshot, dim3((n + 255) / 256), dim3(256), 0, s, (const double*)st.mon, word, out, n);
+        HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t s) override {
+        const size_t b = (size_t)TP::NV * n * sizeof(T);
+        if (q) HIPCHK(hipMemcpyAsync(inj_q, q, b, hipMemcpyDeviceToDevice, s));
+        if (v) HIPCHK(hipMemcpyAsync(inj_v, v, b, hipMemcpyDeviceToDevice, s));
+        if (flags) { HIPCHK(hipMemcpyAsync(inj_flags, flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s)); inj_armed = true; }
+        if (rsi) HIPCHK(hipMemcpyAsync(st.inj_rsi, rsi, (size_t)2 * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* dl_last_error(void) { return g_err.c_str(); }
+int dl_abi_version(void) { return DL_ABI_VERSION; }
+int dl_abi_sizeof(int which) { return which == 0 ? (int)sizeof(dl_model_desc) : which == 1 ? (int)sizeof(dl_refs_desc) : (int)sizeof(dl_config); }
+
+int dl_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_config* cfg, int32_t n_envs, int32_t device, dl_handle* out) {
+    if (!model || !refs || !cfg || !out || n_envs <= 0) return fail(DL_E_INVAL, "dl_create: bad arguments");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DL_E_NODEVICE, "dl_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(DL_E_INVAL, "dl_create: device ordinal out of range");
+    std::string why;
+    if (!check_topology<TP>(*model, why)) return fail(DL_E_INVAL, why);
+    if (cfg->precision != 32 && cfg->precision != 64 && cfg->precision != 0) return fail(DL_E_INVAL, "dl_create: precision must be 32 or 64");
+    dl_env_s* h = cfg->precision == 64 ? static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<double>()) : static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<float>());
+    if (!h) return fail(DL_E_NOMEM, "dl_create: out of host memory");
+    const int rc = h->init(*model, *refs, *cfg, n_envs, device);
+    if (rc != DL_OK) { delete h; return rc; }
+    *out = h;
+    return DL_OK;
+}
+int dl_destroy(dl_handle h) { delete h; return DL_OK; }
+int32_t dl_num_envs(dl_handle h) { return h ? h->n : 0; }
+int32_t dl_obs_dim(dl_handle h) { return h ? TP::OBS : 0; }
+int32_t dl_act_dim(dl_handle h) { return h ? TP::NU : 0; }
+int32_t dl_real_size(dl_handle h) { return h ? h->real_size : 0; }
+
+#define NEED(h) do { if (!(h)) return fail(DL_E_INVAL, "null handle"); } while (0)
+
+int dl_reset(dl_handle h, const uint8_t* mask, const int32_t* init_step, const int32_t* init_pos, float* obs_out, void* stream) {
+    NEED(h);
+    return h->reset(mask, init_step, init_pos, obs_out, (hipStream_t)stream);
+}
+int dl_step(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms, void* stream) {
+    NEED(h);
+    return h->step(actions, obs, rew, done, term_obs, rew_terms, (hipStream_t)stream);
+}
+int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, float* rew, uint8_t* done, void* stream) {
+    NEED(h);
+    if (T <= 0 || !actions || !obs || !rew || !done) return fail(DL_E_INVAL, "dl_rollout_fixed: bad arguments");
+    const size_t n = (size_t)h->n;
+    for (int32_t t = 0; t < T; t++) {
+        const int rc = h->step(actions + (size_t)t * n * TP::NU, obs + (size_t)t * n * TP::OBS, rew + (size_t)t * n, done + (size_t)t * n, nullptr, nullptr, (hipStream_t)stream);
+        if (rc != DL_OK) return rc;
+    }
+    return DL_OK;
+}
+int dl_get_state(dl_handle h, void* qpos, void* qvel, void* qacc_warm, int32_t* cursor, double* walked, void* stream) {
+    NEED(h);
+    return h->get_state(qpos, qvel, qacc_warm, cursor, walked, (hipStream_t)stream);
+}
+int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qacc_warm, const int32_t* cursor, const double* walked, void* stream) {
+    NEED(h);
+    return h->set_state(qpos, qvel, qacc_warm, cursor, walked, (hipStream_t)stream);
+}
+int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream) {
+    NEED(h);
+    return h->forward(ctrl, qacc, ncon, nefc, niter, (hipStream_t)stream);
+}
+/* test hooks (not part of the reference surface): inject end states / exceptions for the next
+ * step (flags int32[N]: 1 = use inj state, 2 = diverge) and a fixed RSI draw (int32[2,N], -1 = off) */
+int dl_debug_inject(dl_handle h, const void* qpos, const void* qvel, const int32_t* flags, const int32_t* rsi, void* stream) {
+    NEED(h);
+    return h->inject(qpos, qvel, flags, rsi, (hipStream_t)stream);
+}
+int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) {
+    NEED(h);
+    static const struct { const char* name; int word; } tab[] = {
+        {"ep_len_smoothed", MON_S_EP_LEN}, {"ep_ret_smoothed", MON_S_EP_RET}, {"mean_reward_smoothed", MON_S_MEAN_REW},
+        {"moved_distance", MON_MOVED}, {"mean_ep_pos_rew_smoothed", MON_S_POS}, {"mean_ep_vel_rew_smoothed", MON_S_VEL},
+        {"mean_ep_com_rew_smoothed", MON_S_COM}, {"mean_abs_ep_torque_smoothed", MON_S_TOR}, {"ep_len", MON_EP_LEN}};
+    for (const auto& t : tab)
+        if (!strcmp(name, t.name)) return h->snapshot(t.word, out, (hipStream_t)stream);
+    return fail(DL_E_INVAL, std::string("dl_stats_snapshot: unknown attribute ") + name);
+}
+
+int dl_moments_update(double* mean, double* var, double* count, const float* x, int32_t B, int32_t D, void* stream) {
+    if (!mean || !var || !count || !x || B <= 0 || D <= 0) return fail(DL_E_INVAL, "dl_moments_update: bad arguments");
+    hipLaunchKernelGGL((k_moments<float>), dim3(D), dim3(256), 0, (hipStream_t)stream, mean, var, (const double*)count, x, B, D);
+    hipLaunchKernelGGL(k_count_add, dim3(1), dim3(1), 0, (hipStream_t)stream, count, (double)B);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_normalize_obs(float* x, const double* mean, const double* var, int32_t B, int32_t D, double eps, double clip, void* stream) {
+    if (!x || !mean || !var || B <= 0 || D <= 0) return fail(DL_E_INVAL, "dl_normalize_obs: bad arguments");
+    const size_t n = (size_t)B * D;
+    hipLaunchKernelGGL(k_normalize_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mean, var, B, D, eps, clip);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* ret_mean, double* ret_var, double* ret_count, int32_t B, double gamma, double eps, double clip, void* stream) {
+    if (!rew || !ret || !done || !ret_mean || !ret_var || !ret_count || B <= 0) return fail(DL_E_INVAL, "dl_normalize_reward: bad arguments");
+    const unsigned g = (unsigned)((B + 255) / 256);
+    hipLaunchKernelGGL(k_ret_accumulate, dim3(g), dim3(256), 0, (hipStream_t)stream, ret, (const float*)rew, B, gamma);
+    hipLaunchKernelGGL((k_moments<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, ret_mean, ret_var, (const double*)ret_count, (const double*)ret, B, 1);
+    hipLaunchKernelGGL(k_count_add, dim3(1), dim3(1), 0, (hipStream_t)stream, ret_count, (double)B);
+    hipLaunchKernelGGL(k_reward_finish, dim3(g), dim3(256), 0, (hipStream_t)stream, rew, ret, done, (const double*)ret_var, B, eps, clip);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val, const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv, float* ret, void* stream) {
+    if (!rew || !val || !ep_start || !last_val || !last_done || !adv || !ret || T <= 0 || N <= 0) return fail(DL_E_INVAL, "dl_gae: bad arguments");
+    hipLaunchKernelGGL(k_gae, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew, val, ep_start, last_val, last_done, gamma, lam, T, N, adv, ret);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_adv_stats(const float* adv, int64_t n, double* out3, void* stream) {
+    if (!adv || !out3 || n <= 0) return fail(DL_E_INVAL, "dl_adv_stats: bad arguments");
+    HIPCHK(hipMemsetAsync(out3, 0, 3 * sizeof(double), (hipStream_t)stream));
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adv_stats, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, adv, (long long)n, out3);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_adv_normalize(float* adv, int64_t n, const double* sums3, void* stream) {
+    if (!adv || !sums3 || n <= 0) return fail(DL_E_INVAL, "dl_adv_normalize: bad arguments");
+    hipLaunchKernelGGL(k_adv_normalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adv, (long long)n, sums3);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+
+}  // extern "C"

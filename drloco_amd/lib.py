@@ -1,0 +1,92 @@
+"""ctypes binding of drloco_amd/csrc/libdrloco_hip.so (the C-ABI in include/drloco_hip.h).
+
+There is no CPU fallback: importing works anywhere (the library links only against
+libamdhip64), but creating an environment without a HIP device raises."""
+import ctypes as C
+import os
+import subprocess
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libdrloco_hip.so')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
+_SOURCES = ['dl_kernels.hip', 'dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp']
+
+_lib = None
+
+
+class DrlocoError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 of the kernels + C-ABI into an in-tree shared library."""
+    srcs = [os.path.join(CSRC, s) for s in _SOURCES] + [os.path.join(INCLUDE, 'drloco_hip.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I' + INCLUDE, '-I' + CSRC,
+           os.path.join(CSRC, 'dl_kernels.hip'), '-o', LIB_PATH]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_V, _I, _P = C.c_void_p, C.c_int32, C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)       -- every symbol include/drloco_hip.h declares
+    'dl_last_error': (C.c_char_p, []),
+    'dl_abi_version': (C.c_int, []),
+    'dl_create': (C.c_int, [C.POINTER(abi.ModelDesc), C.POINTER(abi.RefsDesc), C.POINTER(abi.Config), _I, _I, C.POINTER(_V)]),
+    'dl_destroy': (C.c_int, [_V]),
+    'dl_num_envs': (_I, [_V]),
+    'dl_obs_dim': (_I, [_V]),
+    'dl_act_dim': (_I, [_V]),
+    'dl_real_size': (_I, [_V]),
+    'dl_reset': (C.c_int, [_V, _P, _P, _P, _P, _P]),
+    'dl_step': (C.c_int, [_V, _P, _P, _P, _P, _P, _P, _P]),
+    'dl_rollout_fixed': (C.c_int, [_V, _I, _P, _P, _P, _P, _P]),
+    'dl_get_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
+    'dl_set_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
+    'dl_forward': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
+    'dl_stats_snapshot': (C.c_int, [_V, C.c_char_p, _P, _P]),
+    'dl_moments_update': (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    'dl_normalize_obs': (C.c_int, [_P, _P, _P, _I, _I, C.c_double, C.c_double, _P]),
+    'dl_normalize_reward': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, _P]),
+    'dl_gae': (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _P, _P, _P]),
+    'dl_adv_stats': (C.c_int, [_P, C.c_int64, _P, _P]),
+    'dl_adv_normalize': (C.c_int, [_P, C.c_int64, _P, _P]),
+}
+_EXTRA = {
+    'dl_abi_sizeof': (C.c_int, [C.c_int]),
+    'dl_debug_inject': (C.c_int, [_V, _P, _P, _P, _P, _P]),
+}
+
+
+def load():
+    """Load the HIP library; raises DrlocoError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DrlocoError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in {**_SIGNATURES, **_EXTRA}.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.dl_abi_version() != abi.DL_ABI_VERSION:
+        raise DrlocoError('ABI version mismatch between drloco_amd/abi.py and libdrloco_hip.so')
+    for which, struct in enumerate((abi.ModelDesc, abi.RefsDesc, abi.Config)):
+        if lib.dl_abi_sizeof(which) != C.sizeof(struct):
+            raise DrlocoError(f'struct size mismatch for {struct.__name__}')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DrlocoError(f'drloco_hip error {rc}: {load().dl_last_error().decode()}')

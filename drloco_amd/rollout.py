@@ -1,0 +1,54 @@
+"""Device rollout buffer with the SB3 1.0 return/advantage scan
+(RolloutBuffer.add / compute_returns_and_advantage, constructed via drloco/train.py:110-118)
+and PPO's advantage normalisation, whose statistics are the only rollout-side collective when
+walkers are sharded over GPUs (RCCL all-reduce of three doubles)."""
+import ctypes as C
+
+import torch
+
+from . import lib
+from .vec_env import _ptr, _stream
+
+
+class HipRolloutBuffer:
+    def __init__(self, n_steps, n_envs, obs_dim, act_dim, device, gamma=0.995, gae_lambda=0.95):
+        self._lib = lib.load()
+        self.T, self.N, self.gamma, self.gae_lambda = n_steps, n_envs, gamma, gae_lambda
+        f = lambda *s: torch.zeros(*s, device=device)
+        self.observations, self.actions = f(n_steps, n_envs, obs_dim), f(n_steps, n_envs, act_dim)
+        self.rewards, self.values, self.log_probs = f(n_steps, n_envs), f(n_steps, n_envs), f(n_steps, n_envs)
+        self.episode_starts = torch.zeros(n_steps, n_envs, dtype=torch.uint8, device=device)
+        self.advantages, self.returns = f(n_steps, n_envs), f(n_steps, n_envs)
+        self._sums = torch.zeros(3, dtype=torch.float64, device=device)
+        self.pos = 0
+
+    def reset(self):
+        self.pos = 0
+
+    def add(self, obs, action, reward, episode_start, value, log_prob):
+        t = self.pos
+        self.observations[t].copy_(obs); self.actions[t].copy_(action); self.rewards[t].copy_(reward)
+        self.episode_starts[t].copy_(episode_start); self.values[t].copy_(value); self.log_probs[t].copy_(log_prob)
+        self.pos += 1
+
+    def compute_returns_and_advantage(self, last_values, dones):
+        lv = last_values.to(torch.float32).contiguous()
+        ld = dones.to(torch.uint8).contiguous()
+        lib.check(self._lib.dl_gae(_ptr(self.rewards), _ptr(self.values), _ptr(self.episode_starts), _ptr(lv), _ptr(ld),
+                                   C.c_float(self.gamma), C.c_float(self.gae_lambda), self.T, self.N,
+                                   _ptr(self.advantages), _ptr(self.returns), _stream()))
+        return self.advantages, self.returns
+
+    def advantage_sums(self, adv=None):
+        a = self.advantages if adv is None else adv
+        lib.check(self._lib.dl_adv_stats(_ptr(a), a.numel(), _ptr(self._sums), _stream()))
+        return self._sums
+
+    def normalize_advantages(self, adv=None, process_group=None):
+        """(A - mean)/(std + 1e-8) over all ranks: one all-reduce of [sum, sum^2, n]."""
+        a = self.advantages if adv is None else adv
+        sums = self.advantage_sums(a)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(process_group) > 1:
+            torch.distributed.all_reduce(sums, group=process_group)
+        lib.check(self._lib.dl_adv_normalize(_ptr(a), a.numel(), _ptr(sums), _stream()))
+        return a

@@ -1,0 +1,368 @@
+"""HipVecEnv / HipVecNormalize: the reference's `utils.vec_env()` product
+(VecNormalize(SubprocVecEnv([Monitor(MimicEnv)]*n)), drloco/common/utils.py:97-134) as one
+object over N walkers resident on one MI355X.
+
+The classes are duck-typed after stable_baselines3 1.0's VecEnv / VecNormalize (SB3 and gym are
+not installed in this image): num_envs, observation_space, action_space, reset, step_async,
+step_wait, step, get_attr, set_attr, env_method, seed, close; VecNormalize adds obs_rms,
+ret_rms, normalize_obs, get_original_obs/reward, save/load and `.venv`.
+
+`step()` follows the VecEnv contract and returns numpy arrays (one D2H copy per control step).
+`step_tensors()` keeps everything on the device for GPU-resident rollouts."""
+import ctypes as C
+import pickle
+
+import numpy as np
+import torch
+
+from . import abi, lib, mocap, models
+
+MONITOR_ATTRS = ('ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance',
+                 'mean_ep_pos_rew_smoothed', 'mean_ep_vel_rew_smoothed', 'mean_ep_com_rew_smoothed',
+                 'mean_abs_ep_torque_smoothed')
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (shape/low/high/dtype/sample)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.low = np.full(shape, low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
+
+    def __repr__(self):
+        return f'Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})'
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipVecEnv:
+    """N MimicWalker3dEnv walkers stepped by the HIP kernels (one process per GPU)."""
+
+    def __init__(self, env_id=models.STRAIGHT_WALKER, num_envs=4096, device=None, seed=33, precision=32,
+                 model=None, refs=None, env_index_base=0, **config):
+        if not torch.cuda.is_available():
+            raise lib.DrlocoError('HipVecEnv needs a HIP device; there is no CPU fallback')
+        self._lib = lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self.model = model if model is not None else models.make_model(env_id)
+        self.refs = refs if refs is not None else mocap.RefTable.load()
+        self.cfg = abi.default_config(seed=seed, precision=precision, env_index_base=env_index_base, **config)
+        self.num_envs = int(num_envs)
+        self.precision = precision
+        self.rdtype = torch.float64 if precision == 64 else torch.float32
+        h = C.c_void_p()
+        desc = self.refs.as_desc()
+        with torch.cuda.device(self.device):
+            lib.check(self._lib.dl_create(C.byref(self.model), C.byref(desc), C.byref(self.cfg), self.num_envs,
+                                          self.device.index, C.byref(h)))
+        self._h = h
+        self.nv, self.nu = self.model.nv, self.model.nu
+        self.obs_dim = self._lib.dl_obs_dim(h)
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
+        lo = np.array([self.model.act_ctrlrange[a][0] for a in range(self.nu)], np.float32)
+        self.action_space = Box(0, 0, (self.nu,), np.float32)
+        self.action_space.low[:] = lo
+        self.action_space.high[:] = [self.model.act_ctrlrange[a][1] for a in range(self.nu)]
+        n, dev = self.num_envs, self.device
+        self.obs = torch.zeros(n, self.obs_dim, device=dev)
+        self.rew = torch.zeros(n, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.term_obs = torch.zeros(n, self.obs_dim, device=dev)
+        self.rew_terms = torch.zeros(n, 3, device=dev)
+        self._actions = None
+        # host-side mirrors of Monitor's per-env lists (monitor_wrapper.py:57,120)
+        self._ep_len = np.zeros(n, np.int64)
+        self.ep_lens = [[] for _ in range(n)]
+
+    # ---- VecEnv surface -------------------------------------------------------------------
+    def reset(self, mask=None, init_step=None, init_pos=None):
+        self.reset_tensors(mask, init_step, init_pos)
+        return self.obs.cpu().numpy()
+
+    def reset_tensors(self, mask=None, init_step=None, init_pos=None):
+        dev = self.device
+        m = None if mask is None else torch.as_tensor(mask, dtype=torch.uint8, device=dev).contiguous()
+        s = None if init_step is None else torch.as_tensor(init_step, dtype=torch.int32, device=dev).contiguous()
+        p = None if init_pos is None else torch.as_tensor(init_pos, dtype=torch.int32, device=dev).contiguous()
+        lib.check(self._lib.dl_reset(self._h, _ptr(m), _ptr(s), _ptr(p), _ptr(self.obs), _stream()))
+        return self.obs
+
+    def step_tensors(self, actions):
+        """actions: float32 cuda tensor [N, nu]; returns device tensors (obs, rew, done, term_obs)."""
+        a = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        assert a.shape == (self.num_envs, self.nu)
+        lib.check(self._lib.dl_step(self._h, _ptr(a), _ptr(self.obs), _ptr(self.rew), _ptr(self.done),
+                                    _ptr(self.term_obs), _ptr(self.rew_terms), _stream()))
+        return self.obs, self.rew, self.done, self.term_obs
+
+    def step_async(self, actions):
+        self._actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device)
+
+    def step_wait(self):
+        obs, rew, done, term = self.step_tensors(self._actions)
+        obs_h, rew_h, done_h = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        self._ep_len += 1
+        if done_h.any():
+            term_h = term.cpu().numpy()
+            for i in np.nonzero(done_h)[0]:
+                infos[i]['terminal_observation'] = term_h[i]
+                self.ep_lens[i].append(int(self._ep_len[i]))
+                self._ep_len[i] = 0
+        return obs_h, rew_h, done_h, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def rollout_fixed(self, actions, obs_out=None, rew_out=None, done_out=None):
+        """Synthetic fixed-length rollout: actions float32 cuda [T, N, nu] (no policy)."""
+        T = actions.shape[0]
+        n, dev = self.num_envs, self.device
+        obs_out = torch.empty(T, n, self.obs_dim, device=dev) if obs_out is None else obs_out
+        rew_out = torch.empty(T, n, device=dev) if rew_out is None else rew_out
+        done_out = torch.empty(T, n, dtype=torch.uint8, device=dev) if done_out is None else done_out
+        a = actions.to(device=dev, dtype=torch.float32).contiguous()
+        lib.check(self._lib.dl_rollout_fixed(self._h, T, _ptr(a), _ptr(obs_out), _ptr(rew_out), _ptr(done_out), _stream()))
+        return obs_out, rew_out, done_out
+
+    def get_attr(self, name, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        if name in MONITOR_ATTRS:
+            out = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
+            lib.check(self._lib.dl_stats_snapshot(self._h, name.encode(), _ptr(out), _stream()))
+            vals = out.cpu().numpy()
+            return [float(vals[i]) for i in idx]
+        if name == 'ep_lens':
+            return [list(self.ep_lens[i]) for i in idx]
+        raise AttributeError(name)
+
+    def set_attr(self, name, value, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        if name == 'ep_lens':
+            for i in idx:
+                self.ep_lens[i] = list(value)
+            return
+        raise AttributeError(f'cannot set {name!r} on HipVecEnv')
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        raise NotImplementedError(method_name)
+
+    def seed(self, seed=None):
+        # the reference seeds only gym's np_random, which the env never uses (utils.py:113);
+        # RSI draws come from the counter-based stream keyed by cfg.seed
+        return [seed] * self.num_envs
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.dl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parity hooks ---------------------------------------------------------------------
+    def get_state(self):
+        n, dev = self.num_envs, self.device
+        q = torch.empty(self.nv, n, dtype=self.rdtype, device=dev); v = torch.empty_like(q); w = torch.empty_like(q)
+        cur = torch.empty(abi.DL_CUR_WORDS, n, dtype=torch.int32, device=dev)
+        walked = torch.empty(n, dtype=torch.float64, device=dev)
+        lib.check(self._lib.dl_get_state(self._h, _ptr(q), _ptr(v), _ptr(w), _ptr(cur), _ptr(walked), _stream()))
+        return dict(qpos=q.cpu().numpy(), qvel=v.cpu().numpy(), warm=w.cpu().numpy(), cursor=cur.cpu().numpy(), walked=walked.cpu().numpy())
+
+    def set_state(self, qpos=None, qvel=None, warm=None, cursor=None, walked=None):
+        dev = self.device
+        f = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev).contiguous()
+        q, v, w = f(qpos, self.rdtype), f(qvel, self.rdtype), f(warm, self.rdtype)
+        c, wk = f(cursor, torch.int32), f(walked, torch.float64)
+        lib.check(self._lib.dl_set_state(self._h, _ptr(q), _ptr(v), _ptr(w), _ptr(c), _ptr(wk), _stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def forward(self, ctrl=None):
+        n, dev = self.num_envs, self.device
+        u = None if ctrl is None else torch.as_tensor(np.ascontiguousarray(ctrl), dtype=self.rdtype, device=dev)
+        qacc = torch.empty(self.nv, n, dtype=self.rdtype, device=dev)
+        ncon = torch.empty(n, dtype=torch.int32, device=dev); nefc = torch.empty_like(ncon); nit = torch.empty_like(ncon)
+        lib.check(self._lib.dl_forward(self._h, _ptr(u), _ptr(qacc), _ptr(ncon), _ptr(nefc), _ptr(nit), _stream()))
+        return qacc.cpu().numpy(), ncon.cpu().numpy(), nefc.cpu().numpy(), nit.cpu().numpy()
+
+    def debug_inject(self, qpos=None, qvel=None, flags=None, rsi=None):
+        dev = self.device
+        f = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev).contiguous()
+        q, v, fl, r = f(qpos, self.rdtype), f(qvel, self.rdtype), f(flags, torch.int32), f(rsi, torch.int32)
+        lib.check(self._lib.dl_debug_inject(self._h, _ptr(q), _ptr(v), _ptr(fl), _ptr(r), _stream()))
+        torch.cuda.current_stream().synchronize()
+
+
+class RunningMeanStd:
+    """SB3 1.0 RunningMeanStd with device-resident float64 moments."""
+
+    def __init__(self, shape, device, epsilon=1e-4):
+        d = int(np.prod(shape)) if shape else 1
+        self.shape = tuple(shape)
+        self._mean = torch.zeros(d, dtype=torch.float64, device=device)
+        self._var = torch.ones(d, dtype=torch.float64, device=device)
+        self._count = torch.full((1,), epsilon, dtype=torch.float64, device=device)
+
+    @property
+    def mean(self):
+        return self._mean.cpu().numpy().reshape(self.shape)
+
+    @property
+    def var(self):
+        return self._var.cpu().numpy().reshape(self.shape)
+
+    @property
+    def count(self):
+        return float(self._count.item())
+
+    def state(self):
+        return dict(mean=self.mean, var=self.var, count=self.count)
+
+    def load_state(self, s):
+        self._mean.copy_(torch.as_tensor(np.asarray(s['mean'], np.float64).reshape(-1)))
+        self._var.copy_(torch.as_tensor(np.asarray(s['var'], np.float64).reshape(-1)))
+        self._count.fill_(float(s['count']))
+
+
+class HipVecNormalize:
+    """VecNormalize(venv, norm_obs=True, norm_reward=True, clip 10, gamma 0.99, eps 1e-8) on device."""
+
+    def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
+                 gamma=0.99, epsilon=1e-8):
+        self.venv = venv
+        self._lib = venv._lib
+        self.num_envs, self.observation_space, self.action_space = venv.num_envs, venv.observation_space, venv.action_space
+        self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
+        self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
+        dev = venv.device
+        self.obs_rms = RunningMeanStd((venv.obs_dim,), dev)
+        self.ret_rms = RunningMeanStd((), dev)
+        self.ret = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)
+        self.old_obs = torch.zeros_like(venv.obs)
+        self.old_rew = torch.zeros_like(venv.rew)
+        self.norm_obs_t = torch.zeros_like(venv.obs)
+        self.norm_rew_t = torch.zeros_like(venv.rew)
+
+    def _normalize_obs_inplace(self, x):
+        n = x.shape[0]
+        lib.check(self._lib.dl_normalize_obs(_ptr(x), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), n, x.shape[1],
+                                             self.epsilon, self.clip_obs, _stream()))
+
+    def step_tensors(self, actions):
+        obs, rew, done, term = self.venv.step_tensors(actions)
+        self.old_obs.copy_(obs)
+        self.old_rew.copy_(rew)
+        self.norm_obs_t.copy_(obs)
+        self.norm_rew_t.copy_(rew)
+        n, d = obs.shape
+        if self.norm_obs:
+            if self.training:
+                lib.check(self._lib.dl_moments_update(_ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
+                                                      _ptr(self.old_obs), n, d, _stream()))
+            self._normalize_obs_inplace(self.norm_obs_t)
+        if self.norm_reward:
+            if self.training:
+                lib.check(self._lib.dl_normalize_reward(_ptr(self.norm_rew_t), _ptr(self.ret), _ptr(done), _ptr(self.ret_rms._mean),
+                                                        _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, self.gamma,
+                                                        self.epsilon, self.clip_reward, _stream()))
+            else:
+                self.norm_rew_t.copy_(torch.clamp(rew.double() / torch.sqrt(self.ret_rms._var + self.epsilon), -self.clip_reward, self.clip_reward).float())
+        return self.norm_obs_t, self.norm_rew_t, done, term
+
+    def step_async(self, actions):
+        self._actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.venv.device)
+
+    def step_wait(self):
+        obs, rew, done, term = self.step_tensors(self._actions)
+        done_h = done.cpu().numpy().astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        self.venv._ep_len += 1
+        if done_h.any():
+            t = term.clone()
+            if self.norm_obs:
+                self._normalize_obs_inplace(t)
+            term_h = t.cpu().numpy()
+            for i in np.nonzero(done_h)[0]:
+                infos[i]['terminal_observation'] = term_h[i]
+                self.venv.ep_lens[i].append(int(self.venv._ep_len[i]))
+                self.venv._ep_len[i] = 0
+        return obs.cpu().numpy(), rew.cpu().numpy(), done_h, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def reset(self):
+        """SB3 1.0: ret = 0; first observation is normalised (moments are not updated by reset)."""
+        self.venv.reset_tensors()
+        self.ret.zero_()
+        self.old_obs.copy_(self.venv.obs)
+        self.norm_obs_t.copy_(self.venv.obs)
+        if self.norm_obs:
+            self._normalize_obs_inplace(self.norm_obs_t)
+        return self.norm_obs_t.cpu().numpy()
+
+    def normalize_obs(self, obs):
+        x = torch.as_tensor(np.asarray(obs, np.float32), device=self.venv.device).reshape(-1, self.venv.obs_dim).clone()
+        if self.norm_obs:
+            self._normalize_obs_inplace(x)
+        return x.cpu().numpy().reshape(np.shape(obs))
+
+    def get_original_obs(self):
+        return self.old_obs.cpu().numpy()
+
+    def get_original_reward(self):
+        return self.old_rew.cpu().numpy()
+
+    def get_attr(self, name, indices=None):
+        return self.venv.get_attr(name, indices)
+
+    def set_attr(self, name, value, indices=None):
+        return self.venv.set_attr(name, value, indices)
+
+    def seed(self, seed=None):
+        return self.venv.seed(seed)
+
+    def close(self):
+        self.venv.close()
+
+    # utils.save_model / load_env (drloco/common/utils.py:175-192,234-240) keep the running moments
+    def save(self, path):
+        with open(path, 'wb') as f:
+            pickle.dump(dict(obs_rms=self.obs_rms.state(), ret_rms=self.ret_rms.state(), clip_obs=self.clip_obs,
+                             clip_reward=self.clip_reward, gamma=self.gamma, epsilon=self.epsilon,
+                             norm_obs=self.norm_obs, norm_reward=self.norm_reward), f)
+
+    @staticmethod
+    def load(path, venv):
+        with open(path, 'rb') as f:
+            s = pickle.load(f)
+        vn = HipVecNormalize(venv, norm_obs=s['norm_obs'], norm_reward=s['norm_reward'], clip_obs=s['clip_obs'],
+                             clip_reward=s['clip_reward'], gamma=s['gamma'], epsilon=s['epsilon'])
+        vn.obs_rms.load_state(s['obs_rms'])
+        vn.ret_rms.load_state(s['ret_rms'])
+        return vn
+
+
+def vec_env(env_id=models.STRAIGHT_WALKER, num_envs=4096, seed=33, norm_rew=True, load_path=None, **kw):
+    """Drop-in for drloco.common.utils.vec_env (utils.py:97-134)."""
+    venv = HipVecEnv(env_id, num_envs=num_envs, seed=seed, **kw)
+    if load_path is not None:
+        return HipVecNormalize.load(load_path, venv)
+    return HipVecNormalize(venv, norm_obs=True, norm_reward=norm_rew)

@@ -1,0 +1,104 @@
+// emu.cpp -- TEST INFRASTRUCTURE: compiles the kernels' per-lane source (drloco_amd/csrc/dl_core.hpp,
+// dl_env.hpp) for the host and drives it one lane at a time, so that the device code's logic can be
+// checked against the independent oracle on a machine without a GPU.  Never linked into the product.
+#include <cstdlib>
+#include <vector>
+
+#include "../../drloco_amd/csrc/dl_host.hpp"
+
+using namespace dl;
+using TP = TopoStraight;
+
+template <typename T> struct Emu {
+    DevModel<T, TP> m;
+    DevCfg<T> c;
+    DevState<T> st;
+    std::vector<T> qpos, qvel, warm, comz, table, step_vel, lane;
+    std::vector<int32_t> cur, need, inj, step_off, is_left, inj_flags;
+    std::vector<double> walked, mon;
+    std::vector<T> inj_q, inj_v;
+    int n;
+};
+
+template <typename T> static Emu<T>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
+    std::string why;
+    if (!check_topology<TP>(*d, why)) { fprintf(stderr, "%s\n", why.c_str()); return nullptr; }
+    auto* e = new Emu<T>();
+    e->n = n;
+    fill_dev_model<T, TP>(*d, e->m);
+    fill_dev_cfg<T>(*cfg, *r, e->c);
+    size_t tn = (size_t)r->n_rows * r->total_len;
+    e->table.resize(tn);
+    for (size_t k = 0; k < tn; k++) e->table[k] = (T)r->table[k];
+    e->step_off.assign(r->step_off, r->step_off + r->n_steps + 1);
+    e->is_left.assign(r->step_is_left, r->step_is_left + r->n_steps);
+    e->step_vel.resize(r->n_steps);
+    for (int k = 0; k < r->n_steps; k++) e->step_vel[k] = (T)r->step_vel[k];
+    e->c.table = e->table.data(); e->c.step_off = e->step_off.data(); e->c.step_is_left = e->is_left.data(); e->c.step_vel = e->step_vel.data();
+    e->qpos.assign((size_t)TP::NV * n, 0); e->qvel.assign((size_t)TP::NV * n, 0); e->warm.assign((size_t)TP::NV * n, 0);
+    for (int j = 0; j < TP::NV; j++) for (int i = 0; i < n; i++) e->qpos[(size_t)j * n + i] = (T)d->jnt_qpos0[j];
+    e->comz.assign(n, 0); e->cur.assign((size_t)DL_CUR_WORDS * n, 0); e->need.assign(n, 0); e->inj.assign((size_t)2 * n, -1);
+    for (int i = 0; i < n; i++) e->cur[(size_t)DL_CUR_COUNT * n + i] = 1;
+    e->walked.assign(n, 0); e->mon.assign((size_t)MON_WORDS * n, 0);
+    e->inj_flags.assign(n, 0); e->inj_q.assign((size_t)TP::NV * n, 0); e->inj_v.assign((size_t)TP::NV * n, 0);
+    e->lane.assign(MemLayout<TP>::TOTAL, 0);
+    e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), n};
+    return e;
+}
+
+template <typename T> static void emu_reset(Emu<T>* e, const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs) {
+    LaneMem<T> mem{e->lane.data(), 1};
+    for (int i = 0; i < e->n; i++) {
+        if (mask && !mask[i]) continue;
+        env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, 1, is, ip, obs, nullptr);
+    }
+}
+template <typename T> static void emu_step(Emu<T>* e, const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms) {
+    LaneMem<T> mem{e->lane.data(), 1};
+    for (int i = 0; i < e->n; i++)
+        env_step_lane<T, TP>(e->m, e->c, mem, e->st, i, act, obs, rew, done, term, terms, e->inj_q.data(), e->inj_v.data(), e->inj_flags.data());
+    for (int i = 0; i < e->n; i++) {
+        e->inj_flags[i] = 0;
+        if (e->need[i]) env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, e->need[i], nullptr, nullptr, obs, term);
+    }
+}
+template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+    LaneMem<T> mem{e->lane.data(), 1};
+    int n = e->n;
+    for (int i = 0; i < n; i++) {
+        T q[TP::NV], v[TP::NV], w[TP::NV], u[TP::NU], a[TP::NV];
+        for (int j = 0; j < TP::NV; j++) { q[j] = e->qpos[(size_t)j * n + i]; v[j] = e->qvel[(size_t)j * n + i]; w[j] = e->warm[(size_t)j * n + i]; }
+        for (int k = 0; k < TP::NU; k++) u[k] = ctrl ? ctrl[(size_t)k * n + i] : T(0);
+        EfcInfo<TP> ef; int it;
+        forward<T, TP>(e->m, mem, q, v, u, w, a, ef, it);
+        for (int j = 0; j < TP::NV; j++) qacc[(size_t)j * n + i] = a[j];
+        if (ncon) ncon[i] = ef.ncon;
+        if (nefc) nefc[i] = ef.nefc;
+        if (niter) niter[i] = it;
+    }
+}
+
+#define EMU_API(SUF, T)                                                                                                   \
+    extern "C" void* dle_create_##SUF(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* c, int n) { return emu_create<T>(d, r, c, n); } \
+    extern "C" void dle_destroy_##SUF(void* h) { delete (Emu<T>*)h; }                                                     \
+    extern "C" void dle_reset_##SUF(void* h, const uint8_t* m, const int32_t* is, const int32_t* ip, float* obs) { emu_reset<T>((Emu<T>*)h, m, is, ip, obs); } \
+    extern "C" void dle_step_##SUF(void* h, const float* a, float* o, float* r, uint8_t* d, float* t, float* tt) { emu_step<T>((Emu<T>*)h, a, o, r, d, t, tt); } \
+    extern "C" void dle_forward_##SUF(void* h, const T* u, T* qa, int32_t* nc, int32_t* ne, int32_t* ni) { emu_forward<T>((Emu<T>*)h, u, qa, nc, ne, ni); } \
+    extern "C" void dle_get_state_##SUF(void* h, T* q, T* v, T* w, int32_t* cur, double* walked) {                        \
+        auto* e = (Emu<T>*)h; size_t m = (size_t)TP::NV * e->n;                                                           \
+        if (q) memcpy(q, e->qpos.data(), m * sizeof(T)); if (v) memcpy(v, e->qvel.data(), m * sizeof(T));                 \
+        if (w) memcpy(w, e->warm.data(), m * sizeof(T)); if (cur) memcpy(cur, e->cur.data(), e->cur.size() * 4);          \
+        if (walked) memcpy(walked, e->walked.data(), e->n * 8); }                                                         \
+    extern "C" void dle_set_state_##SUF(void* h, const T* q, const T* v, const T* w, const int32_t* cur, const double* walked) { \
+        auto* e = (Emu<T>*)h; size_t m = (size_t)TP::NV * e->n;                                                           \
+        if (q) memcpy(e->qpos.data(), q, m * sizeof(T)); if (v) memcpy(e->qvel.data(), v, m * sizeof(T));                 \
+        if (w) memcpy(e->warm.data(), w, m * sizeof(T)); if (cur) memcpy(e->cur.data(), cur, e->cur.size() * 4);          \
+        if (walked) memcpy(e->walked.data(), walked, e->n * 8); }                                                         \
+    extern "C" void dle_inject_##SUF(void* h, int i, int flag, const T* q, const T* v) {                                  \
+        auto* e = (Emu<T>*)h; e->inj_flags[i] = flag;                                                                     \
+        if (q) for (int j = 0; j < TP::NV; j++) { e->inj_q[(size_t)j * e->n + i] = q[j]; e->inj_v[(size_t)j * e->n + i] = v[j]; } } \
+    extern "C" void dle_inject_rsi_##SUF(void* h, int i, int s, int p) { auto* e = (Emu<T>*)h; e->inj[i] = s; e->inj[(size_t)e->n + i] = p; } \
+    extern "C" void dle_mon_##SUF(void* h, int word, double* out) { auto* e = (Emu<T>*)h; memcpy(out, e->mon.data() + (size_t)word * e->n, e->n * 8); }
+
+EMU_API(f64, double)
+EMU_API(f32, float)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from drloco_amd import abi
-from conftest import GOLDEN
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def load(name):
