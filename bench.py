@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the DRLoco hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], per GPU; configs[2] is the same per GPU at N = 8):
+  straight_walking 3D walker, 4096 parallel walkers per GPU, fixed 512-step synthetic rollout.
+One "step" of this benchmark = ONE 512-step rollout of all walkers of a rank:
+  per control step   dl_step (5 RK4 mj_steps + mocap cursor + imitation reward + observation +
+                     termination + Monitor statistics + auto-reset/RSI),
+                     VecNormalize moments update + observation/reward normalisation,
+                     rollout-buffer store;
+  per rollout        GAE(lambda) return/advantage scan, advantage statistics + normalisation
+                     (RCCL all-reduce of 3 doubles when N > 1 -- the only collective).
+Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) (seed 4321 + rank), values are synthetic,
+RSI comes from the counter-based stream keyed by the global walker index.  Inputs are resident in
+HBM before the timed region.  value = walkers * 512 * K * N / time  [env-steps/s, whole job].
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 664          # 336 B read + 328 B written per walker and control step
+HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(n_envs, n_steps, seed=4321):
+    """The oracle (a scalar float64 port of the same path) timed on one host core."""
+    import numpy as np
+    from drloco_amd import abi, mocap, models
+    from oracle import oracle as O
+    model, refs = models.make_model(), mocap.RefTable.load()
+    env = O.OracleEnv(model, refs, abi.default_config(seed=1234), n_envs)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    acts = np.clip(0.5 * rng.standard_normal((n_steps, n_envs, 8)), -1, 1)
+    t0 = time.perf_counter()
+    for t in range(n_steps):
+        env.step(acts[t])
+    dt = time.perf_counter() - t0
+    return dict(value=n_envs * n_steps / dt, unit='env-steps/s', cores=1, kind='port',
+                sample=f'{n_envs} walkers x {n_steps} control steps, same action distribution, oracle/dl_oracle.c on 1 host core '
+                       f'({os.cpu_count()} cores present), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--envs-per-gpu', type=int, default=4096)
+    ap.add_argument('--rollout-len', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from drloco_amd import lib
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    import ctypes as C
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+
+    n, T = args.envs_per_gpu, args.rollout_len
+    venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n)
+    vn = HipVecNormalize(venv)
+    buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    actions = torch.clamp(0.5 * torch.randn(T, n, venv.nu, device=dev, generator=gen), -1, 1)
+    values = torch.randn(T, n, device=dev, generator=gen)
+    logp = torch.zeros(n, device=dev)
+    last_values = torch.randn(n, device=dev, generator=gen)
+    vn.reset()
+    episode_start = torch.ones(n, dtype=torch.uint8, device=dev)
+
+    def rollout():
+        nonlocal episode_start
+        buf.reset()
+        obs = vn.norm_obs_t
+        for t in range(T):
+            buf.observations[t].copy_(obs)           # RolloutBuffer.add
+            buf.actions[t].copy_(actions[t])
+            buf.values[t].copy_(values[t])
+            buf.episode_starts[t].copy_(episode_start)
+            obs, rew, done, _ = vn.step_tensors(actions[t])
+            buf.rewards[t].copy_(rew)
+            episode_start = done
+        buf.compute_returns_and_advantage(last_values, episode_start)
+        buf.normalize_advantages()                   # all-reduce of [sum, sum^2, n] when world > 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rollout()
+    lib.check(venv._lib.dl_profile(venv._h, 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rollout()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = C.c_double(), C.c_int32()
+    lib.check(venv._lib.dl_profile_read(venv._h, C.byref(tot_ms), C.byref(launches)))
+    lib.check(venv._lib.dl_profile(venv._h, 0))
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        env_steps = n * T * args.steps * world
+        value = env_steps / dt
+        avg_launch_s = tot_ms.value / max(1, launches.value) / 1e3
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / avg_launch_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'env-steps/s (whole node) 3D straight-walk walker', 'value': value, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'straight_walking 3D walker, {n} parallel envs per GPU, fixed {T}-step synthetic rollout '
+                                   '(env step + VecNormalize + rollout store + GAE + adv-norm)',
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'kernel': 'k_env_step<float,64>', 'avg_launch_us': avg_launch_s * 1e6,
+                         'launches': launches.value, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,
+                         'note': 'the fused dynamics kernel is FP32-VALU/latency bound (SURVEY.md 8d); HBM fraction is reported as the contract asks'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(64, 256)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -30,6 +30,29 @@
 #define DL_HD inline __attribute__((always_inline))
 #endif
 
+// out-of-line call boundary for the forward evaluation (see forward_call)
+#if defined(__HIPCC__)
+#define DL_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define DL_NOINLINE __attribute__((noinline))
+#endif
+
+// lane memory is LDS on the device: keep the address space in the pointer type so that ds_*
+// instructions (not flat_*) are used even across the out-of-line call
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DL_LDS __attribute__((address_space(3)))
+#else
+#define DL_LDS
+#endif
+
+// hide a value from the optimiser (stops it from peeling the solver's phase loop into one copy of
+// the body per phase, which multiplies the code size beyond the instruction cache)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DL_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define DL_OPAQUE(x) asm volatile("" : "+r"(x))
+#endif
+
 namespace dl {
 
 // ------------------------------------------------------------------------------------------
@@ -176,17 +199,41 @@ template <typename T> DL_HD T sdot(SV<T> motion, SV<T> force) { return dot(motio
 // ------------------------------------------------------------------------------------------
 // LDS (or host array) view of one lane's dynamic storage: element (arr, slot) at base[(arr*cap+slot)*stride]
 template <typename T> struct LaneMem {
+    DL_LDS T* base; int stride;
+    DL_HD DL_LDS T& operator()(int idx) const { return base[idx * stride]; }
+};
+// per-lane view of a global (HBM) workspace laid out [word][N]
+template <typename T> struct GlobalMem {
     T* base; int stride;
     DL_HD T& operator()(int idx) const { return base[(size_t)idx * stride]; }
 };
 // slot layout inside LaneMem
 template <typename TP> struct MemLayout {
-    static constexpr int ROW_D = 0, ROW_JAREF = TP::MAXROW, ROW_JV = 2 * TP::MAXROW;
-    static constexpr int CON_PX = 3 * TP::MAXROW;            // contact point relative to the root origin
+    static constexpr int ROW_D = 0, ROW_JAREF = TP::MAXROW, ROW_JV = 2 * TP::MAXROW, ROW_TMP = 3 * TP::MAXROW;
+    static constexpr int CON_PX = 4 * TP::MAXROW;            // contact point relative to the root origin
     static constexpr int CON_PY = CON_PX + TP::MAXCON, CON_PZ = CON_PY + TP::MAXCON;
     static constexpr int CON_TX = CON_PZ + TP::MAXCON, CON_TY = CON_TX + TP::MAXCON;   // first tangent (unit, in the floor plane)
     static constexpr int CON_MU = CON_TY + TP::MAXCON, CON_DIST = CON_MU + TP::MAXCON;
-    static constexpr int TOTAL = CON_DIST + TP::MAXCON;       // elements of T per lane
+    static constexpr int MAT = CON_DIST + TP::MAXCON;         // mass matrix, tree pattern, lower
+    // position of M[i][j] (j ancestor-or-self of i) in the packed pattern
+    static constexpr int mat_index(int i, int j) {
+        int n = 0;
+        for (int a = 0; a < TP::NV; a++)
+            for (int b = 0; b <= a; b++) {
+                if (!TP::dof_anc(a, b)) continue;
+                if (a == i && b == j) return n;
+                n++;
+            }
+        return -1;
+    }
+    static constexpr int mat_count() {
+        int n = 0;
+        for (int a = 0; a < TP::NV; a++)
+            for (int b = 0; b <= a; b++) if (TP::dof_anc(a, b)) n++;
+        return n;
+    }
+    template <int I, int J> static constexpr int MI = mat_index(I, J);   // forces compile-time evaluation
+    static constexpr int TOTAL = MAT + mat_count();           // elements of T per lane
 };
 
 // ------------------------------------------------------------------------------------------
@@ -301,18 +348,38 @@ template <typename T, typename TP> DL_HD void treemat_mul(const TreeMat<T, TP>& 
 }
 
 // ------------------------------------------------------------------------------------------
-// [3P] mj_crb + mj_rne(bias): mass matrix (lower, tree pattern) and bias forces
-template <typename T, typename TP>
-DL_HD void inertia_and_bias(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], TreeMat<T, TP>& M, T (&bias)[TP::NV]) {
-    SI<T> Ib[TP::NB];
-    static_for<TP::NB - 1>([&](auto bi) {
-        constexpr int b = bi.value + 1;
+// [3P] mj_crb + mj_rne(bias) in ONE depth-first sweep over the body tree.
+// subtree<b>() receives the twist / velocity-product acceleration of b's parent, walks b's dofs,
+// forms b's spatial inertia and inertial wrench, recurses into the children (accumulating their
+// composite inertia and wrench -- same reference point, so plain sums), and then emits the rows of
+// the mass matrix (into lane memory) and the bias forces of b's dofs.  Depth-first order keeps only
+// one root-to-leaf chain of temporaries alive at a time (register pressure), unlike the textbook
+// "all bodies down, all bodies up" arrangement.
+template <typename T> struct SubtreeOut { SI<T> Ic; SV<T> W; };
+
+template <typename T, typename TP, int b>
+DL_HD SubtreeOut<T> crb_rne_subtree(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], const LaneMem<T>& mem,
+                                    SV<T> vel, SV<T> acc, T (&bias)[TP::NV]) {
+    using L = MemLayout<TP>;
+    // chain through the dofs of body b (in dof order)
+    static_for<TP::NV>([&](auto ji) {
+        constexpr int j = ji.value;
+        if constexpr (TP::dof_body(j) == b) {
+            const SV<T> S = dof_S<T, TP, j>(k);
+            const SV<T> vJ = {v[j] * S.w, v[j] * S.v};
+            acc = {acc.w + cross(vel.w, vJ.w), acc.v + cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
+            vel = vel + vJ;
+        }
+    });
+    // spatial inertia of b about the reference point (root origin), world orientation
+    SubtreeOut<T> out;
+    {
         const V3<T> c = body_point<T, TP>(k, b, m.body_ipos[b]);
         const T mass = m.body_mass[b];
         const T i0 = m.body_inertia[b][0], i1 = m.body_inertia[b][1], i2 = m.body_inertia[b][2];
         const V3<T> X = k.RX[b], Y = k.RY[b], Z = k.RZ[b];
         const T cc = dot(c, c);
-        SI<T> s;
+        SI<T>& s = out.Ic;
         s.m = mass; s.h = mass * c;
         s.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
         s.I.yy = i0 * X.y * X.y + i1 * Y.y * Y.y + i2 * Z.y * Z.y + mass * (cc - c.y * c.y);
@@ -320,47 +387,47 @@ DL_HD void inertia_and_bias(const DevModel<T, TP>& m, const Kin<T, TP>& k, const
         s.I.xy = i0 * X.x * X.y + i1 * Y.x * Y.y + i2 * Z.x * Z.y - mass * c.x * c.y;
         s.I.xz = i0 * X.x * X.z + i1 * Y.x * Y.z + i2 * Z.x * Z.z - mass * c.x * c.z;
         s.I.yz = i0 * X.y * X.z + i1 * Y.y * Y.z + i2 * Z.y * Z.z - mass * c.y * c.z;
-        Ib[b] = s;
-    });
-    // ---- recursive Newton-Euler with qacc = 0; gravity enters as a base acceleration of -g
-    SV<T> vel[TP::NV], acc[TP::NV];
-    static_for<TP::NV>([&](auto ji) {
-        constexpr int j = ji.value, p = TP::dof_parent(j);
-        const SV<T> S = dof_S<T, TP, j>(k);
-        const SV<T> vJ = {v[j] * S.w, v[j] * S.v};
-        if constexpr (p < 0) {
-            vel[j] = vJ;
-            acc[j] = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};
-        } else {
-            vel[j] = vel[p] + vJ;
-            acc[j] = {acc[p].w + cross(vel[p].w, vJ.w), acc[p].v + cross(vel[p].w, vJ.v) + cross(vel[p].v, vJ.w)};
+        const SV<T> Iv = si_mul(s, vel);
+        const SV<T> Ia = si_mul(s, acc);
+        out.W = {Ia.w + cross(vel.w, Iv.w) + cross(vel.v, Iv.v), Ia.v + cross(vel.w, Iv.v)};
+    }
+    // children
+    static_for<TP::NB>([&](auto ci) {
+        constexpr int c = ci.value;
+        if constexpr (c > b && TP::body_parent(c) == b) {
+            const SubtreeOut<T> ch = crb_rne_subtree<T, TP, c>(m, k, v, mem, vel, acc, bias);
+            si_add(out.Ic, ch.Ic);
+            out.W = out.W + ch.W;
         }
     });
-    SV<T> F[TP::NB];
-    static_for<TP::NB - 1>([&](auto bi) {
-        constexpr int b = bi.value + 1, ld = TP::body_last_dof(b);
-        const SV<T> Iv = si_mul(Ib[b], vel[ld]);
-        const SV<T> Ia = si_mul(Ib[b], acc[ld]);
-        F[b] = {Ia.w + cross(vel[ld].w, Iv.w) + cross(vel[ld].v, Iv.v), Ia.v + cross(vel[ld].w, Iv.v)};
-    });
-    // accumulate wrenches and composite inertias towards the root (same reference point: plain sums)
-    static_for<TP::NB - 2>([&](auto bi) {
-        constexpr int b = TP::NB - 1 - bi.value, p = TP::body_parent(b);
-        if constexpr (p > 0) { F[p] = F[p] + F[b]; si_add(Ib[p], Ib[b]); }
-    });
+    // rows of M and bias entries of b's dofs
     static_for<TP::NV>([&](auto ii) {
-        constexpr int i = ii.value, b = TP::dof_body(i);
-        const SV<T> S = dof_S<T, TP, i>(k);
-        bias[i] = sdot(S, F[b]);
-        const SV<T> f = si_mul(Ib[b], S);
-        static_for<TP::NV>([&](auto ji) {
-            constexpr int j = ji.value;
-            if constexpr (j <= i && TP::dof_anc(i, j)) {
-                const SV<T> Sj = dof_S<T, TP, j>(k);
-                M.a[i][j] = sdot(Sj, f);
-            }
-        });
-        M.a[i][i] += m.armature[i];
+        constexpr int i = ii.value;
+        if constexpr (TP::dof_body(i) == b) {
+            const SV<T> S = dof_S<T, TP, i>(k);
+            bias[i] = sdot(S, out.W);
+            const SV<T> f = si_mul(out.Ic, S);
+            static_for<TP::NV>([&](auto ji) {
+                constexpr int j = ji.value;
+                if constexpr (j <= i && TP::dof_anc(i, j)) {
+                    const SV<T> Sj = dof_S<T, TP, j>(k);
+                    T mij = sdot(Sj, f);
+                    if constexpr (i == j) mij += m.armature[i];
+                    mem(L::MAT + L::template MI<i, j>) = mij;
+                }
+            });
+        }
+    });
+    return out;
+}
+
+template <typename T, typename TP>
+DL_HD void inertia_and_bias(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], const LaneMem<T>& mem, T (&bias)[TP::NV]) {
+    const SV<T> vel0 = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)};
+    const SV<T> acc0 = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};      // gravity as a base acceleration of -g
+    static_for<TP::NB>([&](auto bi) {
+        constexpr int b = bi.value;
+        if constexpr (b > 0 && TP::body_parent(b) == 0) (void)crb_rne_subtree<T, TP, b>(m, k, v, mem, vel0, acc0, bias);
     });
 }
 
@@ -384,60 +451,61 @@ template <typename T, typename TP> DL_HD void body_twists(const Kin<T, TP>& k, c
 template <typename T, typename TP> DL_HD SV<T> twist_of_body(const SV<T> (&vel)[TP::NV], int b) {
     SV<T> r = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)};
     static_for<TP::NB - 1>([&](auto bi) {
-        constexpr int bb = bi.value + 1;
-        if (b == bb) r = vel[TP::body_last_dof(bb)];
+        constexpr int bb = bi.value + 1, ld = TP::body_last_dof(bb);
+        if (b == bb) r = vel[ld];
     });
     return r;
 }
 
-// [3P] solimp sigmoid (getimpedance)
+// [3P] solimp sigmoid (getimpedance); the kernels support the powers 1 and 2 (MuJoCo's default is 2;
+// dl_create rejects anything else) so that no pow() expansion is inlined
 template <typename T> DL_HD T impedance(const T* si, T pos) {
-    T x = dl_abs(pos) / si[2];
-    if (x >= T(1)) return si[1];
-    if (x <= T(0)) return si[0];
+    const T x = dl_abs(pos) / si[2];
     T y;
     if (si[4] == T(1)) y = x;
-    else if (si[4] == T(2)) y = (x <= si[3]) ? x * x / si[3] : T(1) - (T(1) - x) * (T(1) - x) / (T(1) - si[3]);
-    else if (x <= si[3]) y = dl_pow(x, si[4]) / dl_pow(si[3], si[4] - T(1));
-    else y = T(1) - dl_pow(T(1) - x, si[4]) / dl_pow(T(1) - si[3], si[4] - T(1));
-    return si[0] + y * (si[1] - si[0]);
+    else y = (x <= si[3]) ? x * x / si[3] : T(1) - (T(1) - x) * (T(1) - x) / (T(1) - si[3]);
+    const T imp = si[0] + y * (si[1] - si[0]);
+    return x >= T(1) ? si[1] : (x <= T(0) ? si[0] : imp);
 }
 
-// [3P] mj_collision (plane vs capsule / box) + mj_makeConstraint + mj_makeImpedance +
-// mj_referenceConstraint.  Writes contacts and rows (D, Jaref := -aref) into lane memory.
+// [3P] mj_collision (plane vs capsule / box) + the position-dependent part of mj_makeConstraint /
+// mj_makeImpedance: contacts and, per row, D and K*imp*pos (stored in ROW_JAREF; the velocity
+// part B*(J v) of -aref is added by the solver's first pass).
 template <typename T, typename TP>
-DL_HD void make_constraints(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&q)[TP::NV], const T (&v)[TP::NV],
+DL_HD void make_constraints(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&q)[TP::NV],
                             const LaneMem<T>& mem, EfcInfo<TP>& e) {
     using L = MemLayout<TP>;
     e.nlim = 0; e.ncon = 0; e.lim_code = 0; e.con_body = 0;
-    // joint limits: rows +-e_j
+    // joint limits: rows +-e_j (detected per dof; finished in the row loop below)
     static_for<TP::NV>([&](auto ji) {
         constexpr int j = ji.value;
         if constexpr (TP::dof_limited(j)) {
             const T dlo = q[j] - m.range[j][0], dhi = m.range[j][1] - q[j];
             const bool lo = dlo < T(0), hi = dhi < T(0);
             if (lo || hi) {
-                const T dist = lo ? dlo : dhi;
-                const T imp = impedance(m.solimp, dist);
-                const T R = dl_max(T(1e-15), (T(1) - imp) * m.dof_invw[j] / imp);
-                const T vel = lo ? v[j] : -v[j];
                 const int r = e.nlim;
-                mem(L::ROW_D + r) = T(1) / R;
-                mem(L::ROW_JAREF + r) = m.solB * vel + m.solK * imp * dist;      // = -aref
+                mem(L::ROW_JAREF + r) = lo ? dlo : dhi;
+                mem(L::ROW_D + r) = m.dof_invw[j];
                 e.lim_code |= (uint64_t)(j | (lo ? 0 : 16)) << (5 * r);
                 e.nlim = r + 1;
             }
         }
     });
+    for (int r = 0; r < e.nlim; r++) {
+        const T dist = mem(L::ROW_JAREF + r);
+        const T imp = impedance(m.solimp, dist);
+        const T R = dl_max(T(1e-15), (T(1) - imp) * mem(L::ROW_D + r) / imp);
+        mem(L::ROW_D + r) = T(1) / R;
+        mem(L::ROW_JAREF + r) = m.solK * imp * dist;
+    }
     // contacts
-    auto add_contact = [&](int body, T mu, T invw, V3<T> p, T dist, T tx, T ty) {
+    auto add_contact = [&](int body, T mu, V3<T> p, T dist, T tx, T ty) {
         const int c = e.ncon;
         if (c >= TP::MAXCON) return;
         mem(L::CON_PX + c) = p.x; mem(L::CON_PY + c) = p.y; mem(L::CON_PZ + c) = p.z;
         mem(L::CON_TX + c) = tx; mem(L::CON_TY + c) = ty; mem(L::CON_MU + c) = mu; mem(L::CON_DIST + c) = dist;
         e.con_body |= (uint64_t)body << (3 * c);
         e.ncon = c + 1;
-        (void)invw;
     };
     static_for<TP::NG>([&](auto gi) {
         constexpr int g = gi.value, b = TP::geom_body(g);
@@ -455,7 +523,7 @@ DL_HD void make_constraints(const DevModel<T, TP>& m, const Kin<T, TP>& k, const
             for (int s = 0; s < 2; s++) {
                 const V3<T> c = gp + (s == 0 ? half : -half) * ax;
                 const T dist = k.rootz + c.z - rad;
-                if (dist < T(0)) add_contact(b, m.geom_mu[g], m.body_invw[b], mk<T>(c.x, c.y, c.z - (rad + T(0.5) * dist)), dist, tx, ty);
+                if (dist < T(0)) add_contact(b, m.geom_mu[g], mk<T>(c.x, c.y, c.z - (rad + T(0.5) * dist)), dist, tx, ty);
             }
         } else {
             const V3<T> ex = gm[0] * k.RX[b] + gm[3] * k.RY[b] + gm[6] * k.RZ[b];
@@ -470,48 +538,38 @@ DL_HD void make_constraints(const DevModel<T, TP>& m, const Kin<T, TP>& k, const
                 const V3<T> corner = sx * ex + sy * ey + sz * ez;
                 const T dist = k.rootz + gp.z + corner.z;
                 if (cnt < 4 && dist < T(0) && !(corner.z > T(0))) {
-                    add_contact(b, m.geom_mu[g], m.body_invw[b], mk<T>(gp.x + corner.x, gp.y + corner.y, gp.z + corner.z - T(0.5) * dist), dist, T(0), T(1));
+                    add_contact(b, m.geom_mu[g], mk<T>(gp.x + corner.x, gp.y + corner.y, gp.z + corner.z - T(0.5) * dist), dist, T(0), T(1));
                     cnt++;
                 }
             });
         }
     });
     // contact rows: 4 pyramid edges n +- mu t1, n +- mu t2; t1 = (tx, ty, 0), t2 = n x t1 = (-ty, tx, 0)
-    SV<T> vel[TP::NV];
-    body_twists<T, TP>(k, v, vel);
     for (int c = 0; c < e.ncon; c++) {
         const int body = (int)((e.con_body >> (3 * c)) & 7);
-        const V3<T> p = mk<T>(mem(L::CON_PX + c), mem(L::CON_PY + c), mem(L::CON_PZ + c));
-        const T tx = mem(L::CON_TX + c), ty = mem(L::CON_TY + c), mu = mem(L::CON_MU + c), dist = mem(L::CON_DIST + c);
+        const T mu = mem(L::CON_MU + c), dist = mem(L::CON_DIST + c);
         T invw = T(0);
         static_for<TP::NB - 1>([&](auto bi) { if (body == bi.value + 1) invw = m.body_invw[bi.value + 1]; });
-        const SV<T> tw = twist_of_body<T, TP>(vel, body);
-        const V3<T> pv = tw.v + cross(tw.w, p);
-        const T vn = pv.z, vt1 = tx * pv.x + ty * pv.y, vt2 = -ty * pv.x + tx * pv.y;
         const T imp = impedance(m.solimp, dist);
         const T diag = invw * (T(1) + mu * mu);
         const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag / imp);
         const T D = T(1) / R, kd = m.solK * imp * dist;
         const int r = e.nlim + 4 * c;
         mem(L::ROW_D + r) = D; mem(L::ROW_D + r + 1) = D; mem(L::ROW_D + r + 2) = D; mem(L::ROW_D + r + 3) = D;
-        mem(L::ROW_JAREF + r) = m.solB * (vn + mu * vt1) + kd;
-        mem(L::ROW_JAREF + r + 1) = m.solB * (vn - mu * vt1) + kd;
-        mem(L::ROW_JAREF + r + 2) = m.solB * (vn + mu * vt2) + kd;
-        mem(L::ROW_JAREF + r + 3) = m.solB * (vn - mu * vt2) + kd;
+        mem(L::ROW_JAREF + r) = kd; mem(L::ROW_JAREF + r + 1) = kd; mem(L::ROW_JAREF + r + 2) = kd; mem(L::ROW_JAREF + r + 3) = kd;
     }
     e.nefc = e.nlim + 4 * e.ncon;
 }
 
-// out[r] (+)= (J x)[r] for all rows; arr selects the destination array in lane memory
-template <typename T, typename TP, bool ACCUM>
-DL_HD void mul_J(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& mem, const T (&x)[TP::NV], int arr) {
+// ROW_JV[r] = (J x)[r] for all rows, matrix free: body twists under x, then point velocities
+template <typename T, typename TP>
+DL_HD void mul_J(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& mem, const T (&x)[TP::NV]) {
     using L = MemLayout<TP>;
     for (int r = 0; r < e.nlim; r++) {
         const int code = (int)((e.lim_code >> (5 * r)) & 31), j = code & 15;
         T xj = T(0);
-        static_for<TP::NV>([&](auto ji) { if (j == ji.value) xj = x[ji.value]; });
-        const T val = (code & 16) ? -xj : xj;
-        if (ACCUM) mem(arr + r) += val; else mem(arr + r) = val;
+        static_for<TP::NV>([&](auto ji) { if constexpr (TP::dof_limited(ji.value)) if (j == ji.value) xj = x[ji.value]; });
+        mem(L::ROW_JV + r) = (code & 16) ? -xj : xj;
     }
     if (e.ncon == 0) return;
     SV<T> vel[TP::NV];
@@ -523,9 +581,8 @@ DL_HD void mul_J(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& me
         const SV<T> tw = twist_of_body<T, TP>(vel, body);
         const V3<T> pv = tw.v + cross(tw.w, p);
         const T vn = pv.z, vt1 = mu * (tx * pv.x + ty * pv.y), vt2 = mu * (-ty * pv.x + tx * pv.y);
-        const int r = arr + e.nlim + 4 * c;
-        if (ACCUM) { mem(r) += vn + vt1; mem(r + 1) += vn - vt1; mem(r + 2) += vn + vt2; mem(r + 3) += vn - vt2; }
-        else { mem(r) = vn + vt1; mem(r + 1) = vn - vt1; mem(r + 2) = vn + vt2; mem(r + 3) = vn - vt2; }
+        const int r = L::ROW_JV + e.nlim + 4 * c;
+        mem(r) = vn + vt1; mem(r + 1) = vn - vt1; mem(r + 2) = vn + vt2; mem(r + 3) = vn - vt2;
     }
 }
 
@@ -534,7 +591,7 @@ DL_HD void mul_J(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& me
 template <typename T, typename TP>
 DL_HD void contact_jac(const Kin<T, TP>& k, int body, V3<T> p, T tx, T ty, T (&jn)[TP::NV], T (&jt1)[TP::NV], T (&jt2)[TP::NV]) {
     uint32_t mask = 0;
-    static_for<TP::NB - 1>([&](auto bi) { if (body == bi.value + 1) mask = TP::body_mask(bi.value + 1); });
+    static_for<TP::NB - 1>([&](auto bi) { constexpr uint32_t bm = TP::body_mask(bi.value + 1); if (body == bi.value + 1) mask = bm; });
     static_for<TP::NV>([&](auto ji) {
         constexpr int j = ji.value;
         V3<T> w;
@@ -546,66 +603,100 @@ DL_HD void contact_jac(const Kin<T, TP>& k, int body, V3<T> p, T tx, T ty, T (&j
 }
 
 // ------------------------------------------------------------------------------------------
-// line search on the piecewise quadratic along `search` (MuJoCo's bracketing scheme)
+// exact line search on the piecewise quadratic along the search direction (MuJoCo's scheme:
+// Newton steps from one side until the derivative changes sign, then a bracketed search over
+// {Newton from both ends, midpoint}).  Written as a state machine around ONE evaluation site so
+// that the row loop is emitted once.
 template <typename T> struct LsPoint { T alpha, cost, d1, d2; };
 
-template <typename T, typename TP>
-DL_HD LsPoint<T> ls_eval(const LaneMem<T>& mem, int nefc, T g0, T g1, T g2, T alpha) {
-    using L = MemLayout<TP>;
-    T cost = g0 + alpha * g1 + alpha * alpha * g2, d1 = g1 + T(2) * alpha * g2, d2 = T(2) * g2;
-    for (int r = 0; r < nefc; r++) {
-        const T jv = mem(L::ROW_JV + r);
-        const T x = mem(L::ROW_JAREF + r) + alpha * jv;
-        if (x < T(0)) {
-            const T D = mem(L::ROW_D + r);
-            cost += T(0.5) * D * x * x; d1 += D * x * jv; d2 += D * jv * jv;
-        }
-    }
-    return {alpha, cost, d1, d2};
-}
-
-template <typename T, typename TP>
-DL_HD bool ls_update_bracket(const LaneMem<T>& mem, int nefc, T g0, T g1, T g2, LsPoint<T>& p, const LsPoint<T> (&cand)[3], LsPoint<T>& pnext) {
+template <typename T> DL_HD bool ls_update_bracket(LsPoint<T>& p, const LsPoint<T> (&cand)[3]) {
     bool flag = false;
     for (int i = 0; i < 3; i++) {
         if (p.d1 < T(0) && cand[i].d1 < T(0) && p.d1 < cand[i].d1) { p = cand[i]; flag = true; }
         else if (p.d1 > T(0) && cand[i].d1 > T(0) && p.d1 > cand[i].d1) { p = cand[i]; flag = true; }
     }
-    if (flag) pnext = ls_eval<T, TP>(mem, nefc, g0, g1, g2, p.alpha - p.d1 / p.d2);
     return flag;
 }
 
 template <typename T, typename TP>
 DL_HD T linesearch(const LaneMem<T>& mem, int nefc, T g0, T g1, T g2, T gtol, int maxit) {
-    LsPoint<T> p0 = ls_eval<T, TP>(mem, nefc, g0, g1, g2, T(0));
-    LsPoint<T> p1 = ls_eval<T, TP>(mem, nefc, g0, g1, g2, -p0.d1 / p0.d2);
-    if (p0.cost < p1.cost) p1 = p0;
-    if (dl_abs(p1.d1) < gtol) return p1.alpha;
-    const T dir = p1.d1 < T(0) ? T(1) : T(-1);
-    LsPoint<T> p2 = p1, pmid, p1next, p2next;
-    bool p2update = false;
-    int it = 0;
-    while (p1.d1 * dir <= -gtol && it < maxit) {
-        p2 = p1; p2update = true;
-        p1 = ls_eval<T, TP>(mem, nefc, g0, g1, g2, p1.alpha - p1.d1 / p1.d2);
-        it++;
-        if (dl_abs(p1.d1) < gtol) return p1.alpha;
-    }
-    if (it >= maxit || !p2update) return p1.alpha;
-    p2next = p1;
-    p1next = ls_eval<T, TP>(mem, nefc, g0, g1, g2, p1.alpha - p1.d1 / p1.d2);
-    while (it < maxit) {
-        pmid = ls_eval<T, TP>(mem, nefc, g0, g1, g2, T(0.5) * (p1.alpha + p2.alpha));
-        it++;
-        const LsPoint<T> cand[3] = {p1next, p2next, pmid};
-        int best = -1;
-        T bestcost = T(0);
-        for (int i = 0; i < 3; i++)
-            if (dl_abs(cand[i].d1) < gtol && (best < 0 || cand[i].cost < bestcost)) { best = i; bestcost = cand[i].cost; }
-        if (best >= 0) return best == 0 ? cand[0].alpha : (best == 1 ? cand[1].alpha : cand[2].alpha);
-        const bool b1 = ls_update_bracket<T, TP>(mem, nefc, g0, g1, g2, p1, cand, p1next);
-        const bool b2 = ls_update_bracket<T, TP>(mem, nefc, g0, g1, g2, p2, cand, p2next);
-        if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : T(0);
+    using L = MemLayout<TP>;
+    LsPoint<T> p0 = {T(0), T(0), T(0), T(1)}, p1 = p0, p2 = p0, pmid = p0, p1next = p0, p2next = p0;
+    LsPoint<T> cand[3] = {p0, p0, p0};
+    T dir = T(1), alpha = T(0);
+    bool p2update = false, b1 = false, b2 = false;
+    int it = 0, state = 0;
+    for (;;) {
+        // ---- the single evaluation site
+        LsPoint<T> pe;
+        {
+            T cost = g0 + alpha * g1 + alpha * alpha * g2, d1 = g1 + T(2) * alpha * g2, d2 = T(2) * g2;
+            for (int r = 0; r < nefc; r++) {
+                const T jv = mem(L::ROW_JV + r);
+                const T x = mem(L::ROW_JAREF + r) + alpha * jv;
+                if (x < T(0)) {
+                    const T D = mem(L::ROW_D + r);
+                    cost += T(0.5) * D * x * x; d1 += D * x * jv; d2 += D * jv * jv;
+                }
+            }
+            pe = {alpha, cost, d1, d2};
+        }
+        bool end_onesided = false, end_iter = false;
+        if (state == 0) {                       // p0 = f(0)
+            p0 = pe; alpha = -p0.d1 / p0.d2; state = 1;
+            continue;
+        } else if (state == 1) {                // p1 = Newton point from 0
+            p1 = pe;
+            if (p0.cost < p1.cost) p1 = p0;
+            if (dl_abs(p1.d1) < gtol) return p1.alpha;
+            dir = p1.d1 < T(0) ? T(1) : T(-1);
+            p2 = p1;
+            if (p1.d1 * dir <= -gtol && it < maxit) { p2 = p1; p2update = true; alpha = p1.alpha - p1.d1 / p1.d2; state = 2; continue; }
+            end_onesided = true;
+        } else if (state == 2) {                // one-sided Newton iterations
+            p1 = pe; it++;
+            if (dl_abs(p1.d1) < gtol) return p1.alpha;
+            if (p1.d1 * dir <= -gtol && it < maxit) { p2 = p1; alpha = p1.alpha - p1.d1 / p1.d2; continue; }
+            end_onesided = true;
+        } else if (state == 3) {                // p1next after the bracket was found
+            p1next = pe;
+            end_iter = true;
+        } else if (state == 4) {                // midpoint of the bracket
+            pmid = pe; it++;
+            cand[0] = p1next; cand[1] = p2next; cand[2] = pmid;
+            int best = -1;
+            T bestcost = T(0), bestalpha = T(0);
+            for (int i = 0; i < 3; i++)
+                if (dl_abs(cand[i].d1) < gtol && (best < 0 || cand[i].cost < bestcost)) { best = i; bestcost = cand[i].cost; bestalpha = cand[i].alpha; }
+            if (best >= 0) return bestalpha;
+            b1 = ls_update_bracket(p1, cand);
+            if (b1) { alpha = p1.alpha - p1.d1 / p1.d2; state = 5; continue; }
+            b2 = ls_update_bracket(p2, cand);
+            if (b2) { alpha = p2.alpha - p2.d1 / p2.d2; state = 6; continue; }
+            end_iter = true;
+        } else if (state == 5) {                // Newton point from the updated p1
+            p1next = pe;
+            b2 = ls_update_bracket(p2, cand);
+            if (b2) { alpha = p2.alpha - p2.d1 / p2.d2; state = 6; continue; }
+            end_iter = true;
+        } else {                                // state 6: Newton point from the updated p2
+            p2next = pe;
+            end_iter = true;
+        }
+        if (end_onesided) {
+            if (it >= maxit || !p2update) return p1.alpha;
+            p2next = p1;
+            alpha = p1.alpha - p1.d1 / p1.d2;
+            state = 3;
+            continue;
+        }
+        if (end_iter) {
+            if (state != 3 && !b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : T(0);
+            if (it >= maxit) break;
+            b1 = false; b2 = false;
+            alpha = T(0.5) * (p1.alpha + p2.alpha);
+            state = 4;
+        }
     }
     if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
     if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
@@ -613,110 +704,24 @@ DL_HD T linesearch(const LaneMem<T>& mem, int nefc, T g0, T g1, T g2, T gtol, in
 }
 
 // ------------------------------------------------------------------------------------------
-// solver state update at the current qacc: cost, gradient, Hessian factor, Newton direction.
-// ROW_JAREF holds J qacc - aref.
-template <typename T, typename TP>
-DL_HD void solver_update(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& mem, const TreeMat<T, TP>& M,
-                         const T (&qacc)[TP::NV], const T (&Ma)[TP::NV], const T (&smooth)[TP::NV], const T (&qacc_smooth)[TP::NV],
-                         T& cost, T& gauss, T (&grad)[TP::NV], T (&Mgrad)[TP::NV]) {
-    using L = MemLayout<TP>;
-    TreeMat<T, TP> H;
-    static_for<TP::NV>([&](auto ii) {
-        constexpr int i = ii.value;
-        static_for<TP::NV>([&](auto ji) {
-            constexpr int j = ji.value;
-            if constexpr (j <= i && TP::dof_anc(i, j)) H.a[i][j] = M.a[i][j];
-        });
-    });
-    T fcon[TP::NV];
-    static_for<TP::NV>([&](auto ii) { fcon[ii.value] = T(0); });
-    T c = T(0);
-    for (int r = 0; r < e.nlim; r++) {
-        const T jar = mem(L::ROW_JAREF + r);
-        if (jar < T(0)) {
-            const T D = mem(L::ROW_D + r);
-            const int code = (int)((e.lim_code >> (5 * r)) & 31), j = code & 15;
-            const T f = (code & 16) ? D * jar : -D * jar;      // J^T f with J = -+1
-            c += T(0.5) * D * jar * jar;
-            static_for<TP::NV>([&](auto ji) {
-                if constexpr (TP::dof_limited(ji.value)) if (j == ji.value) { fcon[ji.value] += f; H.a[ji.value][ji.value] += D; }
-            });
-        }
-    }
-    for (int cc = 0; cc < e.ncon; cc++) {
-        const int r0 = e.nlim + 4 * cc;
-        T jar[4], Dr[4];
-        bool any = false;
-        for (int s = 0; s < 4; s++) { jar[s] = mem(L::ROW_JAREF + r0 + s); Dr[s] = mem(L::ROW_D + r0 + s); any = any || jar[s] < T(0); }
-        if (!any) continue;
-        const int body = (int)((e.con_body >> (3 * cc)) & 7);
-        const V3<T> p = mk<T>(mem(L::CON_PX + cc), mem(L::CON_PY + cc), mem(L::CON_PZ + cc));
-        const T tx = mem(L::CON_TX + cc), ty = mem(L::CON_TY + cc), mu = mem(L::CON_MU + cc);
-        T jn[TP::NV], jt1[TP::NV], jt2[TP::NV];
-        contact_jac<T, TP>(k, body, p, tx, ty, jn, jt1, jt2);
-        for (int s = 0; s < 4; s++) {
-            if (!(jar[s] < T(0))) continue;
-            const T D = Dr[s], f = -D * jar[s];
-            const T sg = (s & 1) ? -mu : mu;
-            c += T(0.5) * D * jar[s] * jar[s];
-            T row[TP::NV];
-            static_for<TP::NV>([&](auto ji) {
-                constexpr int j = ji.value;
-                row[j] = jn[j] + sg * (s < 2 ? jt1[j] : jt2[j]);
-                fcon[j] += row[j] * f;
-            });
-            static_for<TP::NV>([&](auto ii) {
-                constexpr int i = ii.value;
-                const T di = D * row[i];
-                static_for<TP::NV>([&](auto ji) {
-                    constexpr int j = ji.value;
-                    if constexpr (j <= i && TP::dof_anc(i, j)) H.a[i][j] += di * row[j];
-                });
-            });
-        }
-    }
-    T g = T(0);
-    static_for<TP::NV>([&](auto ii) {
-        constexpr int i = ii.value;
-        g += T(0.5) * (Ma[i] - smooth[i]) * (qacc[i] - qacc_smooth[i]);
-        grad[i] = Ma[i] - smooth[i] - fcon[i];
-        Mgrad[i] = grad[i];
-    });
-    gauss = g;
-    cost = c + g;
-    ltdl_factor<T, TP>(H);
-    ltdl_solve<T, TP>(H, Mgrad);
-}
-
-// cost of a candidate acceleration (warmstart choice); uses ROW_JV as scratch for J a
-template <typename T, typename TP>
-DL_HD T candidate_cost(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& mem, const TreeMat<T, TP>& M,
-                       const T (&a)[TP::NV], const T (&smooth)[TP::NV], const T (&qacc_smooth)[TP::NV]) {
-    using L = MemLayout<TP>;
-    T Ma[TP::NV];
-    treemat_mul<T, TP>(M, a, Ma);
-    mul_J<T, TP, false>(k, e, mem, a, L::ROW_JV);
-    T cost = T(0);
-    for (int r = 0; r < e.nefc; r++) {
-        const T x = mem(L::ROW_JV + r) + mem(L::ROW_JAREF + r);     // J a - aref (JAREF holds -aref here)
-        if (x < T(0)) cost += T(0.5) * mem(L::ROW_D + r) * x * x;
-    }
-    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; cost += T(0.5) * (Ma[i] - smooth[i]) * (a[i] - qacc_smooth[i]); });
-    return cost;
-}
-
-// [3P] mj_forward: returns qacc; `warm` is qacc_warmstart (input only)
+// [3P] mj_forward: returns qacc; `warm` is qacc_warmstart (input only).
+//
+// After kinematics / inertia / bias / collision the rest is ONE loop whose body is emitted once:
+//   phase -1  x = qvel      : J x completes -aref;  H = M -> factor -> qacc_smooth = M^-1 qfrc_smooth
+//   phase  0  x = qacc_smooth: candidate cost
+//   phase  1  x = warmstart  : candidate cost, choose the cheaper start, initial Hessian
+//   phase >=2 x = search     : exact line search, move, incremental Hessian update
+// every phase >= 1 ends with cost / gradient / factorisation of H / Newton direction.
 template <typename T, typename TP>
 DL_HD void forward(const DevModel<T, TP>& m, const LaneMem<T>& mem, const T (&q)[TP::NV], const T (&v)[TP::NV],
                    const T (&ctrl)[TP::NU], const T (&warm)[TP::NV], T (&qacc)[TP::NV], EfcInfo<TP>& e, int& niter) {
     using L = MemLayout<TP>;
     Kin<T, TP> k;
     kinematics<T, TP>(m, q, k);
-    TreeMat<T, TP> M;
     T smooth[TP::NV], qacc_smooth[TP::NV];
     {
         T bias[TP::NV];
-        inertia_and_bias<T, TP>(m, k, v, M, bias);
+        inertia_and_bias<T, TP>(m, k, v, mem, bias);      // M goes to lane memory
         static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; smooth[j] = -m.damping[j] * v[j] - bias[j]; });
         static_for<TP::NU>([&](auto ai) {
             constexpr int a = ai.value;
@@ -724,97 +729,242 @@ DL_HD void forward(const DevModel<T, TP>& m, const LaneMem<T>& mem, const T (&q)
             smooth[TP::act_dof(a)] += m.gear[a] * dl_clamp(u, m.force_lo[a], m.force_hi[a]);
         });
     }
-    {
-        TreeMat<T, TP> LM;
-        static_for<TP::NV>([&](auto ii) {
-            constexpr int i = ii.value;
-            qacc_smooth[i] = smooth[i];
-            static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; if constexpr (j <= i && TP::dof_anc(i, j)) LM.a[i][j] = M.a[i][j]; });
-        });
-        ltdl_factor<T, TP>(LM);
-        ltdl_solve<T, TP>(LM, qacc_smooth);
-    }
-    make_constraints<T, TP>(m, k, q, v, mem, e);
+    make_constraints<T, TP>(m, k, q, mem, e);
+    const int nefc = e.nefc;
     niter = 0;
-    if (e.nefc == 0) {
-        static_for<TP::NV>([&](auto ii) { qacc[ii.value] = qacc_smooth[ii.value]; });
-        return;
-    }
-    // warmstart: the cheaper of qacc_warmstart and qacc_smooth
-    {
-        const T cw = candidate_cost<T, TP>(k, e, mem, M, warm, smooth, qacc_smooth);
-        const T cs = candidate_cost<T, TP>(k, e, mem, M, qacc_smooth, smooth, qacc_smooth);
-        const bool use_warm = !(cw > cs);
-        static_for<TP::NV>([&](auto ii) { qacc[ii.value] = use_warm ? warm[ii.value] : qacc_smooth[ii.value]; });
-    }
-    T Ma[TP::NV], grad[TP::NV], search[TP::NV], Mv[TP::NV];
-    treemat_mul<T, TP>(M, qacc, Ma);
-    mul_J<T, TP, true>(k, e, mem, qacc, L::ROW_JAREF);        // JAREF: -aref -> J qacc - aref
-    T cost, gauss;
-    solver_update<T, TP>(k, e, mem, M, qacc, Ma, smooth, qacc_smooth, cost, gauss, grad, search);
-    static_for<TP::NV>([&](auto ii) { search[ii.value] = -search[ii.value]; });
+
+    TreeMat<T, TP> H;                    // M + sum_active D row row^T, kept in registers across the Newton iterations
+    uint64_t act_lo = 0, act_hi = 0;     // per-row "quadratic" state
+    T x[TP::NV], Mx[TP::NV], Ma[TP::NV], rhs[TP::NV];
+    T cost = T(0), gauss = T(0), cost_s = T(0);
     const T nvf = T(TP::NV);
     const T scale = T(1) / (m.meaninertia * nvf);
-    int iter = 0;
-    while (iter < m.iterations) {
-        T s2 = T(0);
-        static_for<TP::NV>([&](auto ii) { s2 += search[ii.value] * search[ii.value]; });
-        const T snorm = dl_sqrt(s2);
-        if (snorm < T(1e-15)) break;
-        treemat_mul<T, TP>(M, search, Mv);
-        mul_J<T, TP, false>(k, e, mem, search, L::ROW_JV);
-        T g1 = T(0), g2 = T(0);
-        static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; g1 += search[i] * (Ma[i] - smooth[i]); g2 += T(0.5) * search[i] * Mv[i]; });
-        const T gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * nvf + m.ls_reltol * dl_abs(g1);
-        const T alpha = linesearch<T, TP>(mem, e.nefc, gauss, g1, g2, gtol, m.ls_iterations);
-        if (alpha == T(0)) break;
-        static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; qacc[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; });
-        for (int r = 0; r < e.nefc; r++) mem(L::ROW_JAREF + r) += alpha * mem(L::ROW_JV + r);
+    int phase = -1, iter = 0;
+    static_for<TP::NV>([&](auto ii) { x[ii.value] = v[ii.value]; Mx[ii.value] = T(0); Ma[ii.value] = T(0); rhs[ii.value] = T(0); qacc[ii.value] = T(0); });
+    for (;;) {
+        // ---- x -> M x (phases >= 0) and J x (whenever there are rows)
+        if (phase >= 0) {
+            static_for<TP::NV>([&](auto ir) { Mx[ir.value] = mem(L::MAT + L::template MI<ir.value, ir.value>) * x[ir.value]; });
+            static_for<TP::NV>([&](auto ir) {
+                constexpr int i = ir.value;
+                static_for<TP::NV>([&](auto jr) {
+                    constexpr int j = jr.value;
+                    if constexpr (j < i && TP::dof_anc(i, j)) { const T mij = mem(L::MAT + L::template MI<i, j>); Mx[i] += mij * x[j]; Mx[j] += mij * x[i]; }
+                });
+            });
+        }
+        if (nefc > 0) mul_J<T, TP>(k, e, mem, x);
+        T alpha = T(0);
+        bool stop = false;
+        if (phase == -1) {
+            for (int r = 0; r < nefc; r++) mem(L::ROW_JAREF + r) += m.solB * mem(L::ROW_JV + r);      // -aref complete
+        } else if (phase <= 1) {
+            // cost of the candidate start x
+            T c = T(0);
+            for (int r = 0; r < nefc; r++) {
+                const T jar = mem(L::ROW_JV + r) + mem(L::ROW_JAREF + r);
+                if (jar < T(0)) c += T(0.5) * mem(L::ROW_D + r) * jar * jar;
+            }
+            static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; c += T(0.5) * (Mx[i] - smooth[i]) * (x[i] - qacc_smooth[i]); });
+            if (phase == 0) {
+                cost_s = c;
+                for (int r = 0; r < nefc; r++) mem(L::ROW_TMP + r) = mem(L::ROW_JV + r);
+            } else {
+                const bool use_warm = !(c > cost_s);
+                // M qacc_smooth = qfrc_smooth by construction
+                static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; qacc[i] = use_warm ? warm[i] : qacc_smooth[i]; Ma[i] = use_warm ? Mx[i] : smooth[i]; });
+                for (int r = 0; r < nefc; r++) mem(L::ROW_JAREF + r) += use_warm ? mem(L::ROW_JV + r) : mem(L::ROW_TMP + r);
+            }
+        } else {
+            T s2 = T(0), g1 = T(0), g2 = T(0);
+            static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; s2 += x[i] * x[i]; g1 += x[i] * (Ma[i] - smooth[i]); g2 += T(0.5) * x[i] * Mx[i]; });
+            const T snorm = dl_sqrt(s2);
+            if (snorm < T(1e-15)) stop = true;
+            else {
+                const T gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * nvf + m.ls_reltol * dl_abs(g1);
+                alpha = linesearch<T, TP>(mem, nefc, gauss, g1, g2, gtol, m.ls_iterations);
+                if (alpha == T(0)) stop = true;
+                else {
+                    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; qacc[i] += alpha * x[i]; Ma[i] += alpha * Mx[i]; });
+                    for (int r = 0; r < nefc; r++) mem(L::ROW_JAREF + r) += alpha * mem(L::ROW_JV + r);
+                }
+            }
+        }
+        if (stop) break;
+        if (phase == 0) { phase = 1; static_for<TP::NV>([&](auto ii) { x[ii.value] = warm[ii.value]; }); continue; }
+
+        // ---- Hessian: H = M at the start, then add/remove rows whose state flipped
         const T oldcost = cost;
-        solver_update<T, TP>(k, e, mem, M, qacc, Ma, smooth, qacc_smooth, cost, gauss, grad, search);
-        T gn = T(0);
-        static_for<TP::NV>([&](auto ii) { gn += grad[ii.value] * grad[ii.value]; search[ii.value] = -search[ii.value]; });
-        const T improvement = scale * (oldcost - cost), gradient = scale * dl_sqrt(gn);
-        iter++;
-        if (improvement < m.tolerance || gradient < m.tolerance) break;
+        if (phase <= 1) {
+            static_for<TP::NV>([&](auto ii) {
+                constexpr int i = ii.value;
+                static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; if constexpr (j <= i && TP::dof_anc(i, j)) H.a[i][j] = mem(L::MAT + L::template MI<i, j>); });
+            });
+        }
+        SV<T> W[TP::NB];                  // constraint wrench per body (about the reference point)
+        T fcon[TP::NV];
+        T c = T(0);
+        if (phase >= 1) {
+            static_for<TP::NB>([&](auto bi) { W[bi.value] = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)}; });
+            static_for<TP::NV>([&](auto ii) { fcon[ii.value] = T(0); });
+            for (int r = 0; r < e.nlim; r++) {
+                const T jar = mem(L::ROW_JAREF + r), D = mem(L::ROW_D + r);
+                const bool on = jar < T(0), was = (act_lo >> r) & 1ull;
+                const int code = (int)((e.lim_code >> (5 * r)) & 31), j = code & 15;
+                const T f = on ? ((code & 16) ? D * jar : -D * jar) : T(0);
+                if (on) c += T(0.5) * D * jar * jar;
+                const T dH = (on == was) ? T(0) : (on ? D : -D);
+                static_for<TP::NV>([&](auto ji) {
+                    if constexpr (TP::dof_limited(ji.value)) if (j == ji.value) { fcon[ji.value] += f; H.a[ji.value][ji.value] += dH; }
+                });
+                if (on != was) act_lo ^= 1ull << r;
+            }
+            for (int cc = 0; cc < e.ncon; cc++) {
+                const int r0 = e.nlim + 4 * cc;
+                const int body = (int)((e.con_body >> (3 * cc)) & 7);
+                const V3<T> p = mk<T>(mem(L::CON_PX + cc), mem(L::CON_PY + cc), mem(L::CON_PZ + cc));
+                const T tx = mem(L::CON_TX + cc), ty = mem(L::CON_TY + cc), mu = mem(L::CON_MU + cc);
+                T fs[4], Dr[4];
+                unsigned flips = 0, ons = 0;
+                for (int s = 0; s < 4; s++) {
+                    const int r = r0 + s;
+                    const T jar = mem(L::ROW_JAREF + r);
+                    Dr[s] = mem(L::ROW_D + r);
+                    const bool on = jar < T(0);
+                    const bool was = r < 64 ? ((act_lo >> r) & 1ull) : ((act_hi >> (r - 64)) & 1ull);
+                    fs[s] = on ? -Dr[s] * jar : T(0);
+                    if (on) { c += T(0.5) * Dr[s] * jar * jar; ons |= 1u << s; }
+                    if (on != was) { flips |= 1u << s; if (r < 64) act_lo ^= 1ull << r; else act_hi ^= 1ull << (r - 64); }
+                }
+                if (ons) {
+                    // world force of the pyramid edges and its moment about the reference point
+                    const T fn = fs[0] + fs[1] + fs[2] + fs[3], f1 = mu * (fs[0] - fs[1]), f2 = mu * (fs[2] - fs[3]);
+                    const V3<T> F = mk<T>(f1 * tx - f2 * ty, f1 * ty + f2 * tx, fn);
+                    const V3<T> Nm = cross(p, F);
+                    static_for<TP::NB - 1>([&](auto bi) {
+                        constexpr int b = bi.value + 1;
+                        if (body == b) { W[b].w = W[b].w + Nm; W[b].v = W[b].v + F; }
+                    });
+                }
+                if (flips) {
+                    T jn[TP::NV], jt1[TP::NV], jt2[TP::NV];
+                    contact_jac<T, TP>(k, body, p, tx, ty, jn, jt1, jt2);
+                    for (int s = 0; s < 4; s++) {
+                        if (!((flips >> s) & 1u)) continue;
+                        const T D = ((ons >> s) & 1u) ? Dr[s] : -Dr[s];
+                        const T sg = (s & 1) ? -mu : mu;
+                        T row[TP::NV];
+                        static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; row[j] = jn[j] + sg * (s < 2 ? jt1[j] : jt2[j]); });
+                        static_for<TP::NV>([&](auto ii) {
+                            constexpr int i = ii.value;
+                            const T di = D * row[i];
+                            static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; if constexpr (j <= i && TP::dof_anc(i, j)) H.a[i][j] += di * row[j]; });
+                        });
+                    }
+                }
+            }
+            // J^T f: wrenches to the root, then project on the motion subspaces
+            static_for<TP::NB - 2>([&](auto bi) {
+                constexpr int b = TP::NB - 1 - bi.value, pb = TP::body_parent(b);
+                if constexpr (pb > 0) W[pb] = W[pb] + W[b];
+            });
+            T g = T(0);
+            static_for<TP::NV>([&](auto ii) {
+                constexpr int i = ii.value;
+                fcon[i] += sdot(dof_S<T, TP, i>(k), W[TP::dof_body(i)]);
+                g += T(0.5) * (Ma[i] - smooth[i]) * (qacc[i] - qacc_smooth[i]);
+                rhs[i] = Ma[i] - smooth[i] - fcon[i];           // gradient
+            });
+            gauss = g;
+            cost = c + g;
+        } else {
+            static_for<TP::NV>([&](auto ii) { rhs[ii.value] = smooth[ii.value]; });
+        }
+        // termination tests of the previous Newton step (need the new cost and gradient)
+        if (phase >= 2) {
+            T gn = T(0);
+            static_for<TP::NV>([&](auto ii) { gn += rhs[ii.value] * rhs[ii.value]; });
+            const T improvement = scale * (oldcost - cost), gradient = scale * dl_sqrt(gn);
+            iter++;
+            if (improvement < m.tolerance || gradient < m.tolerance || iter >= m.iterations) break;
+        }
+        // ---- factorise a copy of H and solve
+        {
+            TreeMat<T, TP> Hf;
+            static_for<TP::NV>([&](auto ii) {
+                constexpr int i = ii.value;
+                static_for<TP::NV>([&](auto ji) {
+                    constexpr int j = ji.value;
+                    if constexpr (j <= i && TP::dof_anc(i, j)) Hf.a[i][j] = H.a[i][j];
+                });
+            });
+            ltdl_factor<T, TP>(Hf);
+            ltdl_solve<T, TP>(Hf, rhs);
+        }
+        if (phase == -1) {
+            static_for<TP::NV>([&](auto ii) { qacc_smooth[ii.value] = rhs[ii.value]; x[ii.value] = rhs[ii.value]; });
+            if (nefc == 0) { static_for<TP::NV>([&](auto ii) { qacc[ii.value] = qacc_smooth[ii.value]; }); break; }
+            phase = 0;
+        } else {
+            static_for<TP::NV>([&](auto ii) { x[ii.value] = -rhs[ii.value]; });     // Newton direction
+            phase = phase + 1;
+        }
     }
     niter = iter;
 }
 
-// [3P] mj_step, RK4 (mj_RungeKutta N=4).  Returns true on divergence (mj_checkPos/Vel/Acc).
+// The forward evaluation behind a real call: keeps the optimiser from hoisting its (many)
+// loop-invariant sub-expressions out of the RK4 / frame-skip loops of the callers, which would
+// keep hundreds of values alive across the whole evaluation and spill them.
 template <typename T, typename TP>
-DL_HD bool mj_step_rk4(const DevModel<T, TP>& m, const LaneMem<T>& mem, T (&q)[TP::NV], T (&v)[TP::NV], const T (&ctrl)[TP::NU], T (&warm)[TP::NV]) {
-    bool bad = false;
-    static_for<TP::NV>([&](auto ii) { bad = bad || dl_bad(q[ii.value]) || dl_bad(v[ii.value]); });
-    if (bad) return true;
-    const T h = m.timestep;
-    T q0[TP::NV], v0[TP::NV], qs[TP::NV], vs[TP::NV], dq[TP::NV], dv[TP::NV], acc[TP::NV];
-    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; q0[i] = q[i]; v0[i] = v[i]; qs[i] = q[i]; vs[i] = v[i]; dq[i] = T(0); dv[i] = T(0); });
+DL_NOINLINE void forward_call(const DevModel<T, TP>* m, DL_LDS T* lane_base, int lane_stride, const T* q, const T* v, const T* ctrl, const T* warm,
+                              T* qacc, int* info) {
+    T ql[TP::NV], vl[TP::NV], wl[TP::NV], ul[TP::NU], al[TP::NV];
+    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; ql[i] = q[i]; vl[i] = v[i]; wl[i] = warm[i]; });
+    static_for<TP::NU>([&](auto ii) { ul[ii.value] = ctrl[ii.value]; });
     EfcInfo<TP> e;
     int niter;
+    forward<T, TP>(*m, LaneMem<T>{lane_base, lane_stride}, ql, vl, ul, wl, al, e, niter);
+    static_for<TP::NV>([&](auto ii) { qacc[ii.value] = al[ii.value]; });
+    info[0] = e.ncon; info[1] = e.nefc; info[2] = niter;
+}
+
+// [3P] mj_step, RK4 (mj_RungeKutta N=4).  Returns true on divergence (mj_checkPos/Vel/Acc).
+// The RK4 bookkeeping (start state, weighted sums) is staged in the lane's global workspace `gw`
+// (4*NV words, coalesced [word][N]) instead of being held in registers across the four forward
+// evaluations.
+template <typename T, typename TP>
+DL_HD bool mj_step_rk4(const DevModel<T, TP>& m, const LaneMem<T>& mem, const GlobalMem<T>& gw, T (&q)[TP::NV], T (&v)[TP::NV], const T (&ctrl)[TP::NU], T (&warm)[TP::NV]) {
+    constexpr int NV = TP::NV;
+    bool bad = false;
+    static_for<NV>([&](auto ii) { bad = bad || dl_bad(q[ii.value]) || dl_bad(v[ii.value]); });
+    if (bad) return true;
+    const T h = m.timestep;
+    static_for<NV>([&](auto ii) { constexpr int i = ii.value; gw(i) = q[i]; gw(NV + i) = v[i]; gw(2 * NV + i) = T(0); gw(3 * NV + i) = T(0); });
+    int info[3];
 #pragma unroll 1
     for (int stage = 0; stage < 4; stage++) {
-        forward<T, TP>(m, mem, qs, vs, ctrl, warm, acc, e, niter);
-        static_for<TP::NV>([&](auto ii) { warm[ii.value] = acc[ii.value]; });
+        T acc[NV];
+        forward_call<T, TP>(&m, mem.base, mem.stride, q, v, ctrl, warm, acc, info);
+        static_for<NV>([&](auto ii) { warm[ii.value] = acc[ii.value]; });
         if (stage == 0) {
             bool b2 = false;
-            static_for<TP::NV>([&](auto ii) { b2 = b2 || dl_bad(acc[ii.value]); });
+            static_for<NV>([&](auto ii) { b2 = b2 || dl_bad(acc[ii.value]); });
             if (b2) { bad = true; break; }
         }
         // classic tableau: stage weights 1/6 1/3 1/3 1/6, next-stage step 1/2 1/2 1
         const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
         const T a = stage == 2 ? T(1) : T(0.5);
-        static_for<TP::NV>([&](auto ii) {
+        static_for<NV>([&](auto ii) {
             constexpr int i = ii.value;
-            dq[i] += wgt * vs[i]; dv[i] += wgt * acc[i];
-            const T vstage = vs[i];
-            qs[i] = q0[i] + h * a * vstage;
-            vs[i] = v0[i] + h * a * acc[i];
+            const T dq = gw(2 * NV + i) + wgt * v[i], dv = gw(3 * NV + i) + wgt * acc[i];
+            gw(2 * NV + i) = dq; gw(3 * NV + i) = dv;
+            const T vstage = v[i];
+            if (stage < 3) { q[i] = gw(i) + h * a * vstage; v[i] = gw(NV + i) + h * a * acc[i]; }
+            else { q[i] = gw(i) + h * dq; v[i] = gw(NV + i) + h * dv; }
         });
     }
-    if (bad) return true;
-    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; q[i] = q0[i] + h * dq[i]; v[i] = v0[i] + h * dv[i]; });
-    return false;
+    return bad;
 }
 
 }  // namespace dl

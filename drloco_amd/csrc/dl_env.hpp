@@ -31,6 +31,7 @@ template <typename T> struct DevState {
     double* mon;             // [MON_WORDS][N]
     int32_t* need_reset;     // [N]: 0 none, 1 auto reset after done, 2 double reset after a diverged step
     int32_t* inj_rsi;        // [2][N]: injected RSI draw for all later resets (step < 0: none); test hook
+    T* work;                 // [4*NV][N] staging of the RK4 bookkeeping
     int32_t n;
 };
 
@@ -163,8 +164,9 @@ DL_HD void env_step_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const Lan
     else if (flag == 1) {
         static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; q[j] = inj_q[(size_t)j * n + i]; v[j] = inj_v[(size_t)j * n + i]; });
     } else {
+        const GlobalMem<T> gw{st.work + i, n};
 #pragma unroll 1
-        for (int kf = 0; kf < m.frame_skip && !exc; kf++) exc = mj_step_rk4<T, TP>(m, mem, q, v, ctrl, warm);
+        for (int kf = 0; kf < m.frame_skip && !exc; kf++) exc = mj_step_rk4<T, TP>(m, mem, gw, q, v, ctrl, warm);
     }
     T tor = T(0);
     static_for<TP::NU>([&](auto ai) { constexpr int a = ai.value; tor += dl_abs(dl_clamp(ctrl[a], m.force_lo[a], m.force_hi[a])); });
@@ -243,9 +245,8 @@ DL_HD void env_reset_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const La
             comz = low;
         }
         // set_state -> mj_forward: qacc of the initial state seeds the warmstart
-        EfcInfo<TP> e;
-        int niter;
-        forward<T, TP>(m, mem, q, v, zero_u, zero_w, warm, e, niter);
+        int info[3];
+        forward_call<T, TP>(&m, mem.base, mem.stride, q, v, zero_u, zero_w, warm, info);
         cursor_next(c, cur);
         get_obs<T, TP>(c, cur, q, v, o);
         if (nrep == 2 && rep == 0 && term_obs) static_for<TP::OBS>([&](auto ki) { term_obs[(size_t)i * TP::OBS + ki.value] = o[ki.value]; });

@@ -35,6 +35,8 @@ template <typename TP> inline bool check_topology(const dl_model_desc& d, std::s
     for (int s = 0; s < TP::NS; s++) if (d.site_body[s] != TP::site_body(s)) return fail("site_body", s);
     for (int a = 0; a < TP::NU; a++) if (d.act_dof[a] != TP::act_dof(a)) return fail("act_dof", a);
     if (d.body_pos[1][0] != 0 || d.body_pos[1][1] != 0) { why = "root body must sit above the origin"; return false; }
+    if (d.solimp[4] != 1.0 && d.solimp[4] != 2.0) { why = "unsupported solimp power (kernels implement 1 and 2)"; return false; }
+    if (!(d.solimp[2] > 1e-15) || d.solimp[0] == d.solimp[1]) { why = "unsupported solimp (flat impedance)"; return false; }
     return true;
 }
 

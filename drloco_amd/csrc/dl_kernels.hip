@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP> m, con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= st.n) return;
-    LaneMem<T> mem{reinterpret_cast<T*>(smem) + threadIdx.x, BLOCK};
+    LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
     env_step_lane<T, TP>(m, c, mem, st, i, actions, obs, rew, done, term_obs, rew_terms, inj_q, inj_v, inj_flags);
 }
 
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP> m, co
     if (mode == 0) nrep = st.need_reset[i];
     else nrep = (mask == nullptr || mask[i]) ? 1 : 0;
     if (nrep == 0) return;
-    LaneMem<T> mem{reinterpret_cast<T*>(smem) + threadIdx.x, BLOCK};
+    LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
     env_reset_lane<T, TP>(m, c, mem, st, i, nrep, init_step, init_pos, obs, term_obs);
 }
 
@@ -52,17 +52,16 @@ __global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP> m, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x, n = st.n;
     if (i >= n) return;
-    LaneMem<T> mem{reinterpret_cast<T*>(smem) + threadIdx.x, BLOCK};
+    LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
     T q[TP::NV], v[TP::NV], w[TP::NV], u[TP::NU], a[TP::NV];
     static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; q[j] = st.qpos[(size_t)j * n + i]; v[j] = st.qvel[(size_t)j * n + i]; w[j] = st.warm[(size_t)j * n + i]; });
     static_for<TP::NU>([&](auto ai) { constexpr int k = ai.value; u[k] = ctrl ? ctrl[(size_t)k * n + i] : T(0); });
-    EfcInfo<TP> e;
-    int it;
-    forward<T, TP>(m, mem, q, v, u, w, a, e, it);
+    int info[3];
+    forward_call<T, TP>(&m, mem.base, mem.stride, q, v, u, w, a, info);
     static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; qacc[(size_t)j * n + i] = a[j]; });
-    if (ncon) ncon[i] = e.ncon;
-    if (nefc) nefc[i] = e.nefc;
-    if (niter) niter[i] = it;
+    if (ncon) ncon[i] = info[0];
+    if (nefc) nefc[i] = info[1];
+    if (niter) niter[i] = info[2];
 }
 
 template <typename T> __global__ void k_fill(T* p, T val, size_t n) {
@@ -178,7 +177,7 @@ static int fail(int code, const std::string& what) { g_err = what; return code; 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(DL_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct dl_env_s {
-    virtual ~dl_env_s() {}
+    virtual ~dl_env_s() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
     int n = 0, device = 0, real_size = 4;
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
@@ -188,6 +187,20 @@ struct dl_env_s {
     virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
+    // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    void prof_begin(hipStream_t s) {
+        if (!prof) return;
+        if (ev_used + 2 > ev.size()) { hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return; ev.push_back(a); ev.push_back(b); }
+        (void)hipEventRecord(ev[ev_used], s);
+    }
+    void prof_end(hipStream_t s) {
+        if (!prof || ev_used + 2 > ev.size()) return;
+        (void)hipEventRecord(ev[ev_used + 1], s);
+        ev_used += 2;
+    }
 };
 
 template <typename T> struct EnvImpl final : dl_env_s {
@@ -225,10 +238,11 @@ template <typename T> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&stage, tn))) return rc;
         HIPCHK(hipMemcpy(stage, r.table, tn * sizeof(double), hipMemcpyHostToDevice));
         k_copy_cast<T><<<(unsigned)((tn + 255) / 256), 256>>>(table, stage, tn);
+        HIPCHK(hipDeviceSynchronize());            // `stage` is reused below
         if ((rc = dalloc(&svel, r.n_steps))) return rc;
         HIPCHK(hipMemcpy(stage, r.step_vel, r.n_steps * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(hipDeviceSynchronize());
         k_copy_cast<T><<<1, 256>>>(svel, stage, r.n_steps);
+        HIPCHK(hipDeviceSynchronize());
         if ((rc = dalloc(&soff, r.n_steps + 1))) return rc;
         if ((rc = dalloc(&sleft, r.n_steps))) return rc;
         HIPCHK(hipMemcpy(soff, r.step_off, (r.n_steps + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -245,6 +259,7 @@ template <typename T> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&st.mon, (size_t)MON_WORDS * n))) return rc;
         if ((rc = dalloc(&st.need_reset, n))) return rc;
         if ((rc = dalloc(&st.inj_rsi, (size_t)2 * n))) return rc;
+        if ((rc = dalloc(&st.work, (size_t)4 * TP::NV * n))) return rc;
         if ((rc = dalloc(&inj_q, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&inj_v, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&inj_flags, n))) return rc;
@@ -269,8 +284,10 @@ template <typename T> struct EnvImpl final : dl_env_s {
     }
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
+        prof_begin(s);
         hipLaunchKernelGGL((k_env_step<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, act, obs, rew, done, term, terms,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
+        prof_end(s);
         HIPCHK(hipGetLastError());
         if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
         hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term);
@@ -392,6 +409,29 @@ int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) 
     for (const auto& t : tab)
         if (!strcmp(name, t.name)) return h->snapshot(t.word, out, (hipStream_t)stream);
     return fail(DL_E_INVAL, std::string("dl_stats_snapshot: unknown attribute ") + name);
+}
+
+int dl_profile(dl_handle h, int32_t enable) {
+    NEED(h);
+    h->prof = enable != 0;
+    h->ev_used = 0;
+    return DL_OK;
+}
+int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches) {
+    NEED(h);
+    double tot = 0;
+    int cnt = 0;
+    for (size_t k = 0; k + 1 < h->ev_used; k += 2) {
+        HIPCHK(hipEventSynchronize(h->ev[k + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[k], h->ev[k + 1]));
+        tot += ms;
+        cnt++;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
+    h->ev_used = 0;
+    return DL_OK;
 }
 
 int dl_moments_update(double* mean, double* var, double* count, const float* x, int32_t B, int32_t D, void* stream) {

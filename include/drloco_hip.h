@@ -205,6 +205,12 @@ int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t
  * mean_abs_ep_torque_smoothed.  out: double[N] device. */
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream);
 
+/* Measurement hooks (no reference counterpart): when enabled, every launch of the dominant
+ * kernel (the fused env-step kernel) is bracketed by HIP events on its launch stream;
+ * dl_profile_read waits for them and returns the summed duration and the launch count. */
+int dl_profile(dl_handle h, int32_t enable);
+int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches);
+
 /* ---- reductions of the SB3 layer (stable-baselines3==1.0, docs/conda_env.yml:30) ---- */
 
 /* RunningMeanStd.update (VecNormalize): Chan parallel update of (mean[D], var[D], count[1])

@@ -13,7 +13,7 @@ template <typename T> struct Emu {
     DevModel<T, TP> m;
     DevCfg<T> c;
     DevState<T> st;
-    std::vector<T> qpos, qvel, warm, comz, table, step_vel, lane;
+    std::vector<T> qpos, qvel, warm, comz, table, step_vel, lane, work;
     std::vector<int32_t> cur, need, inj, step_off, is_left, inj_flags;
     std::vector<double> walked, mon;
     std::vector<T> inj_q, inj_v;
@@ -42,7 +42,8 @@ template <typename T> static Emu<T>* emu_create(const dl_model_desc* d, const dl
     e->walked.assign(n, 0); e->mon.assign((size_t)MON_WORDS * n, 0);
     e->inj_flags.assign(n, 0); e->inj_q.assign((size_t)TP::NV * n, 0); e->inj_v.assign((size_t)TP::NV * n, 0);
     e->lane.assign(MemLayout<TP>::TOTAL, 0);
-    e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), n};
+    e->work.assign((size_t)4 * TP::NV * n, 0);
+    e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), e->work.data(), n};
     return e;
 }
 
@@ -69,12 +70,12 @@ template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc,
         T q[TP::NV], v[TP::NV], w[TP::NV], u[TP::NU], a[TP::NV];
         for (int j = 0; j < TP::NV; j++) { q[j] = e->qpos[(size_t)j * n + i]; v[j] = e->qvel[(size_t)j * n + i]; w[j] = e->warm[(size_t)j * n + i]; }
         for (int k = 0; k < TP::NU; k++) u[k] = ctrl ? ctrl[(size_t)k * n + i] : T(0);
-        EfcInfo<TP> ef; int it;
-        forward<T, TP>(e->m, mem, q, v, u, w, a, ef, it);
+        int info[3];
+        forward_call<T, TP>(&e->m, mem.base, mem.stride, q, v, u, w, a, info);
         for (int j = 0; j < TP::NV; j++) qacc[(size_t)j * n + i] = a[j];
-        if (ncon) ncon[i] = ef.ncon;
-        if (nefc) nefc[i] = ef.nefc;
-        if (niter) niter[i] = it;
+        if (ncon) ncon[i] = info[0];
+        if (nefc) nefc[i] = info[1];
+        if (niter) niter[i] = info[2];
     }
 }
 

@@ -1,0 +1,68 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/drloco_hip.h declares, agrees with the ctypes mirror on struct sizes, and refuses
+to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from drloco_amd import abi, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def L():
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    return lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'drloco_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f'{n} declared in drloco_hip.h but not exported'
+        assert n in lib._SIGNATURES, f'{n} has no ctypes signature in drloco_amd/lib.py'
+    assert sorted(lib._SIGNATURES) == names
+
+
+def test_struct_sizes_and_version(L):
+    assert L.dl_abi_version() == abi.DL_ABI_VERSION
+    for which, st in enumerate((abi.ModelDesc, abi.RefsDesc, abi.Config)):
+        assert L.dl_abi_sizeof(which) == C.sizeof(st)
+
+
+def test_no_cpu_fallback(L, model, refs):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a device is present')
+    h = C.c_void_p()
+    desc = refs.as_desc()
+    cfg = abi.default_config()
+    rc = L.dl_create(C.byref(model), C.byref(desc), C.byref(cfg), 4, 0, C.byref(h))
+    assert rc == abi.DL_E_NODEVICE and not h
+    assert b'no HIP device' in L.dl_last_error()
+    from drloco_amd.vec_env import HipVecEnv
+    with pytest.raises(lib.DrlocoError):
+        HipVecEnv(num_envs=4)
+
+
+def test_null_handle_is_rejected(L):
+    assert L.dl_step(None, None, None, None, None, None, None, None) == abi.DL_E_INVAL
+    assert L.dl_num_envs(None) == 0
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'drloco_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('the oracle', '').replace("oracle's", '').replace('CPU oracle', '').lower() or f in ('dl_core.hpp',), (dirpath, f)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3: N walkers, a few dozen control steps (keeps profiles short)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from drloco_amd.vec_env import HipVecEnv
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--envs', type=int, default=4096)
+ap.add_argument('--steps', type=int, default=40)
+ap.add_argument('--warm', type=int, default=60)
+args = ap.parse_args()
+env = HipVecEnv(num_envs=args.envs)
+env.reset_tensors()
+g = torch.Generator(device='cuda'); g.manual_seed(4321)
+acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, 8, device='cuda', generator=g), -1, 1)
+for t in range(args.warm + args.steps):
+    env.step_tensors(acts[t])
+torch.cuda.synchronize()
+print('done')
