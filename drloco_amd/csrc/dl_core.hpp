@@ -31,7 +31,9 @@
 #endif
 
 // out-of-line call boundary for the forward evaluation (see forward_call)
-#if defined(__HIPCC__)
+#if defined(DL_INLINE_FORWARD)
+#define DL_NOINLINE DL_HD
+#elif defined(__HIPCC__)
 #define DL_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define DL_NOINLINE __attribute__((noinline))
@@ -43,6 +45,14 @@
 #define DL_LDS __attribute__((address_space(3)))
 #else
 #define DL_LDS
+#endif
+
+// model parameters live in a device buffer that is immutable while kernels run: address it
+// through the constant address space so that uniform parameter reads become scalar loads
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DL_CONST __attribute__((address_space(4)))
+#else
+#define DL_CONST
 #endif
 
 // hide a value from the optimiser (stops it from peeling the solver's phase loop into one copy of
@@ -233,7 +243,11 @@ template <typename TP> struct MemLayout {
         return n;
     }
     template <int I, int J> static constexpr int MI = mat_index(I, J);   // forces compile-time evaluation
-    static constexpr int TOTAL = MAT + mat_count();           // elements of T per lane
+    // arguments / result of forward_call (kept in lane memory so that nothing crosses the call in
+    // private scratch memory)
+    static constexpr int IO_Q = MAT + mat_count(), IO_V = IO_Q + TP::NV, IO_WARM = IO_V + TP::NV, IO_QACC = IO_WARM + TP::NV;
+    static constexpr int IO_CTRL = IO_QACC + TP::NV;
+    static constexpr int TOTAL = IO_CTRL + TP::NU;            // elements of T per lane
 };
 
 // ------------------------------------------------------------------------------------------
@@ -249,7 +263,7 @@ template <typename T, typename TP> DL_HD V3<T> dof_anchor(const Kin<T, TP>& k, i
 
 // [3P] mj_kinematics for slide/hinge trees whose slides sit on the root body
 template <typename T, typename TP>
-DL_HD void kinematics(const DevModel<T, TP>& m, const T (&q)[TP::NV], Kin<T, TP>& k) {
+DL_HD void kinematics(const DL_CONST DevModel<T, TP>& m, const T (&q)[TP::NV], Kin<T, TP>& k) {
     k.RX[0] = mk<T>(1, 0, 0); k.RY[0] = mk<T>(0, 1, 0); k.RZ[0] = mk<T>(0, 0, 1);
     k.pos[0] = mk<T>(0, 0, 0);
     k.rootz = m.body_pos[1][2];
@@ -284,7 +298,7 @@ DL_HD void kinematics(const DevModel<T, TP>& m, const T (&q)[TP::NV], Kin<T, TP>
     });
 }
 
-template <typename T, typename TP> DL_HD V3<T> body_point(const Kin<T, TP>& k, int b, const T* local) {
+template <typename T, typename TP> DL_HD V3<T> body_point(const Kin<T, TP>& k, int b, const DL_CONST T* local) {
     return k.pos[b] + local[0] * k.RX[b] + local[1] * k.RY[b] + local[2] * k.RZ[b];
 }
 
@@ -358,7 +372,7 @@ template <typename T, typename TP> DL_HD void treemat_mul(const TreeMat<T, TP>& 
 template <typename T> struct SubtreeOut { SI<T> Ic; SV<T> W; };
 
 template <typename T, typename TP, int b>
-DL_HD SubtreeOut<T> crb_rne_subtree(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], const LaneMem<T>& mem,
+DL_HD SubtreeOut<T> crb_rne_subtree(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], const LaneMem<T>& mem,
                                     SV<T> vel, SV<T> acc, T (&bias)[TP::NV]) {
     using L = MemLayout<TP>;
     // chain through the dofs of body b (in dof order)
@@ -422,7 +436,7 @@ DL_HD SubtreeOut<T> crb_rne_subtree(const DevModel<T, TP>& m, const Kin<T, TP>& 
 }
 
 template <typename T, typename TP>
-DL_HD void inertia_and_bias(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], const LaneMem<T>& mem, T (&bias)[TP::NV]) {
+DL_HD void inertia_and_bias(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&v)[TP::NV], const LaneMem<T>& mem, T (&bias)[TP::NV]) {
     const SV<T> vel0 = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)};
     const SV<T> acc0 = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};      // gravity as a base acceleration of -g
     static_for<TP::NB>([&](auto bi) {
@@ -459,7 +473,7 @@ template <typename T, typename TP> DL_HD SV<T> twist_of_body(const SV<T> (&vel)[
 
 // [3P] solimp sigmoid (getimpedance); the kernels support the powers 1 and 2 (MuJoCo's default is 2;
 // dl_create rejects anything else) so that no pow() expansion is inlined
-template <typename T> DL_HD T impedance(const T* si, T pos) {
+template <typename T> DL_HD T impedance(const DL_CONST T* si, T pos) {
     const T x = dl_abs(pos) / si[2];
     T y;
     if (si[4] == T(1)) y = x;
@@ -472,7 +486,7 @@ template <typename T> DL_HD T impedance(const T* si, T pos) {
 // mj_makeImpedance: contacts and, per row, D and K*imp*pos (stored in ROW_JAREF; the velocity
 // part B*(J v) of -aref is added by the solver's first pass).
 template <typename T, typename TP>
-DL_HD void make_constraints(const DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&q)[TP::NV],
+DL_HD void make_constraints(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&q)[TP::NV],
                             const LaneMem<T>& mem, EfcInfo<TP>& e) {
     using L = MemLayout<TP>;
     e.nlim = 0; e.ncon = 0; e.lim_code = 0; e.con_body = 0;
@@ -510,7 +524,7 @@ DL_HD void make_constraints(const DevModel<T, TP>& m, const Kin<T, TP>& k, const
     static_for<TP::NG>([&](auto gi) {
         constexpr int g = gi.value, b = TP::geom_body(g);
         const V3<T> gp = body_point<T, TP>(k, b, m.geom_pos[g]);
-        const T* gm = m.geom_mat[g];
+        const DL_CONST T* gm = m.geom_mat[g];
         if constexpr (TP::geom_type(g) == 0) {
             // capsule: axis = third column of the geom frame
             const V3<T> ax = gm[2] * k.RX[b] + gm[5] * k.RY[b] + gm[8] * k.RZ[b];
@@ -713,7 +727,7 @@ DL_HD T linesearch(const LaneMem<T>& mem, int nefc, T g0, T g1, T g2, T gtol, in
 //   phase >=2 x = search     : exact line search, move, incremental Hessian update
 // every phase >= 1 ends with cost / gradient / factorisation of H / Newton direction.
 template <typename T, typename TP>
-DL_HD void forward(const DevModel<T, TP>& m, const LaneMem<T>& mem, const T (&q)[TP::NV], const T (&v)[TP::NV],
+DL_HD void forward(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, const T (&q)[TP::NV], const T (&v)[TP::NV],
                    const T (&ctrl)[TP::NU], const T (&warm)[TP::NV], T (&qacc)[TP::NV], EfcInfo<TP>& e, int& niter) {
     using L = MemLayout<TP>;
     Kin<T, TP> k;
@@ -917,16 +931,39 @@ DL_HD void forward(const DevModel<T, TP>& m, const LaneMem<T>& mem, const T (&q)
 // loop-invariant sub-expressions out of the RK4 / frame-skip loops of the callers, which would
 // keep hundreds of values alive across the whole evaluation and spill them.
 template <typename T, typename TP>
-DL_NOINLINE void forward_call(const DevModel<T, TP>* m, DL_LDS T* lane_base, int lane_stride, const T* q, const T* v, const T* ctrl, const T* warm,
-                              T* qacc, int* info) {
+DL_NOINLINE int forward_call(const DL_CONST DevModel<T, TP>* m, DL_LDS T* lane_base, int lane_stride) {
+    using L = MemLayout<TP>;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DL_INLINE_FORWARD)
+    asm volatile("" : "+s"(m));     // launder the (uniform) model pointer: parameter-derived values must not be hoisted out of the callers' loops
+#elif defined(__HIP_DEVICE_COMPILE__)
+    {   // pointer arguments arrive in VGPRs; the model pointer is wave-uniform: move it to SGPRs so
+        // that parameter reads are scalar loads
+        const uint64_t p = (uint64_t)m;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        m = (const DL_CONST DevModel<T, TP>*)(((uint64_t)hi << 32) | lo);
+        lane_stride = __builtin_amdgcn_readfirstlane(lane_stride);
+    }
+#endif
+    const LaneMem<T> mem{lane_base, lane_stride};
     T ql[TP::NV], vl[TP::NV], wl[TP::NV], ul[TP::NU], al[TP::NV];
-    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; ql[i] = q[i]; vl[i] = v[i]; wl[i] = warm[i]; });
-    static_for<TP::NU>([&](auto ii) { ul[ii.value] = ctrl[ii.value]; });
+    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; ql[i] = mem(L::IO_Q + i); vl[i] = mem(L::IO_V + i); wl[i] = mem(L::IO_WARM + i); });
+    static_for<TP::NU>([&](auto ii) { ul[ii.value] = mem(L::IO_CTRL + ii.value); });
     EfcInfo<TP> e;
     int niter;
-    forward<T, TP>(*m, LaneMem<T>{lane_base, lane_stride}, ql, vl, ul, wl, al, e, niter);
-    static_for<TP::NV>([&](auto ii) { qacc[ii.value] = al[ii.value]; });
-    info[0] = e.ncon; info[1] = e.nefc; info[2] = niter;
+    forward<T, TP>(*m, mem, ql, vl, ul, wl, al, e, niter);
+    static_for<TP::NV>([&](auto ii) { mem(L::IO_QACC + ii.value) = al[ii.value]; });
+    return e.ncon | (e.nefc << 8) | (niter << 16);
+}
+// convenience wrapper: arrays in, arrays out (through the lane-memory IO slots)
+template <typename T, typename TP>
+DL_HD int forward_io(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, const T (&q)[TP::NV], const T (&v)[TP::NV], const T (&ctrl)[TP::NU],
+                     const T (&warm)[TP::NV], T (&qacc)[TP::NV]) {
+    using L = MemLayout<TP>;
+    static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; mem(L::IO_Q + i) = q[i]; mem(L::IO_V + i) = v[i]; mem(L::IO_WARM + i) = warm[i]; });
+    static_for<TP::NU>([&](auto ii) { mem(L::IO_CTRL + ii.value) = ctrl[ii.value]; });
+    const int info = forward_call<T, TP>(&m, mem.base, mem.stride);
+    static_for<TP::NV>([&](auto ii) { qacc[ii.value] = mem(L::IO_QACC + ii.value); });
+    return info;
 }
 
 // [3P] mj_step, RK4 (mj_RungeKutta N=4).  Returns true on divergence (mj_checkPos/Vel/Acc).
@@ -934,18 +971,17 @@ DL_NOINLINE void forward_call(const DevModel<T, TP>* m, DL_LDS T* lane_base, int
 // (4*NV words, coalesced [word][N]) instead of being held in registers across the four forward
 // evaluations.
 template <typename T, typename TP>
-DL_HD bool mj_step_rk4(const DevModel<T, TP>& m, const LaneMem<T>& mem, const GlobalMem<T>& gw, T (&q)[TP::NV], T (&v)[TP::NV], const T (&ctrl)[TP::NU], T (&warm)[TP::NV]) {
+DL_HD bool mj_step_rk4(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, const GlobalMem<T>& gw, T (&q)[TP::NV], T (&v)[TP::NV], const T (&ctrl)[TP::NU], T (&warm)[TP::NV]) {
     constexpr int NV = TP::NV;
     bool bad = false;
     static_for<NV>([&](auto ii) { bad = bad || dl_bad(q[ii.value]) || dl_bad(v[ii.value]); });
     if (bad) return true;
     const T h = m.timestep;
     static_for<NV>([&](auto ii) { constexpr int i = ii.value; gw(i) = q[i]; gw(NV + i) = v[i]; gw(2 * NV + i) = T(0); gw(3 * NV + i) = T(0); });
-    int info[3];
 #pragma unroll 1
     for (int stage = 0; stage < 4; stage++) {
         T acc[NV];
-        forward_call<T, TP>(&m, mem.base, mem.stride, q, v, ctrl, warm, acc, info);
+        (void)forward_io<T, TP>(m, mem, q, v, ctrl, warm, acc);
         static_for<NV>([&](auto ii) { warm[ii.value] = acc[ii.value]; });
         if (stage == 0) {
             bool b2 = false;

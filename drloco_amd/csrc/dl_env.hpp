@@ -135,7 +135,7 @@ DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const 
 // one control step of walker i.  Writes obs only for walkers that continue; finished walkers get
 // term_obs and need_reset = 1 (their obs row is written by env_reset_lane).
 template <typename T, typename TP>
-DL_HD void env_step_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const LaneMem<T>& mem, const DevState<T>& st, int i,
+DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, const LaneMem<T>& mem, const DevState<T>& st, int i,
                          const float* actions, float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
                          const T* inj_q, const T* inj_v, const int32_t* inj_flags) {
     const int n = st.n;
@@ -143,8 +143,6 @@ DL_HD void env_step_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const Lan
     int32_t cur[DL_CUR_WORDS];
     static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; q[j] = st.qpos[(size_t)j * n + i]; v[j] = st.qvel[(size_t)j * n + i]; warm[j] = st.warm[(size_t)j * n + i]; });
     static_for<DL_CUR_WORDS>([&](auto ki) { cur[ki.value] = st.cur[(size_t)ki.value * n + i]; });
-    const T comz = st.comz_off[i];
-    double walked = st.walked[i];
     // _rescale_actions, then mirror_action with the cursor BEFORE refs.next()
     T raw[TP::NU];
     static_for<TP::NU>([&](auto ai) {
@@ -168,6 +166,10 @@ DL_HD void env_step_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const Lan
 #pragma unroll 1
         for (int kf = 0; kf < m.frame_skip && !exc; kf++) exc = mj_step_rk4<T, TP>(m, mem, gw, q, v, ctrl, warm);
     }
+    // everything that is only needed after the physics is loaded here (nothing but q, v, warm, ctrl
+    // and the cursor stays live across the forward evaluations)
+    const T comz = st.comz_off[i];
+    double walked = st.walked[i];
     T tor = T(0);
     static_for<TP::NU>([&](auto ai) { constexpr int a = ai.value; tor += dl_abs(dl_clamp(ctrl[a], m.force_lo[a], m.force_hi[a])); });
     const double tor_mean = (double)tor / TP::NU;
@@ -211,7 +213,7 @@ DL_HD void env_step_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const Lan
 // MujocoEnv.reset + reset_model for walker i, `nrep` times in a row (2 after a diverged step:
 // the first reset's observation is the terminal observation).
 template <typename T, typename TP>
-DL_HD void env_reset_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const LaneMem<T>& mem, const DevState<T>& st, int i, int nrep,
+DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, const LaneMem<T>& mem, const DevState<T>& st, int i, int nrep,
                           const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs) {
     const int n = st.n;
     T q[TP::NV], v[TP::NV], warm[TP::NV], zero_u[TP::NU], zero_w[TP::NV];
@@ -245,8 +247,7 @@ DL_HD void env_reset_lane(const DevModel<T, TP>& m, const DevCfg<T>& c, const La
             comz = low;
         }
         // set_state -> mj_forward: qacc of the initial state seeds the warmstart
-        int info[3];
-        forward_call<T, TP>(&m, mem.base, mem.stride, q, v, zero_u, zero_w, warm, info);
+        (void)forward_io<T, TP>(m, mem, q, v, zero_u, zero_w, warm);
         cursor_next(c, cur);
         get_obs<T, TP>(c, cur, q, v, o);
         if (nrep == 2 && rep == 0 && term_obs) static_for<TP::OBS>([&](auto ki) { term_obs[(size_t)i * TP::OBS + ki.value] = o[ki.value]; });

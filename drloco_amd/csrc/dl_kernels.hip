@@ -21,20 +21,21 @@ using TP = TopoStraight;
 template <typename T> struct KernelGeom { static constexpr int BLOCK = sizeof(T) == 4 ? 64 : 32; };
 
 template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP> m, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
+__global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP>* __restrict__ mp, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
                                                     float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= st.n) return;
     LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
+    const DL_CONST DevModel<T, TP>& m = *(const DL_CONST DevModel<T, TP>*)mp;
     env_step_lane<T, TP>(m, c, mem, st, i, actions, obs, rew, done, term_obs, rew_terms, inj_q, inj_v, inj_flags);
 }
 
 // mode 0: reset walkers whose need_reset > 0 (auto reset after a step); mode 1: reset walkers
 // selected by mask (NULL = all)
 template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP> m, const DevCfg<T> c, const DevState<T> st, int mode, const uint8_t* mask,
+__global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP>* __restrict__ mp, const DevCfg<T> c, const DevState<T> st, int mode, const uint8_t* mask,
                                                      const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -44,24 +45,25 @@ __global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP> m, co
     else nrep = (mask == nullptr || mask[i]) ? 1 : 0;
     if (nrep == 0) return;
     LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
+    const DL_CONST DevModel<T, TP>& m = *(const DL_CONST DevModel<T, TP>*)mp;
     env_reset_lane<T, TP>(m, c, mem, st, i, nrep, init_step, init_pos, obs, term_obs);
 }
 
 template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP> m, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+__global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP>* __restrict__ mp, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x, n = st.n;
     if (i >= n) return;
     LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
+    const DL_CONST DevModel<T, TP>& m = *(const DL_CONST DevModel<T, TP>*)mp;
     T q[TP::NV], v[TP::NV], w[TP::NV], u[TP::NU], a[TP::NV];
     static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; q[j] = st.qpos[(size_t)j * n + i]; v[j] = st.qvel[(size_t)j * n + i]; w[j] = st.warm[(size_t)j * n + i]; });
     static_for<TP::NU>([&](auto ai) { constexpr int k = ai.value; u[k] = ctrl ? ctrl[(size_t)k * n + i] : T(0); });
-    int info[3];
-    forward_call<T, TP>(&m, mem.base, mem.stride, q, v, u, w, a, info);
+    const int info = forward_io<T, TP>(m, mem, q, v, u, w, a);
     static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; qacc[(size_t)j * n + i] = a[j]; });
-    if (ncon) ncon[i] = info[0];
-    if (nefc) nefc[i] = info[1];
-    if (niter) niter[i] = info[2];
+    if (ncon) ncon[i] = info & 255;
+    if (nefc) nefc[i] = (info >> 8) & 255;
+    if (niter) niter[i] = info >> 16;
 }
 
 template <typename T> __global__ void k_fill(T* p, T val, size_t n) {
@@ -206,7 +208,8 @@ struct dl_env_s {
 template <typename T> struct EnvImpl final : dl_env_s {
     static constexpr int BLOCK = KernelGeom<T>::BLOCK;
     static constexpr size_t LDS = (size_t)MemLayout<TP>::TOTAL * BLOCK * sizeof(T);
-    DevModel<T, TP> m;
+    DevModel<T, TP> m;          // host copy
+    DevModel<T, TP>* md = nullptr;   // device copy (read through the constant address space by the kernels)
     DevCfg<T> c;
     DevState<T> st;
     std::vector<void*> allocs;
@@ -229,6 +232,11 @@ template <typename T> struct EnvImpl final : dl_env_s {
         HIPCHK(hipSetDevice(device));
         fill_dev_model<T, TP>(d, m);
         fill_dev_cfg<T>(cfg, r, c);
+        {
+            int rc0;
+            if ((rc0 = dalloc(&md, 1))) return rc0;
+            HIPCHK(hipMemcpy(md, &m, sizeof m, hipMemcpyHostToDevice));
+        }
         if (r.n_rows != 2 * TP::NV) return fail(DL_E_INVAL, "refs.n_rows must be 2*nv");
         int rc;
         // reference table -> device, in the arithmetic type of the kernels
@@ -278,19 +286,19 @@ template <typename T> struct EnvImpl final : dl_env_s {
     }
     int reset(const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs, hipStream_t s) override {
         if ((is == nullptr) != (ip == nullptr)) return fail(DL_E_INVAL, "init_step and init_pos must be given together");
-        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr);
+        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
         prof_begin(s);
-        hipLaunchKernelGGL((k_env_step<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, act, obs, rew, done, term, terms,
+        hipLaunchKernelGGL((k_env_step<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, act, obs, rew, done, term, terms,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
         prof_end(s);
         HIPCHK(hipGetLastError());
         if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
-        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term);
+        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
@@ -314,7 +322,7 @@ template <typename T> struct EnvImpl final : dl_env_s {
     }
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
         if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
-        hipLaunchKernelGGL((k_forward<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, m, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+        hipLaunchKernelGGL((k_forward<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }

@@ -70,12 +70,11 @@ template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc,
         T q[TP::NV], v[TP::NV], w[TP::NV], u[TP::NU], a[TP::NV];
         for (int j = 0; j < TP::NV; j++) { q[j] = e->qpos[(size_t)j * n + i]; v[j] = e->qvel[(size_t)j * n + i]; w[j] = e->warm[(size_t)j * n + i]; }
         for (int k = 0; k < TP::NU; k++) u[k] = ctrl ? ctrl[(size_t)k * n + i] : T(0);
-        int info[3];
-        forward_call<T, TP>(&e->m, mem.base, mem.stride, q, v, u, w, a, info);
+        const int info = forward_io<T, TP>(e->m, mem, q, v, u, w, a);
         for (int j = 0; j < TP::NV; j++) qacc[(size_t)j * n + i] = a[j];
-        if (ncon) ncon[i] = info[0];
-        if (nefc) nefc[i] = info[1];
-        if (niter) niter[i] = info[2];
+        if (ncon) ncon[i] = info & 255;
+        if (nefc) nefc[i] = (info >> 8) & 255;
+        if (niter) niter[i] = info >> 16;
     }
 }
 

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/<tag>/ profile directory (tools/gpu_round_profile.sh) into the small
+text/json files kept under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+out = {}
+stats = glob.glob(os.path.join(src, 'bench_trace', '*', '*kernel_stats.csv'))
+lines = []
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (kernel_stats.csv, top rows)')
+    lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
+    for r in rows[:14]:
+        lines.append(f'{r["Name"][:70]:70s} {r["Calls"]:>7s} {float(r["AverageNs"]) / 1e3:12.2f} {float(r["MinNs"]) / 1e3:10.2f} {float(r["MaxNs"]) / 1e3:10.2f} {float(r["Percentage"]):7.2f}')
+        if 'k_env_step' in r['Name']:
+            out['k_env_step_avg_us'] = float(r['AverageNs']) / 1e3
+            out['k_env_step_calls'] = int(r['Calls'])
+pmc = {}
+for p in sorted(glob.glob(os.path.join(src, 'pmc*', '*', '*counter_collection.csv'))):
+    acc = collections.defaultdict(list)
+    meta = None
+    for r in csv.DictReader(open(p)):
+        if 'k_env_step' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+            meta = r
+    for k, v in acc.items():
+        pmc[k] = sum(v) / len(v)
+    if meta:
+        out['vgpr'] = meta.get('VGPR_Count'); out['agpr'] = meta.get('Accum_VGPR_Count'); out['sgpr'] = meta.get('SGPR_Count')
+        out['lds_bytes'] = meta.get('LDS_Block_Size'); out['scratch_bytes_per_lane'] = meta.get('Scratch_Size')
+        out['grid'] = meta.get('Grid_Size'); out['workgroup'] = meta.get('Workgroup_Size')
+out['pmc_per_launch'] = pmc
+if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
+    # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads
+    # (MI355X_MICROARCH.md, HBM section) -> doubled for the corrected figure
+    out['hbm_bytes_per_launch_raw'] = (pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024
+    out['hbm_bytes_per_launch'] = (2 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024
+lines.append('')
+lines.append('PMC counters of k_env_step<float,64> (average per launch, whole grid; separate rocprofv3 --pmc passes):')
+for k in sorted(pmc):
+    lines.append(f'  {k:24s} {pmc[k]:16.1f}')
+lines.append('')
+lines.append(json.dumps({k: v for k, v in out.items() if k != 'pmc_per_launch'}))
+b = os.path.join(src, 'bench.json')
+if os.path.exists(b):
+    lines.append('')
+    lines.append('bench.py (default flags) on the same box:')
+    lines.append(open(b).read().strip())
+open(os.path.join(dst, f'{tag}_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+if 'hbm_bytes_per_launch' in out:
+    json.dump({'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
+               'source': f'profiles/{tag}_summary.txt', 'correction': 'FETCH_SIZE doubled (gfx950: 128 B requests tallied at 64 B), WRITE_SIZE as reported'},
+              open(os.path.join(dst, 'traffic_env_step.json'), 'w'))
+print('\n'.join(lines))
