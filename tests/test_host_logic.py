@@ -1,0 +1,96 @@
+"""CPU tests of the host-side logic that does not need a device: MJCF parsing vs the baked
+model, mocap conversion, descriptor plumbing, the kernels' source running on the host
+(tests/host_emu) against the independent oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from drloco_amd import abi, mjcf, mocap, models
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'host_emu'))
+REF_XML = '/root/reference/drloco/mujoco/xml/walker3d_flat_feet.xml'
+REF_MAT = '/root/reference/mocaps/straight_walking/Trajecs_Constant_Speed_400Hz.mat'
+
+
+@pytest.fixture(scope='module')
+def emu():
+    import emu as E
+    E.lib()
+    return E
+
+
+def test_baked_model_constants(model):
+    assert (model.nbody, model.nv, model.nu, model.ngeom, model.nsite, model.frame_skip) == (8, 14, 8, 7, 8, 5)
+    assert abs(sum(model.body_mass[:8]) - 80.5) < 1e-12
+    assert model.timestep == 0.001 and model.jnt_qpos0[2] == 1.08
+    # thigh capsule runs from z=-0.05 down to z=-0.45: the geom frame's z axis points down
+    assert model.geom_mat[1][8] == pytest.approx(-1.0)
+    assert [model.act_dof[a] for a in range(8)] == list(range(6, 14))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XML), reason='reference checkout not present')
+def test_mjcf_parser_matches_baked_model(model):
+    parsed = mjcf.parse_mjcf(REF_XML, frame_skip=5)
+    assert bytes(parsed) == bytes(model)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAT), reason='reference checkout not present')
+def test_mocap_conversion_is_reproducible(refs):
+    t = mocap.convert_straight_walk_mat(REF_MAT)
+    assert np.array_equal(t.table, refs.table) and np.array_equal(t.step_off, refs.step_off)
+    assert np.array_equal(t.step_vel, refs.step_vel) and np.array_equal(t.step_is_left, refs.step_is_left)
+
+
+def test_mjcf_rejects_unsupported(tmp_path):
+    p = tmp_path / 'm.xml'
+    p.write_text('<mujoco><compiler angle="degree" coordinate="local" inertiafromgeom="false"/><option integrator="RK4"/></mujoco>')
+    with pytest.raises(ValueError):
+        mjcf.parse_mjcf(str(p), 5)
+    with pytest.raises(ValueError):
+        models.make_model('NoSuchWalker')
+
+
+@pytest.mark.parametrize('precision,tol', [(64, 1e-10), (32, 5e-3)])
+def test_kernel_source_on_host_matches_oracle_forward(emu, oracle, model, refs, precision, tol):
+    """drloco_amd/csrc/dl_core.hpp compiled for the host vs oracle/dl_oracle.c: two independent
+    formulations of the same dynamics."""
+    n = 192
+    cfg = abi.default_config()
+    rng = np.random.default_rng(0)
+    q = np.array(model.jnt_qpos0[:14])[:, None] + 0.25 * rng.standard_normal((14, n)); q[2] = rng.uniform(0.85, 1.3, n)
+    v = 1.5 * rng.standard_normal((14, n)); w = rng.standard_normal((14, n)); u = rng.uniform(-300, 300, (8, n))
+    o = oracle.OracleEnv(model, refs, cfg, n); e = emu.EmuEnv(model, refs, cfg, n, precision)
+    o.set_state(qpos=q, qvel=v, warm=w); e.set_state(qpos=q, qvel=v, warm=w)
+    qa, nc, ne, ni = o.forward(u); qb, nc2, ne2, ni2 = e.forward(u)
+    assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2)
+    err = np.abs(qa - qb) / (1 + np.abs(qa))
+    assert err.max() < tol
+
+
+def test_kernel_source_on_host_matches_oracle_rollout(emu, oracle, model, refs):
+    n, T = 48, 110
+    cfg = abi.default_config()
+    o = oracle.OracleEnv(model, refs, cfg, n); e = emu.EmuEnv(model, refs, cfg, n, 64)
+    np.testing.assert_allclose(e.reset(), o.reset(), atol=2e-6)
+    rng = np.random.default_rng(1)
+    nd = 0
+    for t in range(T):
+        a = np.clip(0.5 * rng.standard_normal((n, 8)), -1, 1).astype(np.float32)
+        o1, r1, d1, t1, _ = o.step(a.astype(np.float64)); o2, r2, d2, t2, _ = e.step(a)
+        assert np.array_equal(d1, d2)
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6)
+        np.testing.assert_allclose(r2, r1, atol=1e-6)
+        nd += int(d1.sum())
+    s1, s2 = o.get_state(), e.get_state()
+    assert np.array_equal(s1['cursor'], s2['cursor'])
+    np.testing.assert_allclose(s2['walked'], s1['walked'], rtol=1e-9, atol=1e-12)
+    assert nd > 0
+
+
+def test_config_defaults_follow_the_reference():
+    c = abi.default_config()
+    assert list(c.rew_weights) == [0.8, 0.2, 0.0] and c.alive_bonus == 0.2 and c.ep_dur_max == 3000
+    assert c.mirror_policy == 1 and c.ctrl_freq == 200.0 and c.com_z_min == 0.5
