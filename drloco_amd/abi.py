@@ -10,8 +10,9 @@ DL_MAX_BODY, DL_MAX_DOF, DL_MAX_GEOM, DL_MAX_SITE, DL_MAX_ACT = 12, 20, 12, 8, 1
 DL_JNT_SLIDE, DL_JNT_HINGE = 0, 1
 DL_GEOM_CAPSULE, DL_GEOM_BOX = 0, 1
 (DL_CUR_I_STEP, DL_CUR_POS, DL_CUR_RSI_STEP, DL_CUR_COUNT, DL_CUR_EP_DUR, DL_CUR_HAS_DIST,
- DL_CUR_EPISODE, DL_CUR_READ_STEP) = range(8)
-DL_CUR_WORDS = 8
+ DL_CUR_EPISODE, DL_CUR_READ_STEP, DL_CUR_EVAL_K) = range(9)
+DL_CUR_WORDS = 9
+EVAL_N_TIMES = 20        # drloco/config/config.py:23
 DL_OK, DL_E_INVAL, DL_E_NODEVICE, DL_E_HIP, DL_E_NOMEM = 0, -1, -2, -3, -4
 
 _d, _i = C.c_double, C.c_int32

@@ -214,7 +214,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
 // the first reset's observation is the terminal observation).
 template <typename T, typename TP>
 DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, const LaneMem<T>& mem, const DevState<T>& st, int i, int nrep,
-                          const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs) {
+                          const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs, int eval_mode) {
     const int n = st.n;
     T q[TP::NV], v[TP::NV], warm[TP::NV], zero_u[TP::NU], zero_w[TP::NV];
     int32_t cur[DL_CUR_WORDS];
@@ -225,13 +225,20 @@ DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c,
     float o[TP::OBS];
 #pragma unroll 1
     for (int rep = 0; rep < nrep; rep++) {
-        int s, p;
+        int s, p, read = -1;
         if (init_step) { s = init_step[i]; p = init_pos[i]; }
+        else if (eval_mode) {
+            // _get_deterministic_init_state (straight_walk_trajecs.py:237-265) incl. quirk Q3
+            s = cur[DL_CUR_EVAL_K];
+            p = (int)(0.75 * (double)(c.step_off[s + 1] - c.step_off[s]));
+            read = 0;
+            cur[DL_CUR_EVAL_K] = (s + 1 >= 20) ? 0 : s + 1;
+        }
         else if (st.inj_rsi && st.inj_rsi[i] >= 0) { s = st.inj_rsi[i]; p = st.inj_rsi[(size_t)n + i]; }
         else rsi_draw(c, (uint32_t)(c.env_index_base + i), (uint32_t)cur[DL_CUR_EPISODE], s, p);
         cur[DL_CUR_EPISODE] += 1;
         cur[DL_CUR_EP_DUR] = 0;
-        cur[DL_CUR_I_STEP] = s; cur[DL_CUR_RSI_STEP] = s; cur[DL_CUR_READ_STEP] = s; cur[DL_CUR_POS] = p; cur[DL_CUR_HAS_DIST] = 0;
+        cur[DL_CUR_I_STEP] = s; cur[DL_CUR_RSI_STEP] = s; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s; cur[DL_CUR_POS] = p; cur[DL_CUR_HAS_DIST] = 0;
         ref_lookup<T, TP>(c, cur, T(0), q, v);
         // lowest foot-sole corner onto the floor (mimic_env.py:547-559)
         {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP>* __res
 // selected by mask (NULL = all)
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP>* __restrict__ mp, const DevCfg<T> c, const DevState<T> st, int mode, const uint8_t* mask,
-                                                     const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs) {
+                                                     const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs, int eval_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= st.n) return;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP>* __re
     if (nrep == 0) return;
     LaneMem<T> mem{(DL_LDS T*)smem + threadIdx.x, BLOCK};
     const DL_CONST DevModel<T, TP>& m = *(const DL_CONST DevModel<T, TP>*)mp;
-    env_reset_lane<T, TP>(m, c, mem, st, i, nrep, init_step, init_pos, obs, term_obs);
+    env_reset_lane<T, TP>(m, c, mem, st, i, nrep, init_step, init_pos, obs, term_obs, eval_mode);
 }
 
 template <typename T, int BLOCK>
@@ -180,7 +180,7 @@ static int fail(int code, const std::string& what) { g_err = what; return code; 
 
 struct dl_env_s {
     virtual ~dl_env_s() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-    int n = 0, device = 0, real_size = 4;
+    int n = 0, device = 0, real_size = 4, eval_mode = 0;
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
     virtual int step(const float*, float*, float*, uint8_t*, float*, float*, hipStream_t) = 0;
@@ -286,7 +286,7 @@ template <typename T> struct EnvImpl final : dl_env_s {
     }
     int reset(const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs, hipStream_t s) override {
         if ((is == nullptr) != (ip == nullptr)) return fail(DL_E_INVAL, "init_step and init_pos must be given together");
-        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr);
+        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr, eval_mode);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
@@ -298,7 +298,7 @@ template <typename T> struct EnvImpl final : dl_env_s {
         prof_end(s);
         HIPCHK(hipGetLastError());
         if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
-        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term);
+        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term, eval_mode);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
@@ -375,6 +375,11 @@ int32_t dl_real_size(dl_handle h) { return h ? h->real_size : 0; }
 int dl_reset(dl_handle h, const uint8_t* mask, const int32_t* init_step, const int32_t* init_pos, float* obs_out, void* stream) {
     NEED(h);
     return h->reset(mask, init_step, init_pos, obs_out, (hipStream_t)stream);
+}
+int dl_set_eval(dl_handle h, int32_t on) {
+    NEED(h);
+    h->eval_mode = on != 0;
+    return DL_OK;
 }
 int dl_step(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms, void* stream) {
     NEED(h);

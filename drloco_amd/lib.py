@@ -47,6 +47,7 @@ _SIGNATURES = {
     'dl_act_dim': (_I, [_V]),
     'dl_real_size': (_I, [_V]),
     'dl_reset': (C.c_int, [_V, _P, _P, _P, _P, _P]),
+    'dl_set_eval': (C.c_int, [_V, _I]),
     'dl_step': (C.c_int, [_V, _P, _P, _P, _P, _P, _P, _P]),
     'dl_rollout_fixed': (C.c_int, [_V, _I, _P, _P, _P, _P, _P]),
     'dl_get_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),

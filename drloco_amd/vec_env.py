@@ -158,7 +158,31 @@ class HipVecEnv:
         raise AttributeError(f'cannot set {name!r} on HipVecEnv')
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
+        if method_name == 'activate_evaluation':
+            self.activate_evaluation()
+            return [None] * self.num_envs
+        if method_name == 'get_walked_distance':
+            return list(self.get_walked_distance())
         raise NotImplementedError(method_name)
+
+    # ---- MimicEnv surface used by the evaluation loop (drloco/common/callback.py:285-314) ----
+    def activate_evaluation(self, on=True):
+        """MimicEnv.activate_evaluation (mimic_env.py:245-249): deterministic init states from now on."""
+        lib.check(self._lib.dl_set_eval(self._h, int(on)))
+        self._eval = bool(on)
+
+    def is_evaluation_on(self):
+        return getattr(self, '_eval', False)
+
+    def get_walked_distance(self):
+        walked = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
+        lib.check(self._lib.dl_get_state(self._h, None, None, None, None, _ptr(walked), _stream()))
+        return walked.cpu().numpy()
+
+    @property
+    def envs(self):
+        """`eval_env.venv.envs[0].env` of the reference's evaluation loop resolves to per-walker views."""
+        return [_WalkerView(self, i) for i in range(self.num_envs)]
 
     def seed(self, seed=None):
         # the reference seeds only gym's np_random, which the env never uses (utils.py:113);
@@ -207,6 +231,31 @@ class HipVecEnv:
         q, v, fl, r = f(qpos, self.rdtype), f(qvel, self.rdtype), f(flags, torch.int32), f(rsi, torch.int32)
         lib.check(self._lib.dl_debug_inject(self._h, _ptr(q), _ptr(v), _ptr(fl), _ptr(r), _stream()))
         torch.cuda.current_stream().synchronize()
+
+
+class _WalkerView:
+    """Stands in for `Monitor(MimicEnv)` of one walker: `.env` is the walker itself."""
+
+    def __init__(self, venv, index):
+        self._venv, self._i = venv, index
+
+    @property
+    def env(self):
+        return self
+
+    def activate_evaluation(self):
+        self._venv.activate_evaluation()        # a handle-wide switch (the reference evaluates on a 1-env DummyVecEnv)
+
+    def is_evaluation_on(self):
+        return self._venv.is_evaluation_on()
+
+    def get_walked_distance(self):
+        return float(self._venv.get_walked_distance()[self._i])
+
+    def __getattr__(self, name):
+        if name in MONITOR_ATTRS or name == 'ep_lens':
+            return self._venv.get_attr(name, self._i)[0]
+        raise AttributeError(name)
 
 
 class RunningMeanStd:

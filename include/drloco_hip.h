@@ -63,7 +63,8 @@ extern "C" {
 #define DL_CUR_HAS_DIST 5   /* 1 once the cursor rolled into a later step (COM-x offset active) */
 #define DL_CUR_EPISODE 6    /* number of resets so far (RSI random-stream counter) */
 #define DL_CUR_READ_STEP 7  /* step whose table the cursor reads (differs from I_STEP only after an eval init, quirk Q3) */
-#define DL_CUR_WORDS 8
+#define DL_CUR_EVAL_K 8     /* refs.n_deterministic_inits: next step index of the deterministic (evaluation) init */
+#define DL_CUR_WORDS 9
 
 /* compiled model: the subset of an MJCF model the path needs.  One degree of freedom per
  * joint (slide/hinge only, nq == nv) as in walker3d_flat_feet.xml / walker_165cm_65kg.xml. */
@@ -170,6 +171,11 @@ int32_t dl_real_size(dl_handle h); /* 4 or 8: element size of state arrays */
  * are left untouched. */
 int dl_reset(dl_handle h, const uint8_t* mask, const int32_t* init_step, const int32_t* init_pos,
              float* obs_out, void* stream);
+
+/* MimicEnv.activate_evaluation (mimic_env.py:245-249) for every walker of the handle: later resets
+ * use _get_deterministic_init_state (straight_walk_trajecs.py:237-265, incl. quirk Q3: the state is
+ * read from step 0's table at 75 % of step k's length, k cycling 0..19) instead of RSI. */
+int dl_set_eval(dl_handle h, int32_t on);
 
 /* One control step of every walker: MimicEnv.step (mimic_env.py:60-126) followed by the
  * vec-env auto-reset (SubprocVecEnv worker: terminal_observation + reset).

@@ -736,6 +736,7 @@ struct dlo_env_s {
     double* step_vel;
     walker_t* w;
     data_t d;
+    int eval_mode;
 };
 
 dlo_env* dlo_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_config* cfg, int32_t n) {
@@ -871,13 +872,22 @@ static void reset_walker(dlo_env* e, int i, int inj_step, int inj_pos, double* o
     const dl_model_desc* m = &e->mm.m;
     int32_t* c = w->cur;
     int32_t s, p;
+    int read = -1;
     if (inj_step >= 0) { s = inj_step; p = inj_pos; }
+    else if (e->eval_mode) {
+        /* _get_deterministic_init_state (straight_walk_trajecs.py:237-265): step k, 75 % of ITS length,
+         * but the kinematics are read from step 0's table (quirk Q3) */
+        s = c[DL_CUR_EVAL_K];
+        p = (int32_t)(0.75 * step_len(e, s));
+        read = 0;
+        c[DL_CUR_EVAL_K] = (s + 1 >= 20) ? 0 : s + 1;
+    }
     else if (w->inject_rsi) { s = w->inj_rsi_step; p = w->inj_rsi_pos; }
     else dlo_rsi_draw(e->cfg.seed, (uint32_t)(e->cfg.env_index_base + i), (uint32_t)c[DL_CUR_EPISODE], e->n_steps, e->step_off, &s, &p);
     c[DL_CUR_EPISODE] += 1;
     c[DL_CUR_EP_DUR] = 0;
     w->walked = 0;
-    c[DL_CUR_I_STEP] = s; c[DL_CUR_RSI_STEP] = s; c[DL_CUR_READ_STEP] = s; c[DL_CUR_POS] = p; c[DL_CUR_HAS_DIST] = 0;
+    c[DL_CUR_I_STEP] = s; c[DL_CUR_RSI_STEP] = s; c[DL_CUR_READ_STEP] = read >= 0 ? read : s; c[DL_CUR_POS] = p; c[DL_CUR_HAS_DIST] = 0;
     w->comz_off = 0;
     ref_lookup(e, w, w->q, w->v);
     double low = lowest_site(e, w->q);
@@ -1038,6 +1048,7 @@ void dlo_forward(dlo_env* e, const double* ctrl, double* qacc, int32_t* ncon, in
         if (niter) niter[i] = e->d.niter;
     }
 }
+void dlo_set_eval(dlo_env* e, int32_t on) { e->eval_mode = on != 0; }
 void dlo_inject_exception(dlo_env* e, int32_t i) { e->w[i].inject_exc = 1; }
 void dlo_inject_rsi(dlo_env* e, int32_t i, int32_t step, int32_t pos) {
     e->w[i].inject_rsi = step >= 0;

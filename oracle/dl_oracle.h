@@ -51,6 +51,8 @@ void dlo_set_state(dlo_env* e, const double* qpos, const double* qvel, const dou
                    const int32_t* cursor, const double* walked);
 void dlo_forward(dlo_env* e, const double* ctrl, double* qacc, int32_t* ncon, int32_t* nefc,
                  int32_t* niter);
+/* MimicEnv.activate_evaluation for all walkers */
+void dlo_set_eval(dlo_env* e, int32_t on);
 /* inject a "MujocoException" for walker i at its next step (mimic_env.py:86-91) */
 void dlo_inject_exception(dlo_env* e, int32_t i);
 /* all following resets of walker i use (step,pos) as the RSI draw; step < 0 clears */

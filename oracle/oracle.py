@@ -156,6 +156,9 @@ class OracleEnv:
         lib().dlo_forward(self.h, _p(u), _p(qacc), _p(ncon, C.c_int32), _p(nefc, C.c_int32), _p(nit, C.c_int32))
         return qacc, ncon, nefc, nit
 
+    def set_eval(self, on=True):
+        lib().dlo_set_eval(self.h, C.c_int32(int(on)))
+
     def inject_exception(self, i):
         lib().dlo_inject_exception(self.h, C.c_int32(i))
 

@@ -407,6 +407,28 @@ def main():
               et_positions=np.array(mon.et_positions),
               difficult_rsi_phases=np.array(mon.difficult_rsi_phases))
     np.savez_compressed(os.path.join(OUT, 'G7_monitor.npz'), **g7)
+    # ---------------- G8: deterministic (evaluation) init states ----------------
+    env = make_env(walker_mod, refs_mod)
+    env._EVAL_MODEL = True
+    n = 45
+    g8 = dict(i_step=np.zeros(n, np.int32), pos=np.zeros(n, np.int32), trajec_len=np.zeros(n, np.int32),
+              qpos=np.zeros((n, 14)), qvel=np.zeros((n, 14)), is_left=np.zeros(n, np.int32))
+    for k in range(n):
+        q, v = env.get_init_state(not env.is_evaluation_on() and not env._FOLLOW_DESIRED_SPEED_PROFILE)
+        g8['i_step'][k], g8['pos'][k], g8['trajec_len'][k] = env.refs._i_step, env.refs._pos, env.refs._trajec_len
+        g8['qpos'][k], g8['qvel'][k] = np.asarray(q, float), np.asarray(v, float)
+        g8['is_left'][k] = env.refs.is_step_left()
+    # cursor trace after one evaluation init (k = 0 again after 45 = 2*20 + 5 -> next is k = 5)
+    q, v = env.get_init_state(False)
+    T = 160
+    tr = dict(t_i_step=np.zeros(T, np.int32), t_pos=np.zeros(T, np.int32), t_len=np.zeros(T, np.int32), t_comx=np.zeros(T), t_phase=np.zeros(T))
+    tr['t_start'] = np.array([env.refs._i_step, env.refs._pos, env.refs._trajec_len])
+    for t in range(T):
+        env.refs.next()
+        tr['t_i_step'][t], tr['t_pos'][t], tr['t_len'][t] = env.refs._i_step, env.refs._pos, env.refs._trajec_len
+        tr['t_comx'][t] = float(env.refs.get_qpos()[0])
+        tr['t_phase'][t] = env.refs.get_phase_variable()
+    np.savez_compressed(os.path.join(OUT, 'G8_eval_init.npz'), **g8, **tr)
     print('golden fixtures written to', OUT)
 
 

@@ -18,6 +18,7 @@ template <typename T> struct Emu {
     std::vector<double> walked, mon;
     std::vector<T> inj_q, inj_v;
     int n;
+    int eval_mode = 0;
 };
 
 template <typename T> static Emu<T>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
@@ -51,7 +52,7 @@ template <typename T> static void emu_reset(Emu<T>* e, const uint8_t* mask, cons
     LaneMem<T> mem{e->lane.data(), 1};
     for (int i = 0; i < e->n; i++) {
         if (mask && !mask[i]) continue;
-        env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, 1, is, ip, obs, nullptr);
+        env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, 1, is, ip, obs, nullptr, e->eval_mode);
     }
 }
 template <typename T> static void emu_step(Emu<T>* e, const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms) {
@@ -60,7 +61,7 @@ template <typename T> static void emu_step(Emu<T>* e, const float* act, float* o
         env_step_lane<T, TP>(e->m, e->c, mem, e->st, i, act, obs, rew, done, term, terms, e->inj_q.data(), e->inj_v.data(), e->inj_flags.data());
     for (int i = 0; i < e->n; i++) {
         e->inj_flags[i] = 0;
-        if (e->need[i]) env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, e->need[i], nullptr, nullptr, obs, term);
+        if (e->need[i]) env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, e->need[i], nullptr, nullptr, obs, term, e->eval_mode);
     }
 }
 template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
@@ -98,6 +99,7 @@ template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc,
         auto* e = (Emu<T>*)h; e->inj_flags[i] = flag;                                                                     \
         if (q) for (int j = 0; j < TP::NV; j++) { e->inj_q[(size_t)j * e->n + i] = q[j]; e->inj_v[(size_t)j * e->n + i] = v[j]; } } \
     extern "C" void dle_inject_rsi_##SUF(void* h, int i, int s, int p) { auto* e = (Emu<T>*)h; e->inj[i] = s; e->inj[(size_t)e->n + i] = p; } \
+    extern "C" void dle_set_eval_##SUF(void* h, int on) { ((Emu<T>*)h)->eval_mode = on; }                                \
     extern "C" void dle_mon_##SUF(void* h, int word, double* out) { auto* e = (Emu<T>*)h; memcpy(out, e->mon.data() + (size_t)word * e->n, e->n * 8); }
 
 EMU_API(f64, double)

@@ -97,6 +97,9 @@ class EmuEnv:
         q = np.ascontiguousarray(qpos, self.rt); v = np.ascontiguousarray(qvel, self.rt)
         self._f('inject')(self.h, C.c_int(i), C.c_int(1), _p(q, self.ct), _p(v, self.ct))
 
+    def set_eval(self, on=True):
+        self._f('set_eval')(self.h, C.c_int(int(on)))
+
     def inject_exception(self, i):
         self._f('inject')(self.h, C.c_int(i), C.c_int(2), None, None)
 

@@ -422,3 +422,26 @@ def test_vecnormalize_save_load_and_attrs(torch_cuda, model, refs, tmp_path):
     vn.set_attr('ep_lens', [])
     assert all(len(x) == 0 for x in vn.get_attr('ep_lens'))
     assert vn.normalize_obs(vn.get_original_obs()).shape == (96, 29)
+
+
+def test_evaluation_mode_matches_oracle(torch_cuda, oracle, model, refs):
+    """activate_evaluation -> deterministic init states (quirk Q3), through the eval-loop surface."""
+    n = 32
+    dev, orc = make_pair(oracle, model, refs, n, 64)
+    view = dev.envs[0].env                       # what callback.py:285-286 does
+    view.activate_evaluation()
+    orc.set_eval(True)
+    assert dev.is_evaluation_on()
+    for rep in range(3):
+        np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
+    s1, s2 = orc.get_state(), dev.get_state()
+    assert np.array_equal(s1['cursor'], s2['cursor'])
+    assert (s2['cursor'][abi.DL_CUR_EVAL_K] == 3).all() and (s2['cursor'][abi.DL_CUR_READ_STEP] == 0).all()
+    rng = np.random.default_rng(0)
+    for t in range(100):
+        a = np.clip(0.5 * rng.standard_normal((n, 8)), -1, 1).astype(np.float32)
+        o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2)
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6)
+    np.testing.assert_allclose(view.get_walked_distance(), orc.get_state()['walked'][0], rtol=1e-6)
+    assert np.array_equal(orc.get_state()['cursor'], dev.get_state()['cursor'])

@@ -199,3 +199,35 @@ def test_rsi_stream_is_deterministic_and_in_range(oracle, refs):
             assert (s, p) == oracle.rsi_draw(1234, env_id, ep, refs.step_off)
             seen.add(s)
     assert len(seen) == 30
+
+
+def test_G8_evaluation_init(oracle, model, refs):
+    """_get_deterministic_init_state incl. quirk Q3 (state read from step 0's table)."""
+    g = load('G8_eval_init.npz')
+    env = make_env(oracle, model, refs, n=1, ep_dur_max=10 ** 9)
+    env.set_eval(True)
+    n = len(g['i_step'])
+    for k in range(n):
+        env.reset()
+        st = env.get_state()
+        cur = st['cursor'][:, 0]
+        assert cur[abi.DL_CUR_I_STEP] == g['i_step'][k] == k % 20
+        assert cur[abi.DL_CUR_POS] - 2 == g['pos'][k]          # reset_model advances the cursor once
+        assert cur[abi.DL_CUR_READ_STEP] == 0 and refs.step_len[0] == g['trajec_len'][k]
+        assert cur[abi.DL_CUR_EVAL_K] == (k + 1) % 20
+        assert np.array_equal(np.delete(st['qpos'][:, 0], 2), np.delete(g['qpos'][k], 2))
+        assert np.array_equal(st['qvel'][:, 0], g['qvel'][k])
+    # cursor trace after the next evaluation init: rolls from step 0's table into step k+1 with step k's end-x
+    env.reset()
+    q_up = np.array(model.jnt_qpos0[:14])
+    T = len(g['t_i_step'])
+    for t in range(T):
+        st = env.get_state()['cursor'][:, 0]
+        assert st[abi.DL_CUR_I_STEP] == g['t_i_step'][t] and st[abi.DL_CUR_POS] == g['t_pos'][t], t
+        assert refs.step_len[st[abi.DL_CUR_READ_STEP]] == g['t_len'][t]
+        qr, _ = env.ref_lookup(0)
+        assert qr[0] == g['t_comx'][t], t
+        env.inject_state(0, q_up, np.zeros(14))
+        obs, _, done, _, _ = env.step(np.zeros((1, 8)))
+        assert not done[0]
+    assert g['t_i_step'].max() > g['t_start'][0]      # the trace crossed a rollover
