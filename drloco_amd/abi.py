@@ -8,6 +8,7 @@ import ctypes as C
 DL_ABI_VERSION = 1
 DL_MAX_BODY, DL_MAX_DOF, DL_MAX_GEOM, DL_MAX_SITE, DL_MAX_ACT = 12, 20, 12, 8, 16
 DL_JNT_SLIDE, DL_JNT_HINGE = 0, 1
+DL_ENV_STRAIGHT, DL_ENV_LOCO3D = 0, 1
 DL_GEOM_CAPSULE, DL_GEOM_BOX = 0, 1
 (DL_CUR_I_STEP, DL_CUR_POS, DL_CUR_RSI_STEP, DL_CUR_COUNT, DL_CUR_EP_DUR, DL_CUR_HAS_DIST,
  DL_CUR_EPISODE, DL_CUR_READ_STEP, DL_CUR_EVAL_K) = range(9)
@@ -55,8 +56,16 @@ class Config(C.Structure):
     _fields_ = [
         ('rew_weights', _d * 3), ('rew_scale', _d), ('alive_bonus', _d), ('com_z_min', _d),
         ('ctrl_freq', _d), ('ep_dur_max', _i), ('mirror_policy', _i), ('precision', _i),
-        ('env_index_base', _i), ('seed', C.c_uint64),
+        ('env_index_base', _i), ('seed', C.c_uint64), ('env_kind', _i), ('reserved', _i),
     ]
+
+
+def loco3d_config(**kw):
+    """Defaults for MimicWalker165cm65kg: CTRL_FREQ 100 (config.py:20); the policy-mirroring modification
+    must be off because Loco3dReferenceTrajectories has no is_step_left."""
+    base = dict(env_kind=DL_ENV_LOCO3D, ctrl_freq=100.0, mirror_policy=0)
+    base.update(kw)
+    return default_config(**base)
 
 
 def default_config(**kw):
@@ -72,6 +81,7 @@ def default_config(**kw):
     c.precision = 32
     c.env_index_base = 0
     c.seed = 1234
+    c.env_kind = DL_ENV_STRAIGHT
     for k, v in kw.items():
         if k == 'rew_weights':
             c.rew_weights[:] = list(v)

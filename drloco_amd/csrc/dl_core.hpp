@@ -74,6 +74,7 @@ template <int N, typename F> DL_HD void static_for(F&& f) { static_for_impl(f, s
 // ------------------------------------------------------------------------------------------
 // topology of walker3d_flat_feet.xml (/root/reference/drloco/mujoco/xml/walker3d_flat_feet.xml:15-80)
 struct TopoStraight {
+    static constexpr int ENV_KIND = 0;             // DL_ENV_STRAIGHT
     static constexpr int NB = 8, NV = 14, NU = 8, NG = 7, NS = 8, NLIM = 8;
     static constexpr int MAXCON = 18;              // 5 capsules x 2 + 2 boxes x 4
     static constexpr int MAXROW = NLIM + 4 * MAXCON; // 80
@@ -138,6 +139,70 @@ struct TopoStraight {
     static constexpr int act_neg(int k) { return act_neg_[k]; }
 };
 
+
+// topology of walker_165cm_65kg.xml (/root/reference/drloco/mujoco/xml/walker_165cm_65kg.xml:15-95):
+// pelvis (3 slides + 3 hinges) -> torso (3 lumbar hinges), and two legs of hip (3 hinges), knee, ankle
+struct TopoWalker165 {
+    static constexpr int ENV_KIND = 1;             // DL_ENV_LOCO3D
+    static constexpr int NB = 9, NV = 19, NU = 13, NG = 8, NS = 8, NLIM = 13;
+    static constexpr int MAXCON = 24;              // 4 boxes x 4 + 4 capsules x 2
+    static constexpr int MAXROW = NLIM + 4 * MAXCON; // 109
+    static constexpr int OBS = 47;                 // 8 joint-phase features + 2 desired velocities + 18 + 19
+    static constexpr int body_parent_[NB] = {0, 0, 1, 1, 3, 4, 1, 6, 7};
+    static constexpr int dof_body_[NV] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 5, 6, 6, 6, 7, 8};
+    static constexpr int dof_type_[NV] = {0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static constexpr int dof_axis_[NV] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 0, 2, 1, 1, 1, 0, 2, 1, 1};
+    static constexpr int dof_sign_[NV] = {1, -1, 1, 1, -1, 1, 1, -1, 1, -1, 1, -1, -1, 1, -1, -1, -1, -1, -1};
+    static constexpr int dof_parent_[NV] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 5, 9, 10, 11, 12, 5, 14, 15, 16, 17};
+    static constexpr int dof_limited_[NV] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static constexpr int geom_body_[NG] = {1, 2, 3, 4, 5, 6, 7, 8};
+    static constexpr int geom_type_[NG] = {1, 1, 0, 0, 1, 0, 0, 1};
+    static constexpr int site_body_[NS] = {5, 5, 5, 5, 8, 8, 8, 8};
+    // motors: lumbar_extension, lumbar_bending, lumbar_rotation, then the legs (xml:81-95)
+    static constexpr int act_dof_[NU] = {7, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18};
+    static constexpr int body_parent(int b) { return body_parent_[b]; }
+    static constexpr int dof_body(int j) { return dof_body_[j]; }
+    static constexpr int dof_type(int j) { return dof_type_[j]; }
+    static constexpr int dof_axis(int j) { return dof_axis_[j]; }
+    static constexpr int dof_sign(int j) { return dof_sign_[j]; }
+    static constexpr int dof_parent(int j) { return dof_parent_[j]; }
+    static constexpr int dof_limited(int j) { return dof_limited_[j]; }
+    static constexpr int geom_body(int g) { return geom_body_[g]; }
+    static constexpr int geom_type(int g) { return geom_type_[g]; }
+    static constexpr int site_body(int s) { return site_body_[s]; }
+    static constexpr int act_dof(int a) { return act_dof_[a]; }
+    static constexpr bool dof_anc(int i, int j) {
+        while (i >= 0) { if (i == j) return true; i = dof_parent_[i]; }
+        return false;
+    }
+    static constexpr bool body_anc(int b, int j) {
+        while (b > 0) { if (dof_body_[j] == b) return true; b = body_parent_[b]; }
+        return false;
+    }
+    static constexpr int body_last_dof(int b) {
+        while (b > 0) {
+            int last = -1;
+            for (int j = 0; j < NV; j++) if (dof_body_[j] == b) last = j;
+            if (last >= 0) return last;
+            b = body_parent_[b];
+        }
+        return -1;
+    }
+    static constexpr uint32_t body_mask(int b) {
+        uint32_t m = 0;
+        for (int j = 0; j < NV; j++) if (body_anc(b, j)) m |= 1u << j;
+        return m;
+    }
+    // joints whose (angle, velocity) phase plot replaces the phase variable (mimic_walker_165cm_65kg.py:40-43)
+    static constexpr int phase_joint_[4] = {9, 12, 14, 17};
+    static constexpr int phase_joint(int k) { return phase_joint_[k]; }
+    // no policy mirroring for this walker (Loco3dReferenceTrajectories has no is_step_left)
+    static constexpr int obs_perm(int k) { return k; }
+    static constexpr int obs_neg(int) { return 0; }
+    static constexpr int act_perm(int k) { return k; }
+    static constexpr int act_neg(int) { return 0; }
+};
+
 // ------------------------------------------------------------------------------------------
 // numeric model parameters (uniform across lanes: kernel argument -> SGPRs / scalar loads)
 template <typename T, typename TP> struct DevModel {
@@ -160,6 +225,7 @@ template <typename T> struct DevCfg {
     const int32_t* step_off;   // [n_steps+1]
     const int32_t* step_is_left;
     const T* step_vel;
+    const double* pref;        // loco3d: prefix sums [2][total_len+1] of the reference pelvis x / z velocity rows
 };
 
 // ------------------------------------------------------------------------------------------
@@ -179,6 +245,8 @@ DL_HD float dl_abs(float x) { return fabsf(x); }
 DL_HD double dl_abs(double x) { return fabs(x); }
 DL_HD float dl_exp(float x) { return expf(x); }
 DL_HD double dl_exp(double x) { return exp(x); }
+DL_HD float dl_atan2(float y, float x) { return atan2f(y, x); }
+DL_HD double dl_atan2(double y, double x) { return atan2(y, x); }
 DL_HD float dl_pow(float x, float y) { return powf(x, y); }
 DL_HD double dl_pow(double x, double y) { return pow(x, y); }
 // float sincos: Cody-Waite reduction by pi/2 (3 constants) + minimax polynomials on [-pi/4, pi/4].
@@ -245,7 +313,9 @@ template <typename TP> struct MemLayout {
     static constexpr int CON_PY = CON_PX + TP::MAXCON, CON_PZ = CON_PY + TP::MAXCON;
     static constexpr int CON_TX = CON_PZ + TP::MAXCON, CON_TY = CON_TX + TP::MAXCON;   // first tangent (unit, in the floor plane)
     static constexpr int CON_MU = CON_TY + TP::MAXCON, CON_DIST = CON_MU + TP::MAXCON;
-    static constexpr int MAT = CON_DIST + TP::MAXCON;         // mass matrix, tree pattern, lower
+    static constexpr int CON_BODY = CON_DIST + TP::MAXCON;    // body id of the contact (small integer stored as T)
+    static constexpr int LIM_CODE = CON_BODY + TP::MAXCON;    // per limit row: dof | 32 * upper-side flag
+    static constexpr int MAT = LIM_CODE + TP::NLIM;           // mass matrix, tree pattern, lower
     // position of M[i][j] (j ancestor-or-self of i) in the packed pattern
     static constexpr int mat_index(int i, int j) {
         int n = 0;
@@ -469,9 +539,7 @@ DL_HD void inertia_and_bias(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>&
 // ------------------------------------------------------------------------------------------
 // constraint bookkeeping of one evaluation
 template <typename TP> struct EfcInfo {
-    int nlim, ncon, nefc;
-    uint64_t lim_code;   // 5 bits per limit row: dof (4) | upper-side flag (1)
-    uint64_t con_body;   // 3 bits per contact: body id
+    int nlim, ncon, nefc;    // limit codes and contact bodies live in lane memory (LIM_CODE / CON_BODY)
 };
 
 // twist of every body under generalised velocity x (for J x) -- returns vel per dof
@@ -510,7 +578,7 @@ template <typename T, typename TP>
 DL_HD void make_constraints(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>& k, const T (&q)[TP::NV],
                             const LaneMem<T>& mem, EfcInfo<TP>& e) {
     using L = MemLayout<TP>;
-    e.nlim = 0; e.ncon = 0; e.lim_code = 0; e.con_body = 0;
+    e.nlim = 0; e.ncon = 0;
     // joint limits: rows +-e_j (detected per dof; finished in the row loop below)
     static_for<TP::NV>([&](auto ji) {
         constexpr int j = ji.value;
@@ -521,7 +589,7 @@ DL_HD void make_constraints(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>&
                 const int r = e.nlim;
                 mem(L::ROW_JAREF + r) = lo ? dlo : dhi;
                 mem(L::ROW_D + r) = m.dof_invw[j];
-                e.lim_code |= (uint64_t)(j | (lo ? 0 : 16)) << (5 * r);
+                mem(L::LIM_CODE + r) = T(j | (lo ? 0 : 32));
                 e.nlim = r + 1;
             }
         }
@@ -539,7 +607,7 @@ DL_HD void make_constraints(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>&
         if (c >= TP::MAXCON) return;
         mem(L::CON_PX + c) = p.x; mem(L::CON_PY + c) = p.y; mem(L::CON_PZ + c) = p.z;
         mem(L::CON_TX + c) = tx; mem(L::CON_TY + c) = ty; mem(L::CON_MU + c) = mu; mem(L::CON_DIST + c) = dist;
-        e.con_body |= (uint64_t)body << (3 * c);
+        mem(L::CON_BODY + c) = T(body);
         e.ncon = c + 1;
     };
     static_for<TP::NG>([&](auto gi) {
@@ -581,7 +649,7 @@ DL_HD void make_constraints(const DL_CONST DevModel<T, TP>& m, const Kin<T, TP>&
     });
     // contact rows: 4 pyramid edges n +- mu t1, n +- mu t2; t1 = (tx, ty, 0), t2 = n x t1 = (-ty, tx, 0)
     for (int c = 0; c < e.ncon; c++) {
-        const int body = (int)((e.con_body >> (3 * c)) & 7);
+        const int body = (int)mem(L::CON_BODY + c);
         const T mu = mem(L::CON_MU + c), dist = mem(L::CON_DIST + c);
         T invw = T(0);
         static_for<TP::NB - 1>([&](auto bi) { if (body == bi.value + 1) invw = m.body_invw[bi.value + 1]; });
@@ -601,16 +669,16 @@ template <typename T, typename TP>
 DL_HD void mul_J(const Kin<T, TP>& k, const EfcInfo<TP>& e, const LaneMem<T>& mem, const T (&x)[TP::NV]) {
     using L = MemLayout<TP>;
     for (int r = 0; r < e.nlim; r++) {
-        const int code = (int)((e.lim_code >> (5 * r)) & 31), j = code & 15;
+        const int code = (int)mem(L::LIM_CODE + r), j = code & 31;
         T xj = T(0);
         static_for<TP::NV>([&](auto ji) { if constexpr (TP::dof_limited(ji.value)) if (j == ji.value) xj = x[ji.value]; });
-        mem(L::ROW_JV + r) = (code & 16) ? -xj : xj;
+        mem(L::ROW_JV + r) = (code & 32) ? -xj : xj;
     }
     if (e.ncon == 0) return;
     SV<T> vel[TP::NV];
     body_twists<T, TP>(k, x, vel);
     for (int c = 0; c < e.ncon; c++) {
-        const int body = (int)((e.con_body >> (3 * c)) & 7);
+        const int body = (int)mem(L::CON_BODY + c);
         const V3<T> p = mk<T>(mem(L::CON_PX + c), mem(L::CON_PY + c), mem(L::CON_PZ + c));
         const T tx = mem(L::CON_TX + c), ty = mem(L::CON_TY + c), mu = mem(L::CON_MU + c);
         const SV<T> tw = twist_of_body<T, TP>(vel, body);
@@ -847,8 +915,8 @@ DL_HD void forward(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, con
             for (int r = 0; r < e.nlim; r++) {
                 const T jar = mem(L::ROW_JAREF + r), D = mem(L::ROW_D + r);
                 const bool on = jar < T(0), was = (act_lo >> r) & 1ull;
-                const int code = (int)((e.lim_code >> (5 * r)) & 31), j = code & 15;
-                const T f = on ? ((code & 16) ? D * jar : -D * jar) : T(0);
+                const int code = (int)mem(L::LIM_CODE + r), j = code & 31;
+                const T f = on ? ((code & 32) ? D * jar : -D * jar) : T(0);
                 if (on) c += T(0.5) * D * jar * jar;
                 const T dH = (on == was) ? T(0) : (on ? D : -D);
                 static_for<TP::NV>([&](auto ji) {
@@ -858,7 +926,7 @@ DL_HD void forward(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, con
             }
             for (int cc = 0; cc < e.ncon; cc++) {
                 const int r0 = e.nlim + 4 * cc;
-                const int body = (int)((e.con_body >> (3 * cc)) & 7);
+                const int body = (int)mem(L::CON_BODY + cc);
                 const V3<T> p = mk<T>(mem(L::CON_PX + cc), mem(L::CON_PY + cc), mem(L::CON_PZ + cc));
                 const T tx = mem(L::CON_TX + cc), ty = mem(L::CON_TY + cc), mu = mem(L::CON_MU + cc);
                 T fs[4], Dr[4];

@@ -62,7 +62,13 @@ DL_HD void ref_lookup(const DevCfg<T>& c, const int32_t (&cur)[DL_CUR_WORDS], T 
     else qr[2] -= comz_off;
 }
 
-template <typename T> DL_HD void cursor_next(const DevCfg<T>& c, int32_t (&cur)[DL_CUR_WORDS]) {
+template <typename T, typename TP> DL_HD void cursor_next(const DevCfg<T>& c, int32_t (&cur)[DL_CUR_WORDS]) {
+    if constexpr (TP::ENV_KIND == 1) {
+        // BaseReferenceTrajectories.next (drloco/ref_trajecs/base_ref_trajecs.py:95-103): wrap to the start
+        cur[DL_CUR_POS] += c.stride;
+        if (cur[DL_CUR_POS] >= c.step_off[1] - c.step_off[0] - 1) cur[DL_CUR_POS] = 0;
+        return;
+    }
     cur[DL_CUR_POS] += c.stride;
     const int rs = cur[DL_CUR_READ_STEP];
     const int dif = cur[DL_CUR_POS] - (c.step_off[rs + 1] - c.step_off[rs]) + 1;
@@ -77,6 +83,24 @@ template <typename T> DL_HD void cursor_next(const DevCfg<T>& c, int32_t (&cur)[
 
 template <typename T, typename TP>
 DL_HD void get_obs(const DevCfg<T>& c, const int32_t (&cur)[DL_CUR_WORDS], const T (&q)[TP::NV], const T (&v)[TP::NV], float (&o)[TP::OBS]) {
+    if constexpr (TP::ENV_KIND == 1) {
+        // MimicWalker165cm65kg: 4 x (phase angle, phase radius) from joint phase plots
+        // (mimic_env.py:330-401), 2 desired velocities = mean reference pelvis x / z velocity over the
+        // next 0.5 s (loco3d_trajecs.py:51-97, through float64 prefix sums), qpos[1:], qvel
+        static_for<4>([&](auto ki) {
+            constexpr int kk = ki.value, j = TP::phase_joint(kk);
+            o[2 * kk] = (float)(dl_atan2(v[j], -q[j]) * T(0.31830988618379067154));
+            o[2 * kk + 1] = (float)(dl_sqrt(q[j] * q[j] + v[j] * v[j]) / T(5));
+        });
+        const int L = c.step_off[1] - c.step_off[0], pos = cur[DL_CUR_POS];
+        const int end = pos + 250 < L - 1 ? pos + 250 : L - 1;
+        const double cnt = (double)(end - pos);
+        o[8] = (float)((c.pref[end] - c.pref[pos]) / cnt);
+        o[9] = (float)((c.pref[(size_t)c.total_len + 1 + end] - c.pref[(size_t)c.total_len + 1 + pos]) / cnt);
+        static_for<TP::NV - 1>([&](auto ji) { o[10 + ji.value] = (float)q[ji.value + 1]; });
+        static_for<TP::NV>([&](auto ji) { o[9 + TP::NV + ji.value] = (float)v[ji.value]; });
+        return;
+    }
     const int rs = cur[DL_CUR_READ_STEP];
     T raw[TP::OBS];
     raw[0] = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
@@ -150,7 +174,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
         const T x = dl_clamp((T)actions[(size_t)i * TP::NU + a], T(-1), T(1));
         raw[a] = x > T(0) ? x * m.ctrl_hi[a] : dl_abs(x) * m.ctrl_lo[a];
     });
-    const bool mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+    const bool mirr_a = TP::ENV_KIND == 0 && c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
     static_for<TP::NU>([&](auto ai) {
         constexpr int a = ai.value;
         const T mir = TP::act_neg(a) ? -raw[TP::act_perm(a)] : raw[TP::act_perm(a)];
@@ -182,7 +206,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
         terms[0] = terms[1] = terms[2] = 1.0;    // the in-step reset() re-evaluated the reward terms (:562)
         st.need_reset[i] = 2;
     } else {
-        cursor_next(c, cur);
+        cursor_next<T, TP>(c, cur);
         float o[TP::OBS];
         get_obs<T, TP>(c, cur, q, v, o);
         cur[DL_CUR_EP_DUR] += 1;
@@ -227,6 +251,7 @@ DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c,
     for (int rep = 0; rep < nrep; rep++) {
         int s, p, read = -1;
         if (init_step) { s = init_step[i]; p = init_pos[i]; }
+        else if (eval_mode && TP::ENV_KIND == 1) { s = 0; p = 0; }   // base get_deterministic_init_state(0 %)
         else if (eval_mode) {
             // _get_deterministic_init_state (straight_walk_trajecs.py:237-265) incl. quirk Q3
             s = cur[DL_CUR_EVAL_K];
@@ -255,7 +280,7 @@ DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c,
         }
         // set_state -> mj_forward: qacc of the initial state seeds the warmstart
         (void)forward_io<T, TP>(m, mem, q, v, zero_u, zero_w, warm);
-        cursor_next(c, cur);
+        cursor_next<T, TP>(c, cur);
         get_obs<T, TP>(c, cur, q, v, o);
         if (nrep == 2 && rep == 0 && term_obs) static_for<TP::OBS>([&](auto ki) { term_obs[(size_t)i * TP::OBS + ki.value] = o[ki.value]; });
     }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "dl_env.hpp"
 
@@ -85,6 +86,18 @@ template <typename T> inline void fill_dev_cfg(const dl_config& c, const dl_refs
     o.inv_ctrl_freq = (T)(1.0 / c.ctrl_freq);
     o.ep_dur_max = c.ep_dur_max; o.mirror_policy = c.mirror_policy; o.env_index_base = c.env_index_base; o.seed = c.seed;
     o.n_steps = r.n_steps; o.total_len = r.total_len; o.stride = r.stride;
+}
+
+// float64 prefix sums of the two desired-velocity rows (rows nv, nv+1 of the table): [2][total_len+1]
+inline void loco3d_prefix_sums(const dl_refs_desc& r, int nv, std::vector<double>& out) {
+    const size_t L = (size_t)r.total_len;
+    out.assign(2 * (L + 1), 0.0);
+    for (int k = 0; k < 2; k++) {
+        const double* row = r.table + (size_t)(nv + k) * L;
+        double acc = 0;
+        for (size_t i = 0; i < L; i++) { out[k * (L + 1) + i] = acc; acc += row[i]; }
+        out[k * (L + 1) + L] = acc;
+    }
 }
 
 }  // namespace dl

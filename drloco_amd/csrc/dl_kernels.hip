@@ -15,12 +15,15 @@
 #include "dl_host.hpp"
 
 using namespace dl;
-using TP = TopoStraight;
 
 // ------------------------------------------------------------------------------------------
-template <typename T> struct KernelGeom { static constexpr int BLOCK = sizeof(T) == 4 ? 64 : 32; };
+// lanes per workgroup: as many as fit the per-lane LDS footprint into one CU's 160 KiB
+template <typename T, typename TP> struct KernelGeom {
+    static constexpr size_t PER_LANE = (size_t)MemLayout<TP>::TOTAL * sizeof(T);
+    static constexpr int BLOCK = PER_LANE * 64 <= 163840 ? 64 : (PER_LANE * 32 <= 163840 ? 32 : 16);
+};
 
-template <typename T, int BLOCK>
+template <typename T, typename TP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP>* __restrict__ mp, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
                                                     float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags) {
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const DevModel<T, TP>* __res
 
 // mode 0: reset walkers whose need_reset > 0 (auto reset after a step); mode 1: reset walkers
 // selected by mask (NULL = all)
-template <typename T, int BLOCK>
+template <typename T, typename TP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP>* __restrict__ mp, const DevCfg<T> c, const DevState<T> st, int mode, const uint8_t* mask,
                                                      const int32_t* init_step, const int32_t* init_pos, float* obs, float* term_obs, int eval_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_reset(const DevModel<T, TP>* __re
     env_reset_lane<T, TP>(m, c, mem, st, i, nrep, init_step, init_pos, obs, term_obs, eval_mode);
 }
 
-template <typename T, int BLOCK>
+template <typename T, typename TP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP>* __restrict__ mp, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x * BLOCK + threadIdx.x, n = st.n;
@@ -180,7 +183,7 @@ static int fail(int code, const std::string& what) { g_err = what; return code; 
 
 struct dl_env_s {
     virtual ~dl_env_s() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-    int n = 0, device = 0, real_size = 4, eval_mode = 0;
+    int n = 0, device = 0, real_size = 4, eval_mode = 0, obs_dim = 0, act_dim = 0;
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
     virtual int step(const float*, float*, float*, uint8_t*, float*, float*, hipStream_t) = 0;
@@ -205,8 +208,8 @@ struct dl_env_s {
     }
 };
 
-template <typename T> struct EnvImpl final : dl_env_s {
-    static constexpr int BLOCK = KernelGeom<T>::BLOCK;
+template <typename T, typename TP> struct EnvImpl final : dl_env_s {
+    static constexpr int BLOCK = KernelGeom<T, TP>::BLOCK;
     static constexpr size_t LDS = (size_t)MemLayout<TP>::TOTAL * BLOCK * sizeof(T);
     DevModel<T, TP> m;          // host copy
     DevModel<T, TP>* md = nullptr;   // device copy (read through the constant address space by the kernels)
@@ -228,7 +231,7 @@ template <typename T> struct EnvImpl final : dl_env_s {
     int grid() const { return (n + BLOCK - 1) / BLOCK; }
 
     int init(const dl_model_desc& d, const dl_refs_desc& r, const dl_config& cfg, int n_, int device_) override {
-        n = n_; device = device_; real_size = sizeof(T);
+        n = n_; device = device_; real_size = sizeof(T); obs_dim = TP::OBS; act_dim = TP::NU;
         HIPCHK(hipSetDevice(device));
         fill_dev_model<T, TP>(d, m);
         fill_dev_cfg<T>(cfg, r, c);
@@ -256,6 +259,15 @@ template <typename T> struct EnvImpl final : dl_env_s {
         HIPCHK(hipMemcpy(soff, r.step_off, (r.n_steps + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(sleft, r.step_is_left, r.n_steps * sizeof(int32_t), hipMemcpyHostToDevice));
         c.table = table; c.step_off = soff; c.step_is_left = sleft; c.step_vel = svel;
+        if (TP::ENV_KIND == 1) {
+            if (r.n_steps != 1) return fail(DL_E_INVAL, "loco3d reference tables are one continuous trajectory (n_steps must be 1)");
+            std::vector<double> pref;
+            loco3d_prefix_sums(r, TP::NV, pref);
+            double* dpref;
+            if ((rc = dalloc(&dpref, pref.size()))) return rc;
+            HIPCHK(hipMemcpy(dpref, pref.data(), pref.size() * sizeof(double), hipMemcpyHostToDevice));
+            c.pref = dpref;
+        }
         // per-walker state
         st.n = n;
         if ((rc = dalloc(&st.qpos, (size_t)TP::NV * n))) return rc;
@@ -276,9 +288,9 @@ template <typename T> struct EnvImpl final : dl_env_s {
         for (int j = 0; j < TP::NV; j++) k_fill<T><<<g256, 256>>>(st.qpos + (size_t)j * n, (T)d.jnt_qpos0[j], (size_t)n);
         k_fill<int32_t><<<g256, 256>>>(st.cur + (size_t)DL_CUR_COUNT * n, 1, (size_t)n);   // count_steps_same_vel = 1
         k_fill<int32_t><<<(unsigned)((2 * n + 255) / 256), 256>>>(st.inj_rsi, -1, (size_t)2 * n);
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step<T, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_reset<T, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward<T, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step<T, TP, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_reset<T, TP, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward<T, TP, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipFree(stage));
         allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)stage));
@@ -286,19 +298,19 @@ template <typename T> struct EnvImpl final : dl_env_s {
     }
     int reset(const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs, hipStream_t s) override {
         if ((is == nullptr) != (ip == nullptr)) return fail(DL_E_INVAL, "init_step and init_pos must be given together");
-        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr, eval_mode);
+        hipLaunchKernelGGL((k_env_reset<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr, eval_mode);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
         prof_begin(s);
-        hipLaunchKernelGGL((k_env_step<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, act, obs, rew, done, term, terms,
+        hipLaunchKernelGGL((k_env_step<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, act, obs, rew, done, term, terms,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
         prof_end(s);
         HIPCHK(hipGetLastError());
         if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
-        hipLaunchKernelGGL((k_env_reset<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term, eval_mode);
+        hipLaunchKernelGGL((k_env_reset<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term, eval_mode);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
@@ -322,7 +334,7 @@ template <typename T> struct EnvImpl final : dl_env_s {
     }
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
         if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
-        hipLaunchKernelGGL((k_forward<T, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+        hipLaunchKernelGGL((k_forward<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
@@ -355,9 +367,16 @@ int dl_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_con
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DL_E_NODEVICE, "dl_create: no HIP device (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(DL_E_INVAL, "dl_create: device ordinal out of range");
     std::string why;
-    if (!check_topology<TP>(*model, why)) return fail(DL_E_INVAL, why);
     if (cfg->precision != 32 && cfg->precision != 64 && cfg->precision != 0) return fail(DL_E_INVAL, "dl_create: precision must be 32 or 64");
-    dl_env_s* h = cfg->precision == 64 ? static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<double>()) : static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<float>());
+    const bool f64 = cfg->precision == 64;
+    dl_env_s* h = nullptr;
+    if (cfg->env_kind == DL_ENV_STRAIGHT) {
+        if (!check_topology<TopoStraight>(*model, why)) return fail(DL_E_INVAL, why);
+        h = f64 ? static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<double, TopoStraight>()) : static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<float, TopoStraight>());
+    } else if (cfg->env_kind == DL_ENV_LOCO3D) {
+        if (!check_topology<TopoWalker165>(*model, why)) return fail(DL_E_INVAL, why);
+        h = f64 ? static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<double, TopoWalker165>()) : static_cast<dl_env_s*>(new (std::nothrow) EnvImpl<float, TopoWalker165>());
+    } else return fail(DL_E_INVAL, "dl_create: unknown env_kind");
     if (!h) return fail(DL_E_NOMEM, "dl_create: out of host memory");
     const int rc = h->init(*model, *refs, *cfg, n_envs, device);
     if (rc != DL_OK) { delete h; return rc; }
@@ -366,8 +385,8 @@ int dl_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_con
 }
 int dl_destroy(dl_handle h) { delete h; return DL_OK; }
 int32_t dl_num_envs(dl_handle h) { return h ? h->n : 0; }
-int32_t dl_obs_dim(dl_handle h) { return h ? TP::OBS : 0; }
-int32_t dl_act_dim(dl_handle h) { return h ? TP::NU : 0; }
+int32_t dl_obs_dim(dl_handle h) { return h ? h->obs_dim : 0; }
+int32_t dl_act_dim(dl_handle h) { return h ? h->act_dim : 0; }
 int32_t dl_real_size(dl_handle h) { return h ? h->real_size : 0; }
 
 #define NEED(h) do { if (!(h)) return fail(DL_E_INVAL, "null handle"); } while (0)
@@ -390,7 +409,7 @@ int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, f
     if (T <= 0 || !actions || !obs || !rew || !done) return fail(DL_E_INVAL, "dl_rollout_fixed: bad arguments");
     const size_t n = (size_t)h->n;
     for (int32_t t = 0; t < T; t++) {
-        const int rc = h->step(actions + (size_t)t * n * TP::NU, obs + (size_t)t * n * TP::OBS, rew + (size_t)t * n, done + (size_t)t * n, nullptr, nullptr, (hipStream_t)stream);
+        const int rc = h->step(actions + (size_t)t * n * h->act_dim, obs + (size_t)t * n * h->obs_dim, rew + (size_t)t * n, done + (size_t)t * n, nullptr, nullptr, (hipStream_t)stream);
         if (rc != DL_OK) return rc;
     }
     return DL_OK;

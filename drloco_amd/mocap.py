@@ -94,6 +94,56 @@ def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200):
     return RefTable(table, off, is_left, vel, int(stride))
 
 
+# loco3d: rows of angJoi / angDJoi used by MimicWalker165cm65kg (mimic_walker_165cm_65kg.py:6-15,
+# loco3d_trajecs.py:7-18): pelvis tx, tz, ty, list, tilt, rotation, lumbar bending, extension,
+# rotation, right hip flexion/adduction/rotation, knee, ankle, left ditto
+LOCO3D_ROWS = [3, 5, 4, 1, 0, 2, 21, 20, 22, 6, 7, 8, 9, 10, 13, 14, 15, 16, 17]
+
+
+def convert_loco3d_mat(mat_path, sample_freq=500, control_freq=100):
+    """loco3d_guoping.mat (angJoi, angDJoi: (37, L)) -> RefTable with one continuous trajectory."""
+    import scipy.io as spio
+    d = spio.loadmat(mat_path, squeeze_me=True)
+    return loco3d_table(np.asarray(d['angJoi'], np.float64), np.asarray(d['angDJoi'], np.float64), sample_freq, control_freq)
+
+
+def loco3d_table(ang, ang_vel, sample_freq=500, control_freq=100):
+    stride = sample_freq / control_freq
+    if stride != int(stride):
+        raise ValueError('sample frequency must be an integer multiple of the control frequency')
+    table = np.concatenate([ang[LOCO3D_ROWS, :], ang_vel[LOCO3D_ROWS, :]], axis=0)
+    L = table.shape[1]
+    return RefTable(table, [0, L], [0], [0.0], int(stride))
+
+
+def synthetic_loco3d(L=60000, seed=0, sample_freq=500.0):
+    """Synthetic stand-in for the missing loco3d_guoping.mat (a large blob absent from the reference
+    checkout, .MISSING_LARGE_BLOBS:1) with the same schema: angJoi / angDJoi (37, L) float64 at 500 Hz,
+    8 clips of band-limited (<= 3 Hz) sinusoid sums scaled to the joint ranges of
+    walker_165cm_65kg.xml, pelvis translating forward at ~1.2 m/s."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(L) / sample_freq
+    ang = np.zeros((37, L)); vel = np.zeros((37, L))
+    amp = {0: 0.05, 1: 0.04, 2: 0.06, 21: 0.05, 20: 0.05, 22: 0.05, 6: 0.45, 7: 0.08, 8: 0.06, 9: 0.5, 10: 0.2,
+           13: 0.45, 14: 0.08, 15: 0.06, 16: 0.5, 17: 0.2}
+    mid = {9: -0.6, 16: -0.6, 7: -0.05, 14: -0.05}
+    clip = (np.arange(L) * 8) // L
+    for row in range(37):
+        a = amp.get(row, 0.02)
+        for c in range(8):
+            m = clip == c
+            f = rng.uniform(0.6, 3.0, 3); ph = rng.uniform(0, 2 * np.pi, 3); w = rng.uniform(0.2, 1.0, 3); w /= w.sum()
+            for k in range(3):
+                ang[row, m] += a * w[k] * np.sin(2 * np.pi * f[k] * t[m] + ph[k])
+                vel[row, m] += a * w[k] * 2 * np.pi * f[k] * np.cos(2 * np.pi * f[k] * t[m] + ph[k])
+        ang[row] += mid.get(row, 0.0)
+    # pelvis translation: tx forward, tz (sim -y) small sway, ty height
+    ang[3] = 1.2 * t + 0.02 * np.sin(2 * np.pi * 1.8 * t); vel[3] = 1.2 + 0.02 * 2 * np.pi * 1.8 * np.cos(2 * np.pi * 1.8 * t)
+    ang[5] = 0.03 * np.sin(2 * np.pi * 0.9 * t); vel[5] = 0.03 * 2 * np.pi * 0.9 * np.cos(2 * np.pi * 0.9 * t)
+    ang[4] = 0.95 + 0.02 * np.sin(2 * np.pi * 1.8 * t + 0.4); vel[4] = 0.02 * 2 * np.pi * 1.8 * np.cos(2 * np.pi * 1.8 * t + 0.4)
+    return ang, vel
+
+
 if __name__ == '__main__':
     import sys
     src = sys.argv[1] if len(sys.argv) > 1 else '/root/reference/mocaps/straight_walking/Trajecs_Constant_Speed_400Hz.mat'

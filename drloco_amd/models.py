@@ -9,10 +9,12 @@ from . import abi
 from .mjcf import ModelBuilder
 
 STRAIGHT_WALKER = 'StraightMimicWalker'       # drloco/mujoco/config.py:5
-WALKER_165CM = 'MimicWalker165cm65kg'         # drloco/mujoco/config.py:6 (not built yet)
+WALKER_165CM = 'MimicWalker165cm65kg'         # drloco/mujoco/config.py:6
 
-SIM_FREQ = {STRAIGHT_WALKER: 1000}            # drloco/mujoco/config.py:13
-CTRL_FREQ = {STRAIGHT_WALKER: 200}            # drloco/config/config.py:20
+SIM_FREQ = {STRAIGHT_WALKER: 1000, WALKER_165CM: 1000}    # drloco/mujoco/config.py:13-14
+CTRL_FREQ = {STRAIGHT_WALKER: 200, WALKER_165CM: 100}      # drloco/config/config.py:20-21
+ENV_KIND = {STRAIGHT_WALKER: abi.DL_ENV_STRAIGHT, WALKER_165CM: abi.DL_ENV_LOCO3D}
+GAMMA = {STRAIGHT_WALKER: 0.995, WALKER_165CM: 0.99}       # drloco/config/hypers.py:68
 
 SLIDE, HINGE = abi.DL_JNT_SLIDE, abi.DL_JNT_HINGE
 
@@ -61,7 +63,55 @@ def walker3d_flat_feet():
     return mb.build()
 
 
-MODEL_BUILDERS = {STRAIGHT_WALKER: walker3d_flat_feet}
+def _leg165(mb, pelvis, side):
+    """walker_165cm_65kg.xml:34-78; side = -1 right, +1 left."""
+    r = side < 0
+    sfx = 'r' if r else 'l'
+    thigh = mb.body('thigh_right' if r else 'thigh_left', pelvis, (0, 0.08 * side, 0), 6.9, (0, 0, -0.2136), (0.122, 0.122, 0.024))
+    mb.joint(f'hip_flexion_{sfx}', thigh, HINGE, (0, -1, 0), limited=True, range=(-0.8727, 0.8727), damping=28, armature=0.01)
+    mb.joint(f'hip_adduction_{sfx}', thigh, HINGE, (1, 0, 0) if r else (-1, 0, 0), limited=True, range=(-0.7854, 0.0873), damping=28, armature=0.01)
+    mb.joint(f'hip_rotation_{sfx}', thigh, HINGE, (0, 0, -1), limited=True, range=(-0.26, 0.26), damping=28, armature=0.01)
+    mb.capsule(thigh, (0, 0, -0.05, 0, 0, -0.4272), 0.05, 0.9)
+    shank = mb.body('shank_right' if r else 'shank_left', thigh, (0, 0, -0.4772), 2.8, (0, 0, -0.2136), (0.04, 0.04, 0.0024))
+    mb.joint(f'knee_angle_{sfx}', shank, HINGE, (0, -1, 0), limited=True, range=(-2.6180, 0.0), damping=12, armature=0.01)
+    mb.capsule(shank, (0, 0, -0.05, 0, 0, -0.4272 if r else -0.45), 0.04, 0.9)
+    foot = mb.body('foot_right' if r else 'foot_left', shank, (0, 0, -0.4772), 1.2, (0.06, 0, -0.07), (0.003, 0.006, 0.005))
+    if r:
+        mb.joint('ankle_angle_r', foot, HINGE, (0, 1, 0), limited=True, range=(-0.3491, 0.6981), damping=20, armature=0.01)
+    else:
+        mb.joint('ankle_angle_l', foot, HINGE, (0, -1, 0), limited=True, range=(-0.6981, 0.3491), damping=20, armature=0.01)
+    mb.box(foot, (0.0675, 0.005 * side, -0.04), (0.11, 0.05, 0.04), 0.9, axisangle=(0, 0, 1, 0.05 * side))
+    fl, fr = (0.04, -0.06) if r else (0.06, -0.04)
+    for x, y in ((0.1775, fl), (0.1775, fr), (-0.0425, 0.05), (-0.0425, -0.05)):
+        mb.site(foot, (x, y, -0.08))
+    return [f'hip_flexion_{sfx}', f'hip_adduction_{sfx}', f'hip_rotation_{sfx}', f'knee_angle_{sfx}', f'ankle_angle_{sfx}']
+
+
+def walker_165cm_65kg():
+    """nq = nv = 19, nu = 13, 65.17 kg (walker_165cm_65kg.xml): pelvis (3 slides + 3 hinges, partly
+    negated axes), torso on three lumbar hinges, two legs with 3-dof hips; boxes on pelvis and torso."""
+    mb = ModelBuilder(timestep=0.001, frame_skip=SIM_FREQ[WALKER_165CM] // CTRL_FREQ[WALKER_165CM])
+    mb.floor_friction = 0.7
+    pelvis = mb.body('pelvis', 0, (0, 0, 1.035), 10.87, (0, 0, 0), (0.51, 0.82, 0.31))
+    mb.box(pelvis, (0, 0, 0.05), (0.05, 0.1, 0.04), 0.9)
+    mb.joint('pelvis_tx', pelvis, SLIDE, (1, 0, 0))
+    mb.joint('pelvis_tz', pelvis, SLIDE, (0, -1, 0))
+    mb.joint('pelvis_ty', pelvis, SLIDE, (0, 0, 1), ref=1.035)
+    mb.joint('pelvis_list', pelvis, HINGE, (1, 0, 0))
+    mb.joint('pelvis_tilt', pelvis, HINGE, (0, -1, 0))
+    mb.joint('pelvis_rotation', pelvis, HINGE, (0, 0, 1))
+    torso = mb.body('torso', pelvis, (0, 0, 0.1075), 32.5, (0, 0, 0.2475), (1.875, 3.0, 1.125))
+    mb.box(torso, (0, 0, 0.2475), (0.05, 0.12, 0.2475), 0.9)
+    mb.joint('lumbar_bending', torso, HINGE, (1, 0, 0), limited=True, range=(-0.2, 0.15))
+    mb.joint('lumbar_extension', torso, HINGE, (0, -1, 0), limited=True, range=(-0.15, 0.15))
+    mb.joint('lumbar_rotation', torso, HINGE, (0, 0, 1), limited=True, range=(-0.15, 0.15))
+    legs = _leg165(mb, pelvis, -1) + _leg165(mb, pelvis, +1)
+    for name in ['lumbar_extension', 'lumbar_bending', 'lumbar_rotation'] + legs:
+        mb.motor(name, gear=1.0, ctrlrange=(-300, 300), forcerange=(-300, 300))
+    return mb.build()
+
+
+MODEL_BUILDERS = {STRAIGHT_WALKER: walker3d_flat_feet, WALKER_165CM: walker_165cm_65kg}
 
 
 def make_model(env_id=STRAIGHT_WALKER):

@@ -56,9 +56,17 @@ class HipVecEnv:
             raise lib.DrlocoError('HipVecEnv needs a HIP device; there is no CPU fallback')
         self._lib = lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self.env_id = env_id
         self.model = model if model is not None else models.make_model(env_id)
-        self.refs = refs if refs is not None else mocap.RefTable.load()
-        self.cfg = abi.default_config(seed=seed, precision=precision, env_index_base=env_index_base, **config)
+        kind = models.ENV_KIND[env_id]
+        if refs is None:
+            if kind == abi.DL_ENV_LOCO3D:
+                raise lib.DrlocoError('MimicWalker165cm65kg needs a reference table: pass refs=mocap.convert_loco3d_mat(path) '
+                                      '(loco3d_guoping.mat is not part of the reference checkout) or a synthetic one')
+            refs = mocap.RefTable.load()
+        self.refs = refs
+        make_cfg = abi.loco3d_config if kind == abi.DL_ENV_LOCO3D else abi.default_config
+        self.cfg = make_cfg(seed=seed, precision=precision, env_index_base=env_index_base, **config)
         self.num_envs = int(num_envs)
         self.precision = precision
         self.rdtype = torch.float64 if precision == 64 else torch.float32

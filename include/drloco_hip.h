@@ -46,6 +46,10 @@ extern "C" {
 #define DL_E_HIP (-3)       /* a HIP runtime call failed */
 #define DL_E_NOMEM (-4)
 
+/* environment kinds (the reference's env_map, drloco/mujoco/config.py:9-10) */
+#define DL_ENV_STRAIGHT 0
+#define DL_ENV_LOCO3D 1
+
 /* joint / geom type codes (subset of MJCF used by the MJCF files under drloco/mujoco/xml) */
 #define DL_JNT_SLIDE 0
 #define DL_JNT_HINGE 1
@@ -147,6 +151,10 @@ typedef struct dl_config {
     int32_t precision;      /* 32 (default) or 64: arithmetic type of the dynamics kernels */
     int32_t env_index_base; /* global index of walker 0 of this shard (multi-GPU) */
     uint64_t seed;          /* RSI random stream seed */
+    int32_t env_kind;       /* DL_ENV_STRAIGHT: MimicWalker3dEnv + StraightWalkingTrajectories;
+                               DL_ENV_LOCO3D: MimicWalker165cm65kgEnv + Loco3dReferenceTrajectories
+                               (drloco/mujoco/config.py:9-10) */
+    int32_t reserved;
 } dl_config;
 
 typedef struct dl_env_s* dl_handle;

@@ -21,6 +21,9 @@
 #define NB DL_MAX_BODY
 #define NV DL_MAX_DOF
 #define MINVAL 1e-15
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #define MAXVAL 1e10
 
 /* ------------------------------------------------------------------ small linear algebra */
@@ -767,6 +770,7 @@ void dlo_destroy(dlo_env* e) {
 }
 
 static int step_len(const dlo_env* e, int s) { return e->step_off[s + 1] - e->step_off[s]; }
+static int obs_dim(const dlo_env* e) { return e->cfg.env_kind == DL_ENV_LOCO3D ? 10 + 2 * e->mm.m.nv - 1 : 1 + 2 * e->mm.m.nv; }
 
 /* refs.get_qpos()/get_qvel() at the cursor (base_ref_trajecs.py:44-56) incl. the COM-x offset of
  * _get_next_step (straight_walk_trajecs.py:338-347, quirk Q1) and the COM-z re-anchoring of
@@ -790,6 +794,12 @@ void dlo_ref_lookup(dlo_env* e, int32_t i, double* qref, double* vref) { ref_loo
 /* StraightWalkingTrajectories.next (straight_walk_trajecs.py:141-159) + _get_next_step (:322-348) */
 static void cursor_next(const dlo_env* e, walker_t* w) {
     int32_t* c = w->cur;
+    if (e->cfg.env_kind == DL_ENV_LOCO3D) {
+        /* BaseReferenceTrajectories.next (base_ref_trajecs.py:95-103): the cursor wraps to 0 */
+        c[DL_CUR_POS] += e->stride;
+        if (c[DL_CUR_POS] >= step_len(e, 0) - 1) c[DL_CUR_POS] = 0;
+        return;
+    }
     c[DL_CUR_POS] += e->stride;
     int dif = c[DL_CUR_POS] - step_len(e, c[DL_CUR_READ_STEP]) + 1;
     if (dif > 0) {
@@ -802,9 +812,36 @@ static void cursor_next(const dlo_env* e, walker_t* w) {
 }
 
 /* MimicEnv._get_obs (mimic_env.py:403-437) + mirror_obs (:440-480) */
+static double np_pairwise(const double* a, int n);
 static void get_obs(const dlo_env* e, const walker_t* w, double* o) {
     int nv = e->mm.m.nv;
     const int32_t* c = w->cur;
+    if (e->cfg.env_kind == DL_ENV_LOCO3D) {
+        /* estimate_phase_vars_from_joint_phase_plots (mimic_env.py:330-401) on the joints
+         * [9,12,14,17] (mimic_walker_165cm_65kg.py:40-43): angle atan2(v,-q)/pi and |(q,v)|/5 */
+        static const int pj[4] = {9, 12, 14, 17};
+        for (int k = 0; k < 4; k++) {
+            double q = w->q[pj[k]], v = w->v[pj[k]];
+            o[2 * k] = atan2(v, -q) / M_PI;
+            o[2 * k + 1] = sqrt(q * q + v * v) / 5;
+        }
+        /* Loco3dReferenceTrajectories.get_desired_walking_velocity_vector (loco3d_trajecs.py:51-97):
+         * mean of the reference pelvis x / z velocities over the next 0.5 s (clipped at the end) */
+        int L = step_len(e, 0), pos = c[DL_CUR_POS], nt = (int)(0.5 * 500);
+        int end = pos + nt < L - 1 ? pos + nt : L - 1;
+        for (int r = 0; r < 2; r++) {
+            const double* row = e->table + (size_t)(nv + r) * e->total_len;
+            /* np.mean of a float64 slice: pairwise summation */
+            int n = end - pos;
+            double sum;
+            if (n <= 0) sum = 0.0 / 0.0; else sum = np_pairwise(row + pos, n);
+            o[8 + r] = sum / (n > 0 ? n : 1);
+            if (n <= 0) o[8 + r] = 0.0 / 0.0;
+        }
+        for (int j = 1; j < nv; j++) o[9 + j] = w->q[j];
+        for (int j = 0; j < nv; j++) o[9 + nv + j] = w->v[j];
+        return;
+    }
     o[0] = (double)c[DL_CUR_POS] / (double)step_len(e, c[DL_CUR_READ_STEP]);
     int iv = c[DL_CUR_I_STEP] - c[DL_CUR_COUNT] + 1;
     o[1] = e->step_vel[iv > 0 ? iv : 0];
@@ -836,6 +873,14 @@ static double np_sum(const double* a, int n) {
     res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     for (; i < n; i++) res += a[i];
     return res;
+}
+
+/* numpy's pairwise summation for any n (np.mean of a contiguous float64 slice) */
+static double np_pairwise(const double* a, int n) {
+    if (n <= 128) return np_sum(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
 }
 
 /* get_imitation_reward (mimic_env.py:592-649) */
@@ -874,6 +919,9 @@ static void reset_walker(dlo_env* e, int i, int inj_step, int inj_pos, double* o
     int32_t s, p;
     int read = -1;
     if (inj_step >= 0) { s = inj_step; p = inj_pos; }
+    else if (e->eval_mode && e->cfg.env_kind == DL_ENV_LOCO3D) {
+        s = 0; p = 0;      /* base get_deterministic_init_state(pos_in_percent=0), base_ref_trajecs.py:66-73 */
+    }
     else if (e->eval_mode) {
         /* _get_deterministic_init_state (straight_walk_trajecs.py:237-265): step k, 75 % of ITS length,
          * but the kinematics are read from step 0's table (quirk Q3) */
@@ -935,7 +983,7 @@ static void monitor_step(walker_t* w, double rew, int done) {
 }
 
 void dlo_reset(dlo_env* e, const uint8_t* mask, const int32_t* init_step, const int32_t* init_pos, double* obs_out) {
-    int od = 1 + 2 * e->mm.m.nv;
+    int od = obs_dim(e);
     for (int i = 0; i < e->n; i++) {
         if (mask && !mask[i]) continue;
         reset_walker(e, i, init_step ? init_step[i] : -1, init_pos ? init_pos[i] : -1, obs_out ? obs_out + (size_t)i * od : NULL);
@@ -945,7 +993,7 @@ void dlo_reset(dlo_env* e, const uint8_t* mask, const int32_t* init_step, const 
 /* MimicEnv.step (mimic_env.py:60-126) + vec-env auto reset */
 void dlo_step(dlo_env* e, const double* actions, double* obs, double* rew, uint8_t* done, double* term_obs, double* rew_terms) {
     const dl_model_desc* m = &e->mm.m;
-    int nv = m->nv, nu = m->nu, od = 1 + 2 * nv;
+    int nv = m->nv, nu = m->nu, od = obs_dim(e);
     for (int i = 0; i < e->n; i++) {
         walker_t* w = &e->w[i];
         int32_t* c = w->cur;
@@ -1063,7 +1111,7 @@ void dlo_inject_state(dlo_env* e, int32_t i, const double* qpos, const double* q
 
 /* test hooks */
 void dlo_observe(dlo_env* e, double* obs, double* imit, double* terms) {
-    int od = 1 + 2 * e->mm.m.nv;
+    int od = obs_dim(e);
     for (int i = 0; i < e->n; i++) {
         walker_t* w = &e->w[i];
         get_obs(e, w, obs + (size_t)i * od);

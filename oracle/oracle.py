@@ -107,7 +107,7 @@ class OracleEnv:
         self._desc = refs.as_desc()
         self.h = C.c_void_p(lib().dlo_create(C.byref(model), C.byref(self._desc), C.byref(cfg), n_envs))
         self.nv, self.nu = model.nv, model.nu
-        self.obs_dim = 1 + 1 + (self.nv - 1) + self.nv
+        self.obs_dim = (10 + 2 * self.nv - 1) if cfg.env_kind == abi.DL_ENV_LOCO3D else (1 + 1 + (self.nv - 1) + self.nv)
 
     def close(self):
         if self.h:

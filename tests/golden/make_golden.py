@@ -156,6 +156,99 @@ def set_refs_cursor(refs, i_step, pos):
     refs._pos = pos
 
 
+def make_loco3d_golden(mimic_env_mod, hypers, rng):
+    """G9: MimicWalker165cm65kgEnv + Loco3dReferenceTrajectories driven on a SYNTHETIC table (the
+    real loco3d_guoping.mat is a missing blob, .MISSING_LARGE_BLOBS:1) written to a temp dir in the
+    reference's own .mat schema (angJoi, angDJoi, rowNameIK)."""
+    import tempfile
+    import scipy.io as spio
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from drloco_amd import mocap as my_mocap          # only the synthetic-data generator is used
+    import drloco.config.config as cfgl
+    L, seed = 3000, 3
+    ang, vel = my_mocap.synthetic_loco3d(L=L, seed=seed)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, 'mocaps', 'loco3d'))
+    spio.savemat(os.path.join(tmp, 'mocaps', 'loco3d', 'loco3d_guoping.mat'),
+                 {'angJoi': ang, 'angDJoi': vel, 'rowNameIK': np.array([f'row{i}' for i in range(37)], dtype=object)})
+    cfgl.ENV_ID = 'MimicWalker165cm65kg'
+    cfgl.CTRL_FREQ = 100
+    hypers.modification = hypers.MOD_CUSTOM_POLICY           # MOD_MIRR_POLICY cannot be used with loco3d refs
+    import drloco.ref_trajecs.loco3d_trajecs as l3
+    l3.get_project_path = lambda: tmp + '/'
+    from drloco.mujoco import mimic_walker_165cm_65kg as w165
+    Env = w165.MimicWalker165cm65kgEnv
+    env = Env.__new__(Env)
+    env.refs = l3.Loco3dReferenceTrajectories(w165.ref_trajecs_qpos_indices, w165.ref_trajecs_qvel_indices, w165.adaptations)
+    env.finished_init = True
+    env._EVAL_MODEL = False; env._FOLLOW_DESIRED_SPEED_PROFILE = False; env._PLAYBACK_REF_TRAJECS = False
+    env.pos_rew, env.vel_rew, env.com_rew = 0, 0, 0
+    env.ep_dur = 0; env.ep_rews = []; env.mean_epret_smoothed = 0; env.walked_distance = 0
+    env.control_freq = 100; env._frame_skip = 10
+    data = types.SimpleNamespace(qpos=np.zeros(19), qvel=np.zeros(19), actuator_force=np.zeros(13), site_xpos=np.zeros((8, 3)))
+    env.sim = types.SimpleNamespace(data=data); env.data = data
+    env.action_space = types.SimpleNamespace(high=np.full(13, 300.0), low=np.full(13, -300.0))
+    refs = env.refs
+    g = dict(L=L, seed=seed, table_checksum=np.array([ang.sum(), vel.sum(), np.abs(ang).sum()]),
+             qpos_rows=np.array(w165.ref_trajecs_qpos_indices), stride=np.array(refs._increment))
+    # cursor trace incl. the wrap (base_ref_trajecs.py:95-103)
+    refs._pos = L - 300
+    T = 200
+    g['c_start'] = np.array(refs._pos)
+    g['c_pos'] = np.zeros(T, np.int32); g['c_desvel'] = np.zeros((T, 2)); g['c_q'] = np.zeros((T, 19)); g['c_v'] = np.zeros((T, 19))
+    for t in range(T):
+        refs.next()
+        g['c_pos'][t] = refs._pos
+        g['c_desvel'][t] = refs.get_desired_walking_velocity_vector(False)
+        g['c_q'][t] = refs.get_qpos(); g['c_v'][t] = refs.get_qvel()
+    # observations / rewards around random cursor positions (incl. the last sample: empty mean -> nan)
+    n = 96
+    g['o_pos'] = np.zeros(n, np.int32); g['o_q'] = np.zeros((n, 19)); g['o_v'] = np.zeros((n, 19))
+    g['o_obs'] = np.zeros((n, 47)); g['o_terms'] = np.zeros((n, 3)); g['o_imit'] = np.zeros(n)
+    import warnings
+    for k in range(n):
+        p = int(rng.integers(0, L)) if k > 2 else [L - 1, L - 2, L - 120][k]
+        refs._pos = p
+        scale = [0.0, 0.01, 0.1, 0.4][k % 4]
+        q = np.asarray(refs.get_qpos(), float) + scale * rng.standard_normal(19)
+        v = np.asarray(refs.get_qvel(), float) + 8 * scale * rng.standard_normal(19)
+        env.sim.data.qpos[:] = q; env.sim.data.qvel[:] = v
+        g['o_pos'][k], g['o_q'][k], g['o_v'][k] = p, q, v
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            g['o_obs'][k] = env._get_obs()
+        g['o_imit'][k] = env.get_imitation_reward()
+        g['o_terms'][k] = [env.pos_rew, env.vel_rew, env.com_rew]
+    # step() trace with injected dynamics (13 actions, no mirroring, wrap inside)
+    T = 120
+    refs._pos = L - 260
+    env.ep_dur = 0; env.walked_distance = 0
+    r2 = np.random.default_rng(11)
+    sq = np.zeros((T, 19)); sv = np.zeros((T, 19))
+    shadow_pos = refs._pos
+    for t in range(T):
+        shadow_pos += 5
+        if shadow_pos >= L - 1: shadow_pos = 0
+        save = refs._pos; refs._pos = shadow_pos
+        sq[t] = np.asarray(refs.get_qpos(), float) + 0.05 * r2.standard_normal(19)
+        sv[t] = np.asarray(refs.get_qvel(), float) + 0.5 * r2.standard_normal(19)
+        refs._pos = save
+    state = {'t': 0}; ctrls = []
+    def do_simulation(ctrl, n_frames):
+        ctrls.append(np.array(ctrl, float)); env.sim.data.qpos[:] = sq[state['t']]; env.sim.data.qvel[:] = sv[state['t']]; state['t'] += 1
+    env.do_simulation = do_simulation
+    acts = r2.uniform(-1.3, 1.3, (T, 13))
+    g['s_start'] = np.array(refs._pos); g['s_actions'] = acts; g['s_q'] = sq; g['s_v'] = sv
+    g['s_obs'] = np.zeros((T, 47)); g['s_rew'] = np.zeros(T); g['s_done'] = np.zeros(T, np.int32); g['s_ctrl'] = np.zeros((T, 13))
+    g['s_walked'] = np.zeros(T); g['s_pos'] = np.zeros(T, np.int32)
+    for t in range(T):
+        o, rew, done, _ = env.step(acts[t])
+        g['s_obs'][t], g['s_rew'][t], g['s_done'][t], g['s_ctrl'][t] = o, rew, done, ctrls[-1]
+        g['s_walked'][t], g['s_pos'][t] = env.walked_distance, refs._pos
+        assert not done
+    np.savez_compressed(os.path.join(OUT, 'G9_loco3d.npz'), **g)
+
+
 def main():
     refs_mod, walker_mod, monitor_mod, utils, hypers, MujocoException = _import_reference()
     import drloco.mujoco.mimic_env as mimic_env_mod
@@ -429,6 +522,7 @@ def main():
         tr['t_comx'][t] = float(env.refs.get_qpos()[0])
         tr['t_phase'][t] = env.refs.get_phase_variable()
     np.savez_compressed(os.path.join(OUT, 'G8_eval_init.npz'), **g8, **tr)
+    make_loco3d_golden(mimic_env_mod, hypers, rng)
     print('golden fixtures written to', OUT)
 
 

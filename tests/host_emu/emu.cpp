@@ -7,9 +7,8 @@
 #include "../../drloco_amd/csrc/dl_host.hpp"
 
 using namespace dl;
-using TP = TopoStraight;
 
-template <typename T> struct Emu {
+template <typename T, typename TP> struct Emu {
     DevModel<T, TP> m;
     DevCfg<T> c;
     DevState<T> st;
@@ -19,12 +18,13 @@ template <typename T> struct Emu {
     std::vector<T> inj_q, inj_v;
     int n;
     int eval_mode = 0;
+    std::vector<double> pref;
 };
 
-template <typename T> static Emu<T>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
+template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
     std::string why;
     if (!check_topology<TP>(*d, why)) { fprintf(stderr, "%s\n", why.c_str()); return nullptr; }
-    auto* e = new Emu<T>();
+    auto* e = new Emu<T, TP>();
     e->n = n;
     fill_dev_model<T, TP>(*d, e->m);
     fill_dev_cfg<T>(*cfg, *r, e->c);
@@ -35,6 +35,7 @@ template <typename T> static Emu<T>* emu_create(const dl_model_desc* d, const dl
     e->is_left.assign(r->step_is_left, r->step_is_left + r->n_steps);
     e->step_vel.resize(r->n_steps);
     for (int k = 0; k < r->n_steps; k++) e->step_vel[k] = (T)r->step_vel[k];
+    if (TP::ENV_KIND == 1) { loco3d_prefix_sums(*r, TP::NV, e->pref); e->c.pref = e->pref.data(); }
     e->c.table = e->table.data(); e->c.step_off = e->step_off.data(); e->c.step_is_left = e->is_left.data(); e->c.step_vel = e->step_vel.data();
     e->qpos.assign((size_t)TP::NV * n, 0); e->qvel.assign((size_t)TP::NV * n, 0); e->warm.assign((size_t)TP::NV * n, 0);
     for (int j = 0; j < TP::NV; j++) for (int i = 0; i < n; i++) e->qpos[(size_t)j * n + i] = (T)d->jnt_qpos0[j];
@@ -48,14 +49,14 @@ template <typename T> static Emu<T>* emu_create(const dl_model_desc* d, const dl
     return e;
 }
 
-template <typename T> static void emu_reset(Emu<T>* e, const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs) {
+template <typename T, typename TP> static void emu_reset(Emu<T, TP>* e, const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs) {
     LaneMem<T> mem{e->lane.data(), 1};
     for (int i = 0; i < e->n; i++) {
         if (mask && !mask[i]) continue;
         env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, 1, is, ip, obs, nullptr, e->eval_mode);
     }
 }
-template <typename T> static void emu_step(Emu<T>* e, const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms) {
+template <typename T, typename TP> static void emu_step(Emu<T, TP>* e, const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms) {
     LaneMem<T> mem{e->lane.data(), 1};
     for (int i = 0; i < e->n; i++)
         env_step_lane<T, TP>(e->m, e->c, mem, e->st, i, act, obs, rew, done, term, terms, e->inj_q.data(), e->inj_v.data(), e->inj_flags.data());
@@ -64,7 +65,7 @@ template <typename T> static void emu_step(Emu<T>* e, const float* act, float* o
         if (e->need[i]) env_reset_lane<T, TP>(e->m, e->c, mem, e->st, i, e->need[i], nullptr, nullptr, obs, term, e->eval_mode);
     }
 }
-template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+template <typename T, typename TP> static void emu_forward(Emu<T, TP>* e, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
     LaneMem<T> mem{e->lane.data(), 1};
     int n = e->n;
     for (int i = 0; i < n; i++) {
@@ -79,28 +80,30 @@ template <typename T> static void emu_forward(Emu<T>* e, const T* ctrl, T* qacc,
     }
 }
 
-#define EMU_API(SUF, T)                                                                                                   \
-    extern "C" void* dle_create_##SUF(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* c, int n) { return emu_create<T>(d, r, c, n); } \
-    extern "C" void dle_destroy_##SUF(void* h) { delete (Emu<T>*)h; }                                                     \
-    extern "C" void dle_reset_##SUF(void* h, const uint8_t* m, const int32_t* is, const int32_t* ip, float* obs) { emu_reset<T>((Emu<T>*)h, m, is, ip, obs); } \
-    extern "C" void dle_step_##SUF(void* h, const float* a, float* o, float* r, uint8_t* d, float* t, float* tt) { emu_step<T>((Emu<T>*)h, a, o, r, d, t, tt); } \
-    extern "C" void dle_forward_##SUF(void* h, const T* u, T* qa, int32_t* nc, int32_t* ne, int32_t* ni) { emu_forward<T>((Emu<T>*)h, u, qa, nc, ne, ni); } \
+#define EMU_API(SUF, T, TP)                                                                                                   \
+    extern "C" void* dle_create_##SUF(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* c, int n) { return emu_create<T, TP>(d, r, c, n); } \
+    extern "C" void dle_destroy_##SUF(void* h) { delete (Emu<T, TP>*)h; }                                                     \
+    extern "C" void dle_reset_##SUF(void* h, const uint8_t* m, const int32_t* is, const int32_t* ip, float* obs) { emu_reset<T, TP>((Emu<T, TP>*)h, m, is, ip, obs); } \
+    extern "C" void dle_step_##SUF(void* h, const float* a, float* o, float* r, uint8_t* d, float* t, float* tt) { emu_step<T, TP>((Emu<T, TP>*)h, a, o, r, d, t, tt); } \
+    extern "C" void dle_forward_##SUF(void* h, const T* u, T* qa, int32_t* nc, int32_t* ne, int32_t* ni) { emu_forward<T, TP>((Emu<T, TP>*)h, u, qa, nc, ne, ni); } \
     extern "C" void dle_get_state_##SUF(void* h, T* q, T* v, T* w, int32_t* cur, double* walked) {                        \
-        auto* e = (Emu<T>*)h; size_t m = (size_t)TP::NV * e->n;                                                           \
+        auto* e = (Emu<T, TP>*)h; size_t m = (size_t)TP::NV * e->n;                                                           \
         if (q) memcpy(q, e->qpos.data(), m * sizeof(T)); if (v) memcpy(v, e->qvel.data(), m * sizeof(T));                 \
         if (w) memcpy(w, e->warm.data(), m * sizeof(T)); if (cur) memcpy(cur, e->cur.data(), e->cur.size() * 4);          \
         if (walked) memcpy(walked, e->walked.data(), e->n * 8); }                                                         \
     extern "C" void dle_set_state_##SUF(void* h, const T* q, const T* v, const T* w, const int32_t* cur, const double* walked) { \
-        auto* e = (Emu<T>*)h; size_t m = (size_t)TP::NV * e->n;                                                           \
+        auto* e = (Emu<T, TP>*)h; size_t m = (size_t)TP::NV * e->n;                                                           \
         if (q) memcpy(e->qpos.data(), q, m * sizeof(T)); if (v) memcpy(e->qvel.data(), v, m * sizeof(T));                 \
         if (w) memcpy(e->warm.data(), w, m * sizeof(T)); if (cur) memcpy(e->cur.data(), cur, e->cur.size() * 4);          \
         if (walked) memcpy(e->walked.data(), walked, e->n * 8); }                                                         \
     extern "C" void dle_inject_##SUF(void* h, int i, int flag, const T* q, const T* v) {                                  \
-        auto* e = (Emu<T>*)h; e->inj_flags[i] = flag;                                                                     \
+        auto* e = (Emu<T, TP>*)h; e->inj_flags[i] = flag;                                                                     \
         if (q) for (int j = 0; j < TP::NV; j++) { e->inj_q[(size_t)j * e->n + i] = q[j]; e->inj_v[(size_t)j * e->n + i] = v[j]; } } \
-    extern "C" void dle_inject_rsi_##SUF(void* h, int i, int s, int p) { auto* e = (Emu<T>*)h; e->inj[i] = s; e->inj[(size_t)e->n + i] = p; } \
-    extern "C" void dle_set_eval_##SUF(void* h, int on) { ((Emu<T>*)h)->eval_mode = on; }                                \
-    extern "C" void dle_mon_##SUF(void* h, int word, double* out) { auto* e = (Emu<T>*)h; memcpy(out, e->mon.data() + (size_t)word * e->n, e->n * 8); }
+    extern "C" void dle_inject_rsi_##SUF(void* h, int i, int s, int p) { auto* e = (Emu<T, TP>*)h; e->inj[i] = s; e->inj[(size_t)e->n + i] = p; } \
+    extern "C" void dle_set_eval_##SUF(void* h, int on) { ((Emu<T, TP>*)h)->eval_mode = on; }                                \
+    extern "C" void dle_mon_##SUF(void* h, int word, double* out) { auto* e = (Emu<T, TP>*)h; memcpy(out, e->mon.data() + (size_t)word * e->n, e->n * 8); }
 
-EMU_API(f64, double)
-EMU_API(f32, float)
+EMU_API(f64, double, TopoStraight)
+EMU_API(f32, float, TopoStraight)
+EMU_API(f64_165, double, TopoWalker165)
+EMU_API(f32_165, float, TopoWalker165)

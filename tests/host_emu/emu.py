@@ -27,7 +27,7 @@ def lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
-        for suf in ('f32', 'f64'):
+        for suf in ('f32', 'f64', 'f32_165', 'f64_165'):
             getattr(_lib, 'dle_create_' + suf).restype = C.c_void_p
     return _lib
 
@@ -38,11 +38,11 @@ def _p(a, t):
 
 class EmuEnv:
     def __init__(self, model, refs, cfg, n_envs, precision=64):
-        self.suf = 'f64' if precision == 64 else 'f32'
+        self.suf = ('f64' if precision == 64 else 'f32') + ('_165' if cfg.env_kind == abi.DL_ENV_LOCO3D else '')
         self.rt = np.float64 if precision == 64 else np.float32
         self.ct = C.c_double if precision == 64 else C.c_float
         self.n, self.nv, self.nu = n_envs, model.nv, model.nu
-        self.obs_dim = 2 * model.nv + 1
+        self.obs_dim = (10 + 2 * model.nv - 1) if cfg.env_kind == abi.DL_ENV_LOCO3D else 2 * model.nv + 1
         self._desc = refs.as_desc()
         self.h = C.c_void_p(self._f('create')(C.byref(model), C.byref(self._desc), C.byref(cfg), n_envs))
         assert self.h

@@ -445,3 +445,91 @@ def test_evaluation_mode_matches_oracle(torch_cuda, oracle, model, refs):
         np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6)
     np.testing.assert_allclose(view.get_walked_distance(), orc.get_state()['walked'][0], rtol=1e-6)
     assert np.array_equal(orc.get_state()['cursor'], dev.get_state()['cursor'])
+
+
+# ---------------------------------------------------------------------------------------------
+# MimicWalker165cm65kg + Loco3dReferenceTrajectories (BASELINE config 4's walker; synthetic table,
+# because loco3d_guoping.mat is a missing blob in the reference checkout)
+def _loco3d_pair(oracle, n, precision, L=6000, seed=0, **cfg):
+    from drloco_amd import mocap, models
+    from drloco_amd.vec_env import HipVecEnv
+    ang, vel = mocap.synthetic_loco3d(L=L, seed=seed)
+    table = mocap.loco3d_table(ang, vel)
+    dev = HipVecEnv(models.WALKER_165CM, num_envs=n, precision=precision, refs=table, **cfg)
+    orc = oracle.OracleEnv(dev.model, table, dev.cfg, n)
+    return dev, orc
+
+
+@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 1e-2)])
+def test_loco3d_forward_dynamics(torch_cuda, oracle, precision, tol):
+    n = 512
+    dev, orc = _loco3d_pair(oracle, n, precision)
+    assert dev.obs_dim == 47 and dev.nu == 13 and dev.nv == 19
+    rng = np.random.default_rng(0)
+    q = np.array(dev.model.jnt_qpos0[:19])[:, None] + 0.2 * rng.standard_normal((19, n)); q[2] = rng.uniform(0.75, 1.2, n)
+    v = 1.5 * rng.standard_normal((19, n)); w = rng.standard_normal((19, n)); u = rng.uniform(-300, 300, (13, n))
+    dev.set_state(qpos=q, qvel=v, warm=w); orc.set_state(qpos=q, qvel=v, warm=w)
+    qa, nc, ne, ni = orc.forward(u); qb, nc2, ne2, ni2 = dev.forward(u)
+    assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2) and nc.max() >= 6
+    err = np.abs(qa - qb) / (1 + np.abs(qa))
+    assert err.max() < tol, err.max()
+    if precision == 32:
+        assert np.median(err.max(axis=0)) < 2e-4
+
+
+def test_loco3d_rollout_f64_matches_oracle(torch_cuda, oracle):
+    n, T = 128, 120
+    dev, orc = _loco3d_pair(oracle, n, 64)
+    np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
+    rng = np.random.default_rng(1)
+    nd = 0
+    for t in range(T):
+        a = np.clip(0.5 * rng.standard_normal((n, 13)), -1, 1).astype(np.float32)
+        o1, r1, d1, t1, _ = orc.step(a.astype(np.float64)); o2, r2, d2, infos = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2), t
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(r2, r1, atol=1e-6)
+        nd += int(d2.sum())
+    assert nd > 10
+    s1, s2 = orc.get_state(), dev.get_state()
+    assert np.array_equal(s1['cursor'], s2['cursor'])
+    np.testing.assert_allclose(s2['walked'], s1['walked'], rtol=1e-6, atol=1e-9)
+
+
+def test_loco3d_single_step_f32(torch_cuda, oracle):
+    n = 1024
+    dev, orc = _loco3d_pair(oracle, n, 32)
+    rng = np.random.default_rng(2)
+    orc.reset(); dev.reset()
+    for t in range(8):
+        orc.step(np.clip(0.3 * rng.standard_normal((n, 13)), -1, 1))
+    st = orc.get_state()
+    dev.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=st['warm'], cursor=st['cursor'], walked=st['walked'])
+    a = np.clip(0.5 * rng.standard_normal((n, 13)), -1, 1).astype(np.float32)
+    o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+    assert np.array_equal(d1.astype(bool), d2)
+    live = ~d2
+    rel = np.abs(r1 - r2)[live] / np.abs(r1[live])
+    assert np.quantile(rel, 0.99) < 1e-4 and rel.max() < 5e-3, (np.quantile(rel, 0.99), rel.max())
+    assert np.array_equal(orc.get_state()['cursor'], dev.get_state()['cursor'])
+
+
+def test_G9_loco3d_trace_on_device(torch_cuda):
+    """The reference's own MimicWalker165cm65kgEnv.step() trace through the device kernels."""
+    from drloco_amd import mocap, models
+    from drloco_amd.vec_env import HipVecEnv
+    with np.load(os.path.join(GOLDEN, 'G9_loco3d.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    ang, vel = mocap.synthetic_loco3d(L=int(g['L']), seed=int(g['seed']))
+    env = HipVecEnv(models.WALKER_165CM, num_envs=1, precision=64, refs=mocap.loco3d_table(ang, vel), ep_dur_max=10 ** 9)
+    cur = np.zeros((abi.DL_CUR_WORDS, 1), np.int32); cur[abi.DL_CUR_POS] = int(g['s_start']); cur[abi.DL_CUR_COUNT] = 1
+    env.set_state(cursor=cur)
+    for t in range(len(g['s_rew'])):
+        env.debug_inject(qpos=g['s_q'][t][:, None], qvel=g['s_v'][t][:, None], flags=np.array([1], np.int32))
+        obs, rew, done, _ = env.step(g['s_actions'][t][None].astype(np.float32))
+        assert not done[0]
+        np.testing.assert_allclose(obs[0], g['s_obs'][t], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(rew[0], g['s_rew'][t], rtol=1e-6)
+        st = env.get_state()
+        assert st['cursor'][abi.DL_CUR_POS, 0] == g['s_pos'][t]
+        np.testing.assert_allclose(st['walked'][0], g['s_walked'][t], rtol=1e-6)

@@ -94,3 +94,41 @@ def test_config_defaults_follow_the_reference():
     c = abi.default_config()
     assert list(c.rew_weights) == [0.8, 0.2, 0.0] and c.alive_bonus == 0.2 and c.ep_dur_max == 3000
     assert c.mirror_policy == 1 and c.ctrl_freq == 200.0 and c.com_z_min == 0.5
+
+
+REF_XML_165 = '/root/reference/drloco/mujoco/xml/walker_165cm_65kg.xml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XML_165), reason='reference checkout not present')
+def test_mjcf_parser_matches_baked_165cm_model():
+    m = models.make_model(models.WALKER_165CM)
+    assert bytes(mjcf.parse_mjcf(REF_XML_165, frame_skip=10)) == bytes(m)
+    assert (m.nv, m.nu, m.nbody, m.ngeom, m.frame_skip) == (19, 13, 9, 8, 10)
+    assert abs(sum(m.body_mass[:9]) - 65.17) < 1e-9
+    # actuator order differs from joint order for the lumbar joints (xml:81-84)
+    assert [m.act_dof[a] for a in range(3)] == [7, 6, 8]
+
+
+def test_kernel_source_on_host_matches_oracle_loco3d(emu, oracle):
+    """Second topology (19 dof, boxes on pelvis/torso, negated axes) + the loco3d env logic."""
+    m = models.make_model(models.WALKER_165CM)
+    ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
+    table = mocap.loco3d_table(ang, vel)
+    cfg = abi.loco3d_config()
+    n = 64
+    o = oracle.OracleEnv(m, table, cfg, n); e = emu.EmuEnv(m, table, cfg, n, 64)
+    rng = np.random.default_rng(0)
+    q = np.array(m.jnt_qpos0[:19])[:, None] + 0.2 * rng.standard_normal((19, n)); q[2] = rng.uniform(0.75, 1.2, n)
+    v = 1.5 * rng.standard_normal((19, n)); w = rng.standard_normal((19, n)); u = rng.uniform(-300, 300, (13, n))
+    o.set_state(qpos=q, qvel=v, warm=w); e.set_state(qpos=q, qvel=v, warm=w)
+    qa, nc, ne, _ = o.forward(u); qb, nc2, ne2, _ = e.forward(u)
+    assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2) and nc.max() >= 6
+    assert (np.abs(qa - qb) / (1 + np.abs(qa))).max() < 1e-9
+    np.testing.assert_allclose(e.reset(), o.reset(), atol=2e-6)
+    for t in range(40):
+        a = np.clip(0.5 * rng.standard_normal((n, 13)), -1, 1).astype(np.float32)
+        o1, r1, d1, _, _ = o.step(a.astype(np.float64)); o2, r2, d2, _, _ = e.step(a)
+        assert np.array_equal(d1, d2)
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6)
+        np.testing.assert_allclose(r2, r1, atol=1e-6)
+    assert np.array_equal(o.get_state()['cursor'], e.get_state()['cursor'])
