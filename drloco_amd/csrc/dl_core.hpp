@@ -146,7 +146,7 @@ struct TopoWalker165 {
     static constexpr int ENV_KIND = 1;             // DL_ENV_LOCO3D
     static constexpr int NB = 9, NV = 19, NU = 13, NG = 8, NS = 8, NLIM = 13;
     static constexpr int MAXCON = 24;              // 4 boxes x 4 + 4 capsules x 2
-    static constexpr int MAXROW = NLIM + 4 * MAXCON; // 109
+    static constexpr int MAXROW = 112;             // NLIM + 4 * MAXCON = 109, padded to a multiple of 4 (rows are processed four at a time)
     static constexpr int OBS = 47;                 // 8 joint-phase features + 2 desired velocities + 18 + 19
     static constexpr int body_parent_[NB] = {0, 0, 1, 1, 3, 4, 1, 6, 7};
     static constexpr int dof_body_[NV] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 5, 6, 6, 6, 7, 8};
@@ -734,13 +734,15 @@ DL_HD T linesearch(const LaneMem<T>& mem, int nefc, T g0, T g1, T g2, T gtol, in
         LsPoint<T> pe;
         {
             T cost = g0 + alpha * g1 + alpha * alpha * g2, d1 = g1 + T(2) * alpha * g2, d2 = T(2) * g2;
-            for (int r = 0; r < nefc; r++) {
-                const T jv = mem(L::ROW_JV + r);
-                const T x = mem(L::ROW_JAREF + r) + alpha * jv;
-                if (x < T(0)) {
-                    const T D = mem(L::ROW_D + r);
-                    cost += T(0.5) * D * x * x; d1 += D * x * jv; d2 += D * jv * jv;
-                }
+            // four rows per trip: the 12 LDS reads of a chunk are independent, so their latency overlaps
+            for (int r = 0; r < nefc; r += 4) {
+                T jv[4], ja[4], Dr[4];
+                static_for<4>([&](auto ki) { constexpr int kk = ki.value; jv[kk] = mem(L::ROW_JV + r + kk); ja[kk] = mem(L::ROW_JAREF + r + kk); Dr[kk] = mem(L::ROW_D + r + kk); });
+                static_for<4>([&](auto ki) {
+                    constexpr int kk = ki.value;
+                    const T x = ja[kk] + alpha * jv[kk];
+                    if (r + kk < nefc && x < T(0)) { cost += T(0.5) * Dr[kk] * x * x; d1 += Dr[kk] * x * jv[kk]; d2 += Dr[kk] * jv[kk] * jv[kk]; }
+                });
             }
             pe = {alpha, cost, d1, d2};
         }
@@ -862,23 +864,40 @@ DL_HD void forward(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, con
         T alpha = T(0);
         bool stop = false;
         if (phase == -1) {
-            for (int r = 0; r < nefc; r++) mem(L::ROW_JAREF + r) += m.solB * mem(L::ROW_JV + r);      // -aref complete
+            for (int r = 0; r < nefc; r += 4) {                                                        // -aref complete
+                T a[4], b[4];
+                static_for<4>([&](auto ki) { a[ki.value] = mem(L::ROW_JAREF + r + ki.value); b[ki.value] = mem(L::ROW_JV + r + ki.value); });
+                static_for<4>([&](auto ki) { mem(L::ROW_JAREF + r + ki.value) = a[ki.value] + m.solB * b[ki.value]; });
+            }
         } else if (phase <= 1) {
             // cost of the candidate start x
             T c = T(0);
-            for (int r = 0; r < nefc; r++) {
-                const T jar = mem(L::ROW_JV + r) + mem(L::ROW_JAREF + r);
-                if (jar < T(0)) c += T(0.5) * mem(L::ROW_D + r) * jar * jar;
+            for (int r = 0; r < nefc; r += 4) {
+                T jv[4], ja[4], Dr[4];
+                static_for<4>([&](auto ki) { constexpr int kk = ki.value; jv[kk] = mem(L::ROW_JV + r + kk); ja[kk] = mem(L::ROW_JAREF + r + kk); Dr[kk] = mem(L::ROW_D + r + kk); });
+                static_for<4>([&](auto ki) {
+                    constexpr int kk = ki.value;
+                    const T jar = jv[kk] + ja[kk];
+                    if (r + kk < nefc && jar < T(0)) c += T(0.5) * Dr[kk] * jar * jar;
+                });
             }
             static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; c += T(0.5) * (Mx[i] - smooth[i]) * (x[i] - qacc_smooth[i]); });
             if (phase == 0) {
                 cost_s = c;
-                for (int r = 0; r < nefc; r++) mem(L::ROW_TMP + r) = mem(L::ROW_JV + r);
+                for (int r = 0; r < nefc; r += 4) {
+                    T a[4];
+                    static_for<4>([&](auto ki) { a[ki.value] = mem(L::ROW_JV + r + ki.value); });
+                    static_for<4>([&](auto ki) { mem(L::ROW_TMP + r + ki.value) = a[ki.value]; });
+                }
             } else {
                 const bool use_warm = !(c > cost_s);
                 // M qacc_smooth = qfrc_smooth by construction
                 static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; qacc[i] = use_warm ? warm[i] : qacc_smooth[i]; Ma[i] = use_warm ? Mx[i] : smooth[i]; });
-                for (int r = 0; r < nefc; r++) mem(L::ROW_JAREF + r) += use_warm ? mem(L::ROW_JV + r) : mem(L::ROW_TMP + r);
+                for (int r = 0; r < nefc; r += 4) {
+                    T a[4], b[4], t[4];
+                    static_for<4>([&](auto ki) { constexpr int kk = ki.value; a[kk] = mem(L::ROW_JAREF + r + kk); b[kk] = mem(L::ROW_JV + r + kk); t[kk] = mem(L::ROW_TMP + r + kk); });
+                    static_for<4>([&](auto ki) { constexpr int kk = ki.value; mem(L::ROW_JAREF + r + kk) = a[kk] + (use_warm ? b[kk] : t[kk]); });
+                }
             }
         } else {
             T s2 = T(0), g1 = T(0), g2 = T(0);
@@ -891,7 +910,11 @@ DL_HD void forward(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, con
                 if (alpha == T(0)) stop = true;
                 else {
                     static_for<TP::NV>([&](auto ii) { constexpr int i = ii.value; qacc[i] += alpha * x[i]; Ma[i] += alpha * Mx[i]; });
-                    for (int r = 0; r < nefc; r++) mem(L::ROW_JAREF + r) += alpha * mem(L::ROW_JV + r);
+                    for (int r = 0; r < nefc; r += 4) {
+                        T a[4], b[4];
+                        static_for<4>([&](auto ki) { a[ki.value] = mem(L::ROW_JAREF + r + ki.value); b[ki.value] = mem(L::ROW_JV + r + ki.value); });
+                        static_for<4>([&](auto ki) { mem(L::ROW_JAREF + r + ki.value) = a[ki.value] + alpha * b[ki.value]; });
+                    }
                 }
             }
         }
