@@ -1,0 +1,707 @@
+// dl_group.hpp -- "16 lanes per walker" formulation of the forward dynamics (device only).
+//
+// The lane-per-walker kernels (dl_core.hpp) leave 15/16 of the chip idle at the benchmark size
+// (4096 walkers = 64 waves on 1024 SIMDs) and their run time is the serial instruction stream of
+// one walker.  Here a walker is spread over a 16-lane DPP row: lane j owns degree of freedom j
+// (and, for j < 8, body j; for the solver also constraint rows j, j+16, ...), four walkers share a
+// wave, 4096 walkers are 1024 waves -- one per SIMD.  Communication inside a walker:
+//   * LDS, laid out so that the 16 lanes of a row hit 16 different banks ([field][16]);
+//   * DPP row rotations for all-reduce sums and broadcasts (full-rate VALU, no LDS round trip);
+//   * a workgroup is one wave, so __syncthreads() is only an LDS wait + compiler fence.
+// The kinematic tree is DATA here (chain tables in GModel), not a compile-time constant.
+//
+// Arithmetic and results follow dl_core.hpp (same model, same solver phases); parity tests compare
+// both device paths with the CPU oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "dl_env.hpp"
+
+namespace dl {
+
+constexpr int GL = 16;          // lanes per walker
+constexpr int GW = 4;           // walkers per wave
+constexpr int G_MAXCHAIN = 12;  // longest root->dof chain
+constexpr int G_MAXB = 8;       // bodies incl. world
+constexpr int G_MAXCAND = 32;   // collision candidate points
+constexpr int G_MAXCON = 20;    // >= 18
+constexpr int G_MAXROW = 80;
+constexpr int G_JC_STRIDE = 49; // 3*16 + 1: contact lanes reading their Jacobian hit different banks
+
+// model as data (host-built from dl_model_desc), read through the constant address space
+template <typename T> struct GModel {
+    int32_t nv, nb, nu, ngeom, nsite, frame_skip, iterations, ls_iterations, ncand, root_last_dof;
+    T timestep, gravity_z, solK, solB, solimp[5], meaninertia, tolerance, ls_tolerance, ls_reltol, root_z0;
+    int32_t dof_body[GL], dof_type[GL], dof_axis[GL], dof_first[GL], dof_limited[GL], dof_depth[GL], dof_is_last[GL];
+    int32_t chain[GL][G_MAXCHAIN];
+    T dof_sign[GL], qpos0[GL], range_lo[GL], range_hi[GL], damping[GL], armature[GL], dof_invw[GL];
+    int32_t dof_act[GL];                       // actuator index driving this dof, or -1
+    T ctrl_lo[GL], ctrl_hi[GL], force_lo[GL], force_hi[GL], gear[GL];   // indexed by dof
+    int32_t body_last_dof[G_MAXB];
+    uint32_t body_submask[G_MAXB];             // bodies in the subtree of b (incl. b)
+    T body_pos[G_MAXB][3], body_mass[G_MAXB], body_ipos[G_MAXB][3], body_inertia[G_MAXB][3], body_invw[G_MAXB];
+    int32_t cand_geom[G_MAXCAND], cand_sub[G_MAXCAND];
+    int32_t geom_body[G_MAXB], geom_type[G_MAXB];
+    T geom_pos[G_MAXB][3], geom_mat[G_MAXB][9], geom_size[G_MAXB][3], geom_mu[G_MAXB];
+    int32_t site_body[8];
+    T site_pos[8][3];
+};
+
+// per-walker LDS layout (in elements of T)
+struct GLds {
+    static constexpr int Q = 0, V = Q + GL, SC = V + GL;             // sin[16], cos[16]
+    static constexpr int AX = SC + 2 * GL;                           // axis(3) anchor(3): [6][16]
+    static constexpr int SM = AX + 6 * GL;                           // motion subspace [6][16]
+    static constexpr int VEC = SM + 6 * GL;                          // vectors [NVEC][16]
+    static constexpr int V_SMOOTH = 0, V_QSM = 1, V_X = 2, V_MX = 3, V_FC = 4, NVEC = 5;
+    static constexpr int MM = VEC + NVEC * GL;                       // M [16 rows][16]
+    static constexpr int CON = MM + GL * GL;                         // contacts [8][G_MAXCON]: px py pz tx ty mu dist body
+    static constexpr int ROW = CON + 8 * G_MAXCON;                   // rows [4][G_MAXROW]: D, JAREF, JV, TMP
+    static constexpr int R_D = 0, R_JAREF = 1, R_JV = 2, R_TMP = 3;
+    static constexpr int LIMC = ROW + 4 * G_MAXROW;                  // limit codes [8]
+    static constexpr int FC = LIMC + 8;                              // contact forces in the contact frame [G_MAXCON][3]
+    static constexpr int MISC = FC + 3 * G_MAXCON;                   // rootz, counts ... [8]
+    static constexpr int JC = MISC + 8;                              // contact Jacobians [G_MAXCON][G_JC_STRIDE]
+    // dynamics temporaries (dead once the constraints are built) share the space of JC
+    static constexpr int BFR = JC;                                   // body frames [12][8]
+    static constexpr int IB = BFR + 12 * G_MAXB;                     // body inertia [10][8]
+    static constexpr int TW = IB + 10 * G_MAXB;                      // twist + acc [12][8]
+    static constexpr int FW = TW + 12 * G_MAXB;                      // body wrench [6][8]
+    static constexpr int IC = FW + 6 * G_MAXB;                       // composite inertia [10][8]
+    static constexpr int WC = IC + 10 * G_MAXB;                      // composite wrench [6][8]
+    static constexpr int DYN_END = WC + 6 * G_MAXB;
+    static constexpr int JC_END = JC + G_MAXCON * G_JC_STRIDE;
+    static constexpr int TOTAL_RAW = JC_END > DYN_END ? JC_END : DYN_END;
+    // walker regions are offset by 16 (mod 32) words so that the two rows of a half-wave use disjoint banks
+    static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
+};
+
+// ------------------------------------------------------------------------------------------
+// DPP row (16-lane) primitives
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f(double x) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// sum over the 16 lanes of a row, result in every lane (row_ror:8,4,2,1)
+template <typename T> __device__ __forceinline__ T gsum(T x) {
+    x += dpp_f<0x128>(x);
+    x += dpp_f<0x124>(x);
+    x += dpp_f<0x122>(x);
+    x += dpp_f<0x121>(x);
+    return x;
+}
+// value of lane k of the row, in every lane
+template <typename T> __device__ __forceinline__ T gbcast(T x, int j, int k) { return gsum(j == k ? x : T(0)); }
+__device__ __forceinline__ bool gany(bool p) { return gsum(p ? 1.0f : 0.0f) > 0.0f; }
+
+template <typename T> __device__ __forceinline__ void g_sync() { __syncthreads(); }
+
+// ------------------------------------------------------------------------------------------
+template <typename T> struct GCtx {
+    DL_LDS T* wb;                        // walker's LDS region
+    const DL_CONST GModel<T>* m;
+    int j;                               // lane in the row
+};
+
+template <typename T> __device__ __forceinline__ V3<T> ld3(DL_LDS T* p, int stride) { return {p[0], p[stride], p[2 * stride]}; }
+
+// rotate the frame (X,Y,Z) about its own coordinate axis `idx` by the angle with (s, c)
+template <typename T> __device__ __forceinline__ void rot_axis(V3<T>& X, V3<T>& Y, V3<T>& Z, int idx, T s, T c) {
+    const V3<T> A = idx == 0 ? Y : (idx == 1 ? Z : X);
+    const V3<T> B = idx == 0 ? Z : (idx == 1 ? X : Y);
+    const V3<T> A2 = c * A + s * B, B2 = c * B - s * A;
+    if (idx == 0) { Y = A2; Z = B2; } else if (idx == 1) { Z = A2; X = B2; } else { X = A2; Y = B2; }
+}
+
+// [3P] mj_kinematics + mj_crb + mj_rne + passive/actuator forces: leaves M (dense, symmetric) and
+// qfrc_smooth in LDS, axes/anchors/motion subspaces in LDS, rootz in MISC[0]
+template <typename T>
+__device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T ctrl_force) {
+    using Ld = GLds;
+    const DL_CONST GModel<T>& m = *g.m;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j, nv = m.nv, nb = m.nb;
+    // ---- A: joint sines / cosines, q, v
+    {
+        T s = T(0), c = T(1);
+        if (j < nv && m.dof_type[j] == 1) dl_sincos(m.dof_sign[j] * (q - m.qpos0[j]), s, c);
+        wb[Ld::SC + j] = s; wb[Ld::SC + GL + j] = c;
+        wb[Ld::Q + j] = q; wb[Ld::V + j] = v;
+        // clear M (row j)
+        for (int a = 0; a < GL; a++) wb[Ld::MM + j * GL + a] = T(0);
+    }
+    g_sync<T>();
+    // ---- B: every dof lane walks its own root->dof chain (no cross-lane dependency)
+    V3<T> my_axis = mk<T>(0, 0, 0), my_anchor = mk<T>(0, 0, 0);
+    if (j < nv) {
+        V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
+        T rootz = m.root_z0;
+        const int depth = m.dof_depth[j];
+        for (int d = 0; d <= depth; d++) {
+            const int a = m.chain[j][d], ba = m.dof_body[a];
+            if (m.dof_first[a] && ba != 1) pos = pos + m.body_pos[ba][0] * X + m.body_pos[ba][1] * Y + m.body_pos[ba][2] * Z;
+            const int idx = m.dof_axis[a];
+            const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
+            const V3<T> ax = m.dof_sign[a] * col;
+            if (a == j) { my_axis = ax; my_anchor = pos; }
+            if (m.dof_type[a] == 0) rootz += ax.z * (wb[Ld::Q + a] - m.qpos0[a]);
+            else rot_axis(X, Y, Z, idx, wb[Ld::SC + a], wb[Ld::SC + GL + a]);
+        }
+        wb[Ld::AX + 0 * GL + j] = my_axis.x; wb[Ld::AX + 1 * GL + j] = my_axis.y; wb[Ld::AX + 2 * GL + j] = my_axis.z;
+        wb[Ld::AX + 3 * GL + j] = my_anchor.x; wb[Ld::AX + 4 * GL + j] = my_anchor.y; wb[Ld::AX + 5 * GL + j] = my_anchor.z;
+        V3<T> Sw, Sv;
+        if (m.dof_type[j] == 0) { Sw = mk<T>(0, 0, 0); Sv = my_axis; } else { Sw = my_axis; Sv = cross(my_anchor, my_axis); }
+        wb[Ld::SM + 0 * GL + j] = Sw.x; wb[Ld::SM + 1 * GL + j] = Sw.y; wb[Ld::SM + 2 * GL + j] = Sw.z;
+        wb[Ld::SM + 3 * GL + j] = Sv.x; wb[Ld::SM + 4 * GL + j] = Sv.y; wb[Ld::SM + 5 * GL + j] = Sv.z;
+        if (m.dof_is_last[j]) {
+            const int b = m.dof_body[j];
+            DL_LDS T* f = wb + Ld::BFR + b;
+            f[0 * G_MAXB] = X.x; f[1 * G_MAXB] = X.y; f[2 * G_MAXB] = X.z;
+            f[3 * G_MAXB] = Y.x; f[4 * G_MAXB] = Y.y; f[5 * G_MAXB] = Y.z;
+            f[6 * G_MAXB] = Z.x; f[7 * G_MAXB] = Z.y; f[8 * G_MAXB] = Z.z;
+            f[9 * G_MAXB] = pos.x; f[10 * G_MAXB] = pos.y; f[11 * G_MAXB] = pos.z;
+        }
+        if (j == m.root_last_dof) wb[Ld::MISC + 0] = rootz;
+    }
+    g_sync<T>();
+    // ---- C: twist / velocity-product acceleration down the chain (dof lanes), body inertia (body lanes)
+    if (j < nv) {
+        SV<T> vel = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)}, acc = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};
+        const int depth = m.dof_depth[j];
+        for (int d = 0; d <= depth; d++) {
+            const int a = m.chain[j][d];
+            const T qd = wb[Ld::V + a];
+            const SV<T> vJ = {qd * ld3(wb + Ld::SM + a, GL), qd * ld3(wb + Ld::SM + 3 * GL + a, GL)};
+            acc = {acc.w + cross(vel.w, vJ.w), acc.v + cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
+            vel = vel + vJ;
+        }
+        if (m.dof_is_last[j]) {
+            DL_LDS T* t = wb + Ld::TW + m.dof_body[j];
+            t[0] = vel.w.x; t[G_MAXB] = vel.w.y; t[2 * G_MAXB] = vel.w.z; t[3 * G_MAXB] = vel.v.x; t[4 * G_MAXB] = vel.v.y; t[5 * G_MAXB] = vel.v.z;
+            t[6 * G_MAXB] = acc.w.x; t[7 * G_MAXB] = acc.w.y; t[8 * G_MAXB] = acc.w.z; t[9 * G_MAXB] = acc.v.x; t[10 * G_MAXB] = acc.v.y; t[11 * G_MAXB] = acc.v.z;
+        }
+    }
+    SI<T> myI;          // body lanes keep their own spatial inertia
+    if (j >= 1 && j < nb) {
+        const int b = j;
+        DL_LDS T* f = wb + Ld::BFR + b;
+        const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
+        const V3<T> c = pos + m.body_ipos[b][0] * X + m.body_ipos[b][1] * Y + m.body_ipos[b][2] * Z;
+        const T mass = m.body_mass[b], i0 = m.body_inertia[b][0], i1 = m.body_inertia[b][1], i2 = m.body_inertia[b][2];
+        const T cc = dot(c, c);
+        myI.m = mass; myI.h = mass * c;
+        myI.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
+        myI.I.yy = i0 * X.y * X.y + i1 * Y.y * Y.y + i2 * Z.y * Z.y + mass * (cc - c.y * c.y);
+        myI.I.zz = i0 * X.z * X.z + i1 * Y.z * Y.z + i2 * Z.z * Z.z + mass * (cc - c.z * c.z);
+        myI.I.xy = i0 * X.x * X.y + i1 * Y.x * Y.y + i2 * Z.x * Z.y - mass * c.x * c.y;
+        myI.I.xz = i0 * X.x * X.z + i1 * Y.x * Y.z + i2 * Z.x * Z.z - mass * c.x * c.z;
+        myI.I.yz = i0 * X.y * X.z + i1 * Y.y * Y.z + i2 * Z.y * Z.z - mass * c.y * c.z;
+        DL_LDS T* ib = wb + Ld::IB + b;
+        ib[0] = myI.m; ib[G_MAXB] = myI.h.x; ib[2 * G_MAXB] = myI.h.y; ib[3 * G_MAXB] = myI.h.z;
+        ib[4 * G_MAXB] = myI.I.xx; ib[5 * G_MAXB] = myI.I.xy; ib[6 * G_MAXB] = myI.I.xz; ib[7 * G_MAXB] = myI.I.yy; ib[8 * G_MAXB] = myI.I.yz; ib[9 * G_MAXB] = myI.I.zz;
+    }
+    g_sync<T>();
+    // ---- D: inertial wrench of each body (body lanes)
+    if (j >= 1 && j < nb) {
+        DL_LDS T* t = wb + Ld::TW + j;
+        const SV<T> vel = {ld3(t, G_MAXB), ld3(t + 3 * G_MAXB, G_MAXB)}, acc = {ld3(t + 6 * G_MAXB, G_MAXB), ld3(t + 9 * G_MAXB, G_MAXB)};
+        const SV<T> Iv = si_mul(myI, vel), Ia = si_mul(myI, acc);
+        const SV<T> F = {Ia.w + cross(vel.w, Iv.w) + cross(vel.v, Iv.v), Ia.v + cross(vel.w, Iv.v)};
+        DL_LDS T* fw = wb + Ld::FW + j;
+        fw[0] = F.w.x; fw[G_MAXB] = F.w.y; fw[2 * G_MAXB] = F.w.z; fw[3 * G_MAXB] = F.v.x; fw[4 * G_MAXB] = F.v.y; fw[5 * G_MAXB] = F.v.z;
+    }
+    g_sync<T>();
+    // ---- E: composite inertia and wrench of every subtree (body lanes sum over their descendants)
+    if (j >= 1 && j < nb) {
+        const uint32_t sub = m.body_submask[j];
+        T acc[16];
+        for (int k = 0; k < 16; k++) acc[k] = T(0);
+        for (int c = 1; c < nb; c++) {
+            if (!((sub >> c) & 1u)) continue;
+            for (int k = 0; k < 10; k++) acc[k] += wb[Ld::IB + k * G_MAXB + c];
+            for (int k = 0; k < 6; k++) acc[10 + k] += wb[Ld::FW + k * G_MAXB + c];
+        }
+        for (int k = 0; k < 10; k++) wb[Ld::IC + k * G_MAXB + j] = acc[k];
+        for (int k = 0; k < 6; k++) wb[Ld::WC + k * G_MAXB + j] = acc[10 + k];
+    }
+    g_sync<T>();
+    // ---- F: bias force, row of the mass matrix, qfrc_smooth (dof lanes)
+    if (j < nv) {
+        const int b = m.dof_body[j];
+        const SV<T> S = {ld3(wb + Ld::SM + j, GL), ld3(wb + Ld::SM + 3 * GL + j, GL)};
+        const SV<T> W = {ld3(wb + Ld::WC + b, G_MAXB), ld3(wb + Ld::WC + 3 * G_MAXB + b, G_MAXB)};
+        const T bias = sdot(S, W);
+        SI<T> Ic;
+        DL_LDS T* ic = wb + Ld::IC + b;
+        Ic.m = ic[0]; Ic.h = ld3(ic + G_MAXB, G_MAXB);
+        Ic.I.xx = ic[4 * G_MAXB]; Ic.I.xy = ic[5 * G_MAXB]; Ic.I.xz = ic[6 * G_MAXB]; Ic.I.yy = ic[7 * G_MAXB]; Ic.I.yz = ic[8 * G_MAXB]; Ic.I.zz = ic[9 * G_MAXB];
+        const SV<T> f = si_mul(Ic, S);
+        const int depth = m.dof_depth[j];
+        for (int d = 0; d <= depth; d++) {
+            const int a = m.chain[j][d];
+            const SV<T> Sa = {ld3(wb + Ld::SM + a, GL), ld3(wb + Ld::SM + 3 * GL + a, GL)};
+            T mij = sdot(Sa, f);
+            if (a == j) mij += m.armature[j];
+            wb[Ld::MM + j * GL + a] = mij;
+            wb[Ld::MM + a * GL + j] = mij;
+        }
+        wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = -m.damping[j] * v - bias + ctrl_force;
+    } else {
+        wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = T(0);
+        wb[Ld::MM + j * GL + j] = T(1);          // padding rows/columns: identity
+    }
+    g_sync<T>();
+}
+
+// dense Cholesky of the 16x16 matrix whose row j is held in lane j (h[0..15], lower part used);
+// afterwards l[a] (a <= j) is row j of the factor.  Column k is gathered with DPP broadcasts.
+template <typename T> __device__ __forceinline__ void g_chol(T (&h)[GL], int j, int n) {
+#pragma unroll
+    for (int k = 0; k < GL; k++) {
+        if (k >= n) break;
+        const T dkk = gbcast(h[k], j, k);
+        const T inv = T(1) / dl_sqrt(dkk);
+        const T lik = (j == k) ? dl_sqrt(dkk) : h[k] * inv;   // lanes j > k: L[j][k]; lanes j < k: unused
+        h[k] = lik;
+#pragma unroll
+        for (int a = k + 1; a < GL; a++) {
+            if (a >= n) break;
+            const T lak = gbcast(lik, j, a);                  // L[a][k]
+            h[a] -= lik * lak;                                // row j, column a (only a <= j matters)
+        }
+    }
+}
+// solve (L L^T) x = b with row j of L in lane j; b_j in, x_j out
+template <typename T> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T b, int j, int n) {
+    // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k]; every lane keeps all y
+    T y[GL];
+    T acc = b;
+#pragma unroll
+    for (int k = 0; k < GL; k++) {
+        if (k >= n) break;
+        const T yk_local = acc / l[k];                        // valid in lane k
+        y[k] = gbcast(yk_local, j, k);
+        acc -= l[k] * y[k];                                   // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
+    }
+    // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k]
+    T x = T(0);
+    T yj = T(0);
+#pragma unroll
+    for (int k = 0; k < GL; k++) if (k < n && j == k) yj = y[k];
+#pragma unroll
+    for (int kk = 0; kk < GL; kk++) {
+        const int k = GL - 1 - kk;
+        if (k >= n) continue;
+        const T contrib = (j > k) ? l[k] * x : T(0);          // L[j][k] x_j, x_j already final for j > k
+        const T s = gsum(contrib);
+        if (j == k) x = (yj - s) / l[k];
+    }
+    return x;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
+// Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
+template <typename T>
+__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T q, int& nlim_out, int& ncon_out) {
+    using Ld = GLds;
+    const DL_CONST GModel<T>& m = *g.m;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j, nv = m.nv;
+    const T rootz = wb[Ld::MISC + 0];
+    // ---- joint limits (dof lanes), ranked by dof order through a ballot
+    bool lim = false, lim_lo = false;
+    T lim_dist = T(0);
+    if (j < nv && m.dof_limited[j]) {
+        const T dlo = q - m.range_lo[j], dhi = m.range_hi[j] - q;
+        lim_lo = dlo < T(0);
+        lim = lim_lo || dhi < T(0);
+        lim_dist = lim_lo ? dlo : dhi;
+    }
+    const uint32_t lmask = (uint32_t)((__ballot(lim) >> (GL * grp)) & 0xFFFFull);
+    const int nlim = __popc(lmask);
+    if (lim) {
+        const int r = __popc(lmask & ((1u << j) - 1u));
+        const T imp = impedance(m.solimp, lim_dist);
+        const T R = dl_max(T(1e-15), (T(1) - imp) * m.dof_invw[j] / imp);
+        wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = T(1) / R;
+        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = m.solK * imp * lim_dist;
+        wb[Ld::LIMC + r] = T(j | (lim_lo ? 0 : 32));
+    }
+    // ---- contact candidates: two passes of 16 (capsule ends and box corners in geom order)
+    bool act[2];
+    V3<T> cp[2];
+    T cdist[2], ctx[2], cty[2];
+    int cgeom[2];
+    for (int pass = 0; pass < 2; pass++) {
+        const int c = j + GL * pass;
+        act[pass] = false; cp[pass] = mk<T>(0, 0, 0); cdist[pass] = T(0); ctx[pass] = T(0); cty[pass] = T(1); cgeom[pass] = 0;
+        if (c < m.ncand) {
+            const int ge = m.cand_geom[c], sub = m.cand_sub[c], b = m.geom_body[ge];
+            cgeom[pass] = ge;
+            DL_LDS T* f = wb + Ld::BFR + b;
+            const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
+            const V3<T> gp = pos + m.geom_pos[ge][0] * X + m.geom_pos[ge][1] * Y + m.geom_pos[ge][2] * Z;
+            const DL_CONST T* gm = m.geom_mat[ge];
+            if (m.geom_type[ge] == 0) {
+                const V3<T> ax = gm[2] * X + gm[5] * Y + gm[8] * Z;
+                const T rad = m.geom_size[ge][0], half = m.geom_size[ge][1];
+                T tx = ax.x, ty = ax.y;
+                const T n2 = tx * tx + ty * ty;
+                if (n2 < T(1e-30)) { tx = T(1); ty = T(0); } else { const T inv = T(1) / dl_sqrt(n2); tx *= inv; ty *= inv; }
+                const V3<T> cc = gp + (sub == 0 ? half : -half) * ax;
+                const T dist = rootz + cc.z - rad;
+                act[pass] = dist < T(0);
+                cp[pass] = mk<T>(cc.x, cc.y, cc.z - (rad + T(0.5) * dist));
+                cdist[pass] = dist; ctx[pass] = tx; cty[pass] = ty;
+            } else {
+                const V3<T> ex = gm[0] * X + gm[3] * Y + gm[6] * Z, ey = gm[1] * X + gm[4] * Y + gm[7] * Z, ez = gm[2] * X + gm[5] * Y + gm[8] * Z;
+                const T sx = (sub & 1) ? m.geom_size[ge][0] : -m.geom_size[ge][0];
+                const T sy = (sub & 2) ? m.geom_size[ge][1] : -m.geom_size[ge][1];
+                const T sz = (sub & 4) ? m.geom_size[ge][2] : -m.geom_size[ge][2];
+                const V3<T> corner = sx * ex + sy * ey + sz * ez;
+                const T dist = rootz + gp.z + corner.z;
+                act[pass] = dist < T(0) && !(corner.z > T(0));
+                cp[pass] = mk<T>(gp.x + corner.x, gp.y + corner.y, gp.z + corner.z - T(0.5) * dist);
+                cdist[pass] = dist; ctx[pass] = T(0); cty[pass] = T(1);
+            }
+        }
+    }
+    // box rule: only the first four qualifying corners of a box make contacts (mjc_PlaneBox)
+    uint32_t cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
+    for (int pass = 0; pass < 2; pass++) {
+        const int c = j + GL * pass;
+        if (c < m.ncand && act[pass] && m.geom_type[cgeom[pass]] == 1) {
+            const int first = c - m.cand_sub[c];                              // first corner of this box in the candidate list
+            const uint32_t before = cm & ((1u << c) - 1u) & ~((1u << first) - 1u);
+            if (__popc(before) >= 4) act[pass] = false;
+        }
+    }
+    cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
+    const int ncon = __popc(cm);
+    for (int pass = 0; pass < 2; pass++) {
+        const int c = j + GL * pass;
+        if (act[pass]) {
+            const int slot = __popc(cm & ((1u << c) - 1u));
+            DL_LDS T* cn = wb + Ld::CON + slot;
+            cn[0] = cp[pass].x; cn[G_MAXCON] = cp[pass].y; cn[2 * G_MAXCON] = cp[pass].z;
+            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = m.geom_mu[cgeom[pass]];
+            cn[6 * G_MAXCON] = cdist[pass]; cn[7 * G_MAXCON] = T(m.geom_body[cgeom[pass]]);
+        }
+    }
+    g_sync<T>();            // BFR (aliased with JC) is dead from here on
+    // ---- per contact: D, K*imp*dist for its 4 pyramid rows, contact-frame Jacobian over the body's chain
+    for (int pass = 0; pass < 2; pass++) {
+        const int c = j + GL * pass;
+        if (c < ncon) {
+            DL_LDS T* cn = wb + Ld::CON + c;
+            const V3<T> p = mk<T>(cn[0], cn[G_MAXCON], cn[2 * G_MAXCON]);
+            const T tx = cn[3 * G_MAXCON], ty = cn[4 * G_MAXCON], mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
+            const int body = (int)cn[7 * G_MAXCON];
+            const T imp = impedance(m.solimp, dist);
+            const T diag = m.body_invw[body] * (T(1) + mu * mu);
+            const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag / imp);
+            const T D = T(1) / R, kd = m.solK * imp * dist;
+            const int r = nlim + 4 * c;
+            for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
+            DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
+            for (int a = 0; a < 3 * GL; a++) jc[a] = T(0);
+            const int last = m.body_last_dof[body], depth = m.dof_depth[last];
+            for (int d = 0; d <= depth; d++) {
+                const int a = m.chain[last][d];
+                const V3<T> ax = ld3(wb + Ld::AX + a, GL);
+                V3<T> w;
+                if (m.dof_type[a] == 0) w = ax;
+                else w = cross(ax, p - ld3(wb + Ld::AX + 3 * GL + a, GL));
+                jc[a] = w.z; jc[GL + a] = tx * w.x + ty * w.y; jc[2 * GL + a] = -ty * w.x + tx * w.y;
+            }
+        }
+    }
+    g_sync<T>();
+    nlim_out = nlim; ncon_out = ncon;
+}
+
+// rows JV = J x for the walker (x in LDS V_X), Mx_j returned
+template <typename T>
+__device__ __forceinline__ T g_apply(const GCtx<T>& g, int nlim, int ncon, bool want_mx) {
+    using Ld = GLds;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j;
+    DL_LDS T* x = wb + Ld::VEC + Ld::V_X * GL;
+    if (j < nlim) {
+        const int code = (int)wb[Ld::LIMC + j];
+        const T xv = x[code & 31];
+        wb[Ld::ROW + Ld::R_JV * G_MAXROW + j] = (code & 32) ? -xv : xv;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        const int c = j + GL * pass;
+        if (c < ncon) {
+            DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
+            T vn = T(0), v1 = T(0), v2 = T(0);
+#pragma unroll
+            for (int a = 0; a < GL; a++) { const T xa = x[a]; vn += jc[a] * xa; v1 += jc[GL + a] * xa; v2 += jc[2 * GL + a] * xa; }
+            const T mu = wb[Ld::CON + 5 * G_MAXCON + c];
+            DL_LDS T* jv = wb + Ld::ROW + Ld::R_JV * G_MAXROW + nlim + 4 * c;
+            jv[0] = vn + mu * v1; jv[1] = vn - mu * v1; jv[2] = vn + mu * v2; jv[3] = vn - mu * v2;
+        }
+    }
+    T mx = T(0);
+    if (want_mx) {
+#pragma unroll
+        for (int a = 0; a < GL; a++) mx += wb[Ld::MM + j * GL + a] * x[a];
+    }
+    return mx;
+}
+
+template <typename T> struct GLs { T alpha, cost, d1, d2; };
+
+// [3P] mj_forward for one walker spread over 16 lanes.  In: q_j, v_j, force of the motor on dof j,
+// warmstart_j.  Out: qacc_j.  nefc/niter for diagnostics.
+template <typename T>
+__device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ctrl_force, T warm, int& ncon_o, int& nefc_o, int& niter_o) {
+    using Ld = GLds;
+    const DL_CONST GModel<T>& m = *g.m;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j, nv = m.nv;
+    g_smooth_dynamics<T>(g, q, v, ctrl_force);
+    const T smooth = wb[Ld::VEC + Ld::V_SMOOTH * GL + j];
+    int nlim, ncon;
+    g_make_constraints<T>(g, grp, q, nlim, ncon);
+    const int nefc = nlim + 4 * ncon;
+    ncon_o = ncon; nefc_o = nefc;
+    DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * G_MAXROW;
+    DL_LDS T* rJA = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW;
+    DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
+    DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
+    DL_LDS T* xl = wb + Ld::VEC + Ld::V_X * GL;
+
+    T h[GL];                   // row j of H = M + sum_active D row^T row
+    T qacc = T(0), Ma = T(0), qsm = T(0), x = (j < nv) ? v : T(0), Mx = T(0), rhs = T(0);
+    T cost = T(0), gauss = T(0), cost_s = T(0);
+    const T nvf = T(nv), scale = T(1) / (m.meaninertia * nvf);
+    bool alive = true;         // this walker still iterates (identical in the 16 lanes of the row)
+    int phase = -1, iter = 0;
+    for (;;) {
+        if (!__any(alive)) break;
+        // ---- x -> LDS, J x, M x
+        xl[j] = x;
+        g_sync<T>();
+        Mx = g_apply<T>(g, nlim, ncon, phase > 0);
+        if (phase == 0) Mx = smooth;
+        g_sync<T>();
+        bool stop = false;
+        if (phase == -1) {
+            for (int r = j; r < nefc; r += GL) rJA[r] += m.solB * rJV[r];
+        } else if (phase <= 1) {
+            T c = T(0);
+            for (int r = j; r < nefc; r += GL) { const T jar = rJV[r] + rJA[r]; if (jar < T(0)) c += T(0.5) * rD[r] * jar * jar; }
+            c += T(0.5) * (Mx - smooth) * (x - qsm);
+            c = gsum(c);
+            if (phase == 0) {
+                cost_s = c;
+                for (int r = j; r < nefc; r += GL) rTM[r] = rJV[r];
+            } else {
+                const bool use_warm = !(c > cost_s);
+                if (alive) { qacc = use_warm ? warm : qsm; Ma = use_warm ? Mx : smooth; }
+                for (int r = j; r < nefc; r += GL) { rJA[r] += use_warm ? rJV[r] : rTM[r]; }
+                g_sync<T>();
+                for (int r = j; r < nefc; r += GL) rTM[r] = T(0);           // from now on: per-row "active" flags
+            }
+        } else {
+            // ---- exact line search (state machine per walker, evaluations in lock step over the wave)
+            const T snorm = dl_sqrt(gsum(x * x));
+            const T g1 = gsum(x * (Ma - smooth)), g2 = gsum(T(0.5) * x * Mx);
+            T alpha_res = T(0);
+            if (snorm < T(1e-15)) stop = true;
+            else {
+                const T gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * nvf + m.ls_reltol * dl_abs(g1);
+                GLs<T> p0 = {T(0), T(0), T(0), T(1)}, p1 = p0, p2 = p0, pmid = p0, p1next = p0, p2next = p0, cand[3] = {p0, p0, p0};
+                T dir = T(1), alpha = T(0);
+                bool p2update = false, b1 = false, b2 = false, ls_done = !alive;
+                int it = 0, state = 0;
+                const int maxit = m.ls_iterations;
+                while (__any(!ls_done)) {
+                    T pc = T(0), pd1 = T(0), pd2 = T(0);
+                    for (int r = j; r < nefc; r += GL) {
+                        const T jv = rJV[r], xx = rJA[r] + alpha * jv;
+                        if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jv; pd2 += D * jv * jv; }
+                    }
+                    pc = gsum(pc); pd1 = gsum(pd1); pd2 = gsum(pd2);
+                    const GLs<T> pe = {alpha, gauss + alpha * g1 + alpha * alpha * g2 + pc, g1 + T(2) * alpha * g2 + pd1, T(2) * g2 + pd2};
+                    if (ls_done) continue;
+                    bool end_onesided = false, end_iter = false;
+                    if (state == 0) { p0 = pe; alpha = -p0.d1 / p0.d2; state = 1; continue; }
+                    else if (state == 1) {
+                        p1 = pe;
+                        if (p0.cost < p1.cost) p1 = p0;
+                        if (dl_abs(p1.d1) < gtol) { alpha_res = p1.alpha; ls_done = true; continue; }
+                        dir = p1.d1 < T(0) ? T(1) : T(-1);
+                        p2 = p1;
+                        if (p1.d1 * dir <= -gtol && it < maxit) { p2 = p1; p2update = true; alpha = p1.alpha - p1.d1 / p1.d2; state = 2; continue; }
+                        end_onesided = true;
+                    } else if (state == 2) {
+                        p1 = pe; it++;
+                        if (dl_abs(p1.d1) < gtol) { alpha_res = p1.alpha; ls_done = true; continue; }
+                        if (p1.d1 * dir <= -gtol && it < maxit) { p2 = p1; alpha = p1.alpha - p1.d1 / p1.d2; continue; }
+                        end_onesided = true;
+                    } else if (state == 3) { p1next = pe; end_iter = true; }
+                    else if (state == 4) {
+                        pmid = pe; it++;
+                        cand[0] = p1next; cand[1] = p2next; cand[2] = pmid;
+                        int best = -1; T bestcost = T(0), bestalpha = T(0);
+                        for (int i = 0; i < 3; i++)
+                            if (dl_abs(cand[i].d1) < gtol && (best < 0 || cand[i].cost < bestcost)) { best = i; bestcost = cand[i].cost; bestalpha = cand[i].alpha; }
+                        if (best >= 0) { alpha_res = bestalpha; ls_done = true; continue; }
+                        b1 = false;
+                        for (int i = 0; i < 3; i++) {
+                            if (p1.d1 < T(0) && cand[i].d1 < T(0) && p1.d1 < cand[i].d1) { p1 = cand[i]; b1 = true; }
+                            else if (p1.d1 > T(0) && cand[i].d1 > T(0) && p1.d1 > cand[i].d1) { p1 = cand[i]; b1 = true; }
+                        }
+                        if (b1) { alpha = p1.alpha - p1.d1 / p1.d2; state = 5; continue; }
+                        b2 = false;
+                        for (int i = 0; i < 3; i++) {
+                            if (p2.d1 < T(0) && cand[i].d1 < T(0) && p2.d1 < cand[i].d1) { p2 = cand[i]; b2 = true; }
+                            else if (p2.d1 > T(0) && cand[i].d1 > T(0) && p2.d1 > cand[i].d1) { p2 = cand[i]; b2 = true; }
+                        }
+                        if (b2) { alpha = p2.alpha - p2.d1 / p2.d2; state = 6; continue; }
+                        end_iter = true;
+                    } else if (state == 5) {
+                        p1next = pe;
+                        b2 = false;
+                        for (int i = 0; i < 3; i++) {
+                            if (p2.d1 < T(0) && cand[i].d1 < T(0) && p2.d1 < cand[i].d1) { p2 = cand[i]; b2 = true; }
+                            else if (p2.d1 > T(0) && cand[i].d1 > T(0) && p2.d1 > cand[i].d1) { p2 = cand[i]; b2 = true; }
+                        }
+                        if (b2) { alpha = p2.alpha - p2.d1 / p2.d2; state = 6; continue; }
+                        end_iter = true;
+                    } else { p2next = pe; end_iter = true; }
+                    if (end_onesided) {
+                        if (it >= maxit || !p2update) { alpha_res = p1.alpha; ls_done = true; continue; }
+                        p2next = p1; alpha = p1.alpha - p1.d1 / p1.d2; state = 3; continue;
+                    }
+                    if (end_iter) {
+                        if (state != 3 && !b1 && !b2) { alpha_res = pmid.cost < p0.cost ? pmid.alpha : T(0); ls_done = true; continue; }
+                        if (it >= maxit) {
+                            if (p1.cost <= p2.cost && p1.cost < p0.cost) alpha_res = p1.alpha;
+                            else if (p2.cost <= p1.cost && p2.cost < p0.cost) alpha_res = p2.alpha;
+                            else alpha_res = T(0);
+                            ls_done = true; continue;
+                        }
+                        b1 = false; b2 = false; alpha = T(0.5) * (p1.alpha + p2.alpha); state = 4;
+                    }
+                }
+                if (alpha_res == T(0)) stop = true;
+                else if (alive) {
+                    qacc += alpha_res * x; Ma += alpha_res * Mx;
+                    for (int r = j; r < nefc; r += GL) rJA[r] += alpha_res * rJV[r];
+                }
+            }
+        }
+        if (stop) alive = false;
+        g_sync<T>();
+        if (phase == 0) { phase = 1; x = (j < nv) ? warm : T(0); continue; }
+
+        // ---- Hessian row: M at the start, then contact / limit rows whose state flipped
+        const T oldcost = cost;
+        if (phase <= 1) {
+#pragma unroll
+            for (int a = 0; a < GL; a++) h[a] = wb[Ld::MM + j * GL + a];
+        }
+        if (phase >= 1) {
+            // per row: force, cost, flip bookkeeping (lanes split the rows)
+            T c = T(0);
+            for (int r = j; r < nefc; r += GL) {
+                const T jar = rJA[r], D = rD[r];
+                const bool on = jar < T(0);
+                rJV[r] = on ? -D * jar : T(0);                         // row force (JV is free now)
+                if (on) c += T(0.5) * D * jar * jar;
+            }
+            g_sync<T>();
+            // limits: flips touch the diagonal, forces go to their dof
+            T fcon = T(0);
+            for (int r = 0; r < nlim; r++) {
+                const int code = (int)wb[Ld::LIMC + r];
+                if ((code & 31) == j) {
+                    const T f = rJV[r], D = rD[r];
+                    const bool on = rJA[r] < T(0), was = rTM[r] != T(0);
+                    fcon += (code & 32) ? -f : f;
+                    if (on != was && alive) {
+                        const T dH = on ? D : -D;
+#pragma unroll
+                        for (int a = 0; a < GL; a++) if (a == j) h[a] += dH;
+                    }
+                }
+            }
+            // contacts: force in the contact frame; Hessian update J_c^T dW J_c for flipped edges
+            for (int cc = 0; cc < ncon; cc++) {
+                const int r0 = nlim + 4 * cc;
+                const T mu = wb[Ld::CON + 5 * G_MAXCON + cc];
+                T f4[4], dD[4];
+                bool anyflip = false;
+                for (int s4 = 0; s4 < 4; s4++) {
+                    f4[s4] = rJV[r0 + s4];
+                    const bool on = rJA[r0 + s4] < T(0), was = rTM[r0 + s4] != T(0);
+                    dD[s4] = (on == was) ? T(0) : (on ? rD[r0 + s4] : -rD[r0 + s4]);
+                    anyflip = anyflip || (on != was);
+                }
+                DL_LDS T* jc = wb + Ld::JC + cc * G_JC_STRIDE;
+                const T jn = jc[j], j1 = jc[GL + j], j2 = jc[2 * GL + j];
+                const T Fn = f4[0] + f4[1] + f4[2] + f4[3], F1 = mu * (f4[0] - f4[1]), F2 = mu * (f4[2] - f4[3]);
+                fcon += jn * Fn + j1 * F1 + j2 * F2;
+                if (__any(anyflip && alive)) {
+                    if (anyflip && alive) {
+                        // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
+                        const T w00 = dD[0] + dD[1] + dD[2] + dD[3];
+                        const T w01 = mu * (dD[0] - dD[1]), w02 = mu * (dD[2] - dD[3]);
+                        const T w11 = mu * mu * (dD[0] + dD[1]), w22 = mu * mu * (dD[2] + dD[3]);
+                        const T t0 = w00 * jn + w01 * j1 + w02 * j2, t1 = w01 * jn + w11 * j1, t2 = w02 * jn + w22 * j2;
+#pragma unroll
+                        for (int a = 0; a < GL; a++) h[a] += jc[a] * t0 + jc[GL + a] * t1 + jc[2 * GL + a] * t2;
+                    }
+                }
+            }
+            g_sync<T>();
+            // remember the active state
+            for (int r = j; r < nefc; r += GL) rTM[r] = (rJA[r] < T(0)) ? T(1) : T(0);
+            const T gpart = T(0.5) * (Ma - smooth) * (qacc - qsm);
+            gauss = gsum(gpart);
+            cost = gsum(c) + gauss;
+            rhs = Ma - smooth - fcon;
+        } else {
+            rhs = smooth;
+        }
+        if (phase >= 2) {
+            const T gn = gsum(rhs * rhs);
+            const T improvement = scale * (oldcost - cost), gradient = scale * dl_sqrt(gn);
+            if (alive) iter++;
+            if (improvement < m.tolerance || gradient < m.tolerance || iter >= m.iterations) alive = false;
+        }
+        // ---- factor H (row j in lane j) and solve
+        {
+            T l[GL];
+#pragma unroll
+            for (int a = 0; a < GL; a++) l[a] = h[a];
+            g_chol<T>(l, j, nv);
+            rhs = g_chol_solve<T>(l, rhs, j, nv);
+        }
+        if (phase == -1) {
+            qsm = rhs; x = rhs;
+            if (nefc == 0) { qacc = qsm; alive = false; }
+            phase = 0;
+        } else {
+            x = -rhs;
+            phase = phase + 1;
+        }
+    }
+    niter_o = iter;
+    return qacc;
+}
+
+}  // namespace dl

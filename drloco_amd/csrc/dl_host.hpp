@@ -100,4 +100,83 @@ inline void loco3d_prefix_sums(const dl_refs_desc& r, int nv, std::vector<double
     }
 }
 
+
+// ---- table-driven model for the 16-lanes-per-walker kernels (dl_group.hpp)
 }  // namespace dl
+#if defined(__HIPCC__)
+#include "dl_group.hpp"
+namespace dl {
+template <typename T> inline bool fill_group_model(const dl_model_desc& d, GModel<T>& g, std::string& why) {
+    std::memset(&g, 0, sizeof g);
+    if (d.nv > GL - 0 || d.nbody > G_MAXB || d.ngeom > G_MAXB || d.nsite > 8) { why = "model too large for the 16-lane kernels"; return false; }
+    g.nv = d.nv; g.nb = d.nbody; g.nu = d.nu; g.ngeom = d.ngeom; g.nsite = d.nsite; g.frame_skip = d.frame_skip;
+    g.iterations = d.iterations; g.ls_iterations = d.ls_iterations;
+    g.timestep = (T)d.timestep; g.gravity_z = (T)d.gravity[2];
+    double tc = d.solref[0], dr = d.solref[1], dmax = d.solimp[1];
+    if (tc < 2 * d.timestep) tc = 2 * d.timestep;
+    g.solK = (T)(1.0 / std::fmax(1e-15, dmax * dmax * tc * tc * dr * dr));
+    g.solB = (T)(2.0 / std::fmax(1e-15, dmax * tc));
+    for (int k = 0; k < 5; k++) g.solimp[k] = (T)d.solimp[k];
+    g.meaninertia = (T)d.meaninertia; g.tolerance = (T)d.tolerance; g.ls_tolerance = (T)d.ls_tolerance;
+    if (sizeof(T) == 4) { g.tolerance = (T)std::fmax(d.tolerance, 1e-6); g.ls_reltol = (T)1e-5; } else g.ls_reltol = (T)0;
+    g.root_z0 = (T)d.body_pos[1][2];
+    // bodies
+    for (int b = 0; b < d.nbody; b++) {
+        for (int k = 0; k < 3; k++) { g.body_pos[b][k] = (T)d.body_pos[b][k]; g.body_ipos[b][k] = (T)d.body_ipos[b][k]; g.body_inertia[b][k] = (T)d.body_inertia[b][k]; }
+        g.body_mass[b] = (T)d.body_mass[b]; g.body_invw[b] = (T)d.body_invweight0[b][0];
+        g.body_last_dof[b] = -1;
+        uint32_t sub = 0;
+        for (int c = 1; c < d.nbody; c++) { int a = c; while (a > 0 && a != b) a = d.body_parent[a]; if (a == b && b > 0) sub |= 1u << c; }
+        g.body_submask[b] = sub;
+    }
+    // dofs: parent dof = previous dof of the same body, else last dof of the nearest ancestor body that has dofs
+    int dof_parent[GL];
+    for (int j = 0; j < d.nv; j++) {
+        const int b = d.jnt_body[j];
+        g.dof_body[j] = b; g.dof_type[j] = d.jnt_type[j]; g.dof_limited[j] = d.jnt_limited[j];
+        int ax = -1; double sg = 0;
+        for (int k = 0; k < 3; k++) if (std::fabs(d.jnt_axis[j][k]) > 0.5) { ax = k; sg = d.jnt_axis[j][k] > 0 ? 1 : -1; }
+        g.dof_axis[j] = ax; g.dof_sign[j] = (T)sg;
+        g.qpos0[j] = (T)d.jnt_qpos0[j]; g.range_lo[j] = (T)d.jnt_range[j][0]; g.range_hi[j] = (T)d.jnt_range[j][1];
+        g.damping[j] = (T)d.jnt_damping[j]; g.armature[j] = (T)d.jnt_armature[j]; g.dof_invw[j] = (T)d.dof_invweight0[j];
+        g.dof_first[j] = (j == 0 || d.jnt_body[j - 1] != b) ? 1 : 0;
+        g.dof_is_last[j] = (j == d.nv - 1 || d.jnt_body[j + 1] != b) ? 1 : 0;
+        if (g.dof_is_last[j]) g.body_last_dof[b] = j;
+        g.dof_act[j] = -1;
+        if (!g.dof_first[j]) dof_parent[j] = j - 1;
+        else {
+            int a = d.body_parent[b], p = -1;
+            while (a > 0 && p < 0) { for (int k = d.nv - 1; k >= 0; k--) if (d.jnt_body[k] == a) { p = k; break; } a = d.body_parent[a]; }
+            dof_parent[j] = p;
+        }
+    }
+    for (int j = 0; j < d.nv; j++) {
+        int tmp[G_MAXCHAIN], n = 0, a = j;
+        while (a >= 0) { if (n >= G_MAXCHAIN) { why = "kinematic chain too long for the 16-lane kernels"; return false; } tmp[n++] = a; a = dof_parent[a]; }
+        g.dof_depth[j] = n - 1;
+        for (int k = 0; k < n; k++) g.chain[j][k] = tmp[n - 1 - k];
+    }
+    g.root_last_dof = g.body_last_dof[1];
+    for (int b = 1; b < d.nbody; b++) if (g.body_last_dof[b] < 0) { why = "every body needs at least one joint"; return false; }
+    for (int a = 0; a < d.nu; a++) {
+        const int j = d.act_dof[a];
+        g.dof_act[j] = a;
+        g.ctrl_lo[j] = (T)d.act_ctrlrange[a][0]; g.ctrl_hi[j] = (T)d.act_ctrlrange[a][1];
+        g.force_lo[j] = (T)d.act_forcerange[a][0]; g.force_hi[j] = (T)d.act_forcerange[a][1]; g.gear[j] = (T)d.act_gear[a];
+    }
+    // geoms and collision candidates in contact order
+    int nc = 0;
+    for (int ge = 0; ge < d.ngeom; ge++) {
+        g.geom_body[ge] = d.geom_body[ge]; g.geom_type[ge] = d.geom_type[ge];
+        for (int k = 0; k < 3; k++) { g.geom_pos[ge][k] = (T)d.geom_pos[ge][k]; g.geom_size[ge][k] = (T)d.geom_size[ge][k]; }
+        for (int k = 0; k < 9; k++) g.geom_mat[ge][k] = (T)d.geom_mat[ge][k];
+        g.geom_mu[ge] = (T)(d.geom_friction[ge] > d.floor_friction ? d.geom_friction[ge] : d.floor_friction);
+        const int cnt = d.geom_type[ge] == DL_GEOM_CAPSULE ? 2 : 8;
+        for (int k = 0; k < cnt; k++) { if (nc >= G_MAXCAND) { why = "too many collision candidates"; return false; } g.cand_geom[nc] = ge; g.cand_sub[nc] = k; nc++; }
+    }
+    g.ncand = nc;
+    for (int s = 0; s < d.nsite; s++) { g.site_body[s] = d.site_body[s]; for (int k = 0; k < 3; k++) g.site_pos[s][k] = (T)d.site_pos[s][k]; }
+    return true;
+}
+}  // namespace dl
+#endif

@@ -69,6 +69,171 @@ __global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP>* __rest
     if (niter) niter[i] = info >> 16;
 }
 
+// forward dynamics with 16 lanes per walker (dl_group.hpp): 4 walkers per 64-lane workgroup
+template <typename T>
+__global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict__ gm, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
+    const int w = blockIdx.x * GW + grp;
+    const bool valid = w < n;
+    const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
+    const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
+    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j};
+    const int nv = m->nv;
+    T q = T(0), v = T(0), wm = T(0), force = T(0);
+    if (j < nv) {
+        q = st.qpos[(size_t)j * n + wi]; v = st.qvel[(size_t)j * n + wi]; wm = st.warm[(size_t)j * n + wi];
+        const int a = m->dof_act[j];
+        if (a >= 0) {
+            const T u = dl_clamp(ctrl ? ctrl[(size_t)a * n + wi] : T(0), m->ctrl_lo[j], m->ctrl_hi[j]);
+            force = m->gear[j] * dl_clamp(u, m->force_lo[j], m->force_hi[j]);
+        }
+    }
+    int nc, ne, ni;
+    const T a = g_forward<T>(g, grp, q, v, force, wm, nc, ne, ni);
+    if (valid && j < nv) qacc[(size_t)j * n + w] = a;
+    if (valid && j == 0) { if (ncon) ncon[w] = nc; if (nefc) nefc[w] = ne; if (niter) niter[w] = ni; }
+}
+
+
+// one control step with 16 lanes per walker (straight walker): action map, 5 x RK4 mj_step through
+// g_forward, cursor / observation / reward / termination / Monitor.  Finished walkers are flagged
+// in need_reset and re-initialised by k_env_reset (lane-per-walker kernel, rare).
+template <typename T>
+__global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
+                                                     float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
+                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags) {
+    using TPS = TopoStraight;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
+    const int w0 = blockIdx.x * GW + grp;
+    const bool valid = w0 < n;
+    const int w = valid ? w0 : n - 1;
+    const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
+    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j};
+    DL_LDS T* wb = g.wb;
+    const int nv = m->nv, nu = m->nu;
+    const bool isdof = j < nv;
+    T q = T(0), v = T(0), warm = T(0);
+    if (isdof) { q = st.qpos[(size_t)j * n + w]; v = st.qvel[(size_t)j * n + w]; warm = st.warm[(size_t)j * n + w]; }
+    int32_t cur[DL_CUR_WORDS];
+#pragma unroll
+    for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w];
+    // ---- _rescale_actions + mirror_action (cursor BEFORE refs.next()), per actuated dof
+    const bool mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+    T ctrl = T(0), force = T(0);
+    const int a = isdof ? m->dof_act[j] : -1;
+    if (a >= 0) {
+        const int src = mirr_a ? TPS::act_perm_[a] : a;
+        const int jsrc = TPS::act_dof_[src];
+        const T x = dl_clamp((T)actions[(size_t)w * nu + src], T(-1), T(1));
+        const T raw = x > T(0) ? x * m->ctrl_hi[jsrc] : dl_abs(x) * m->ctrl_lo[jsrc];
+        ctrl = (mirr_a && TPS::act_neg_[a]) ? -raw : raw;
+        const T u = dl_clamp(ctrl, m->ctrl_lo[j], m->ctrl_hi[j]);
+        force = m->gear[j] * dl_clamp(u, m->force_lo[j], m->force_hi[j]);
+    }
+    const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, m->force_lo[j], m->force_hi[j])) : T(0));
+    // ---- physics
+    bool exc = false;
+    const int flag = inj_flags ? inj_flags[w] : 0;
+    if (flag == 2) exc = true;
+    else if (flag == 1) { if (isdof) { q = inj_q[(size_t)j * n + w]; v = inj_v[(size_t)j * n + w]; } }
+    const bool simulate = flag == 0;
+    if (__any(simulate)) {
+        const T h = m->timestep;
+        const int fs = m->frame_skip;
+#pragma unroll 1
+        for (int kf = 0; kf < fs; kf++) {
+            // mj_checkPos / mj_checkVel
+            if (simulate && !exc && gany(isdof && (dl_bad(q) || dl_bad(v)))) exc = true;
+            const T q0 = q, v0 = v;
+            T dq = T(0), dv = T(0), qs = q, vs = v;
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                int nc, ne, ni;
+                const T acc = g_forward<T>(g, grp, qs, vs, force, warm, nc, ne, ni);
+                if (simulate && !exc) warm = acc;
+                if (stage == 0 && simulate && !exc && gany(isdof && dl_bad(acc))) exc = true;     // mj_checkAcc
+                const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
+                const T al = stage == 2 ? T(1) : T(0.5);
+                dq += wgt * vs; dv += wgt * acc;
+                const T vstage = vs;
+                qs = q0 + h * al * vstage; vs = v0 + h * al * acc;
+            }
+            if (simulate && !exc) { q = q0 + h * dq; v = v0 + h * dv; }
+        }
+    }
+    // ---- environment logic
+    const double tor_mean = (double)tor_sum / nu;
+    double walked = st.walked[w];
+    const T comz = st.comz_off[w];
+    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
+    float r;
+    bool dn;
+    if (exc) {
+        r = 0.0f; dn = true; walked = 0;
+        terms[0] = terms[1] = terms[2] = 1.0;
+        if (valid && j == 0) st.need_reset[w] = 2;
+    } else {
+        cursor_next<T, TPS>(c, cur);
+        // raw observation entries live in LDS: [phase, desvel, q1.., v0..]
+        g_sync<T>();
+        if (isdof) { wb[GLds::Q + j] = q; wb[GLds::V + j] = v; }
+        g_sync<T>();
+        const int rs = cur[DL_CUR_READ_STEP];
+        const T phase_var = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
+        const int iv = cur[DL_CUR_I_STEP] - cur[DL_CUR_COUNT] + 1;
+        const T desvel = c.step_vel[iv > 0 ? iv : 0];
+        const bool mirr_o = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+        auto raw_obs = [&](int k) -> T { return k == 0 ? phase_var : (k == 1 ? desvel : (k < 1 + nv ? wb[GLds::Q + (k - 1)] : wb[GLds::V + (k - 1 - nv)])); };
+        float* dst_base = nullptr;
+        cur[DL_CUR_EP_DUR] += 1;
+        const T vx = dl_clamp(gbcast(v, j, 0), T(-5.5), T(5.5)), vy = dl_clamp(gbcast(v, j, 1), T(-5.5), T(5.5));
+        walked += (double)dl_sqrt(vx * vx + vy * vy) * (double)c.inv_ctrl_freq;
+        const bool timeout = cur[DL_CUR_EP_DUR] >= c.ep_dur_max;
+        const T qz = gbcast(q, j, 2);
+        dn = (qz < c.com_z_min) || timeout;
+        if (dn) r = timeout ? 0.0f : -0.0f;
+        else {
+            // imitation reward: every dof lane contributes its squared differences
+            T dp = T(0), dvv = T(0), dc = T(0);
+            if (isdof) {
+                const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
+                T qr = c.table[(size_t)j * c.total_len + base];
+                const T vr = c.table[(size_t)(nv + j) * c.total_len + base];
+                if (cur[DL_CUR_HAS_DIST]) { if (j == 0) qr += c.table[c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1]; }
+                else if (j == 2) qr -= comz;
+                const T d1 = q - qr, d2 = v - vr;
+                if (j < 3) dc = d1 * d1; else { dp = d1 * d1; dvv = d2 * d2; }
+            }
+            const T tp = dl_exp(T(-3) * gsum(dp)), tv = dl_exp(T(-0.05) * gsum(dvv)), tc = dl_exp(T(-16) * gsum(dc));
+            terms[0] = (double)tp; terms[1] = (double)tv; terms[2] = (double)tc;
+            r = (float)((c.rew_w[0] * tp + c.rew_w[1] * tv + c.rew_w[2] * tc) * c.rew_scale + c.alive_bonus);
+        }
+        dst_base = dn ? term_obs : obs;
+        if (valid && dst_base) {
+            // 29 outputs over 16 lanes: k = j and k = j + 16
+            for (int k = j; k < TPS::OBS; k += GL) {
+                const T plain = raw_obs(k);
+                const T mir = TPS::obs_neg_[k] ? -raw_obs(TPS::obs_perm_[k]) : raw_obs(TPS::obs_perm_[k]);
+                dst_base[(size_t)w * TPS::OBS + k] = (float)(mirr_o ? mir : plain);
+            }
+        }
+        if (valid && dn && j == 0) st.need_reset[w] = 1;
+    }
+    if (valid && j == 0) {
+        monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked);
+        st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
+        if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
+        rew[w] = r;
+        done[w] = dn ? 1 : 0;
+        st.walked[w] = walked;
+#pragma unroll
+        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
+    }
+    if (valid && isdof) { st.qpos[(size_t)j * n + w] = q; st.qvel[(size_t)j * n + w] = v; st.warm[(size_t)j * n + w] = warm; }
+}
+
 template <typename T> __global__ void k_fill(T* p, T val, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = val;
@@ -183,7 +348,7 @@ static int fail(int code, const std::string& what) { g_err = what; return code; 
 
 struct dl_env_s {
     virtual ~dl_env_s() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-    int n = 0, device = 0, real_size = 4, eval_mode = 0, obs_dim = 0, act_dim = 0;
+    int n = 0, device = 0, real_size = 4, eval_mode = 0, obs_dim = 0, act_dim = 0, variant = 0;
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
     virtual int step(const float*, float*, float*, uint8_t*, float*, float*, hipStream_t) = 0;
@@ -216,6 +381,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     DevCfg<T> c;
     DevState<T> st;
     std::vector<void*> allocs;
+    GModel<T>* gmd = nullptr;        // table-driven model of the 16-lane kernels (straight walker only)
     T *inj_q = nullptr, *inj_v = nullptr;
     int32_t* inj_flags = nullptr;
     bool inj_armed = false;
@@ -284,6 +450,18 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&inj_v, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&inj_flags, n))) return rc;
         if ((rc = dalloc(&scratch_obs, (size_t)TP::OBS * n))) return rc;
+        variant = cfg.reserved;
+        if (TP::NV <= GL && TP::NB <= G_MAXB) {
+            GModel<T> gmh;
+            std::string why;
+            if (!fill_group_model<T>(d, gmh, why)) { if (variant == 1) return fail(DL_E_INVAL, why); }
+            else {
+                if ((rc = dalloc(&gmd, 1))) return rc;
+                HIPCHK(hipMemcpy(gmd, &gmh, sizeof gmh, hipMemcpyHostToDevice));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GW * GLds::TOTAL * sizeof(T))));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GW * GLds::TOTAL * sizeof(T))));
+            }
+        } else if (variant == 1) return fail(DL_E_INVAL, "the 16-lane kernels support models with at most 16 dofs");
         const unsigned g256 = (unsigned)((n + 255) / 256);
         for (int j = 0; j < TP::NV; j++) k_fill<T><<<g256, 256>>>(st.qpos + (size_t)j * n, (T)d.jnt_qpos0[j], (size_t)n);
         k_fill<int32_t><<<g256, 256>>>(st.cur + (size_t)DL_CUR_COUNT * n, 1, (size_t)n);   // count_steps_same_vel = 1
@@ -304,10 +482,19 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
+        if (variant == 1 && gmd) {
+            if constexpr (TP::ENV_KIND == 0) {
+                prof_begin(s);
+                hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), GW * GLds::TOTAL * sizeof(T), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
+                                   (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
+                prof_end(s);
+            }
+        } else {
         prof_begin(s);
         hipLaunchKernelGGL((k_env_step<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, act, obs, rew, done, term, terms,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
         prof_end(s);
+        }
         HIPCHK(hipGetLastError());
         if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
         hipLaunchKernelGGL((k_env_reset<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, obs, term, eval_mode);
@@ -334,6 +521,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
         if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
+        if (variant == 1 && gmd) {
+            hipLaunchKernelGGL((k_forward_g16<T>), dim3((n + GW - 1) / GW), dim3(64), GW * GLds::TOTAL * sizeof(T), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+            HIPCHK(hipGetLastError());
+            return DL_OK;
+        }
         hipLaunchKernelGGL((k_forward<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
         HIPCHK(hipGetLastError());
         return DL_OK;

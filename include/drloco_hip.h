@@ -154,7 +154,7 @@ typedef struct dl_config {
     int32_t env_kind;       /* DL_ENV_STRAIGHT: MimicWalker3dEnv + StraightWalkingTrajectories;
                                DL_ENV_LOCO3D: MimicWalker165cm65kgEnv + Loco3dReferenceTrajectories
                                (drloco/mujoco/config.py:9-10) */
-    int32_t reserved;
+    int32_t reserved;       /* kernel variant: 0 = one walker per lane (default), 1 = 16 lanes per walker (straight walker) */
 } dl_config;
 
 typedef struct dl_env_s* dl_handle;
