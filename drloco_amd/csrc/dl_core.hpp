@@ -211,7 +211,7 @@ template <typename T, typename TP> struct DevModel {
     T geom_pos[TP::NG][3], geom_mat[TP::NG][9], geom_size[TP::NG][3], geom_mu[TP::NG], body_invw[TP::NB];
     T site_pos[TP::NS][3];
     T ctrl_lo[TP::NU], ctrl_hi[TP::NU], force_lo[TP::NU], force_hi[TP::NU], gear[TP::NU];
-    T timestep, gravity_z, solK, solB, solimp[5], meaninertia, tolerance, ls_tolerance, ls_reltol;
+    T timestep, gravity_z, solK, solB, solimp[5], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel;
     int32_t iterations, ls_iterations, frame_skip;
 };
 
@@ -1014,7 +1014,10 @@ DL_HD void forward(const DL_CONST DevModel<T, TP>& m, const LaneMem<T>& mem, con
             static_for<TP::NV>([&](auto ii) { gn += rhs[ii.value] * rhs[ii.value]; });
             const T improvement = scale * (oldcost - cost), gradient = scale * dl_sqrt(gn);
             iter++;
-            if (improvement < m.tolerance || gradient < m.tolerance || iter >= m.iterations) break;
+            // float32 (tol_rel > 0): relative terms absorb the rounding noise of cost / gradient
+            T gmag = T(0);
+            static_for<TP::NV>([&](auto ii) { gmag += dl_abs(Ma[ii.value]) + dl_abs(smooth[ii.value]); });
+            if (improvement < m.tolerance + m.tol_rel * scale * dl_abs(cost) || gradient < m.tolerance + m.tol_rel * scale * gmag || iter >= m.iterations) break;
         }
         // ---- factorise a copy of H and solve
         {

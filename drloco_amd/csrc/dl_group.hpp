@@ -32,7 +32,7 @@ constexpr int G_JC_STRIDE = 49; // 3*16 + 1: contact lanes reading their Jacobia
 // model as data (host-built from dl_model_desc), read through the constant address space
 template <typename T> struct GModel {
     int32_t nv, nb, nu, ngeom, nsite, frame_skip, iterations, ls_iterations, ncand, root_last_dof;
-    T timestep, gravity_z, solK, solB, solimp[5], meaninertia, tolerance, ls_tolerance, ls_reltol, root_z0;
+    T timestep, gravity_z, solK, solB, solimp[5], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, root_z0;
     int32_t dof_body[GL], dof_type[GL], dof_axis[GL], dof_first[GL], dof_limited[GL], dof_depth[GL], dof_is_last[GL];
     int32_t chain[GL][G_MAXCHAIN];
     T dof_sign[GL], qpos0[GL], range_lo[GL], range_hi[GL], damping[GL], armature[GL], dof_invw[GL];
@@ -77,6 +77,81 @@ struct GLds {
     static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
 };
 
+// model data needed with per-lane (non-uniform) indices inside the inner loops is staged once per
+// kernel in LDS (shared by the 4 walkers of the wave); everything a lane needs about ITS OWN dof /
+// body / collision candidates is preloaded into registers (GLane).  No vector-memory table lookups
+// remain on the critical path.
+struct GShared {
+    // int region
+    static constexpr int I_PROPS = 0;                 // [16] bit0 type, 1-2 axis, 3 negative axis, 4 first dof of body, 5-7 body, 8-11 depth, 12 last dof of body
+    static constexpr int I_CHAIN_LO = 16, I_CHAIN_HI = 32;   // [16] packed chains: nibble d = d-th dof on the root->dof path
+    static constexpr int I_BODY_LAST = 48;            // [8]
+    static constexpr int I_CAND = 56;                 // [32] bit0 valid, 1 type (box), 2-4 sub, 5-7 body
+    static constexpr int I_END = 88;
+    // T region (offsets in T elements, after the int region)
+    static constexpr int T_QPOS0 = 0;                 // [16]
+    static constexpr int T_BODY_POS = 16;             // [8][3]
+    static constexpr int T_BODY_INVW = 40;            // [8]
+    static constexpr int T_CAND = 48;                 // [32][CAND_W]: pos(3) mat(9) size(3) mu
+    static constexpr int CAND_W = 17;                 // 16 values, padded to an odd stride (bank spread)
+    static constexpr int T_END = T_CAND + 32 * CAND_W;
+    template <typename T> static constexpr int bytes() { return ((I_END * 4 + T_END * (int)sizeof(T) + 255) / 256) * 256; }
+};
+
+template <typename T> struct GLane {
+    int type, axis, first, body, depth, is_last, limited, act;
+    T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
+    uint64_t chain;                                   // own chain, nibble-packed
+    // body lane (j in 1..nb-1)
+    T mass, ipos[3], inertia[3];
+    uint32_t submask;
+};
+
+template <typename T>
+__device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, GLane<T>& ln) {
+    const int jj = j < m.nv ? j : 0;
+    ln.type = m.dof_type[jj]; ln.axis = m.dof_axis[jj]; ln.first = m.dof_first[jj]; ln.body = m.dof_body[jj]; ln.depth = m.dof_depth[jj];
+    ln.is_last = m.dof_is_last[jj]; ln.limited = m.dof_limited[jj]; ln.act = m.dof_act[jj];
+    ln.sign = m.dof_sign[jj]; ln.qpos0 = m.qpos0[jj]; ln.range_lo = m.range_lo[jj]; ln.range_hi = m.range_hi[jj];
+    ln.damping = m.damping[jj]; ln.armature = m.armature[jj]; ln.invw = m.dof_invw[jj];
+    ln.ctrl_lo = m.ctrl_lo[jj]; ln.ctrl_hi = m.ctrl_hi[jj]; ln.force_lo = m.force_lo[jj]; ln.force_hi = m.force_hi[jj]; ln.gear = m.gear[jj];
+    uint64_t ch = 0;
+    for (int d = 0; d < G_MAXCHAIN; d++) ch |= (uint64_t)(m.chain[jj][d] & 15) << (4 * d);
+    ln.chain = ch;
+    const int b = (j >= 1 && j < m.nb) ? j : 1;
+    ln.mass = m.body_mass[b]; ln.submask = m.body_submask[b];
+    for (int k = 0; k < 3; k++) { ln.ipos[k] = m.body_ipos[b][k]; ln.inertia[k] = m.body_inertia[b][k]; }
+}
+
+// fill the shared model block (all 64 lanes of the wave cooperate); call once, then __syncthreads()
+template <typename T>
+__device__ __forceinline__ void g_fill_shared(const DL_CONST GModel<T>& m, DL_LDS int* si, DL_LDS T* stt, int lane) {
+    if (lane < GL) {
+        const int a = lane < m.nv ? lane : 0;
+        si[GShared::I_PROPS + lane] = m.dof_type[a] | (m.dof_axis[a] << 1) | ((m.dof_sign[a] < T(0)) ? 8 : 0) | (m.dof_first[a] << 4) | (m.dof_body[a] << 5) |
+                                      (m.dof_depth[a] << 8) | (m.dof_is_last[a] << 12);
+        uint64_t ch = 0;
+        for (int d = 0; d < G_MAXCHAIN; d++) ch |= (uint64_t)(m.chain[a][d] & 15) << (4 * d);
+        si[GShared::I_CHAIN_LO + lane] = (int)(uint32_t)ch;
+        si[GShared::I_CHAIN_HI + lane] = (int)(uint32_t)(ch >> 32);
+        stt[GShared::T_QPOS0 + lane] = m.qpos0[a];
+    } else if (lane < GL + G_MAXB) {
+        const int b = lane - GL;
+        si[GShared::I_BODY_LAST + b] = m.body_last_dof[b];
+        stt[GShared::T_BODY_INVW + b] = m.body_invw[b];
+        for (int k = 0; k < 3; k++) stt[GShared::T_BODY_POS + 3 * b + k] = m.body_pos[b][k];
+    } else if (lane >= 32) {
+        const int c = lane - 32;                      // 32 candidate slots
+        const bool ok = c < m.ncand;
+        const int ge = ok ? m.cand_geom[c] : 0;
+        si[GShared::I_CAND + c] = (ok ? 1 : 0) | (m.geom_type[ge] << 1) | ((ok ? m.cand_sub[c] : 0) << 2) | (m.geom_body[ge] << 5);
+        DL_LDS T* cd = stt + GShared::T_CAND + c * GShared::CAND_W;
+        for (int k = 0; k < 3; k++) { cd[k] = m.geom_pos[ge][k]; cd[12 + k] = m.geom_size[ge][k]; }
+        for (int k = 0; k < 9; k++) cd[3 + k] = m.geom_mat[ge][k];
+        cd[15] = m.geom_mu[ge];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // DPP row (16-lane) primitives
 template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
@@ -105,9 +180,13 @@ template <typename T> __device__ __forceinline__ void g_sync() { __syncthreads()
 // ------------------------------------------------------------------------------------------
 template <typename T> struct GCtx {
     DL_LDS T* wb;                        // walker's LDS region
-    const DL_CONST GModel<T>* m;
+    const DL_CONST GModel<T>* m;         // uniform scalars only on the hot path
     int j;                               // lane in the row
+    DL_LDS int* si;                      // shared model block (ints)
+    DL_LDS T* st;                        // shared model block (reals)
+    const GLane<T>* ln;                  // this lane's preloaded model data
 };
+__device__ __forceinline__ int chain_at(uint64_t ch, int d) { return (int)((ch >> (4 * d)) & 15u); }
 
 template <typename T> __device__ __forceinline__ V3<T> ld3(DL_LDS T* p, int stride) { return {p[0], p[stride], p[2 * stride]}; }
 
@@ -127,10 +206,11 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
     const int j = g.j, nv = m.nv, nb = m.nb;
+    const GLane<T>& ln = *g.ln;
     // ---- A: joint sines / cosines, q, v
     {
         T s = T(0), c = T(1);
-        if (j < nv && m.dof_type[j] == 1) dl_sincos(m.dof_sign[j] * (q - m.qpos0[j]), s, c);
+        if (j < nv && ln.type == 1) dl_sincos(ln.sign * (q - ln.qpos0), s, c);
         wb[Ld::SC + j] = s; wb[Ld::SC + GL + j] = c;
         wb[Ld::Q + j] = q; wb[Ld::V + j] = v;
         // clear M (row j)
@@ -142,25 +222,29 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
     if (j < nv) {
         V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
         T rootz = m.root_z0;
-        const int depth = m.dof_depth[j];
+        const int depth = ln.depth;
         for (int d = 0; d <= depth; d++) {
-            const int a = m.chain[j][d], ba = m.dof_body[a];
-            if (m.dof_first[a] && ba != 1) pos = pos + m.body_pos[ba][0] * X + m.body_pos[ba][1] * Y + m.body_pos[ba][2] * Z;
-            const int idx = m.dof_axis[a];
+            const int a = chain_at(ln.chain, d);
+            const int pr = g.si[GShared::I_PROPS + a], ba = (pr >> 5) & 7;
+            if ((pr & 16) && ba != 1) {
+                const DL_LDS T* bp = g.st + GShared::T_BODY_POS + 3 * ba;
+                pos = pos + bp[0] * X + bp[1] * Y + bp[2] * Z;
+            }
+            const int idx = (pr >> 1) & 3;
             const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
-            const V3<T> ax = m.dof_sign[a] * col;
+            const V3<T> ax = (pr & 8) ? T(-1) * col : col;
             if (a == j) { my_axis = ax; my_anchor = pos; }
-            if (m.dof_type[a] == 0) rootz += ax.z * (wb[Ld::Q + a] - m.qpos0[a]);
+            if ((pr & 1) == 0) rootz += ax.z * (wb[Ld::Q + a] - g.st[GShared::T_QPOS0 + a]);
             else rot_axis(X, Y, Z, idx, wb[Ld::SC + a], wb[Ld::SC + GL + a]);
         }
         wb[Ld::AX + 0 * GL + j] = my_axis.x; wb[Ld::AX + 1 * GL + j] = my_axis.y; wb[Ld::AX + 2 * GL + j] = my_axis.z;
         wb[Ld::AX + 3 * GL + j] = my_anchor.x; wb[Ld::AX + 4 * GL + j] = my_anchor.y; wb[Ld::AX + 5 * GL + j] = my_anchor.z;
         V3<T> Sw, Sv;
-        if (m.dof_type[j] == 0) { Sw = mk<T>(0, 0, 0); Sv = my_axis; } else { Sw = my_axis; Sv = cross(my_anchor, my_axis); }
+        if (ln.type == 0) { Sw = mk<T>(0, 0, 0); Sv = my_axis; } else { Sw = my_axis; Sv = cross(my_anchor, my_axis); }
         wb[Ld::SM + 0 * GL + j] = Sw.x; wb[Ld::SM + 1 * GL + j] = Sw.y; wb[Ld::SM + 2 * GL + j] = Sw.z;
         wb[Ld::SM + 3 * GL + j] = Sv.x; wb[Ld::SM + 4 * GL + j] = Sv.y; wb[Ld::SM + 5 * GL + j] = Sv.z;
-        if (m.dof_is_last[j]) {
-            const int b = m.dof_body[j];
+        if (ln.is_last) {
+            const int b = ln.body;
             DL_LDS T* f = wb + Ld::BFR + b;
             f[0 * G_MAXB] = X.x; f[1 * G_MAXB] = X.y; f[2 * G_MAXB] = X.z;
             f[3 * G_MAXB] = Y.x; f[4 * G_MAXB] = Y.y; f[5 * G_MAXB] = Y.z;
@@ -173,16 +257,16 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
     // ---- C: twist / velocity-product acceleration down the chain (dof lanes), body inertia (body lanes)
     if (j < nv) {
         SV<T> vel = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)}, acc = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};
-        const int depth = m.dof_depth[j];
+        const int depth = ln.depth;
         for (int d = 0; d <= depth; d++) {
-            const int a = m.chain[j][d];
+            const int a = chain_at(ln.chain, d);
             const T qd = wb[Ld::V + a];
             const SV<T> vJ = {qd * ld3(wb + Ld::SM + a, GL), qd * ld3(wb + Ld::SM + 3 * GL + a, GL)};
             acc = {acc.w + cross(vel.w, vJ.w), acc.v + cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
             vel = vel + vJ;
         }
-        if (m.dof_is_last[j]) {
-            DL_LDS T* t = wb + Ld::TW + m.dof_body[j];
+        if (ln.is_last) {
+            DL_LDS T* t = wb + Ld::TW + ln.body;
             t[0] = vel.w.x; t[G_MAXB] = vel.w.y; t[2 * G_MAXB] = vel.w.z; t[3 * G_MAXB] = vel.v.x; t[4 * G_MAXB] = vel.v.y; t[5 * G_MAXB] = vel.v.z;
             t[6 * G_MAXB] = acc.w.x; t[7 * G_MAXB] = acc.w.y; t[8 * G_MAXB] = acc.w.z; t[9 * G_MAXB] = acc.v.x; t[10 * G_MAXB] = acc.v.y; t[11 * G_MAXB] = acc.v.z;
         }
@@ -192,8 +276,8 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
         const int b = j;
         DL_LDS T* f = wb + Ld::BFR + b;
         const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
-        const V3<T> c = pos + m.body_ipos[b][0] * X + m.body_ipos[b][1] * Y + m.body_ipos[b][2] * Z;
-        const T mass = m.body_mass[b], i0 = m.body_inertia[b][0], i1 = m.body_inertia[b][1], i2 = m.body_inertia[b][2];
+        const V3<T> c = pos + ln.ipos[0] * X + ln.ipos[1] * Y + ln.ipos[2] * Z;
+        const T mass = ln.mass, i0 = ln.inertia[0], i1 = ln.inertia[1], i2 = ln.inertia[2];
         const T cc = dot(c, c);
         myI.m = mass; myI.h = mass * c;
         myI.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
@@ -219,7 +303,7 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
     g_sync<T>();
     // ---- E: composite inertia and wrench of every subtree (body lanes sum over their descendants)
     if (j >= 1 && j < nb) {
-        const uint32_t sub = m.body_submask[j];
+        const uint32_t sub = ln.submask;
         T acc[16];
         for (int k = 0; k < 16; k++) acc[k] = T(0);
         for (int c = 1; c < nb; c++) {
@@ -233,7 +317,7 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
     g_sync<T>();
     // ---- F: bias force, row of the mass matrix, qfrc_smooth (dof lanes)
     if (j < nv) {
-        const int b = m.dof_body[j];
+        const int b = ln.body;
         const SV<T> S = {ld3(wb + Ld::SM + j, GL), ld3(wb + Ld::SM + 3 * GL + j, GL)};
         const SV<T> W = {ld3(wb + Ld::WC + b, G_MAXB), ld3(wb + Ld::WC + 3 * G_MAXB + b, G_MAXB)};
         const T bias = sdot(S, W);
@@ -242,16 +326,16 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
         Ic.m = ic[0]; Ic.h = ld3(ic + G_MAXB, G_MAXB);
         Ic.I.xx = ic[4 * G_MAXB]; Ic.I.xy = ic[5 * G_MAXB]; Ic.I.xz = ic[6 * G_MAXB]; Ic.I.yy = ic[7 * G_MAXB]; Ic.I.yz = ic[8 * G_MAXB]; Ic.I.zz = ic[9 * G_MAXB];
         const SV<T> f = si_mul(Ic, S);
-        const int depth = m.dof_depth[j];
+        const int depth = ln.depth;
         for (int d = 0; d <= depth; d++) {
-            const int a = m.chain[j][d];
+            const int a = chain_at(ln.chain, d);
             const SV<T> Sa = {ld3(wb + Ld::SM + a, GL), ld3(wb + Ld::SM + 3 * GL + a, GL)};
             T mij = sdot(Sa, f);
-            if (a == j) mij += m.armature[j];
+            if (a == j) mij += ln.armature;
             wb[Ld::MM + j * GL + a] = mij;
             wb[Ld::MM + a * GL + j] = mij;
         }
-        wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = -m.damping[j] * v - bias + ctrl_force;
+        wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = -ln.damping * v - bias + ctrl_force;
     } else {
         wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = T(0);
         wb[Ld::MM + j * GL + j] = T(1);          // padding rows/columns: identity
@@ -315,12 +399,13 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
     const int j = g.j, nv = m.nv;
+    const GLane<T>& ln = *g.ln;
     const T rootz = wb[Ld::MISC + 0];
     // ---- joint limits (dof lanes), ranked by dof order through a ballot
     bool lim = false, lim_lo = false;
     T lim_dist = T(0);
-    if (j < nv && m.dof_limited[j]) {
-        const T dlo = q - m.range_lo[j], dhi = m.range_hi[j] - q;
+    if (j < nv && ln.limited) {
+        const T dlo = q - ln.range_lo, dhi = ln.range_hi - q;
         lim_lo = dlo < T(0);
         lim = lim_lo || dhi < T(0);
         lim_dist = lim_lo ? dlo : dhi;
@@ -330,7 +415,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
     if (lim) {
         const int r = __popc(lmask & ((1u << j) - 1u));
         const T imp = impedance(m.solimp, lim_dist);
-        const T R = dl_max(T(1e-15), (T(1) - imp) * m.dof_invw[j] / imp);
+        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw / imp);
         wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = T(1) / R;
         wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = m.solK * imp * lim_dist;
         wb[Ld::LIMC + r] = T(j | (lim_lo ? 0 : 32));
@@ -339,20 +424,22 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
     bool act[2];
     V3<T> cp[2];
     T cdist[2], ctx[2], cty[2];
-    int cgeom[2];
+    int cinf[2];
     for (int pass = 0; pass < 2; pass++) {
         const int c = j + GL * pass;
-        act[pass] = false; cp[pass] = mk<T>(0, 0, 0); cdist[pass] = T(0); ctx[pass] = T(0); cty[pass] = T(1); cgeom[pass] = 0;
-        if (c < m.ncand) {
-            const int ge = m.cand_geom[c], sub = m.cand_sub[c], b = m.geom_body[ge];
-            cgeom[pass] = ge;
+        act[pass] = false; cp[pass] = mk<T>(0, 0, 0); cdist[pass] = T(0); ctx[pass] = T(0); cty[pass] = T(1);
+        const int cinfo = g.si[GShared::I_CAND + c];
+        cinf[pass] = cinfo;
+        const DL_LDS T* cd = g.st + GShared::T_CAND + c * GShared::CAND_W;
+        if (cinfo & 1) {
+            const int sub = (cinfo >> 2) & 7, b = (cinfo >> 5) & 7;
             DL_LDS T* f = wb + Ld::BFR + b;
             const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
-            const V3<T> gp = pos + m.geom_pos[ge][0] * X + m.geom_pos[ge][1] * Y + m.geom_pos[ge][2] * Z;
-            const DL_CONST T* gm = m.geom_mat[ge];
-            if (m.geom_type[ge] == 0) {
+            const V3<T> gp = pos + cd[0] * X + cd[1] * Y + cd[2] * Z;
+            const DL_LDS T* gm = cd + 3;
+            if (((cinfo >> 1) & 1) == 0) {
                 const V3<T> ax = gm[2] * X + gm[5] * Y + gm[8] * Z;
-                const T rad = m.geom_size[ge][0], half = m.geom_size[ge][1];
+                const T rad = cd[12], half = cd[13];
                 T tx = ax.x, ty = ax.y;
                 const T n2 = tx * tx + ty * ty;
                 if (n2 < T(1e-30)) { tx = T(1); ty = T(0); } else { const T inv = T(1) / dl_sqrt(n2); tx *= inv; ty *= inv; }
@@ -363,9 +450,9 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
                 cdist[pass] = dist; ctx[pass] = tx; cty[pass] = ty;
             } else {
                 const V3<T> ex = gm[0] * X + gm[3] * Y + gm[6] * Z, ey = gm[1] * X + gm[4] * Y + gm[7] * Z, ez = gm[2] * X + gm[5] * Y + gm[8] * Z;
-                const T sx = (sub & 1) ? m.geom_size[ge][0] : -m.geom_size[ge][0];
-                const T sy = (sub & 2) ? m.geom_size[ge][1] : -m.geom_size[ge][1];
-                const T sz = (sub & 4) ? m.geom_size[ge][2] : -m.geom_size[ge][2];
+                const T sx = (sub & 1) ? cd[12] : -cd[12];
+                const T sy = (sub & 2) ? cd[13] : -cd[13];
+                const T sz = (sub & 4) ? cd[14] : -cd[14];
                 const V3<T> corner = sx * ex + sy * ey + sz * ez;
                 const T dist = rootz + gp.z + corner.z;
                 act[pass] = dist < T(0) && !(corner.z > T(0));
@@ -378,8 +465,8 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
     uint32_t cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
     for (int pass = 0; pass < 2; pass++) {
         const int c = j + GL * pass;
-        if (c < m.ncand && act[pass] && m.geom_type[cgeom[pass]] == 1) {
-            const int first = c - m.cand_sub[c];                              // first corner of this box in the candidate list
+        if (act[pass] && ((cinf[pass] >> 1) & 1)) {
+            const int first = c - ((cinf[pass] >> 2) & 7);                             // first corner of this box in the candidate list
             const uint32_t before = cm & ((1u << c) - 1u) & ~((1u << first) - 1u);
             if (__popc(before) >= 4) act[pass] = false;
         }
@@ -392,8 +479,8 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
             const int slot = __popc(cm & ((1u << c) - 1u));
             DL_LDS T* cn = wb + Ld::CON + slot;
             cn[0] = cp[pass].x; cn[G_MAXCON] = cp[pass].y; cn[2 * G_MAXCON] = cp[pass].z;
-            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = m.geom_mu[cgeom[pass]];
-            cn[6 * G_MAXCON] = cdist[pass]; cn[7 * G_MAXCON] = T(m.geom_body[cgeom[pass]]);
+            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = g.st[GShared::T_CAND + c * GShared::CAND_W + 15];
+            cn[6 * G_MAXCON] = cdist[pass]; cn[7 * G_MAXCON] = T((cinf[pass] >> 5) & 7);
         }
     }
     g_sync<T>();            // BFR (aliased with JC) is dead from here on
@@ -406,19 +493,21 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
             const T tx = cn[3 * G_MAXCON], ty = cn[4 * G_MAXCON], mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
             const int body = (int)cn[7 * G_MAXCON];
             const T imp = impedance(m.solimp, dist);
-            const T diag = m.body_invw[body] * (T(1) + mu * mu);
+            const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
             const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag / imp);
             const T D = T(1) / R, kd = m.solK * imp * dist;
             const int r = nlim + 4 * c;
             for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
             DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
             for (int a = 0; a < 3 * GL; a++) jc[a] = T(0);
-            const int last = m.body_last_dof[body], depth = m.dof_depth[last];
+            const int last = g.si[GShared::I_BODY_LAST + body];
+            const int depth = (g.si[GShared::I_PROPS + last] >> 8) & 15;
+            const uint64_t bch = (uint64_t)(uint32_t)g.si[GShared::I_CHAIN_LO + last] | ((uint64_t)(uint32_t)g.si[GShared::I_CHAIN_HI + last] << 32);
             for (int d = 0; d <= depth; d++) {
-                const int a = m.chain[last][d];
+                const int a = chain_at(bch, d);
                 const V3<T> ax = ld3(wb + Ld::AX + a, GL);
                 V3<T> w;
-                if (m.dof_type[a] == 0) w = ax;
+                if ((g.si[GShared::I_PROPS + a] & 1) == 0) w = ax;
                 else w = cross(ax, p - ld3(wb + Ld::AX + 3 * GL + a, GL));
                 jc[a] = w.z; jc[GL + a] = tx * w.x + ty * w.y; jc[2 * GL + a] = -ty * w.x + tx * w.y;
             }
@@ -681,7 +770,10 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ct
             const T gn = gsum(rhs * rhs);
             const T improvement = scale * (oldcost - cost), gradient = scale * dl_sqrt(gn);
             if (alive) iter++;
-            if (improvement < m.tolerance || gradient < m.tolerance || iter >= m.iterations) alive = false;
+            // float32: cost and gradient carry rounding noise proportional to their magnitude; without the
+            // relative terms a converged walker whose step no longer changes qacc can iterate forever
+            const T gmag = gsum(dl_abs(Ma) + dl_abs(smooth));
+            if (improvement < m.tolerance + m.tol_rel * scale * dl_abs(cost) || gradient < m.tolerance + m.tol_rel * scale * gmag || iter >= m.iterations) alive = false;
         }
         // ---- factor H (row j in lane j) and solve
         {

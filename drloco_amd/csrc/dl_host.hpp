@@ -74,8 +74,8 @@ template <typename T, typename TP> inline void fill_dev_model(const dl_model_des
     m.tolerance = (T)d.tolerance;
     m.ls_tolerance = (T)d.ls_tolerance;
     // float32 cannot resolve MuJoCo's 1e-8 tolerances: stop the solver / line search at its own resolution
-    if (sizeof(T) == 4) { m.tolerance = (T)std::fmax(d.tolerance, 1e-6); m.ls_reltol = (T)1e-5; }
-    else m.ls_reltol = (T)0;
+    if (sizeof(T) == 4) { m.tolerance = (T)std::fmax(d.tolerance, 1e-6); m.ls_reltol = (T)1e-5; m.tol_rel = (T)1e-6; }
+    else { m.ls_reltol = (T)0; m.tol_rel = (T)0; }
     m.iterations = d.iterations; m.ls_iterations = d.ls_iterations; m.frame_skip = d.frame_skip;
 }
 
@@ -118,7 +118,7 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
     g.solB = (T)(2.0 / std::fmax(1e-15, dmax * tc));
     for (int k = 0; k < 5; k++) g.solimp[k] = (T)d.solimp[k];
     g.meaninertia = (T)d.meaninertia; g.tolerance = (T)d.tolerance; g.ls_tolerance = (T)d.ls_tolerance;
-    if (sizeof(T) == 4) { g.tolerance = (T)std::fmax(d.tolerance, 1e-6); g.ls_reltol = (T)1e-5; } else g.ls_reltol = (T)0;
+    if (sizeof(T) == 4) { g.tolerance = (T)std::fmax(d.tolerance, 1e-6); g.ls_reltol = (T)1e-5; g.tol_rel = (T)1e-6; } else { g.ls_reltol = (T)0; g.tol_rel = (T)0; }
     g.root_z0 = (T)d.body_pos[1][2];
     // bodies
     for (int b = 0; b < d.nbody; b++) {

@@ -78,15 +78,21 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     const bool valid = w < n;
     const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j};
+    DL_LDS int* si = (DL_LDS int*)smem;
+    DL_LDS T* stt = (DL_LDS T*)(smem + GShared::I_END * 4);
+    g_fill_shared<T>(*m, si, stt, lane);
+    GLane<T> ln;
+    g_load_lane<T>(*m, j, ln);
+    __syncthreads();
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln};
     const int nv = m->nv;
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < nv) {
         q = st.qpos[(size_t)j * n + wi]; v = st.qvel[(size_t)j * n + wi]; wm = st.warm[(size_t)j * n + wi];
-        const int a = m->dof_act[j];
+        const int a = ln.act;
         if (a >= 0) {
-            const T u = dl_clamp(ctrl ? ctrl[(size_t)a * n + wi] : T(0), m->ctrl_lo[j], m->ctrl_hi[j]);
-            force = m->gear[j] * dl_clamp(u, m->force_lo[j], m->force_hi[j]);
+            const T u = dl_clamp(ctrl ? ctrl[(size_t)a * n + wi] : T(0), ln.ctrl_lo, ln.ctrl_hi);
+            force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
         }
     }
     int nc, ne, ni;
@@ -110,7 +116,13 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     const bool valid = w0 < n;
     const int w = valid ? w0 : n - 1;
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j};
+    DL_LDS int* si = (DL_LDS int*)smem;
+    DL_LDS T* stt = (DL_LDS T*)(smem + GShared::I_END * 4);
+    g_fill_shared<T>(*m, si, stt, lane);
+    GLane<T> ln;
+    g_load_lane<T>(*m, j, ln);
+    __syncthreads();
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln};
     DL_LDS T* wb = g.wb;
     const int nv = m->nv, nu = m->nu;
     const bool isdof = j < nv;
@@ -122,17 +134,17 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     // ---- _rescale_actions + mirror_action (cursor BEFORE refs.next()), per actuated dof
     const bool mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
     T ctrl = T(0), force = T(0);
-    const int a = isdof ? m->dof_act[j] : -1;
+    const int a = isdof ? ln.act : -1;
     if (a >= 0) {
         const int src = mirr_a ? TPS::act_perm_[a] : a;
         const int jsrc = TPS::act_dof_[src];
         const T x = dl_clamp((T)actions[(size_t)w * nu + src], T(-1), T(1));
         const T raw = x > T(0) ? x * m->ctrl_hi[jsrc] : dl_abs(x) * m->ctrl_lo[jsrc];
         ctrl = (mirr_a && TPS::act_neg_[a]) ? -raw : raw;
-        const T u = dl_clamp(ctrl, m->ctrl_lo[j], m->ctrl_hi[j]);
-        force = m->gear[j] * dl_clamp(u, m->force_lo[j], m->force_hi[j]);
+        const T u = dl_clamp(ctrl, ln.ctrl_lo, ln.ctrl_hi);
+        force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
     }
-    const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, m->force_lo[j], m->force_hi[j])) : T(0));
+    const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
     // ---- physics
     bool exc = false;
     const int flag = inj_flags ? inj_flags[w] : 0;
@@ -458,8 +470,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             else {
                 if ((rc = dalloc(&gmd, 1))) return rc;
                 HIPCHK(hipMemcpy(gmd, &gmh, sizeof gmh, hipMemcpyHostToDevice));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GW * GLds::TOTAL * sizeof(T))));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GW * GLds::TOTAL * sizeof(T))));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)))));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)))));
             }
         } else if (variant == 1) return fail(DL_E_INVAL, "the 16-lane kernels support models with at most 16 dofs");
         const unsigned g256 = (unsigned)((n + 255) / 256);
@@ -485,7 +497,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (variant == 1 && gmd) {
             if constexpr (TP::ENV_KIND == 0) {
                 prof_begin(s);
-                hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), GW * GLds::TOTAL * sizeof(T), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
+                hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
                                    (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
                 prof_end(s);
             }
@@ -522,7 +534,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
         if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
         if (variant == 1 && gmd) {
-            hipLaunchKernelGGL((k_forward_g16<T>), dim3((n + GW - 1) / GW), dim3(64), GW * GLds::TOTAL * sizeof(T), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+            hipLaunchKernelGGL((k_forward_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
