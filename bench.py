@@ -57,6 +57,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--rollout-len', type=int, default=512)
+    ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -79,7 +80,7 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     n, T = args.envs_per_gpu, args.rollout_len
-    venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n)
+    venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
     vn = HipVecNormalize(venv)
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
     gen = torch.Generator(device=dev)
@@ -148,7 +149,7 @@ def main():
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_env_step<float,64>', 'avg_launch_us': avg_launch_s * 1e6,
+                         'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,
                          'note': 'the fused dynamics kernel is FP32-VALU/latency bound (SURVEY.md 8d); HBM fraction is reported as the contract asks'},
         }

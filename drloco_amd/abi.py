@@ -56,7 +56,7 @@ class Config(C.Structure):
     _fields_ = [
         ('rew_weights', _d * 3), ('rew_scale', _d), ('alive_bonus', _d), ('com_z_min', _d),
         ('ctrl_freq', _d), ('ep_dur_max', _i), ('mirror_policy', _i), ('precision', _i),
-        ('env_index_base', _i), ('seed', C.c_uint64), ('env_kind', _i), ('reserved', _i),
+        ('env_index_base', _i), ('seed', C.c_uint64), ('env_kind', _i), ('lanes_per_walker', _i),
     ]
 
 
@@ -82,6 +82,7 @@ def default_config(**kw):
     c.env_index_base = 0
     c.seed = 1234
     c.env_kind = DL_ENV_STRAIGHT
+    c.lanes_per_walker = 0          # auto
     for k, v in kw.items():
         if k == 'rew_weights':
             c.rew_weights[:] = list(v)

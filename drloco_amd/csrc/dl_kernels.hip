@@ -151,6 +151,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     if (flag == 2) exc = true;
     else if (flag == 1) { if (isdof) { q = inj_q[(size_t)j * n + w]; v = inj_v[(size_t)j * n + w]; } }
     const bool simulate = flag == 0;
+    int dbg_it = 0, dbg_max = 0, dbg_rows = 0;
     if (__any(simulate)) {
         const T h = m->timestep;
         const int fs = m->frame_skip;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             for (int stage = 0; stage < 4; stage++) {
                 int nc, ne, ni;
                 const T acc = g_forward<T>(g, grp, qs, vs, force, warm, nc, ne, ni);
+                dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
                 if (simulate && !exc) warm = acc;
                 if (stage == 0 && simulate && !exc && gany(isdof && dl_bad(acc))) exc = true;     // mj_checkAcc
                 const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
@@ -232,6 +234,9 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             }
         }
         if (valid && dn && j == 0) st.need_reset[w] = 1;
+    }
+    if (valid && j == 0 && st.dbg) {
+        st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
     }
     if (valid && j == 0) {
         monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked);
@@ -369,6 +374,7 @@ struct dl_env_s {
     virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
+    virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -391,7 +397,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     DevModel<T, TP> m;          // host copy
     DevModel<T, TP>* md = nullptr;   // device copy (read through the constant address space by the kernels)
     DevCfg<T> c;
-    DevState<T> st;
+    DevState<T> st{};
     std::vector<void*> allocs;
     GModel<T>* gmd = nullptr;        // table-driven model of the 16-lane kernels (straight walker only)
     T *inj_q = nullptr, *inj_v = nullptr;
@@ -462,18 +468,20 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&inj_v, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&inj_flags, n))) return rc;
         if ((rc = dalloc(&scratch_obs, (size_t)TP::OBS * n))) return rc;
-        variant = cfg.reserved;
-        if (TP::NV <= GL && TP::NB <= G_MAXB) {
+        if (cfg.lanes_per_walker != 0 && cfg.lanes_per_walker != 1 && cfg.lanes_per_walker != GL) return fail(DL_E_INVAL, "lanes_per_walker must be 0 (auto), 1 or 16");
+        variant = cfg.lanes_per_walker == 1 ? 0 : 1;      // auto prefers the 16-lane kernels
+        if (TP::ENV_KIND == 0 && TP::NV <= GL && TP::NB <= G_MAXB) {
             GModel<T> gmh;
             std::string why;
-            if (!fill_group_model<T>(d, gmh, why)) { if (variant == 1) return fail(DL_E_INVAL, why); }
+            if (!fill_group_model<T>(d, gmh, why)) { if (cfg.lanes_per_walker == GL) return fail(DL_E_INVAL, why); variant = 0; }
             else {
                 if ((rc = dalloc(&gmd, 1))) return rc;
                 HIPCHK(hipMemcpy(gmd, &gmh, sizeof gmh, hipMemcpyHostToDevice));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)))));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)))));
             }
-        } else if (variant == 1) return fail(DL_E_INVAL, "the 16-lane kernels support models with at most 16 dofs");
+        } else if (cfg.lanes_per_walker == GL) return fail(DL_E_INVAL, "the 16-lane kernels support the straight walker (<= 16 dofs, <= 8 bodies)");
+        else variant = 0;
         const unsigned g256 = (unsigned)((n + 255) / 256);
         for (int j = 0; j < TP::NV; j++) k_fill<T><<<g256, 256>>>(st.qpos + (size_t)j * n, (T)d.jnt_qpos0[j], (size_t)n);
         k_fill<int32_t><<<g256, 256>>>(st.cur + (size_t)DL_CUR_COUNT * n, 1, (size_t)n);   // count_steps_same_vel = 1
@@ -545,6 +553,12 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int snapshot(int word, double* out, hipStream_t s) override {
         hipLaunchKernelGGL(k_mon_snapshot, dim3((n + 255) / 256), dim3(256), 0, s, (const double*)st.mon, word, out, n);
         HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    int counters(int32_t* out, int clear, hipStream_t s) override {
+        if (!st.dbg) { int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; }
+        if (out) HIPCHK(hipMemcpyAsync(out, st.dbg, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (clear) HIPCHK(hipMemsetAsync(st.dbg, 0, (size_t)4 * n * sizeof(int32_t), s));
         return DL_OK;
     }
     int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t s) override {
@@ -635,6 +649,12 @@ int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t
 int dl_debug_inject(dl_handle h, const void* qpos, const void* qvel, const int32_t* flags, const int32_t* rsi, void* stream) {
     NEED(h);
     return h->inject(qpos, qvel, flags, rsi, (hipStream_t)stream);
+}
+/* diagnostics of the 16-lane step kernel (enabled by the first call): out int32[4, N] device or NULL =
+ * per walker {sum of Newton iterations, max iterations of the last step, sum of constraint rows, diverged steps} */
+int dl_debug_counters(dl_handle h, int32_t* out, int32_t clear, void* stream) {
+    NEED(h);
+    return h->counters(out, clear, (hipStream_t)stream);
 }
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) {
     NEED(h);

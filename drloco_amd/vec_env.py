@@ -233,6 +233,13 @@ class HipVecEnv:
         lib.check(self._lib.dl_forward(self._h, _ptr(u), _ptr(qacc), _ptr(ncon), _ptr(nefc), _ptr(nit), _stream()))
         return qacc.cpu().numpy(), ncon.cpu().numpy(), nefc.cpu().numpy(), nit.cpu().numpy()
 
+    def debug_counters(self, clear=True):
+        """Solver diagnostics of the 16-lane step kernel: int32 [4, N] = sum iterations, max iterations of the
+        last step, sum constraint rows, diverged steps (since the last clear).  The first call enables them."""
+        out = torch.zeros(4, self.num_envs, dtype=torch.int32, device=self.device)
+        lib.check(self._lib.dl_debug_counters(self._h, _ptr(out), int(clear), _stream()))
+        return out.cpu().numpy()
+
     def debug_inject(self, qpos=None, qvel=None, flags=None, rsi=None):
         dev = self.device
         f = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev).contiguous()

@@ -154,7 +154,8 @@ typedef struct dl_config {
     int32_t env_kind;       /* DL_ENV_STRAIGHT: MimicWalker3dEnv + StraightWalkingTrajectories;
                                DL_ENV_LOCO3D: MimicWalker165cm65kgEnv + Loco3dReferenceTrajectories
                                (drloco/mujoco/config.py:9-10) */
-    int32_t reserved;       /* kernel variant: 0 = one walker per lane (default), 1 = 16 lanes per walker (straight walker) */
+    int32_t lanes_per_walker; /* launch geometry of the dynamics kernels: 1 = one walker per lane, 16 = one walker per
+                               16-lane DPP row (models with <= 16 dofs), 0 = auto (16 where supported, else 1) */
 } dl_config;
 
 typedef struct dl_env_s* dl_handle;

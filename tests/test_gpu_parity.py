@@ -26,6 +26,9 @@ def torch_cuda():
     return torch
 
 
+LANES = pytest.mark.parametrize('lanes', [1, 16], ids=['lane-per-walker', '16-lanes-per-walker'])
+
+
 def make_pair(oracle, model, refs, n, precision, **cfg):
     from drloco_amd.vec_env import HipVecEnv
     dev = HipVecEnv(num_envs=n, precision=precision, model=model, refs=refs, **cfg)
@@ -43,10 +46,11 @@ def random_states(model, n, seed):
     return q, v, w, u
 
 
+@LANES
 @pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 5e-3)])
-def test_forward_dynamics(torch_cuda, oracle, model, refs, precision, tol):
+def test_forward_dynamics(torch_cuda, oracle, model, refs, precision, tol, lanes):
     n = 1024
-    dev, orc = make_pair(oracle, model, refs, n, precision)
+    dev, orc = make_pair(oracle, model, refs, n, precision, lanes_per_walker=lanes)
     q, v, w, u = random_states(model, n, 0)
     dev.set_state(qpos=q, qvel=v, warm=w)
     orc.set_state(qpos=q, qvel=v, warm=w)
@@ -62,10 +66,11 @@ def test_forward_dynamics(torch_cuda, oracle, model, refs, precision, tol):
         assert np.median(err.max(axis=0)) < 1e-4
 
 
-def test_rollout_f64_matches_oracle(torch_cuda, oracle, model, refs):
+@LANES
+def test_rollout_f64_matches_oracle(torch_cuda, oracle, model, refs, lanes):
     """Whole rollouts incl. auto-resets: the float64 kernels track the oracle step by step."""
     n, T = 256, 150
-    dev, orc = make_pair(oracle, model, refs, n, 64)
+    dev, orc = make_pair(oracle, model, refs, n, 64, lanes_per_walker=lanes)
     rng = np.random.default_rng(1)
     o1 = orc.reset()
     o2 = dev.reset()
@@ -90,10 +95,11 @@ def test_rollout_f64_matches_oracle(torch_cuda, oracle, model, refs):
         np.testing.assert_allclose(dev.get_attr(name), orc.stats(name), rtol=1e-5, atol=1e-6, err_msg=name)
 
 
-def test_single_step_f32(torch_cuda, oracle, model, refs):
+@LANES
+def test_single_step_f32(torch_cuda, oracle, model, refs, lanes):
     """The product precision: one control step (5 RK4 substeps) from identical states."""
     n = 2048
-    dev, orc = make_pair(oracle, model, refs, n, 32)
+    dev, orc = make_pair(oracle, model, refs, n, 32, lanes_per_walker=lanes)
     rng = np.random.default_rng(2)
     steps = rng.integers(0, 30, n).astype(np.int32)
     pos = (rng.random(n) * refs.step_len[steps]).astype(np.int32)
@@ -120,11 +126,12 @@ def test_single_step_f32(torch_cuda, oracle, model, refs):
     assert rel.max() < 1e-4, rel.max()         # north_star: reward parity within 1e-4 relative
 
 
-def test_rollout_f32_statistics(torch_cuda, oracle, model, refs):
+@LANES
+def test_rollout_f32_statistics(torch_cuda, oracle, model, refs, lanes):
     """Over a horizon the fp32 and fp64 trajectories of a contact-rich system separate (chaos), so
     the horizon-level check is statistical: mean reward and mean episode length agree."""
     n, T = 1024, 120
-    dev, orc = make_pair(oracle, model, refs, n, 32)
+    dev, orc = make_pair(oracle, model, refs, n, 32, lanes_per_walker=lanes)
     rng = np.random.default_rng(3)
     orc.reset(); dev.reset()
     R1 = R2 = 0.0; D1 = D2 = 0
@@ -143,16 +150,17 @@ def test_rollout_f32_statistics(torch_cuda, oracle, model, refs):
     assert D1 > 50 and abs(int(D1) - int(D2)) / D1 < 0.1
 
 
+@LANES
 @pytest.mark.parametrize('precision', [32, 64])
 @pytest.mark.parametrize('case', ['fall', 'timeout', 'exception', 'rollover'])
-def test_G4_step_traces_on_device(torch_cuda, model, refs, precision, case):
+def test_G4_step_traces_on_device(torch_cuda, model, refs, precision, case, lanes):
     """The reference's own step() traces (injected dynamics) through the HIP env kernels."""
     from drloco_amd.vec_env import HipVecEnv
     with np.load(os.path.join(GOLDEN, 'G4_step_traces.npz')) as z:
         G = {k.split('__')[1]: z[k] for k in z.files if k.startswith(case + '__')}
     i0, p0, count0, ep0 = G['start']
     T = int(G['nsteps'])
-    env = HipVecEnv(num_envs=1, precision=precision, model=model, refs=refs)
+    env = HipVecEnv(num_envs=1, precision=precision, model=model, refs=refs, lanes_per_walker=lanes)
     cur = np.zeros((abi.DL_CUR_WORDS, 1), np.int32)
     cur[abi.DL_CUR_I_STEP] = cur[abi.DL_CUR_RSI_STEP] = cur[abi.DL_CUR_READ_STEP] = i0
     cur[abi.DL_CUR_POS], cur[abi.DL_CUR_COUNT], cur[abi.DL_CUR_EP_DUR] = p0, count0, ep0
@@ -185,13 +193,14 @@ def test_G4_step_traces_on_device(torch_cuda, model, refs, precision, case):
             np.testing.assert_allclose(infos[0]['terminal_observation'], G['obs'][t], **tol)
 
 
-def test_G2_cursor_on_device(torch_cuda, model, refs):
+@LANES
+def test_G2_cursor_on_device(torch_cuda, model, refs, lanes):
     from drloco_amd.vec_env import HipVecEnv
     with np.load(os.path.join(GOLDEN, 'G2_cursor_traces.npz')) as z:
         g = {k: z[k] for k in z.files}
     K, T = g['i_step'].shape
     T = 700
-    env = HipVecEnv(num_envs=K, model=model, refs=refs, ep_dur_max=10 ** 9)
+    env = HipVecEnv(num_envs=K, model=model, refs=refs, ep_dur_max=10 ** 9, lanes_per_walker=lanes)
     cur = np.zeros((abi.DL_CUR_WORDS, K), np.int32)
     cur[abi.DL_CUR_I_STEP] = cur[abi.DL_CUR_RSI_STEP] = cur[abi.DL_CUR_READ_STEP] = g['starts'][:, 0]
     cur[abi.DL_CUR_POS], cur[abi.DL_CUR_COUNT] = g['starts'][:, 1], g['count_in']
@@ -299,12 +308,13 @@ def test_vecnormalize_matches_numpy(torch_cuda, oracle, model, refs):
     np.testing.assert_allclose(vn.ret_rms.var, rvar[0], rtol=1e-5)
 
 
-def test_full_size_properties(torch_cuda, model, refs):
+@LANES
+def test_full_size_properties(torch_cuda, model, refs, lanes):
     """BASELINE config 2 size (4096 walkers): size-independent properties."""
     import torch
     from drloco_amd.vec_env import HipVecEnv
     n, T = 4096, 24
-    env = HipVecEnv(num_envs=n, model=model, refs=refs)
+    env = HipVecEnv(num_envs=n, model=model, refs=refs, lanes_per_walker=lanes)
     env.reset_tensors()
     st0 = env.get_state()
     # (1) every walker starts with its lowest foot corner on the floor and q = reference
@@ -318,12 +328,12 @@ def test_full_size_properties(torch_cuda, model, refs):
     d = done.bool()
     assert (rew[d] == 0).all() and (rew[~d] > 0.2).all() and (rew[~d] <= 1.2 + 1e-6).all()
     # (3) determinism: the same rollout from the same state gives identical bits
-    env2 = HipVecEnv(num_envs=n, model=model, refs=refs)
+    env2 = HipVecEnv(num_envs=n, model=model, refs=refs, lanes_per_walker=lanes)
     env2.reset_tensors()
     obs2, rew2, done2 = env2.rollout_fixed(acts)
     assert torch.equal(obs, obs2) and torch.equal(rew, rew2) and torch.equal(done, done2)
     # (4) sharding invariance: walkers [1024, 2048) simulated alone (env_index_base) match
-    env3 = HipVecEnv(num_envs=1024, model=model, refs=refs, env_index_base=1024)
+    env3 = HipVecEnv(num_envs=1024, model=model, refs=refs, env_index_base=1024, lanes_per_walker=lanes)
     env3.reset_tensors()
     obs3, rew3, done3 = env3.rollout_fixed(acts[:, 1024:2048].contiguous())
     assert torch.equal(obs[:, 1024:2048], obs3) and torch.equal(done[:, 1024:2048], done3)
@@ -342,10 +352,11 @@ def test_library_fails_loudly_without_fallback(torch_cuda, model, refs):
         HipVecEnv(num_envs=4, model=bad, refs=refs)
 
 
-@pytest.mark.parametrize('n', [1, 63, 65, 130])
-def test_ragged_sizes(torch_cuda, oracle, model, refs, n):
+@LANES
+@pytest.mark.parametrize('n', [1, 3, 63, 65, 130])
+def test_ragged_sizes(torch_cuda, oracle, model, refs, n, lanes):
     """Walker counts that do not fill a 64-lane wave / span several workgroups."""
-    dev, orc = make_pair(oracle, model, refs, n, 64)
+    dev, orc = make_pair(oracle, model, refs, n, 64, lanes_per_walker=lanes)
     np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
     rng = np.random.default_rng(n)
     for t in range(6):
@@ -368,6 +379,9 @@ def test_bad_arguments_are_rejected(torch_cuda, model, refs):
     cfg.precision = 16
     assert lb.dl_create(C.byref(model), C.byref(desc), C.byref(cfg), 8, 0, C.byref(h)) == abi.DL_E_INVAL
     cfg.precision = 32
+    cfg.lanes_per_walker = 8
+    assert lb.dl_create(C.byref(model), C.byref(desc), C.byref(cfg), 8, 0, C.byref(h)) == abi.DL_E_INVAL
+    cfg.lanes_per_walker = 0
     assert lb.dl_create(C.byref(model), C.byref(desc), C.byref(cfg), 8, 0, C.byref(h)) == 0
     assert lb.dl_step(h, None, None, None, None, None, None, None) == abi.DL_E_INVAL      # NULL arrays
     assert lb.dl_gae(None, None, None, None, None, C.c_float(0.99), C.c_float(0.95), 4, 4, None, None, None) == abi.DL_E_INVAL
@@ -376,11 +390,12 @@ def test_bad_arguments_are_rejected(torch_cuda, model, refs):
     lb.dl_destroy(h)
 
 
-def test_divergence_takes_the_exception_path(torch_cuda, oracle, model, refs):
+@LANES
+def test_divergence_takes_the_exception_path(torch_cuda, oracle, model, refs, lanes):
     """A walker whose state blows up ends its episode with reward 0 and is re-initialised twice
     (mimic_env.py:86-91 + the vec env's own reset), like the reference's MujocoException path."""
     n = 64
-    dev, orc = make_pair(oracle, model, refs, n, 64)
+    dev, orc = make_pair(oracle, model, refs, n, 64, lanes_per_walker=lanes)
     dev.reset(); orc.reset()
     st = orc.get_state()
     st['qvel'][0, 5] = 1e12          # mj_checkVel trips
@@ -424,10 +439,11 @@ def test_vecnormalize_save_load_and_attrs(torch_cuda, model, refs, tmp_path):
     assert vn.normalize_obs(vn.get_original_obs()).shape == (96, 29)
 
 
-def test_evaluation_mode_matches_oracle(torch_cuda, oracle, model, refs):
+@LANES
+def test_evaluation_mode_matches_oracle(torch_cuda, oracle, model, refs, lanes):
     """activate_evaluation -> deterministic init states (quirk Q3), through the eval-loop surface."""
     n = 32
-    dev, orc = make_pair(oracle, model, refs, n, 64)
+    dev, orc = make_pair(oracle, model, refs, n, 64, lanes_per_walker=lanes)
     view = dev.envs[0].env                       # what callback.py:285-286 does
     view.activate_evaluation()
     orc.set_eval(True)

@@ -12,9 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--steps', type=int, default=40)
 ap.add_argument('--warm', type=int, default=60)
-ap.add_argument('--variant', type=int, default=0)
+ap.add_argument('--variant', type=int, default=0, help='lanes per walker: 0 auto, 1, 16')
 args = ap.parse_args()
-env = HipVecEnv(num_envs=args.envs, reserved=args.variant)
+env = HipVecEnv(num_envs=args.envs, lanes_per_walker=args.variant)
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
 acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, 8, device='cuda', generator=g), -1, 1)
