@@ -163,16 +163,20 @@ template <int CTRL> __device__ __forceinline__ double dpp_f(double x) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
-// sum over the 16 lanes of a row, result in every lane (row_ror:8,4,2,1)
+// sum over the 16 lanes of a row, result in every lane (row_ror:8,4,2,1).  Every lane must get the SAME
+// bits (the solver's stopping decisions are taken per lane from these sums): with rotations the partial sums
+// have period 8, 4, 2, 1, so commutativity alone guarantees it -- provided the compiler does not contract a
+// multiply feeding x into the first add (fma(a_i, b_i, t_{i+8}) != fma(a_{i+8}, b_{i+8}, t_i)).  The empty
+// asm hides the producer of x; the pragma keeps the adds themselves un-contracted.
 template <typename T> __device__ __forceinline__ T gsum(T x) {
+#pragma clang fp contract(off)
+    asm volatile("" : "+v"(x));
     x += dpp_f<0x128>(x);
     x += dpp_f<0x124>(x);
     x += dpp_f<0x122>(x);
     x += dpp_f<0x121>(x);
     return x;
 }
-// value of lane k of the row, in every lane
-template <typename T> __device__ __forceinline__ T gbcast(T x, int j, int k) { return gsum(j == k ? x : T(0)); }
 __device__ __forceinline__ bool gany(bool p) { return gsum(p ? 1.0f : 0.0f) > 0.0f; }
 
 template <typename T> __device__ __forceinline__ void g_sync() { __syncthreads(); }
@@ -343,49 +347,58 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
     g_sync<T>();
 }
 
+// value of lane K of the row in every lane: ONE DPP instruction (row_newbcast:K, gfx90a+), usually folded
+// into the consuming VALU instruction
+template <int K> __device__ __forceinline__ float rbcast(float x) { return dpp_f<0x150 + K>(x); }
+template <int K> __device__ __forceinline__ double rbcast(double x) { return dpp_f<0x150 + K>(x); }
+
+// 1/sqrt(x): float = v_rsq_f32 + one Newton step (<= 1 ulp-ish, no denormal fix-ups); double = exact path
+__device__ __forceinline__ float dl_rsqrt(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    return y * fmaf(-0.5f * x * y, y, 1.5f);
+}
+__device__ __forceinline__ double dl_rsqrt(double x) { return 1.0 / sqrt(x); }
+
 // dense Cholesky of the 16x16 matrix whose row j is held in lane j (h[0..15], lower part used);
-// afterwards l[a] (a <= j) is row j of the factor.  Column k is gathered with DPP broadcasts.
-template <typename T> __device__ __forceinline__ void g_chol(T (&h)[GL], int j, int n) {
-#pragma unroll
-    for (int k = 0; k < GL; k++) {
-        if (k >= n) break;
-        const T dkk = gbcast(h[k], j, k);
-        const T inv = T(1) / dl_sqrt(dkk);
-        const T lik = (j == k) ? dl_sqrt(dkk) : h[k] * inv;   // lanes j > k: L[j][k]; lanes j < k: unused
-        h[k] = lik;
-#pragma unroll
-        for (int a = k + 1; a < GL; a++) {
-            if (a >= n) break;
-            const T lak = gbcast(lik, j, a);                  // L[a][k]
-            h[a] -= lik * lak;                                // row j, column a (only a <= j matters)
+// afterwards h[a] (a <= j) is row j of the factor and invd = 1 / L[j][j].  Column k is gathered with
+// row broadcasts (one DPP each).  Pivots are floored at `floor_` (mju_cholFactor's mjMINVAL guard).
+template <typename T> __device__ __forceinline__ void g_chol(T (&h)[GL], T& invd, int j, int n, T floor_) {
+    static_for<GL>([&](auto kk) {
+        constexpr int k = kk.value;
+        if (k < n) {
+            const T dkk = dl_max(rbcast<k>(h[k]), floor_);
+            const T inv = dl_rsqrt(dkk);
+            const T lik = (j == k) ? dkk * inv : h[k] * inv;      // lanes j > k: L[j][k]; lane k: L[k][k]; lanes j < k: unused
+            h[k] = lik;
+            if (j == k) invd = inv;
+            static_for<GL - 1 - k>([&](auto aa) {
+                constexpr int a = k + 1 + aa.value;
+                if (a < n) h[a] -= lik * rbcast<a>(lik);          // row j, column a (only a <= j matters)
+            });
         }
-    }
+    });
 }
 // solve (L L^T) x = b with row j of L in lane j; b_j in, x_j out
-template <typename T> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T b, int j, int n) {
-    // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k]; every lane keeps all y
-    T y[GL];
-    T acc = b;
-#pragma unroll
-    for (int k = 0; k < GL; k++) {
-        if (k >= n) break;
-        const T yk_local = acc / l[k];                        // valid in lane k
-        y[k] = gbcast(yk_local, j, k);
-        acc -= l[k] * y[k];                                   // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
-    }
+template <typename T> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T invd, T b, int j, int n) {
+    // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k]
+    T acc = b, yj = T(0);
+    static_for<GL>([&](auto kk) {
+        constexpr int k = kk.value;
+        if (k < n) {
+            const T yloc = acc * invd;                            // valid in lane k
+            if (j == k) yj = yloc;
+            acc -= l[k] * rbcast<k>(yloc);                        // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
+        }
+    });
     // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k]
     T x = T(0);
-    T yj = T(0);
-#pragma unroll
-    for (int k = 0; k < GL; k++) if (k < n && j == k) yj = y[k];
-#pragma unroll
-    for (int kk = 0; kk < GL; kk++) {
-        const int k = GL - 1 - kk;
-        if (k >= n) continue;
-        const T contrib = (j > k) ? l[k] * x : T(0);          // L[j][k] x_j, x_j already final for j > k
-        const T s = gsum(contrib);
-        if (j == k) x = (yj - s) / l[k];
-    }
+    static_for<GL>([&](auto kk) {
+        constexpr int k = GL - 1 - kk.value;
+        if (k < n) {
+            const T s = gsum((j > k) ? l[k] * x : T(0));          // x_j is final for j > k
+            if (j == k) x = (yj - s) * invd;
+        }
+    });
     return x;
 }
 
@@ -777,11 +790,11 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ct
         }
         // ---- factor H (row j in lane j) and solve
         {
-            T l[GL];
+            T l[GL], invd = T(1);
 #pragma unroll
             for (int a = 0; a < GL; a++) l[a] = h[a];
-            g_chol<T>(l, j, nv);
-            rhs = g_chol_solve<T>(l, rhs, j, nv);
+            g_chol<T>(l, invd, j, nv, T(1e-10));
+            rhs = g_chol_solve<T>(l, invd, rhs, j, nv);
         }
         if (phase == -1) {
             qsm = rhs; x = rhs;

@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
                 int nc, ne, ni;
                 const T acc = g_forward<T>(g, grp, qs, vs, force, warm, nc, ne, ni);
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
+                if (st.dbgf && valid && ni >= m->iterations) {
+                    st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)warm;
+                }
                 if (simulate && !exc) warm = acc;
                 if (stage == 0 && simulate && !exc && gany(isdof && dl_bad(acc))) exc = true;     // mj_checkAcc
                 const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
@@ -202,10 +205,10 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
         auto raw_obs = [&](int k) -> T { return k == 0 ? phase_var : (k == 1 ? desvel : (k < 1 + nv ? wb[GLds::Q + (k - 1)] : wb[GLds::V + (k - 1 - nv)])); };
         float* dst_base = nullptr;
         cur[DL_CUR_EP_DUR] += 1;
-        const T vx = dl_clamp(gbcast(v, j, 0), T(-5.5), T(5.5)), vy = dl_clamp(gbcast(v, j, 1), T(-5.5), T(5.5));
+        const T vx = dl_clamp(rbcast<0>(v), T(-5.5), T(5.5)), vy = dl_clamp(rbcast<1>(v), T(-5.5), T(5.5));
         walked += (double)dl_sqrt(vx * vx + vy * vy) * (double)c.inv_ctrl_freq;
         const bool timeout = cur[DL_CUR_EP_DUR] >= c.ep_dur_max;
-        const T qz = gbcast(q, j, 2);
+        const T qz = rbcast<2>(q);
         dn = (qz < c.com_z_min) || timeout;
         if (dn) r = timeout ? 0.0f : -0.0f;
         else {
@@ -249,6 +252,16 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
         for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
     }
     if (valid && isdof) { st.qpos[(size_t)j * n + w] = q; st.qvel[(size_t)j * n + w] = v; st.warm[(size_t)j * n + w] = warm; }
+}
+
+// row primitives of dl_group.hpp on known data (tests/test_gpu_parity.py::test_row_primitives)
+__global__ __launch_bounds__(64) void k_selftest(const float* in, float* out) {
+    const int lane = threadIdx.x;
+    const float a = in[lane], b = in[64 + lane];
+    out[lane] = gsum(a * b);                  // product feeding the reduction: must stay lane-uniform
+    out[64 + lane] = rbcast<3>(a);
+    out[128 + lane] = rbcast<15>(a) + rbcast<0>(b);
+    out[192 + lane] = (float)gsum((double)a * (double)b);
 }
 
 template <typename T> __global__ void k_fill(T* p, T val, size_t n) {
@@ -375,6 +388,7 @@ struct dl_env_s {
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
+    virtual int capstate(float* out, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -556,9 +570,14 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         return DL_OK;
     }
     int counters(int32_t* out, int clear, hipStream_t s) override {
-        if (!st.dbg) { int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; }
+        if (!st.dbg) { int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; if ((rc = dalloc(&st.dbgf, (size_t)48 * n))) return rc; }
         if (out) HIPCHK(hipMemcpyAsync(out, st.dbg, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         if (clear) HIPCHK(hipMemsetAsync(st.dbg, 0, (size_t)4 * n * sizeof(int32_t), s));
+        return DL_OK;
+    }
+    int capstate(float* out, hipStream_t s) override {
+        if (!st.dbgf || !out) return fail(DL_E_INVAL, "dl_debug_capstate: enable the counters first");
+        HIPCHK(hipMemcpyAsync(out, st.dbgf, (size_t)48 * n * sizeof(float), hipMemcpyDeviceToDevice, s));
         return DL_OK;
     }
     int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t s) override {
@@ -655,6 +674,18 @@ int dl_debug_inject(dl_handle h, const void* qpos, const void* qvel, const int32
 int dl_debug_counters(dl_handle h, int32_t* out, int32_t clear, void* stream) {
     NEED(h);
     return h->counters(out, clear, (hipStream_t)stream);
+}
+/* in: float[128] device, out: float[256] device (see k_selftest) */
+int dl_debug_selftest(const float* in, float* out, void* stream) {
+    if (!in || !out) return fail(DL_E_INVAL, "dl_debug_selftest: bad arguments");
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+/* float[48, N] device: (q, v, warmstart)[16] of the last evaluation per walker that hit the iteration cap */
+int dl_debug_capstate(dl_handle h, float* out, void* stream) {
+    NEED(h);
+    return h->capstate(out, (hipStream_t)stream);
 }
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) {
     NEED(h);

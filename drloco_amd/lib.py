@@ -67,6 +67,8 @@ _EXTRA = {
     'dl_abi_sizeof': (C.c_int, [C.c_int]),
     'dl_debug_inject': (C.c_int, [_V, _P, _P, _P, _P, _P]),
     'dl_debug_counters': (C.c_int, [_V, _P, _I, _P]),
+    'dl_debug_capstate': (C.c_int, [_V, _P, _P]),
+    'dl_debug_selftest': (C.c_int, [_P, _P, _P]),
 }
 
 

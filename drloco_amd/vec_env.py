@@ -240,6 +240,11 @@ class HipVecEnv:
         lib.check(self._lib.dl_debug_counters(self._h, _ptr(out), int(clear), _stream()))
         return out.cpu().numpy()
 
+    def debug_capstate(self):
+        out = torch.zeros(48, self.num_envs, device=self.device)
+        lib.check(self._lib.dl_debug_capstate(self._h, _ptr(out), _stream()))
+        return out.cpu().numpy()
+
     def debug_inject(self, qpos=None, qvel=None, flags=None, rsi=None):
         dev = self.device
         f = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev).contiguous()

@@ -46,6 +46,29 @@ def random_states(model, n, seed):
     return q, v, w, u
 
 
+def test_row_primitives(torch_cuda):
+    """The 16-lane row primitives of dl_group.hpp: the row sum gives identical bits in all 16 lanes (the
+    solver's per-lane stopping decisions rely on it) and row_newbcast:K reads lane K of the own row."""
+    import torch
+    from drloco_amd import lib as L
+    from drloco_amd.vec_env import _ptr, _stream
+    lb = L.load()
+    rng = np.random.default_rng(11)
+    for rep in range(20):
+        x = (rng.standard_normal(128) * 10.0 ** rng.uniform(-3, 3, 128)).astype(np.float32)
+        xin = torch.as_tensor(x, device='cuda'); out = torch.zeros(256, device='cuda')
+        L.check(lb.dl_debug_selftest(_ptr(xin), _ptr(out), _stream()))
+        o = out.cpu().numpy().reshape(4, 4, 16)
+        a, b = x[:64].reshape(4, 16), x[64:].reshape(4, 16)
+        for k in (0, 3):
+            assert (o[k] == o[k][:, :1]).all(), 'row sum differs between lanes'
+        want = (a.astype(np.float64) * b.astype(np.float64)).sum(1)
+        scale = np.abs(a.astype(np.float64) * b).sum(1)
+        assert (np.abs(o[0][:, 0] - want) <= 1e-6 * scale).all() and (np.abs(o[3][:, 0] - want) <= 2e-7 * scale + 1e-30).all()
+        assert np.array_equal(o[1], np.repeat(a[:, 3:4], 16, 1))
+        assert np.array_equal(o[2], np.repeat((a[:, 15] + b[:, 0])[:, None], 16, 1))
+
+
 @LANES
 @pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 5e-3)])
 def test_forward_dynamics(torch_cuda, oracle, model, refs, precision, tol, lanes):
@@ -63,7 +86,7 @@ def test_forward_dynamics(torch_cuda, oracle, model, refs, precision, tol, lanes
     if precision == 64:
         assert np.abs(ni - ni2).max() <= 1 and (ni == ni2).mean() > 0.8
     else:
-        assert np.median(err.max(axis=0)) < 1e-4
+        assert np.median(err.max(axis=0)) < 1e-4, (np.median(err.max(axis=0)), np.quantile(err.max(axis=0), 0.9))
 
 
 @LANES
