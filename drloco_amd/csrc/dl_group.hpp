@@ -55,8 +55,9 @@ struct GLds {
     static constexpr int SM = AX + 6 * GL;                           // motion subspace [6][16]
     static constexpr int VEC = SM + 6 * GL;                          // vectors [NVEC][16]
     static constexpr int V_SMOOTH = 0, V_QSM = 1, V_X = 2, V_MX = 3, V_FC = 4, NVEC = 5;
-    static constexpr int MM = VEC + NVEC * GL;                       // M [16 rows][16]
-    static constexpr int CON = MM + GL * GL;                         // contacts [8][G_MAXCON]: px py pz tx ty mu dist body
+    static constexpr int MS = GL + 1;                                // row stride of M (odd: row-wise and column-wise access are both conflict-free)
+    static constexpr int MM = VEC + NVEC * GL;                       // M [16 rows][MS]
+    static constexpr int CON = MM + GL * MS;                         // contacts [8][G_MAXCON]: px py pz tx ty mu dist body
     static constexpr int ROW = CON + 8 * G_MAXCON;                   // rows [4][G_MAXROW]: D, JAREF, JV, TMP
     static constexpr int R_D = 0, R_JAREF = 1, R_JV = 2, R_TMP = 3;
     static constexpr int LIMC = ROW + 4 * G_MAXROW;                  // limit codes [8]
@@ -179,7 +180,13 @@ template <typename T> __device__ __forceinline__ T gsum(T x) {
 }
 __device__ __forceinline__ bool gany(bool p) { return gsum(p ? 1.0f : 0.0f) > 0.0f; }
 
-template <typename T> __device__ __forceinline__ void g_sync() { __syncthreads(); }
+// A workgroup is ONE wave and a wave's LDS operations execute in order, so lanes exchange data through LDS
+// without s_barrier: what is needed is that the compiler keeps the program order of the LDS accesses.
+template <typename T> __device__ __forceinline__ void g_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ------------------------------------------------------------------------------------------
 template <typename T> struct GCtx {
@@ -218,7 +225,7 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
         wb[Ld::SC + j] = s; wb[Ld::SC + GL + j] = c;
         wb[Ld::Q + j] = q; wb[Ld::V + j] = v;
         // clear M (row j)
-        for (int a = 0; a < GL; a++) wb[Ld::MM + j * GL + a] = T(0);
+        for (int a = 0; a < GL; a++) wb[Ld::MM + j * Ld::MS + a] = T(0);
     }
     g_sync<T>();
     // ---- B: every dof lane walks its own root->dof chain (no cross-lane dependency)
@@ -336,13 +343,13 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
             const SV<T> Sa = {ld3(wb + Ld::SM + a, GL), ld3(wb + Ld::SM + 3 * GL + a, GL)};
             T mij = sdot(Sa, f);
             if (a == j) mij += ln.armature;
-            wb[Ld::MM + j * GL + a] = mij;
-            wb[Ld::MM + a * GL + j] = mij;
+            wb[Ld::MM + j * Ld::MS + a] = mij;
+            wb[Ld::MM + a * Ld::MS + j] = mij;
         }
         wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = -ln.damping * v - bias + ctrl_force;
     } else {
         wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = T(0);
-        wb[Ld::MM + j * GL + j] = T(1);          // padding rows/columns: identity
+        wb[Ld::MM + j * Ld::MS + j] = T(1);          // padding rows/columns: identity
     }
     g_sync<T>();
 }
@@ -359,45 +366,40 @@ __device__ __forceinline__ float dl_rsqrt(float x) {
 }
 __device__ __forceinline__ double dl_rsqrt(double x) { return 1.0 / sqrt(x); }
 
-// dense Cholesky of the 16x16 matrix whose row j is held in lane j (h[0..15], lower part used);
-// afterwards h[a] (a <= j) is row j of the factor and invd = 1 / L[j][j].  Column k is gathered with
-// row broadcasts (one DPP each).  Pivots are floored at `floor_` (mju_cholFactor's mjMINVAL guard).
-template <typename T> __device__ __forceinline__ void g_chol(T (&h)[GL], T& invd, int j, int n, T floor_) {
-    static_for<GL>([&](auto kk) {
+// dense Cholesky of the N x N matrix whose row j is held in lane j: strictly-lower entries in h[0..j-1], the
+// diagonal separately in hd.  Afterwards h[a] (a < j) is row j of the factor and invd = 1 / L[j][j].  Column k
+// is gathered with row broadcasts (one DPP each).  Pivots are floored (mju_cholFactor's mjMINVAL guard).
+template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], T hd, T& invd, int j, T floor_) {
+    static_for<N>([&](auto kk) {
         constexpr int k = kk.value;
-        if (k < n) {
-            const T dkk = dl_max(rbcast<k>(h[k]), floor_);
-            const T inv = dl_rsqrt(dkk);
-            const T lik = (j == k) ? dkk * inv : h[k] * inv;      // lanes j > k: L[j][k]; lane k: L[k][k]; lanes j < k: unused
-            h[k] = lik;
-            if (j == k) invd = inv;
-            static_for<GL - 1 - k>([&](auto aa) {
-                constexpr int a = k + 1 + aa.value;
-                if (a < n) h[a] -= lik * rbcast<a>(lik);          // row j, column a (only a <= j matters)
-            });
-        }
+        const T dkk = dl_max(rbcast<k>(hd), floor_);
+        const T inv = dl_rsqrt(dkk);
+        const T lik = h[k] * inv;                             // lanes j > k: L[j][k]; other lanes: unused
+        h[k] = lik;
+        if (j == k) invd = inv;
+        hd -= lik * lik;                                      // lanes j > k
+        static_for<N - 1 - k>([&](auto aa) {
+            constexpr int a = k + 1 + aa.value;
+            h[a] -= lik * rbcast<a>(lik);                     // row j, column a (only a < j matters)
+        });
     });
 }
 // solve (L L^T) x = b with row j of L in lane j; b_j in, x_j out
-template <typename T> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T invd, T b, int j, int n) {
+template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T invd, T b, int j) {
     // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k]
     T acc = b, yj = T(0);
-    static_for<GL>([&](auto kk) {
+    static_for<N>([&](auto kk) {
         constexpr int k = kk.value;
-        if (k < n) {
-            const T yloc = acc * invd;                            // valid in lane k
-            if (j == k) yj = yloc;
-            acc -= l[k] * rbcast<k>(yloc);                        // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
-        }
+        const T yloc = acc * invd;                            // valid in lane k
+        if (j == k) yj = yloc;
+        acc -= l[k] * rbcast<k>(yloc);                        // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
     });
     // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k]
     T x = T(0);
-    static_for<GL>([&](auto kk) {
-        constexpr int k = GL - 1 - kk.value;
-        if (k < n) {
-            const T s = gsum((j > k) ? l[k] * x : T(0));          // x_j is final for j > k
-            if (j == k) x = (yj - s) * invd;
-        }
+    static_for<N>([&](auto kk) {
+        constexpr int k = N - 1 - kk.value;
+        const T s = gsum((j > k) ? l[k] * x : T(0));          // x_j is final for j > k
+        if (j == k) x = (yj - s) * invd;
     });
     return x;
 }
@@ -407,7 +409,7 @@ template <typename T> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL]
 // [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
 // Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
 template <typename T>
-__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T q, int& nlim_out, int& ncon_out) {
+__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T q, int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
     using Ld = GLds;
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
@@ -425,8 +427,10 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
     }
     const uint32_t lmask = (uint32_t)((__ballot(lim) >> (GL * grp)) & 0xFFFFull);
     const int nlim = __popc(lmask);
+    my_lim = -1; lim_sign = lim_lo ? T(1) : T(-1);
     if (lim) {
         const int r = __popc(lmask & ((1u << j) - 1u));
+        my_lim = r;
         const T imp = impedance(m.solimp, lim_dist);
         const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw / imp);
         wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = T(1) / R;
@@ -530,280 +534,199 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
     nlim_out = nlim; ncon_out = ncon;
 }
 
-// rows JV = J x for the walker (x in LDS V_X), Mx_j returned
-template <typename T>
-__device__ __forceinline__ T g_apply(const GCtx<T>& g, int nlim, int ncon, bool want_mx) {
+template <typename T> struct GEps;
+template <> struct GEps<float> { static constexpr float value = 1.1920929e-7f; };
+template <> struct GEps<double> { static constexpr double value = 2.220446049250313e-16; };
+
+// rows JV = J x for the walker and (M x)_j; x_j lives in lane j.  The broadcasts of x serve both products.
+// Limit rows are written by the lane of their dof, contact rows by lane c (c, c + 16, ... < ncon).
+template <typename T, int N>
+__device__ __forceinline__ T g_apply(const GCtx<T>& g, int nlim, int ncon, int my_lim, T lim_sign, T x, const T (&mrow)[GL]) {
     using Ld = GLds;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    DL_LDS T* x = wb + Ld::VEC + Ld::V_X * GL;
-    if (j < nlim) {
-        const int code = (int)wb[Ld::LIMC + j];
-        const T xv = x[code & 31];
-        wb[Ld::ROW + Ld::R_JV * G_MAXROW + j] = (code & 32) ? -xv : xv;
-    }
-    for (int pass = 0; pass < 2; pass++) {
-        const int c = j + GL * pass;
-        if (c < ncon) {
-            DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
-            T vn = T(0), v1 = T(0), v2 = T(0);
-#pragma unroll
-            for (int a = 0; a < GL; a++) { const T xa = x[a]; vn += jc[a] * xa; v1 += jc[GL + a] * xa; v2 += jc[2 * GL + a] * xa; }
-            const T mu = wb[Ld::CON + 5 * G_MAXCON + c];
-            DL_LDS T* jv = wb + Ld::ROW + Ld::R_JV * G_MAXROW + nlim + 4 * c;
-            jv[0] = vn + mu * v1; jv[1] = vn - mu * v1; jv[2] = vn + mu * v2; jv[3] = vn - mu * v2;
-        }
-    }
+    T xa[N];
     T mx = T(0);
-    if (want_mx) {
-#pragma unroll
-        for (int a = 0; a < GL; a++) mx += wb[Ld::MM + j * GL + a] * x[a];
+    static_for<N>([&](auto ai) { constexpr int a = ai.value; xa[a] = rbcast<a>(x); mx += mrow[a] * xa[a]; });
+    if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * G_MAXROW + my_lim] = lim_sign * x;
+    for (int c = j; c < ncon; c += GL) {
+        DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
+        T vn = T(0), v1 = T(0), v2 = T(0);
+        static_for<N>([&](auto ai) { constexpr int a = ai.value; vn += jc[a] * xa[a]; v1 += jc[GL + a] * xa[a]; v2 += jc[2 * GL + a] * xa[a]; });
+        const T mu = wb[Ld::CON + 5 * G_MAXCON + c];
+        DL_LDS T* jv = wb + Ld::ROW + Ld::R_JV * G_MAXROW + nlim + 4 * c;
+        jv[0] = vn + mu * v1; jv[1] = vn - mu * v1; jv[2] = vn + mu * v2; jv[3] = vn - mu * v2;
     }
     return mx;
 }
 
-template <typename T> struct GLs { T alpha, cost, d1, d2; };
-
 // [3P] mj_forward for one walker spread over 16 lanes.  In: q_j, v_j, force of the motor on dof j,
 // warmstart_j.  Out: qacc_j.  nefc/niter for diagnostics.
-template <typename T>
-__device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ctrl_force, T warm, int& ncon_o, int& nefc_o, int& niter_o) {
+//
+// Constraint solver: primal Newton on MuJoCo's convex cost  1/2 (a - a_s)^T M (a - a_s) + sum_i 1/2 D_i min(0, (J a - aref)_i)^2
+// (mj_solNewton), started at the warm start.  The minimiser is unique, so the path may differ from MuJoCo's
+// (which first compares the warm start with a_s = M^-1 f_smooth): here the gradient  M a - f_smooth - J^T f  never
+// needs a_s, one factorisation is spent per iteration and none on bookkeeping.  Per iteration:
+//   row forces / cost, J^T f, Hessian rows of constraint rows whose active state flipped (incremental, as MuJoCo),
+//   gradient test, H = L L^T, direction, J dir / M dir, exact line search, step, improvement test.
+// Line search: the 1-D cost is convex piecewise quadratic; safeguarded Newton on its derivative (bracket [lo, hi],
+// Newton candidate, bisection when the candidate leaves the bracket), first trial alpha = 1 (exact when no row
+// changes state).  It is written with selects so that the 4 walkers of a wave do not serialise on it.
+// TIMED: accumulate shader-clock cycles per section into tacc[8] (diagnostics build of k_forward_g16 only):
+// 0 smooth dynamics, 1 constraints, 2 rows/J^T f/Hessian, 3 factor + solve, 4 J dir / M dir, 5 line search + step, 6 #iterations of the wave
+template <typename T, int N, bool TIMED = false>
+__device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ctrl_force, T warm, int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr) {
     using Ld = GLds;
+    long long t_last = 0;
+    if constexpr (TIMED) t_last = (long long)__builtin_readcyclecounter();
+    auto tick = [&](int k) {
+        if constexpr (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[k] += t - t_last; t_last = t; }
+    };
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
-    const int j = g.j, nv = m.nv;
+    const int j = g.j;
     g_smooth_dynamics<T>(g, q, v, ctrl_force);
     const T smooth = wb[Ld::VEC + Ld::V_SMOOTH * GL + j];
-    int nlim, ncon;
-    g_make_constraints<T>(g, grp, q, nlim, ncon);
+    T mrow[GL];
+#pragma unroll
+    for (int a = 0; a < GL; a++) mrow[a] = wb[Ld::MM + j * Ld::MS + a];
+    const T mdiag = wb[Ld::MM + j * Ld::MS + j];
+    tick(0);
+    int nlim, ncon, my_lim;
+    T lim_sign;
+    g_make_constraints<T>(g, grp, q, nlim, ncon, my_lim, lim_sign);
     const int nefc = nlim + 4 * ncon;
     ncon_o = ncon; nefc_o = nefc;
     DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * G_MAXROW;
     DL_LDS T* rJA = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW;
     DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
     DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
-    DL_LDS T* xl = wb + Ld::VEC + Ld::V_X * GL;
-
-    T h[GL];                   // row j of H = M + sum_active D row^T row
-    T qacc = T(0), Ma = T(0), qsm = T(0), x = (j < nv) ? v : T(0), Mx = T(0), rhs = T(0);
-    T cost = T(0), gauss = T(0), cost_s = T(0);
-    const T nvf = T(nv), scale = T(1) / (m.meaninertia * nvf);
+    // jar = J a - aref at a = warm start:  K imp r (stored by g_make_constraints) + J (B v + a)
+    (void)g_apply<T, N>(g, nlim, ncon, my_lim, lim_sign, m.solB * v + warm, mrow);
+    g_sync<T>();
+    for (int r = j; r < nefc; r += GL) { rJA[r] += rJV[r]; rTM[r] = T(0); }     // TMP: per-row "active" flags of the Hessian
+    T qacc = warm, Ma = T(0);
+    static_for<N>([&](auto ai) { constexpr int a = ai.value; Ma += mrow[a] * rbcast<a>(qacc); });
+    T h[GL], hd = mdiag;       // row j of H = M + sum_active D row^T row (off-diagonal part) and its diagonal
+#pragma unroll
+    for (int a = 0; a < GL; a++) h[a] = mrow[a];
+    const T nvf = T(m.nv), scale = T(1) / (m.meaninertia * nvf);
     bool alive = true;         // this walker still iterates (identical in the 16 lanes of the row)
-    int phase = -1, iter = 0;
+    int iter = 0;
+    g_sync<T>();
+    tick(1);
     for (;;) {
+        // ---- row forces and cost at the current point
+        T c = T(0);
+        for (int r = j; r < nefc; r += GL) {
+            const T jar = rJA[r], D = rD[r];
+            const bool on = jar < T(0);
+            rJV[r] = on ? -D * jar : T(0);
+            if (on) c += T(0.5) * D * jar * jar;
+        }
+        g_sync<T>();
+        // ---- J^T f, and the Hessian rows of constraint rows whose state flipped
+        T fcon = T(0);
+        if (my_lim >= 0) {
+            const bool on = rJA[my_lim] < T(0), was = rTM[my_lim] != T(0);
+            fcon = lim_sign * rJV[my_lim];
+            if (on != was && alive) hd += on ? rD[my_lim] : -rD[my_lim];
+        }
+        for (int cc = 0; cc < ncon; cc++) {
+            const int r0 = nlim + 4 * cc;
+            const T mu = wb[Ld::CON + 5 * G_MAXCON + cc], D = rD[r0];
+            T f4[4], dD[4];
+            bool anyflip = false;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                f4[s4] = rJV[r0 + s4];
+                const bool on = rJA[r0 + s4] < T(0), was = rTM[r0 + s4] != T(0);
+                dD[s4] = (on == was) ? T(0) : (on ? D : -D);
+                anyflip = anyflip || (on != was);
+            }
+            DL_LDS T* jc = wb + Ld::JC + cc * G_JC_STRIDE;
+            const T jn = jc[j], j1 = jc[GL + j], j2 = jc[2 * GL + j];
+            const T Fn = f4[0] + f4[1] + f4[2] + f4[3], F1 = mu * (f4[0] - f4[1]), F2 = mu * (f4[2] - f4[3]);
+            fcon += jn * Fn + j1 * F1 + j2 * F2;
+            if (anyflip && alive) {
+                // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
+                const T w00 = dD[0] + dD[1] + dD[2] + dD[3];
+                const T w01 = mu * (dD[0] - dD[1]), w02 = mu * (dD[2] - dD[3]);
+                const T w11 = mu * mu * (dD[0] + dD[1]), w22 = mu * mu * (dD[2] + dD[3]);
+                const T t0 = w00 * jn + w01 * j1 + w02 * j2, t1 = w01 * jn + w11 * j1, t2 = w02 * jn + w22 * j2;
+                hd += jn * t0 + j1 * t1 + j2 * t2;
+                static_for<N>([&](auto ai) { constexpr int a = ai.value; h[a] += rbcast<a>(jn) * t0 + rbcast<a>(j1) * t1 + rbcast<a>(j2) * t2; });
+            }
+        }
+        g_sync<T>();
+        for (int r = j; r < nefc; r += GL) rTM[r] = (rJA[r] < T(0)) ? T(1) : T(0);
+        const T pc0 = gsum(c);
+        const T grad = Ma - smooth - fcon;
+        {
+            const T gn = gsum(grad * grad), gmag = gsum(dl_abs(Ma) + dl_abs(smooth) + dl_abs(fcon));
+            // float32: the gradient carries rounding noise proportional to the magnitude of its terms
+            if (!(scale * dl_sqrt(gn) >= m.tolerance + m.tol_rel * scale * gmag) || iter >= m.iterations) alive = false;   // also stops on NaN
+        }
+        tick(2);
         if (!__any(alive)) break;
-        // ---- x -> LDS, J x, M x
-        xl[j] = x;
-        g_sync<T>();
-        Mx = g_apply<T>(g, nlim, ncon, phase > 0);
-        if (phase == 0) Mx = smooth;
-        g_sync<T>();
-        bool stop = false;
-        if (phase == -1) {
-            for (int r = j; r < nefc; r += GL) rJA[r] += m.solB * rJV[r];
-        } else if (phase <= 1) {
-            T c = T(0);
-            for (int r = j; r < nefc; r += GL) { const T jar = rJV[r] + rJA[r]; if (jar < T(0)) c += T(0.5) * rD[r] * jar * jar; }
-            c += T(0.5) * (Mx - smooth) * (x - qsm);
-            c = gsum(c);
-            if (phase == 0) {
-                cost_s = c;
-                for (int r = j; r < nefc; r += GL) rTM[r] = rJV[r];
-            } else {
-                const bool use_warm = !(c > cost_s);
-                if (alive) { qacc = use_warm ? warm : qsm; Ma = use_warm ? Mx : smooth; }
-                for (int r = j; r < nefc; r += GL) { rJA[r] += use_warm ? rJV[r] : rTM[r]; }
-                g_sync<T>();
-                for (int r = j; r < nefc; r += GL) rTM[r] = T(0);           // from now on: per-row "active" flags
-            }
-        } else {
-            // ---- exact line search (state machine per walker, evaluations in lock step over the wave)
-            const T snorm = dl_sqrt(gsum(x * x));
-            const T g1 = gsum(x * (Ma - smooth)), g2 = gsum(T(0.5) * x * Mx);
-            T alpha_res = T(0);
-            if (snorm < T(1e-15)) stop = true;
-            else {
-                const T gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * nvf + m.ls_reltol * dl_abs(g1);
-                GLs<T> p0 = {T(0), T(0), T(0), T(1)}, p1 = p0, p2 = p0, pmid = p0, p1next = p0, p2next = p0, cand[3] = {p0, p0, p0};
-                T dir = T(1), alpha = T(0);
-                bool p2update = false, b1 = false, b2 = false, ls_done = !alive;
-                int it = 0, state = 0;
-                const int maxit = m.ls_iterations;
-                while (__any(!ls_done)) {
-                    T pc = T(0), pd1 = T(0), pd2 = T(0);
-                    for (int r = j; r < nefc; r += GL) {
-                        const T jv = rJV[r], xx = rJA[r] + alpha * jv;
-                        if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jv; pd2 += D * jv * jv; }
-                    }
-                    pc = gsum(pc); pd1 = gsum(pd1); pd2 = gsum(pd2);
-                    const GLs<T> pe = {alpha, gauss + alpha * g1 + alpha * alpha * g2 + pc, g1 + T(2) * alpha * g2 + pd1, T(2) * g2 + pd2};
-                    if (ls_done) continue;
-                    bool end_onesided = false, end_iter = false;
-                    if (state == 0) { p0 = pe; alpha = -p0.d1 / p0.d2; state = 1; continue; }
-                    else if (state == 1) {
-                        p1 = pe;
-                        if (p0.cost < p1.cost) p1 = p0;
-                        if (dl_abs(p1.d1) < gtol) { alpha_res = p1.alpha; ls_done = true; continue; }
-                        dir = p1.d1 < T(0) ? T(1) : T(-1);
-                        p2 = p1;
-                        if (p1.d1 * dir <= -gtol && it < maxit) { p2 = p1; p2update = true; alpha = p1.alpha - p1.d1 / p1.d2; state = 2; continue; }
-                        end_onesided = true;
-                    } else if (state == 2) {
-                        p1 = pe; it++;
-                        if (dl_abs(p1.d1) < gtol) { alpha_res = p1.alpha; ls_done = true; continue; }
-                        if (p1.d1 * dir <= -gtol && it < maxit) { p2 = p1; alpha = p1.alpha - p1.d1 / p1.d2; continue; }
-                        end_onesided = true;
-                    } else if (state == 3) { p1next = pe; end_iter = true; }
-                    else if (state == 4) {
-                        pmid = pe; it++;
-                        cand[0] = p1next; cand[1] = p2next; cand[2] = pmid;
-                        int best = -1; T bestcost = T(0), bestalpha = T(0);
-                        for (int i = 0; i < 3; i++)
-                            if (dl_abs(cand[i].d1) < gtol && (best < 0 || cand[i].cost < bestcost)) { best = i; bestcost = cand[i].cost; bestalpha = cand[i].alpha; }
-                        if (best >= 0) { alpha_res = bestalpha; ls_done = true; continue; }
-                        b1 = false;
-                        for (int i = 0; i < 3; i++) {
-                            if (p1.d1 < T(0) && cand[i].d1 < T(0) && p1.d1 < cand[i].d1) { p1 = cand[i]; b1 = true; }
-                            else if (p1.d1 > T(0) && cand[i].d1 > T(0) && p1.d1 > cand[i].d1) { p1 = cand[i]; b1 = true; }
-                        }
-                        if (b1) { alpha = p1.alpha - p1.d1 / p1.d2; state = 5; continue; }
-                        b2 = false;
-                        for (int i = 0; i < 3; i++) {
-                            if (p2.d1 < T(0) && cand[i].d1 < T(0) && p2.d1 < cand[i].d1) { p2 = cand[i]; b2 = true; }
-                            else if (p2.d1 > T(0) && cand[i].d1 > T(0) && p2.d1 > cand[i].d1) { p2 = cand[i]; b2 = true; }
-                        }
-                        if (b2) { alpha = p2.alpha - p2.d1 / p2.d2; state = 6; continue; }
-                        end_iter = true;
-                    } else if (state == 5) {
-                        p1next = pe;
-                        b2 = false;
-                        for (int i = 0; i < 3; i++) {
-                            if (p2.d1 < T(0) && cand[i].d1 < T(0) && p2.d1 < cand[i].d1) { p2 = cand[i]; b2 = true; }
-                            else if (p2.d1 > T(0) && cand[i].d1 > T(0) && p2.d1 > cand[i].d1) { p2 = cand[i]; b2 = true; }
-                        }
-                        if (b2) { alpha = p2.alpha - p2.d1 / p2.d2; state = 6; continue; }
-                        end_iter = true;
-                    } else { p2next = pe; end_iter = true; }
-                    if (end_onesided) {
-                        if (it >= maxit || !p2update) { alpha_res = p1.alpha; ls_done = true; continue; }
-                        p2next = p1; alpha = p1.alpha - p1.d1 / p1.d2; state = 3; continue;
-                    }
-                    if (end_iter) {
-                        if (state != 3 && !b1 && !b2) { alpha_res = pmid.cost < p0.cost ? pmid.alpha : T(0); ls_done = true; continue; }
-                        if (it >= maxit) {
-                            if (p1.cost <= p2.cost && p1.cost < p0.cost) alpha_res = p1.alpha;
-                            else if (p2.cost <= p1.cost && p2.cost < p0.cost) alpha_res = p2.alpha;
-                            else alpha_res = T(0);
-                            ls_done = true; continue;
-                        }
-                        b1 = false; b2 = false; alpha = T(0.5) * (p1.alpha + p2.alpha); state = 4;
-                    }
-                }
-                if (alpha_res == T(0)) stop = true;
-                else if (alive) {
-                    qacc += alpha_res * x; Ma += alpha_res * Mx;
-                    for (int r = j; r < nefc; r += GL) rJA[r] += alpha_res * rJV[r];
-                }
-            }
-        }
-        if (stop) alive = false;
-        g_sync<T>();
-        if (phase == 0) { phase = 1; x = (j < nv) ? warm : T(0); continue; }
-
-        // ---- Hessian row: M at the start, then contact / limit rows whose state flipped
-        const T oldcost = cost;
-        if (phase <= 1) {
-#pragma unroll
-            for (int a = 0; a < GL; a++) h[a] = wb[Ld::MM + j * GL + a];
-        }
-        if (phase >= 1) {
-            // per row: force, cost, flip bookkeeping (lanes split the rows)
-            T c = T(0);
-            for (int r = j; r < nefc; r += GL) {
-                const T jar = rJA[r], D = rD[r];
-                const bool on = jar < T(0);
-                rJV[r] = on ? -D * jar : T(0);                         // row force (JV is free now)
-                if (on) c += T(0.5) * D * jar * jar;
-            }
-            g_sync<T>();
-            // limits: flips touch the diagonal, forces go to their dof
-            T fcon = T(0);
-            for (int r = 0; r < nlim; r++) {
-                const int code = (int)wb[Ld::LIMC + r];
-                if ((code & 31) == j) {
-                    const T f = rJV[r], D = rD[r];
-                    const bool on = rJA[r] < T(0), was = rTM[r] != T(0);
-                    fcon += (code & 32) ? -f : f;
-                    if (on != was && alive) {
-                        const T dH = on ? D : -D;
-#pragma unroll
-                        for (int a = 0; a < GL; a++) if (a == j) h[a] += dH;
-                    }
-                }
-            }
-            // contacts: force in the contact frame; Hessian update J_c^T dW J_c for flipped edges
-            for (int cc = 0; cc < ncon; cc++) {
-                const int r0 = nlim + 4 * cc;
-                const T mu = wb[Ld::CON + 5 * G_MAXCON + cc];
-                T f4[4], dD[4];
-                bool anyflip = false;
-                for (int s4 = 0; s4 < 4; s4++) {
-                    f4[s4] = rJV[r0 + s4];
-                    const bool on = rJA[r0 + s4] < T(0), was = rTM[r0 + s4] != T(0);
-                    dD[s4] = (on == was) ? T(0) : (on ? rD[r0 + s4] : -rD[r0 + s4]);
-                    anyflip = anyflip || (on != was);
-                }
-                DL_LDS T* jc = wb + Ld::JC + cc * G_JC_STRIDE;
-                const T jn = jc[j], j1 = jc[GL + j], j2 = jc[2 * GL + j];
-                const T Fn = f4[0] + f4[1] + f4[2] + f4[3], F1 = mu * (f4[0] - f4[1]), F2 = mu * (f4[2] - f4[3]);
-                fcon += jn * Fn + j1 * F1 + j2 * F2;
-                if (__any(anyflip && alive)) {
-                    if (anyflip && alive) {
-                        // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
-                        const T w00 = dD[0] + dD[1] + dD[2] + dD[3];
-                        const T w01 = mu * (dD[0] - dD[1]), w02 = mu * (dD[2] - dD[3]);
-                        const T w11 = mu * mu * (dD[0] + dD[1]), w22 = mu * mu * (dD[2] + dD[3]);
-                        const T t0 = w00 * jn + w01 * j1 + w02 * j2, t1 = w01 * jn + w11 * j1, t2 = w02 * jn + w22 * j2;
-#pragma unroll
-                        for (int a = 0; a < GL; a++) h[a] += jc[a] * t0 + jc[GL + a] * t1 + jc[2 * GL + a] * t2;
-                    }
-                }
-            }
-            g_sync<T>();
-            // remember the active state
-            for (int r = j; r < nefc; r += GL) rTM[r] = (rJA[r] < T(0)) ? T(1) : T(0);
-            const T gpart = T(0.5) * (Ma - smooth) * (qacc - qsm);
-            gauss = gsum(gpart);
-            cost = gsum(c) + gauss;
-            rhs = Ma - smooth - fcon;
-        } else {
-            rhs = smooth;
-        }
-        if (phase >= 2) {
-            const T gn = gsum(rhs * rhs);
-            const T improvement = scale * (oldcost - cost), gradient = scale * dl_sqrt(gn);
-            if (alive) iter++;
-            // float32: cost and gradient carry rounding noise proportional to their magnitude; without the
-            // relative terms a converged walker whose step no longer changes qacc can iterate forever
-            const T gmag = gsum(dl_abs(Ma) + dl_abs(smooth));
-            if (improvement < m.tolerance + m.tol_rel * scale * dl_abs(cost) || gradient < m.tolerance + m.tol_rel * scale * gmag || iter >= m.iterations) alive = false;
-        }
-        // ---- factor H (row j in lane j) and solve
+        if constexpr (TIMED) tacc[6] += 1;
+        // ---- Newton direction
+        T dir;
         {
             T l[GL], invd = T(1);
 #pragma unroll
             for (int a = 0; a < GL; a++) l[a] = h[a];
-            g_chol<T>(l, invd, j, nv, T(1e-10));
-            rhs = g_chol_solve<T>(l, invd, rhs, j, nv);
+            g_chol<T, N>(l, hd, invd, j, T(1e-10));
+            dir = -g_chol_solve<T, N>(l, invd, grad, j);
         }
-        if (phase == -1) {
-            qsm = rhs; x = rhs;
-            if (nefc == 0) { qacc = qsm; alive = false; }
-            phase = 0;
-        } else {
-            x = -rhs;
-            phase = phase + 1;
+        tick(3);
+        const T Md = g_apply<T, N>(g, nlim, ncon, my_lim, lim_sign, dir, mrow);      // rows JV = J dir
+        g_sync<T>();
+        tick(4);
+        // ---- exact line search along dir
+        const T g1s = gsum(dir * (Ma - smooth)), g2 = gsum(T(0.5) * dir * Md), d0 = gsum(dir * grad), snorm = dl_sqrt(gsum(dir * dir));
+        const T gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * nvf + m.ls_reltol * dl_abs(d0);
+        T alpha = T(1), lo = T(0), hi = T(1e30), best_a = T(0), best_dc = T(0), best_mag = T(0), res_a = T(0), res_dc = T(0), res_mag = T(0);
+        bool done = !alive || !(snorm >= T(1e-15));
+        const int maxit = m.ls_iterations;
+        int it = 0;
+        while (__any(!done)) {
+            T pc = T(0), pd1 = T(0), pd2 = T(0);
+            for (int r = j; r < nefc; r += GL) {
+                const T jv = rJV[r], xx = rJA[r] + alpha * jv;
+                if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jv; pd2 += D * jv * jv; }
+            }
+            pc = gsum(pc); pd1 = gsum(pd1); pd2 = gsum(pd2);
+            const T d1 = g1s + T(2) * alpha * g2 + pd1, d2 = T(2) * g2 + pd2;
+            const T dc = alpha * g1s + alpha * alpha * g2 + (pc - pc0);
+            const T mag = dl_abs(alpha * g1s) + alpha * alpha * g2 + pc + pc0;
+            it++;
+            if (!done) {
+                if (d1 < T(0)) lo = alpha; else hi = alpha;
+                const T cand = alpha - d1 / d2;
+                const T mid = hi < T(1e29) ? T(0.5) * (lo + hi) : T(2) * alpha;
+                const T next = (cand > lo && cand < hi) ? cand : mid;
+                // converged: derivative below tolerance, or the iterate no longer moves at working precision
+                const bool conv = dl_abs(d1) < gtol || dl_abs(next - alpha) <= T(4) * GEps<T>::value * alpha;
+                if (dc < best_dc) { best_dc = dc; best_a = alpha; best_mag = mag; }
+                if (conv) { res_a = alpha; res_dc = dc; res_mag = mag; done = true; }
+                else if (it >= maxit) { res_a = best_a; res_dc = best_dc; res_mag = best_mag; done = true; }
+                alpha = next;
+            }
         }
+        // ---- step
+        if (alive) {
+            if (res_a == T(0)) alive = false;                      // no improvement along a descent direction: converged to working precision
+            else {
+                qacc += res_a * dir; Ma += res_a * Md;
+                for (int r = j; r < nefc; r += GL) rJA[r] += res_a * rJV[r];
+                iter++;
+                // mj_solNewton's improvement test (float32: relative to the magnitude of the terms of the cost difference)
+                if (!(scale * -res_dc >= m.tolerance + m.tol_rel * scale * res_mag) || nefc == 0) alive = false;
+            }
+        }
+        g_sync<T>();
+        tick(5);
     }
     niter_o = iter;
     return qacc;

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP>* __rest
 }
 
 // forward dynamics with 16 lanes per walker (dl_group.hpp): 4 walkers per 64-lane workgroup
-template <typename T>
-__global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict__ gm, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+template <typename T, bool TIMED = false>
+__global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict__ gm, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, long long* tim = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
     const int w = blockIdx.x * GW + grp;
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
         }
     }
     int nc, ne, ni;
-    const T a = g_forward<T>(g, grp, q, v, force, wm, nc, ne, ni);
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const T a = g_forward<T, TopoStraight::NV, TIMED>(g, grp, q, v, force, wm, nc, ne, ni, tacc);
+    if constexpr (TIMED) { if (lane == 0) for (int k = 0; k < 8; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k]; }
     if (valid && j < nv) qacc[(size_t)j * n + w] = a;
     if (valid && j == 0) { if (ncon) ncon[w] = nc; if (nefc) nefc[w] = ne; if (niter) niter[w] = ni; }
 }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 int nc, ne, ni;
-                const T acc = g_forward<T>(g, grp, qs, vs, force, warm, nc, ne, ni);
+                const T acc = g_forward<T, TPS::NV>(g, grp, qs, vs, force, warm, nc, ne, ni);
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
                 if (st.dbgf && valid && ni >= m->iterations) {
                     st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)warm;
@@ -389,6 +391,7 @@ struct dl_env_s {
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
+    virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -575,6 +578,17 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (clear) HIPCHK(hipMemsetAsync(st.dbg, 0, (size_t)4 * n * sizeof(int32_t), s));
         return DL_OK;
     }
+    int forward_timed(const void* ctrl, void* qacc, long long* tim, hipStream_t s) override {
+        if (!gmd || !qacc || !tim) return fail(DL_E_INVAL, "dl_debug_forward_timed: needs the 16-lane kernels, qacc and tim");
+        if constexpr (TP::ENV_KIND == 0 && sizeof(T) == 4) {
+            static bool attr = false;
+            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T))))); attr = true; }
+            hipLaunchKernelGGL((k_forward_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, tim);
+            HIPCHK(hipGetLastError());
+            return DL_OK;
+        }
+        return fail(DL_E_INVAL, "dl_debug_forward_timed: float32 straight walker only");
+    }
     int capstate(float* out, hipStream_t s) override {
         if (!st.dbgf || !out) return fail(DL_E_INVAL, "dl_debug_capstate: enable the counters first");
         HIPCHK(hipMemcpyAsync(out, st.dbgf, (size_t)48 * n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -674,6 +688,11 @@ int dl_debug_inject(dl_handle h, const void* qpos, const void* qvel, const int32
 int dl_debug_counters(dl_handle h, int32_t* out, int32_t clear, void* stream) {
     NEED(h);
     return h->counters(out, clear, (hipStream_t)stream);
+}
+/* one forward evaluation (16-lane f32 kernels) with per-section cycle counts: tim int64[8, ceil(N/4)] device */
+int dl_debug_forward_timed(dl_handle h, const void* ctrl, void* qacc, long long* tim, void* stream) {
+    NEED(h);
+    return h->forward_timed(ctrl, qacc, tim, (hipStream_t)stream);
 }
 /* in: float[128] device, out: float[256] device (see k_selftest) */
 int dl_debug_selftest(const float* in, float* out, void* stream) {

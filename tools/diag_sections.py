@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-section cycle counts of one forward evaluation (16-lane f32 kernel) at mid-rollout states."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from drloco_amd import lib
+from drloco_amd.vec_env import HipVecEnv, _ptr, _stream
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--envs', type=int, default=4096)
+ap.add_argument('--warm', type=int, default=80)
+args = ap.parse_args()
+n = args.envs
+env = HipVecEnv(num_envs=n, lanes_per_walker=16, seed=1234)
+env.reset_tensors()
+g = torch.Generator(device='cuda'); g.manual_seed(4321)
+acts = torch.clamp(0.5 * torch.randn(args.warm, n, 8, device='cuda', generator=g), -1, 1)
+for t in range(args.warm):
+    env.step_tensors(acts[t])
+ctrl = (300 * torch.clamp(0.5 * torch.randn(8, n, device='cuda', generator=g), -1, 1)).contiguous()
+nb = (n + 3) // 4
+tim = torch.zeros(8, nb, dtype=torch.int64, device='cuda')
+qacc = torch.zeros(14, n, device='cuda')
+names = ['smooth dynamics', 'constraints', 'rows, J^T f, Hessian', 'factor + solve', 'J dir / M dir', 'line search + step', '(iterations)', '-']
+for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.check(env._lib.dl_debug_forward_timed(env._h, _ptr(ctrl), _ptr(qacc), _ptr(tim), _stream()))
+    e1.record(); torch.cuda.synchronize()
+    t = tim.cpu().numpy().astype(np.float64)
+tot = t[:6].sum(0)
+print(f'kernel {e0.elapsed_time(e1) * 1e3:.1f} us; per wave: total cycles mean {tot.mean():.0f} median {np.median(tot):.0f} max {tot.max():.0f}; wave iterations mean {t[6].mean():.2f} max {t[6].max():.0f}')
+for k in range(6):
+    print(f'  {names[k]:22s} mean {t[k].mean():9.0f}  ({100 * t[k].mean() / tot.mean():5.1f} %)  max {t[k].max():9.0f}   per iteration {t[k].mean() / t[6].mean():8.0f}')
+qa, nc, ne, ni = env.forward(ctrl.cpu().numpy().astype(np.float64))
+print('iters: mean %.2f  hist %s' % (ni.mean(), np.bincount(ni)[:12]))
+print('nefc: mean %.1f  hist(0,1-8,9-16,17-32,33+) %s' % (ne.mean(), [int((ne == 0).sum()), int(((ne > 0) & (ne <= 8)).sum()), int(((ne > 8) & (ne <= 16)).sum()), int(((ne > 16) & (ne <= 32)).sum()), int((ne > 32).sum())]))
+w = ni.reshape(-1, 4).max(1)
+print('per wave max iters: mean %.2f' % w.mean())
