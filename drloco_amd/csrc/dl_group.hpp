@@ -155,13 +155,15 @@ __device__ __forceinline__ void g_fill_shared(const DL_CONST GModel<T>& m, DL_LD
 
 // ------------------------------------------------------------------------------------------
 // DPP row (16-lane) primitives
+// row_ror / row_newbcast read a valid lane of the own row for every lane, so there is no "old" value to keep:
+// bound_ctrl lets the compiler fold the DPP read into the consuming VOP2 instruction (v_add/v_mul/v_fmac ..._dpp)
 template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
 template <int CTRL> __device__ __forceinline__ double dpp_f(double x) {
     const uint64_t u = __builtin_bit_cast(uint64_t, x);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 // sum over the 16 lanes of a row, result in every lane (row_ror:8,4,2,1).  Every lane must get the SAME
