@@ -211,14 +211,13 @@ template <typename T> __device__ __forceinline__ void rot_axis(V3<T>& X, V3<T>& 
     if (idx == 0) { Y = A2; Z = B2; } else if (idx == 1) { Z = A2; X = B2; } else { X = A2; Y = B2; }
 }
 
-// [3P] mj_kinematics + mj_crb + mj_rne + passive/actuator forces: leaves M (dense, symmetric) and
-// qfrc_smooth in LDS, axes/anchors/motion subspaces in LDS, rootz in MISC[0]
+// [3P] mj_kinematics: joint axes / anchors / motion subspaces, body frames (BFR) and rootz (MISC[0]) in LDS
 template <typename T>
-__device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T ctrl_force) {
+__device__ __forceinline__ void g_kinematics(const GCtx<T>& g, T q, T v) {
     using Ld = GLds;
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
-    const int j = g.j, nv = m.nv, nb = m.nb;
+    const int j = g.j, nv = m.nv;
     const GLane<T>& ln = *g.ln;
     // ---- A: joint sines / cosines, q, v
     {
@@ -267,6 +266,40 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T 
         if (j == m.root_last_dof) wb[Ld::MISC + 0] = rootz;
     }
     g_sync<T>();
+}
+
+// height of the lowest foot-sole site above the floor at the configuration last passed to g_kinematics
+// (reset_model's COM-z adjustment, drloco/mujoco/mimic_env.py:547-559); identical in the 16 lanes of the row
+template <typename T>
+__device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
+    using Ld = GLds;
+    const DL_CONST GModel<T>& m = *g.m;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j;
+    T low = T(1e30);
+    if (j < m.nsite) {
+        const int b = m.site_body[j];
+        DL_LDS T* f = wb + Ld::BFR + b;
+        const T pz = f[11 * G_MAXB] + m.site_pos[j][0] * f[2 * G_MAXB] + m.site_pos[j][1] * f[5 * G_MAXB] + m.site_pos[j][2] * f[8 * G_MAXB];
+        low = wb[Ld::MISC + 0] + pz;
+    }
+    low = dl_min(low, dpp_f<0x128>(low));
+    low = dl_min(low, dpp_f<0x124>(low));
+    low = dl_min(low, dpp_f<0x122>(low));
+    low = dl_min(low, dpp_f<0x121>(low));
+    return low;
+}
+
+// [3P] mj_kinematics + mj_crb + mj_rne + passive/actuator forces: leaves M (dense, symmetric) and
+// qfrc_smooth in LDS, axes/anchors/motion subspaces in LDS, rootz in MISC[0]
+template <typename T>
+__device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T ctrl_force) {
+    using Ld = GLds;
+    const DL_CONST GModel<T>& m = *g.m;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j, nv = m.nv, nb = m.nb;
+    const GLane<T>& ln = *g.ln;
+    g_kinematics<T>(g, q, v);
     // ---- C: twist / velocity-product acceleration down the chain (dof lanes), body inertia (body lanes)
     if (j < nv) {
         SV<T> vel = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)}, acc = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};

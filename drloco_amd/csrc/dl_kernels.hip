@@ -105,12 +105,12 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
 
 
 // one control step with 16 lanes per walker (straight walker): action map, 5 x RK4 mj_step through
-// g_forward, cursor / observation / reward / termination / Monitor.  Finished walkers are flagged
-// in need_reset and re-initialised by k_env_reset (lane-per-walker kernel, rare).
+// g_forward, cursor / observation / reward / termination / Monitor, and the vec-env auto reset of finished
+// walkers (RSI draw, mocap lookup, foot-site kinematics, first observation) in the same launch.
 template <typename T>
 __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
                                                      float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
-                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags) {
+                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode) {
     using TPS = TopoStraight;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
@@ -185,27 +185,34 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     // ---- environment logic
     const double tor_mean = (double)tor_sum / nu;
     double walked = st.walked[w];
-    const T comz = st.comz_off[w];
+    T comz = st.comz_off[w];
     double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
     float r;
     bool dn;
-    if (exc) {
-        r = 0.0f; dn = true; walked = 0;
-        terms[0] = terms[1] = terms[2] = 1.0;
-        if (valid && j == 0) st.need_reset[w] = 2;
-    } else {
-        cursor_next<T, TPS>(c, cur);
-        // raw observation entries live in LDS: [phase, desvel, q1.., v0..]
-        g_sync<T>();
-        if (isdof) { wb[GLds::Q + j] = q; wb[GLds::V + j] = v; }
-        g_sync<T>();
+    // observation (mimic_env.py:403-437 + mirror_obs :440-480) from q, v staged in LDS: 29 outputs over 16 lanes
+    auto write_obs = [&](float* dst_base) {
         const int rs = cur[DL_CUR_READ_STEP];
         const T phase_var = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
         const int iv = cur[DL_CUR_I_STEP] - cur[DL_CUR_COUNT] + 1;
         const T desvel = c.step_vel[iv > 0 ? iv : 0];
         const bool mirr_o = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
         auto raw_obs = [&](int k) -> T { return k == 0 ? phase_var : (k == 1 ? desvel : (k < 1 + nv ? wb[GLds::Q + (k - 1)] : wb[GLds::V + (k - 1 - nv)])); };
-        float* dst_base = nullptr;
+        if (valid && dst_base) {
+            for (int k = j; k < TPS::OBS; k += GL) {
+                const T plain = raw_obs(k);
+                const T mir = TPS::obs_neg_[k] ? -raw_obs(TPS::obs_perm_[k]) : raw_obs(TPS::obs_perm_[k]);
+                dst_base[(size_t)w * TPS::OBS + k] = (float)(mirr_o ? mir : plain);
+            }
+        }
+    };
+    if (exc) {
+        r = 0.0f; dn = true; walked = 0;
+        terms[0] = terms[1] = terms[2] = 1.0;
+    } else {
+        cursor_next<T, TPS>(c, cur);
+        g_sync<T>();
+        if (isdof) { wb[GLds::Q + j] = q; wb[GLds::V + j] = v; }
+        g_sync<T>();
         cur[DL_CUR_EP_DUR] += 1;
         const T vx = dl_clamp(rbcast<0>(v), T(-5.5), T(5.5)), vy = dl_clamp(rbcast<1>(v), T(-5.5), T(5.5));
         walked += (double)dl_sqrt(vx * vx + vy * vy) * (double)c.inv_ctrl_freq;
@@ -229,26 +236,57 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             terms[0] = (double)tp; terms[1] = (double)tv; terms[2] = (double)tc;
             r = (float)((c.rew_w[0] * tp + c.rew_w[1] * tv + c.rew_w[2] * tc) * c.rew_scale + c.alive_bonus);
         }
-        dst_base = dn ? term_obs : obs;
-        if (valid && dst_base) {
-            // 29 outputs over 16 lanes: k = j and k = j + 16
-            for (int k = j; k < TPS::OBS; k += GL) {
-                const T plain = raw_obs(k);
-                const T mir = TPS::obs_neg_[k] ? -raw_obs(TPS::obs_perm_[k]) : raw_obs(TPS::obs_perm_[k]);
-                dst_base[(size_t)w * TPS::OBS + k] = (float)(mirr_o ? mir : plain);
-            }
-        }
-        if (valid && dn && j == 0) st.need_reset[w] = 1;
+        write_obs(dn ? term_obs : obs);
     }
     if (valid && j == 0 && st.dbg) {
         st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
     }
     if (valid && j == 0) {
         monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked);
-        st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
         if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
         rew[w] = r;
         done[w] = dn ? 1 : 0;
+    }
+    // ---- vec-env auto reset inside the same launch (SubprocVecEnv worker: obs = env.reset() after done; a
+    // diverged step resets twice, the first reset's observation being the terminal observation):
+    // MujocoEnv.reset -> reset_model (mimic_env.py:526-572).  The warm start of the new episode is zero: the
+    // solver's minimiser does not depend on it.
+    const int nrep = exc ? 2 : (dn ? 1 : 0);
+    if (nrep > 0) {
+#pragma unroll 1
+        for (int rep = 0; rep < nrep; rep++) {
+            int s0, p0, read = -1;
+            if (eval_mode) {
+                s0 = cur[DL_CUR_EVAL_K];
+                p0 = (int)(0.75 * (double)(c.step_off[s0 + 1] - c.step_off[s0]));
+                read = 0;
+                cur[DL_CUR_EVAL_K] = (s0 + 1 >= 20) ? 0 : s0 + 1;
+            }
+            else if (st.inj_rsi && st.inj_rsi[w] >= 0) { s0 = st.inj_rsi[w]; p0 = st.inj_rsi[(size_t)n + w]; }
+            else rsi_draw(c, (uint32_t)(c.env_index_base + w), (uint32_t)cur[DL_CUR_EPISODE], s0, p0);
+            cur[DL_CUR_EPISODE] += 1;
+            cur[DL_CUR_EP_DUR] = 0;
+            cur[DL_CUR_I_STEP] = s0; cur[DL_CUR_RSI_STEP] = s0; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s0; cur[DL_CUR_POS] = p0; cur[DL_CUR_HAS_DIST] = 0;
+            if (isdof) {
+                const int base = c.step_off[cur[DL_CUR_READ_STEP]] + p0;
+                q = c.table[(size_t)j * c.total_len + base];
+                v = c.table[(size_t)(nv + j) * c.total_len + base];
+            }
+            g_kinematics<T>(g, q, v);
+            comz = g_lowest_site<T>(g);
+            if (j == 2) { q -= comz; wb[GLds::Q + 2] = q; }
+            warm = T(0);
+            cursor_next<T, TPS>(c, cur);
+            g_sync<T>();
+            write_obs((nrep == 2 && rep == 0) ? term_obs : obs);
+            g_sync<T>();
+        }
+        walked = 0;
+        terms[0] = terms[1] = terms[2] = 1.0;       // reset_model's sanity check evaluates the reward terms at the init state (:562)
+        if (valid && j == 0) st.comz_off[w] = comz;
+    }
+    if (valid && j == 0) {
+        st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
         st.walked[w] = walked;
 #pragma unroll
         for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
@@ -523,9 +561,12 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             if constexpr (TP::ENV_KIND == 0) {
                 prof_begin(s);
                 hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
-                                   (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
+                                   (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), eval_mode);
                 prof_end(s);
             }
+            HIPCHK(hipGetLastError());
+            if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
+            return DL_OK;                 // finished walkers were re-initialised inside the launch
         } else {
         prof_begin(s);
         hipLaunchKernelGGL((k_env_step<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, act, obs, rew, done, term, terms,
