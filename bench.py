@@ -8,9 +8,10 @@ Workload (BASELINE.json configs[1], per GPU; configs[2] is the same per GPU at N
   straight_walking 3D walker, 4096 parallel walkers per GPU, fixed 512-step synthetic rollout.
 One "step" of this benchmark = ONE 512-step rollout of all walkers of a rank:
   per control step   dl_step (5 RK4 mj_steps + mocap cursor + imitation reward + observation +
-                     termination + Monitor statistics + auto-reset/RSI),
-                     VecNormalize moments update + observation/reward normalisation,
-                     rollout-buffer store;
+                     termination + Monitor statistics + auto-reset/RSI) -> raw obs/reward, done flags
+                     into the next episode_starts slot of the rollout buffer,
+                     dl_vecnormalize_step (moments update + observation/reward normalisation) -> the
+                     rollout buffer's observations[t+1] / rewards[t] slots (3 launches per control step);
   per rollout        GAE(lambda) return/advantage scan, advantage statistics + normalisation
                      (RCCL all-reduce of 3 doubles when N > 1 -- the only collective).
 Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) (seed 4321 + rank), values are synthetic,
@@ -85,26 +86,25 @@ def main():
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
-    actions = torch.clamp(0.5 * torch.randn(T, n, venv.nu, device=dev, generator=gen), -1, 1)
-    values = torch.randn(T, n, device=dev, generator=gen)
-    logp = torch.zeros(n, device=dev)
+    # what the policy would have produced lives where it would have written it: in the rollout buffer
+    buf.actions.copy_(torch.clamp(0.5 * torch.randn(T, n, venv.nu, device=dev, generator=gen), -1, 1))
+    buf.values.copy_(torch.randn(T, n, device=dev, generator=gen))
     last_values = torch.randn(n, device=dev, generator=gen)
     vn.reset()
-    episode_start = torch.ones(n, dtype=torch.uint8, device=dev)
+    last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
+    last_done = torch.ones(n, dtype=torch.uint8, device=dev)
 
     def rollout():
-        nonlocal episode_start
+        # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
+        # (dl_step -> episode_starts[t+1]; dl_vecnormalize_step -> observations[t+1], rewards[t])
         buf.reset()
-        obs = vn.norm_obs_t
+        buf.observations[0].copy_(last_obs)
+        buf.episode_starts[0].copy_(last_done)
         for t in range(T):
-            buf.observations[t].copy_(obs)           # RolloutBuffer.add
-            buf.actions[t].copy_(actions[t])
-            buf.values[t].copy_(values[t])
-            buf.episode_starts[t].copy_(episode_start)
-            obs, rew, done, _ = vn.step_tensors(actions[t])
-            buf.rewards[t].copy_(rew)
-            episode_start = done
-        buf.compute_returns_and_advantage(last_values, episode_start)
+            nxt = t + 1 < T
+            vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t],
+                            done_out=buf.episode_starts[t + 1] if nxt else last_done)
+        buf.compute_returns_and_advantage(last_values, last_done)
         buf.normalize_advantages()                   # all-reduce of [sum, sum^2, n] when world > 1
 
     def barrier():

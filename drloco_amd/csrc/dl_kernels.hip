@@ -375,6 +375,87 @@ __global__ void k_reward_finish(float* rew, double* ret, const uint8_t* done, co
     if (done[i]) ret[i] = 0;
 }
 
+// ---- VecNormalize.step_wait fused into two launches -------------------------------------------------------
+// k_vn_reduce: grid = VN_BLOCKS + 1.  Blocks [0, VN_BLOCKS) read slabs of x[B, D] with coalesced loads (thread t
+// always meets column t % D) and leave per-column partial sums of (x - K) and (x - K)^2, K = the running mean
+// (shift against cancellation); the last block to arrive merges them into (mean, var) with RunningMeanStd's Chan
+// update.  Block VN_BLOCKS advances the discounted returns ret = ret*gamma + r and merges their moments.
+// The counts are read here and advanced by k_vn_apply (stream order), so every merge sees the old count.
+constexpr int VN_BLOCKS = 32;
+__global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
+                                                   double* ret, double* ret_mean, double* ret_var, const double* ret_count,
+                                                   int B, int D, double gamma, int flags, double* work, unsigned* arrive) {
+    __shared__ double sh[2][256];
+    __shared__ bool is_last;
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x == VN_BLOCKS) {
+        if (!(flags & 4)) return;
+        const double K = *ret_mean;
+        double s = 0, ss = 0;
+        for (int i = t; i < B; i += blockDim.x) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; const double d = r - K; s += d; ss += d * d; }
+        __shared__ double sh2[4];
+        s = block_sum(s, sh2); ss = block_sum(ss, sh2);
+        if (t == 0) {
+            const double bm = K + s / B, bv = ss / B - (s / B) * (s / B);
+            const double cnt = *ret_count, tot = cnt + B, delta = bm - *ret_mean;
+            const double M2 = *ret_var * cnt + bv * B + delta * delta * cnt * B / tot;
+            *ret_mean = *ret_mean + delta * B / tot;
+            *ret_var = M2 / tot;
+        }
+        return;
+    }
+    if (!(flags & 1)) return;
+    const int rpb = blockDim.x / D, nthr = rpb * D;       // rows per pass of this block
+    double s = 0, ss = 0;
+    const int col = t % D, rsub = t / D;
+    if (t < nthr) {
+        const double K = mean[col];
+        for (int row = blockIdx.x * rpb + rsub; row < B; row += VN_BLOCKS * rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
+    }
+    sh[0][t] = s; sh[1][t] = ss;
+    __syncthreads();
+    if (t < D) {
+        for (int r = 1; r < rpb; r++) { s += sh[0][r * D + t]; ss += sh[1][r * D + t]; }
+        work[((size_t)blockIdx.x * D + t) * 2] = s; work[((size_t)blockIdx.x * D + t) * 2 + 1] = ss;
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) is_last = atomicAdd(arrive, 1u) == (unsigned)(VN_BLOCKS - 1);
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (t < D) {
+        double S = 0, SS = 0;
+        for (int b = 0; b < VN_BLOCKS; b++) { S += __builtin_nontemporal_load(&work[((size_t)b * D + t) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * D + t) * 2 + 1]); }
+        const double K = mean[t], bm = K + S / B, bv = SS / B - (S / B) * (S / B);
+        const double cnt = *count, tot = cnt + B, delta = bm - K;
+        const double M2 = var[t] * cnt + bv * B + delta * delta * cnt * B / tot;
+        mean[t] = K + delta * B / tot;
+        var[t] = M2 / tot;
+    }
+    if (t == 0) *arrive = 0;
+}
+// k_vn_apply: obs_out = clip((obs - mean)/sqrt(var + eps)); rew_out = clip(r/sqrt(ret_var + eps)); ret[done] = 0; counts += B
+__global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, const float* __restrict__ rew, const uint8_t* __restrict__ done,
+                                                  const double* __restrict__ mean, const double* __restrict__ var, double* count,
+                                                  double* ret, const double* __restrict__ ret_var, double* ret_count,
+                                                  int B, int D, double eps, double clip_obs, double clip_rew, int flags, float* obs_out, float* rew_out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) { if (flags & 1) *count += (double)B; if (flags & 4) *ret_count += (double)B; }
+    if (idx < (size_t)B * D) {
+        const int k = (int)(idx % D);
+        double y = (double)x[idx];
+        if (flags & 2) { y = (y - mean[k]) / sqrt(var[k] + eps); y = y < -clip_obs ? -clip_obs : (y > clip_obs ? clip_obs : y); }
+        obs_out[idx] = (float)y;
+    }
+    if (idx < (size_t)B) {
+        double y = (double)rew[idx];
+        if (flags & 8) { y = y / sqrt(*ret_var + eps); y = y < -clip_rew ? -clip_rew : (y > clip_rew ? clip_rew : y); }
+        rew_out[idx] = (float)y;
+        if ((flags & 4) && done[idx]) ret[idx] = 0;
+    }
+}
+
 // RolloutBuffer.compute_returns_and_advantage: one lane per walker, reverse scan over T
 __global__ void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const float* __restrict__ last_val,
                       const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N, float* adv, float* ret) {
@@ -802,6 +883,22 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
     hipLaunchKernelGGL((k_moments<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, ret_mean, ret_var, (const double*)ret_count, (const double*)ret, B, 1);
     hipLaunchKernelGGL(k_count_add, dim3(1), dim3(1), 0, (hipStream_t)stream, ret_count, (double)B);
     hipLaunchKernelGGL(k_reward_finish, dim3(g), dim3(256), 0, (hipStream_t)stream, rew, ret, done, (const double*)ret_var, B, eps, clip);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean, double* obs_var, double* obs_count,
+                         double* ret, double* ret_mean, double* ret_var, double* ret_count, int32_t B, int32_t D, double gamma, double eps,
+                         double clip_obs, double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace, void* stream) {
+    if (!obs || !rew || !done || !obs_mean || !obs_var || !obs_count || !ret || !ret_mean || !ret_var || !ret_count || !obs_out || !rew_out || !workspace || B <= 0 || D <= 0 || D > 128)
+        return fail(DL_E_INVAL, "dl_vecnormalize_step: bad arguments");
+    double* work = (double*)workspace;
+    unsigned* arrive = (unsigned*)(work + (size_t)2 * VN_BLOCKS * D);
+    if (flags & 5)
+        hipLaunchKernelGGL(k_vn_reduce, dim3(VN_BLOCKS + 1), dim3(256), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
+                           (const double*)ret_count, B, D, gamma, flags, work, arrive);
+    const size_t ne = (size_t)B * D;
+    hipLaunchKernelGGL(k_vn_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, rew, done, (const double*)obs_mean, (const double*)obs_var, obs_count,
+                       ret, (const double*)ret_var, ret_count, B, D, eps, clip_obs, clip_rew, flags, obs_out, rew_out);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

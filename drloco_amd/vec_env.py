@@ -107,13 +107,15 @@ class HipVecEnv:
         lib.check(self._lib.dl_reset(self._h, _ptr(m), _ptr(s), _ptr(p), _ptr(self.obs), _stream()))
         return self.obs
 
-    def step_tensors(self, actions):
-        """actions: float32 cuda tensor [N, nu]; returns device tensors (obs, rew, done, term_obs)."""
+    def step_tensors(self, actions, done_out=None):
+        """actions: float32 cuda tensor [N, nu]; returns device tensors (obs, rew, done, term_obs).
+        done_out: optional uint8 [N] destination for the done flags (e.g. the next episode_starts slot)."""
         a = actions.to(device=self.device, dtype=torch.float32).contiguous()
         assert a.shape == (self.num_envs, self.nu)
-        lib.check(self._lib.dl_step(self._h, _ptr(a), _ptr(self.obs), _ptr(self.rew), _ptr(self.done),
+        done = self.done if done_out is None else done_out
+        lib.check(self._lib.dl_step(self._h, _ptr(a), _ptr(self.obs), _ptr(self.rew), _ptr(done),
                                     _ptr(self.term_obs), _ptr(self.rew_terms), _stream()))
-        return self.obs, self.rew, self.done, self.term_obs
+        return self.obs, self.rew, done, self.term_obs
 
     def step_async(self, actions):
         self._actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device)
@@ -323,36 +325,39 @@ class HipVecNormalize:
         self.obs_rms = RunningMeanStd((venv.obs_dim,), dev)
         self.ret_rms = RunningMeanStd((), dev)
         self.ret = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)
-        self.old_obs = torch.zeros_like(venv.obs)
-        self.old_rew = torch.zeros_like(venv.rew)
         self.norm_obs_t = torch.zeros_like(venv.obs)
         self.norm_rew_t = torch.zeros_like(venv.rew)
+        self._vn_work = torch.zeros(2 * 32 * venv.obs_dim + 2, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
+
+    # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
+    @property
+    def old_obs(self):
+        return self.venv.obs
+
+    @property
+    def old_rew(self):
+        return self.venv.rew
 
     def _normalize_obs_inplace(self, x):
         n = x.shape[0]
         lib.check(self._lib.dl_normalize_obs(_ptr(x), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), n, x.shape[1],
                                              self.epsilon, self.clip_obs, _stream()))
 
-    def step_tensors(self, actions):
-        obs, rew, done, term = self.venv.step_tensors(actions)
-        self.old_obs.copy_(obs)
-        self.old_rew.copy_(rew)
-        self.norm_obs_t.copy_(obs)
-        self.norm_rew_t.copy_(rew)
+    def step_tensors(self, actions, obs_out=None, rew_out=None, done_out=None):
+        """One control step + VecNormalize.step_wait, everything on the device: dl_step, then the two launches
+        of dl_vecnormalize_step.  obs_out / rew_out / done_out may be rollout-buffer slots (float32 [N, obs],
+        float32 [N], uint8 [N]); by default the results land in norm_obs_t / norm_rew_t / venv.done."""
+        obs, rew, done, term = self.venv.step_tensors(actions, done_out=done_out)
         n, d = obs.shape
-        if self.norm_obs:
-            if self.training:
-                lib.check(self._lib.dl_moments_update(_ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
-                                                      _ptr(self.old_obs), n, d, _stream()))
-            self._normalize_obs_inplace(self.norm_obs_t)
-        if self.norm_reward:
-            if self.training:
-                lib.check(self._lib.dl_normalize_reward(_ptr(self.norm_rew_t), _ptr(self.ret), _ptr(done), _ptr(self.ret_rms._mean),
-                                                        _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, self.gamma,
-                                                        self.epsilon, self.clip_reward, _stream()))
-            else:
-                self.norm_rew_t.copy_(torch.clamp(rew.double() / torch.sqrt(self.ret_rms._var + self.epsilon), -self.clip_reward, self.clip_reward).float())
-        return self.norm_obs_t, self.norm_rew_t, done, term
+        obs_out = self.norm_obs_t if obs_out is None else obs_out
+        rew_out = self.norm_rew_t if rew_out is None else rew_out
+        flags = (1 if (self.norm_obs and self.training) else 0) | (2 if self.norm_obs else 0) | \
+                (4 if (self.norm_reward and self.training) else 0) | (8 if self.norm_reward else 0)
+        lib.check(self._lib.dl_vecnormalize_step(
+            _ptr(obs), _ptr(rew), _ptr(done), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
+            _ptr(self.ret), _ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, d,
+            self.gamma, self.epsilon, self.clip_obs, self.clip_reward, flags, _ptr(obs_out), _ptr(rew_out), _ptr(self._vn_work), _stream()))
+        return obs_out, rew_out, done, term
 
     def step_async(self, actions):
         self._actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.venv.device)
@@ -381,7 +386,6 @@ class HipVecNormalize:
         """SB3 1.0: ret = 0; first observation is normalised (moments are not updated by reset)."""
         self.venv.reset_tensors()
         self.ret.zero_()
-        self.old_obs.copy_(self.venv.obs)
         self.norm_obs_t.copy_(self.venv.obs)
         if self.norm_obs:
             self._normalize_obs_inplace(self.norm_obs_t)

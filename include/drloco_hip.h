@@ -240,6 +240,19 @@ int dl_normalize_obs(float* x, const double* mean, const double* var, int32_t B,
 int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* ret_mean,
                         double* ret_var, double* ret_count, int32_t B, double gamma, double eps,
                         double clip, void* stream);
+/* VecNormalize.step_wait for one batch in two launches (the fused form of the three calls above):
+ *   obs_rms.update(obs); obs_out = clip((obs - mean)/sqrt(var + eps), +-clip_obs);
+ *   ret = ret*gamma + rew; ret_rms.update(ret); rew_out = clip(rew/sqrt(ret_var + eps), +-clip_rew); ret[done] = 0.
+ * flags: 1 update the observation moments (training), 2 normalise observations, 4 advance ret and update its
+ * moments (training), 8 normalise rewards.  obs/rew are not modified (get_original_obs / get_original_reward);
+ * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
+ * zero-initialised once by the caller and owned by this call sequence. */
+#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * (D) + 2))
+int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean,
+                         double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
+                         double* ret_count, int32_t B, int32_t D, double gamma, double eps, double clip_obs,
+                         double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace,
+                         void* stream);
 /* RolloutBuffer.compute_returns_and_advantage: arrays are [T, N] time-major float;
  * ep_start[t] = "obs_t starts an episode"; last_val float[N]; last_done uint8[N]. */
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val,

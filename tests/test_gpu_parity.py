@@ -283,6 +283,36 @@ def test_sb3_reductions(torch_cuda, oracle):
     L.check(lb.dl_normalize_obs(_ptr(xt), _ptr(tm), _ptr(tv), B, D, 1e-8, 10.0, _stream()))
     want = np.clip((x.astype(np.float64) - mean) / np.sqrt(var + 1e-8), -10, 10)
     np.testing.assert_allclose(xt.cpu().numpy(), want, atol=1e-6)
+    # the fused two-launch form of VecNormalize.step_wait against the same numpy restatement
+    for D2, B2 in ((29, 4096), (47, 1000), (1, 7)):
+        m2 = np.zeros(D2); v2 = np.ones(D2); c2 = 1e-4; rm = np.zeros(1); rv = np.ones(1); rc = 1e-4; ret = np.zeros(B2)
+        tm2 = torch.zeros(D2, dtype=torch.float64, device='cuda'); tv2 = torch.ones(D2, dtype=torch.float64, device='cuda')
+        tc2 = torch.full((1,), 1e-4, dtype=torch.float64, device='cuda')
+        trm = torch.zeros(1, dtype=torch.float64, device='cuda'); trv = torch.ones(1, dtype=torch.float64, device='cuda')
+        trc = torch.full((1,), 1e-4, dtype=torch.float64, device='cuda'); tret = torch.zeros(B2, dtype=torch.float64, device='cuda')
+        work = torch.zeros(2 * 32 * D2 + 2, dtype=torch.float64, device='cuda')
+        for it in range(4):
+            x = (rng.standard_normal((B2, D2)) * rng.uniform(0.1, 5, D2) + rng.uniform(-20, 20, D2)).astype(np.float32)
+            r = rng.uniform(0, 1.2, B2).astype(np.float32); dn = (rng.random(B2) < 0.1).astype(np.uint8)
+            c2 = oracle.moments_update(m2, v2, c2, x.astype(np.float64))
+            on = np.clip((x.astype(np.float64) - m2) / np.sqrt(v2 + 1e-8), -10, 10)
+            ret = ret * 0.99 + r
+            rc = oracle.moments_update(rm, rv, rc, ret[:, None])
+            rn = np.clip(r / np.sqrt(rv[0] + 1e-8), -10, 10)
+            ret[dn.astype(bool)] = 0
+            xt2, rt, dt = torch.as_tensor(x, device='cuda'), torch.as_tensor(r, device='cuda'), torch.as_tensor(dn, device='cuda')
+            oo, ro = torch.empty_like(xt2), torch.empty_like(rt)
+            L.check(lb.dl_vecnormalize_step(_ptr(xt2), _ptr(rt), _ptr(dt), _ptr(tm2), _ptr(tv2), _ptr(tc2), _ptr(tret), _ptr(trm), _ptr(trv), _ptr(trc),
+                                            B2, D2, 0.99, 1e-8, 10.0, 10.0, 15, _ptr(oo), _ptr(ro), _ptr(work), _stream()))
+            np.testing.assert_allclose(tm2.cpu().numpy(), m2, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(tv2.cpu().numpy(), v2, rtol=1e-10)
+            np.testing.assert_allclose(trm.cpu().numpy(), rm, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(trv.cpu().numpy(), rv, rtol=1e-10)
+            assert abs(tc2.item() - c2) < 1e-9 and abs(trc.item() - rc) < 1e-9
+            np.testing.assert_allclose(oo.cpu().numpy(), on, atol=2e-6)
+            np.testing.assert_allclose(ro.cpu().numpy(), rn, atol=1e-6)
+            np.testing.assert_allclose(tret.cpu().numpy(), ret, rtol=1e-12, atol=1e-12)
+            assert torch.equal(xt2.cpu(), torch.as_tensor(x))          # inputs untouched
     # GAE against the oracle's float32 scan (bit-exact: same operation order)
     T, N = 64, 512
     buf = HipRolloutBuffer(T, N, 29, 8, 'cuda', gamma=0.995, gae_lambda=0.95)
