@@ -119,7 +119,7 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
     uint64_t ch = 0;
     for (int d = 0; d < G_MAXCHAIN; d++) ch |= (uint64_t)(m.chain[jj][d] & 15) << (4 * d);
     ln.chain = ch;
-    const int b = (j >= 1 && j < m.nb) ? j : 1;
+    const int b = ln.body;                            // inertial parameters of the body this dof belongs to
     ln.mass = m.body_mass[b]; ln.submask = m.body_submask[b];
     for (int k = 0; k < 3; k++) { ln.ipos[k] = m.body_ipos[b][k]; ln.inertia[k] = m.body_inertia[b][k]; }
 }
@@ -211,64 +211,151 @@ template <typename T> __device__ __forceinline__ void rot_axis(V3<T>& X, V3<T>& 
     if (idx == 0) { Y = A2; Z = B2; } else if (idx == 1) { Z = A2; X = B2; } else { X = A2; Y = B2; }
 }
 
-// [3P] mj_kinematics: joint axes / anchors / motion subspaces, body frames (BFR) and rootz (MISC[0]) in LDS
-template <typename T>
-__device__ __forceinline__ void g_kinematics(const GCtx<T>& g, T q, T v) {
+// value of lane K of the row in every lane: ONE DPP instruction (row_newbcast:K, gfx90a+), usually folded
+// into the consuming VALU instruction
+template <int K> __device__ __forceinline__ float rbcast(float x) { return dpp_f<0x150 + K>(x); }
+template <int K> __device__ __forceinline__ double rbcast(double x) { return dpp_f<0x150 + K>(x); }
+
+
+// ------------------------------------------------------------------------------------------
+// Compile-time topology for the lane-per-dof layout.  The dof order of a model is topological and mostly
+// contiguous: a "run" is a maximal sequence ..., j-1, j with dof_parent(j) == j-1 (straight walker: root + right
+// leg = dofs 0..9, left leg = 10..13 hanging off dof 5).  Sums over a dof's ancestor chain / over its subtree
+// are then segmented scans inside the runs (row_shr / row_shl DPP steps) plus one broadcast per run boundary.
+template <typename TP> struct GTopoTab {
+    uint32_t anc[GL];        // bit a: dof a is on the root -> j chain (incl. j)
+    uint32_t bodies[GL];     // bit b: dof j moves body b
+    int32_t rs[GL], re[GL];  // first / last dof of the run of j
+    int32_t last[GL];        // j is the last dof of its body
+};
+template <typename TP> constexpr GTopoTab<TP> g_make_topo() {
+    GTopoTab<TP> t{};
+    for (int j = 0; j < GL; j++) { t.anc[j] = 0; t.bodies[j] = 0; t.rs[j] = j; t.re[j] = j; t.last[j] = 0; }
+    for (int j = 0; j < TP::NV; j++) {
+        for (int a = 0; a < TP::NV; a++) if (TP::dof_anc(j, a)) t.anc[j] |= 1u << a;
+        for (int b = 1; b < TP::NB; b++) if (TP::body_anc(b, j)) t.bodies[j] |= 1u << b;
+        int r = j; while (r > 0 && TP::dof_parent(r) == r - 1) r--;
+        t.rs[j] = r;
+        int e = j; while (e + 1 < TP::NV && TP::dof_parent(e + 1) == e) e++;
+        t.re[j] = e;
+        t.last[j] = (j == TP::NV - 1 || TP::dof_body(j + 1) != TP::dof_body(j)) ? 1 : 0;
+    }
+    return t;
+}
+template <typename TP> struct GTopo {
+    static constexpr GTopoTab<TP> tab = g_make_topo<TP>();
+    static constexpr bool dof_first(int j) { return j == 0 || TP::dof_body(j - 1) != TP::dof_body(j); }
+    static constexpr bool run_start(int j) { return j == 0 || TP::dof_parent(j) != j - 1; }
+    static constexpr int max_run() { int m = 1; for (int j = 0; j < TP::NV; j++) { const int l = tab.re[j] - tab.rs[j] + 1; if (l > m) m = l; } return m; }
+    static constexpr bool slides_first() {       // slide joints: root body only, world-aligned (before any hinge)
+        bool hinge = false;
+        for (int j = 0; j < TP::NV; j++) { if (TP::dof_type(j) == 1) hinge = true; else if (hinge || TP::dof_body(j) != 1) return false; }
+        return true;
+    }
+};
+// this lane's topology words (registers)
+template <typename T> struct GLaneTopo {
+    uint32_t anc, bodies;
+    int rs;
+    bool last;
+    T ms[4], ns[4];          // 1/0: lane j - 2^k (j + 2^k) belongs to the same run
+};
+template <typename T, typename TP> __device__ __forceinline__ void g_lane_topo(int j, GLaneTopo<T>& lt) {
+    const auto& tb = GTopo<TP>::tab;
+    lt.anc = tb.anc[j]; lt.bodies = tb.bodies[j]; lt.rs = tb.rs[j]; lt.last = tb.last[j] != 0;
+    const int re = tb.re[j];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { lt.ms[k] = (j - (1 << k) >= lt.rs) ? T(1) : T(0); lt.ns[k] = (j + (1 << k) <= re) ? T(1) : T(0); }
+}
+// x_j <- sum over the dofs a on the root -> j chain of x_a
+template <typename T, typename TP> __device__ __forceinline__ T g_chain_sum(T x, int j, const GLaneTopo<T>& lt) {
+    constexpr int MR = GTopo<TP>::max_run();
+    x += lt.ms[0] * dpp_f<0x111>(x);
+    if constexpr (MR > 2) x += lt.ms[1] * dpp_f<0x112>(x);
+    if constexpr (MR > 4) x += lt.ms[2] * dpp_f<0x114>(x);
+    if constexpr (MR > 8) x += lt.ms[3] * dpp_f<0x118>(x);
+    static_for<TP::NV>([&](auto ri) {
+        constexpr int r = ri.value;
+        if constexpr (r > 0 && GTopo<TP>::run_start(r)) { constexpr int P = TP::dof_parent(r); x += (lt.rs == r ? T(1) : T(0)) * rbcast<P>(x); }
+    });
+    return x;
+}
+// x_j <- sum over the dofs d of the subtree of j (j on the root -> d chain) of x_d
+template <typename T, typename TP> __device__ __forceinline__ T g_subtree_sum(T x, int j, const GLaneTopo<T>& lt) {
+    constexpr int MR = GTopo<TP>::max_run();
+    x += lt.ns[0] * dpp_f<0x101>(x);
+    if constexpr (MR > 2) x += lt.ns[1] * dpp_f<0x102>(x);
+    if constexpr (MR > 4) x += lt.ns[2] * dpp_f<0x104>(x);
+    if constexpr (MR > 8) x += lt.ns[3] * dpp_f<0x108>(x);
+    static_for<TP::NV>([&](auto ri) {
+        constexpr int r = TP::NV - 1 - ri.value;           // deepest runs first
+        if constexpr (r > 0 && GTopo<TP>::run_start(r)) {
+            constexpr int P = TP::dof_parent(r);
+            constexpr uint32_t ancP = GTopo<TP>::tab.anc[P];
+            x += (((ancP >> j) & 1u) ? T(1) : T(0)) * rbcast<r>(x);
+        }
+    });
+    return x;
+}
+// rotate the frame (X,Y,Z) about its own coordinate axis IDX (compile time) by the angle with (s, c)
+template <int IDX, typename T> __device__ __forceinline__ void rot_axis_c(V3<T>& X, V3<T>& Y, V3<T>& Z, T s, T c) {
+    if constexpr (IDX == 0) { const V3<T> A = c * Y + s * Z, B = c * Z - s * Y; Y = A; Z = B; }
+    else if constexpr (IDX == 1) { const V3<T> A = c * Z + s * X, B = c * X - s * Z; Z = A; X = B; }
+    else { const V3<T> A = c * X + s * Y, B = c * Y - s * X; X = A; Y = B; }
+}
+
+// what a dof lane keeps in registers after the kinematics
+template <typename T> struct GKin { V3<T> X, Y, Z, pos, axis; T rootz; };
+
+// [3P] mj_kinematics.  Lane j ends with the frame after dof j (= the frame of its body if j is the body's last
+// dof), the origin of its body relative to the root origin, and its joint axis.  Every lane runs the SAME
+// straight-line code over all hinges in dof order; hinges that are not on the lane's chain enter as the identity
+// (s, c) = (0, 1), so no lane waits for another one and nothing goes through LDS except the body frames that the
+// collision stage reads (BFR) and rootz (MISC[0]).
+template <typename T, typename TP>
+__device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T q, GKin<T>& k) {
+    static_assert(GTopo<TP>::slides_first(), "slide joints must be world-aligned root joints");
     using Ld = GLds;
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
-    const int j = g.j, nv = m.nv;
+    const int j = g.j;
     const GLane<T>& ln = *g.ln;
-    // ---- A: joint sines / cosines, q, v
-    {
-        T s = T(0), c = T(1);
-        if (j < nv && ln.type == 1) dl_sincos(ln.sign * (q - ln.qpos0), s, c);
-        wb[Ld::SC + j] = s; wb[Ld::SC + GL + j] = c;
-        wb[Ld::Q + j] = q; wb[Ld::V + j] = v;
-        // clear M (row j)
-        for (int a = 0; a < GL; a++) wb[Ld::MM + j * Ld::MS + a] = T(0);
-    }
-    g_sync<T>();
-    // ---- B: every dof lane walks its own root->dof chain (no cross-lane dependency)
-    V3<T> my_axis = mk<T>(0, 0, 0), my_anchor = mk<T>(0, 0, 0);
-    if (j < nv) {
-        V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
-        T rootz = m.root_z0;
-        const int depth = ln.depth;
-        for (int d = 0; d <= depth; d++) {
-            const int a = chain_at(ln.chain, d);
-            const int pr = g.si[GShared::I_PROPS + a], ba = (pr >> 5) & 7;
-            if ((pr & 16) && ba != 1) {
-                const DL_LDS T* bp = g.st + GShared::T_BODY_POS + 3 * ba;
-                pos = pos + bp[0] * X + bp[1] * Y + bp[2] * Z;
-            }
-            const int idx = (pr >> 1) & 3;
-            const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
-            const V3<T> ax = (pr & 8) ? T(-1) * col : col;
-            if (a == j) { my_axis = ax; my_anchor = pos; }
-            if ((pr & 1) == 0) rootz += ax.z * (wb[Ld::Q + a] - g.st[GShared::T_QPOS0 + a]);
-            else rot_axis(X, Y, Z, idx, wb[Ld::SC + a], wb[Ld::SC + GL + a]);
+    const T dq = (j < TP::NV) ? q - ln.qpos0 : T(0);
+    T s = T(0), c = T(1);
+    if (j < TP::NV && ln.type == 1) dl_sincos(ln.sign * dq, s, c);
+    V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
+    T rootz = m.root_z0;
+    static_for<TP::NV>([&](auto ai) {
+        constexpr int a = ai.value;
+        const bool in = (lt.anc >> a) & 1u;
+        if constexpr (GTopo<TP>::dof_first(a) && TP::dof_body(a) != 1) {
+            constexpr int b = TP::dof_body(a);
+            const T f = in ? T(1) : T(0);
+            const T bx = f * m.body_pos[b][0], by = f * m.body_pos[b][1], bz = f * m.body_pos[b][2];
+            pos = pos + bx * X + by * Y + bz * Z;
         }
-        wb[Ld::AX + 0 * GL + j] = my_axis.x; wb[Ld::AX + 1 * GL + j] = my_axis.y; wb[Ld::AX + 2 * GL + j] = my_axis.z;
-        wb[Ld::AX + 3 * GL + j] = my_anchor.x; wb[Ld::AX + 4 * GL + j] = my_anchor.y; wb[Ld::AX + 5 * GL + j] = my_anchor.z;
-        V3<T> Sw, Sv;
-        if (ln.type == 0) { Sw = mk<T>(0, 0, 0); Sv = my_axis; } else { Sw = my_axis; Sv = cross(my_anchor, my_axis); }
-        wb[Ld::SM + 0 * GL + j] = Sw.x; wb[Ld::SM + 1 * GL + j] = Sw.y; wb[Ld::SM + 2 * GL + j] = Sw.z;
-        wb[Ld::SM + 3 * GL + j] = Sv.x; wb[Ld::SM + 4 * GL + j] = Sv.y; wb[Ld::SM + 5 * GL + j] = Sv.z;
-        if (ln.is_last) {
-            const int b = ln.body;
-            DL_LDS T* f = wb + Ld::BFR + b;
-            f[0 * G_MAXB] = X.x; f[1 * G_MAXB] = X.y; f[2 * G_MAXB] = X.z;
-            f[3 * G_MAXB] = Y.x; f[4 * G_MAXB] = Y.y; f[5 * G_MAXB] = Y.z;
-            f[6 * G_MAXB] = Z.x; f[7 * G_MAXB] = Z.y; f[8 * G_MAXB] = Z.z;
-            f[9 * G_MAXB] = pos.x; f[10 * G_MAXB] = pos.y; f[11 * G_MAXB] = pos.z;
+        if constexpr (TP::dof_type(a) == 1) {
+            const T sa = rbcast<a>(s), ca = rbcast<a>(c);
+            rot_axis_c<TP::dof_axis(a)>(X, Y, Z, in ? sa : T(0), in ? ca : T(1));
+        } else if constexpr (TP::dof_axis(a) == 2) {
+            rootz += T(TP::dof_sign(a)) * rbcast<a>(dq);
         }
-        if (j == m.root_last_dof) wb[Ld::MISC + 0] = rootz;
+    });
+    const int idx = ln.axis;
+    const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
+    k.X = X; k.Y = Y; k.Z = Z; k.pos = pos; k.axis = ln.sign * col; k.rootz = rootz;
+    if (j < TP::NV && lt.last) {
+        DL_LDS T* f = wb + Ld::BFR + ln.body;
+        f[0 * G_MAXB] = X.x; f[1 * G_MAXB] = X.y; f[2 * G_MAXB] = X.z;
+        f[3 * G_MAXB] = Y.x; f[4 * G_MAXB] = Y.y; f[5 * G_MAXB] = Y.z;
+        f[6 * G_MAXB] = Z.x; f[7 * G_MAXB] = Z.y; f[8 * G_MAXB] = Z.z;
+        f[9 * G_MAXB] = pos.x; f[10 * G_MAXB] = pos.y; f[11 * G_MAXB] = pos.z;
     }
+    if (j == 0) wb[Ld::MISC + 0] = rootz;
     g_sync<T>();
 }
 
-// height of the lowest foot-sole site above the floor at the configuration last passed to g_kinematics
+// height of the lowest foot-sole site above the floor at the configuration last passed to g_fk
 // (reset_model's COM-z adjustment, drloco/mujoco/mimic_env.py:547-559); identical in the 16 lanes of the row
 template <typename T>
 __device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
@@ -290,109 +377,84 @@ __device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
     return low;
 }
 
-// [3P] mj_kinematics + mj_crb + mj_rne + passive/actuator forces: leaves M (dense, symmetric) and
-// qfrc_smooth in LDS, axes/anchors/motion subspaces in LDS, rootz in MISC[0]
-template <typename T>
-__device__ __forceinline__ void g_smooth_dynamics(const GCtx<T>& g, T q, T v, T ctrl_force) {
+// [3P] mj_kinematics + mj_crb + mj_rne + passive/actuator forces, one dof per lane, everything in registers:
+//   spatial quantities in world orientation about the root origin (parent <-> child transforms are the identity),
+//   body twist / velocity-product acceleration = chain sums of the joint contributions (segmented scans),
+//   spatial inertia + inertial wrench of a body on the lane of its last dof,
+//   composite inertia / wrench = subtree sums, bias_j = S_j . W_j, M[j][a] = S_a . (Ic_j S_j) for a on the chain of j.
+// The lower triangle of M is mirrored through LDS once so that every lane holds its full row (mrow).
+// Out: mrow, qfrc_smooth_j; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
+template <typename T, typename TP>
+__device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, GKin<T>& k, T (&mrow)[GL], T& mdiag) {
     using Ld = GLds;
+    constexpr int NV = TP::NV;
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
-    const int j = g.j, nv = m.nv, nb = m.nb;
+    const int j = g.j;
     const GLane<T>& ln = *g.ln;
-    g_kinematics<T>(g, q, v);
-    // ---- C: twist / velocity-product acceleration down the chain (dof lanes), body inertia (body lanes)
-    if (j < nv) {
-        SV<T> vel = {mk<T>(0, 0, 0), mk<T>(0, 0, 0)}, acc = {mk<T>(0, 0, 0), mk<T>(0, 0, -m.gravity_z)};
-        const int depth = ln.depth;
-        for (int d = 0; d <= depth; d++) {
-            const int a = chain_at(ln.chain, d);
-            const T qd = wb[Ld::V + a];
-            const SV<T> vJ = {qd * ld3(wb + Ld::SM + a, GL), qd * ld3(wb + Ld::SM + 3 * GL + a, GL)};
-            acc = {acc.w + cross(vel.w, vJ.w), acc.v + cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
-            vel = vel + vJ;
-        }
-        if (ln.is_last) {
-            DL_LDS T* t = wb + Ld::TW + ln.body;
-            t[0] = vel.w.x; t[G_MAXB] = vel.w.y; t[2 * G_MAXB] = vel.w.z; t[3 * G_MAXB] = vel.v.x; t[4 * G_MAXB] = vel.v.y; t[5 * G_MAXB] = vel.v.z;
-            t[6 * G_MAXB] = acc.w.x; t[7 * G_MAXB] = acc.w.y; t[8 * G_MAXB] = acc.w.z; t[9 * G_MAXB] = acc.v.x; t[10 * G_MAXB] = acc.v.y; t[11 * G_MAXB] = acc.v.z;
-        }
-    }
-    SI<T> myI;          // body lanes keep their own spatial inertia
-    if (j >= 1 && j < nb) {
-        const int b = j;
-        DL_LDS T* f = wb + Ld::BFR + b;
-        const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
-        const V3<T> c = pos + ln.ipos[0] * X + ln.ipos[1] * Y + ln.ipos[2] * Z;
-        const T mass = ln.mass, i0 = ln.inertia[0], i1 = ln.inertia[1], i2 = ln.inertia[2];
+    g_fk<T, TP>(g, lt, q, k);
+    const bool isdof = j < NV;
+    mdiag = T(1);
+    // motion subspace of dof j and its joint velocity contribution
+    SV<T> S;
+    if (ln.type == 0) { S.w = mk<T>(0, 0, 0); S.v = k.axis; } else { S.w = k.axis; S.v = cross(k.pos, k.axis); }
+    if (!isdof) { S.w = mk<T>(0, 0, 0); S.v = mk<T>(0, 0, 0); }
+    const T qd = isdof ? v : T(0);
+    const SV<T> vJ = {qd * S.w, qd * S.v};
+    SV<T> vel;
+    vel.w.x = g_chain_sum<T, TP>(vJ.w.x, j, lt); vel.w.y = g_chain_sum<T, TP>(vJ.w.y, j, lt); vel.w.z = g_chain_sum<T, TP>(vJ.w.z, j, lt);
+    vel.v.x = g_chain_sum<T, TP>(vJ.v.x, j, lt); vel.v.y = g_chain_sum<T, TP>(vJ.v.y, j, lt); vel.v.z = g_chain_sum<T, TP>(vJ.v.z, j, lt);
+    // velocity-product acceleration: sum over the chain of (twist of the parent) x (joint velocity); the twist of
+    // the parent is vel - vJ and vJ x vJ = 0
+    const SV<T> cJ = {cross(vel.w, vJ.w), cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
+    SV<T> acc;
+    acc.w.x = g_chain_sum<T, TP>(cJ.w.x, j, lt); acc.w.y = g_chain_sum<T, TP>(cJ.w.y, j, lt); acc.w.z = g_chain_sum<T, TP>(cJ.w.z, j, lt);
+    acc.v.x = g_chain_sum<T, TP>(cJ.v.x, j, lt); acc.v.y = g_chain_sum<T, TP>(cJ.v.y, j, lt); acc.v.z = g_chain_sum<T, TP>(cJ.v.z, j, lt) - m.gravity_z;
+    // spatial inertia and inertial wrench of the body whose last dof this is (zero on the other lanes)
+    SI<T> I;
+    {
+        const T mass = (isdof && lt.last) ? ln.mass : T(0);
+        const T i0 = (isdof && lt.last) ? ln.inertia[0] : T(0), i1 = (isdof && lt.last) ? ln.inertia[1] : T(0), i2 = (isdof && lt.last) ? ln.inertia[2] : T(0);
+        const V3<T>&X = k.X, &Y = k.Y, &Z = k.Z;
+        const V3<T> c = k.pos + ln.ipos[0] * X + ln.ipos[1] * Y + ln.ipos[2] * Z;
         const T cc = dot(c, c);
-        myI.m = mass; myI.h = mass * c;
-        myI.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
-        myI.I.yy = i0 * X.y * X.y + i1 * Y.y * Y.y + i2 * Z.y * Z.y + mass * (cc - c.y * c.y);
-        myI.I.zz = i0 * X.z * X.z + i1 * Y.z * Y.z + i2 * Z.z * Z.z + mass * (cc - c.z * c.z);
-        myI.I.xy = i0 * X.x * X.y + i1 * Y.x * Y.y + i2 * Z.x * Z.y - mass * c.x * c.y;
-        myI.I.xz = i0 * X.x * X.z + i1 * Y.x * Y.z + i2 * Z.x * Z.z - mass * c.x * c.z;
-        myI.I.yz = i0 * X.y * X.z + i1 * Y.y * Y.z + i2 * Z.y * Z.z - mass * c.y * c.z;
-        DL_LDS T* ib = wb + Ld::IB + b;
-        ib[0] = myI.m; ib[G_MAXB] = myI.h.x; ib[2 * G_MAXB] = myI.h.y; ib[3 * G_MAXB] = myI.h.z;
-        ib[4 * G_MAXB] = myI.I.xx; ib[5 * G_MAXB] = myI.I.xy; ib[6 * G_MAXB] = myI.I.xz; ib[7 * G_MAXB] = myI.I.yy; ib[8 * G_MAXB] = myI.I.yz; ib[9 * G_MAXB] = myI.I.zz;
+        I.m = mass; I.h = mass * c;
+        I.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
+        I.I.yy = i0 * X.y * X.y + i1 * Y.y * Y.y + i2 * Z.y * Z.y + mass * (cc - c.y * c.y);
+        I.I.zz = i0 * X.z * X.z + i1 * Y.z * Y.z + i2 * Z.z * Z.z + mass * (cc - c.z * c.z);
+        I.I.xy = i0 * X.x * X.y + i1 * Y.x * Y.y + i2 * Z.x * Z.y - mass * c.x * c.y;
+        I.I.xz = i0 * X.x * X.z + i1 * Y.x * Y.z + i2 * Z.x * Z.z - mass * c.x * c.z;
+        I.I.yz = i0 * X.y * X.z + i1 * Y.y * Y.z + i2 * Z.y * Z.z - mass * c.y * c.z;
     }
-    g_sync<T>();
-    // ---- D: inertial wrench of each body (body lanes)
-    if (j >= 1 && j < nb) {
-        DL_LDS T* t = wb + Ld::TW + j;
-        const SV<T> vel = {ld3(t, G_MAXB), ld3(t + 3 * G_MAXB, G_MAXB)}, acc = {ld3(t + 6 * G_MAXB, G_MAXB), ld3(t + 9 * G_MAXB, G_MAXB)};
-        const SV<T> Iv = si_mul(myI, vel), Ia = si_mul(myI, acc);
-        const SV<T> F = {Ia.w + cross(vel.w, Iv.w) + cross(vel.v, Iv.v), Ia.v + cross(vel.w, Iv.v)};
-        DL_LDS T* fw = wb + Ld::FW + j;
-        fw[0] = F.w.x; fw[G_MAXB] = F.w.y; fw[2 * G_MAXB] = F.w.z; fw[3 * G_MAXB] = F.v.x; fw[4 * G_MAXB] = F.v.y; fw[5 * G_MAXB] = F.v.z;
+    SV<T> F;
+    {
+        const SV<T> Iv = si_mul(I, vel), Ia = si_mul(I, acc);
+        F = {Ia.w + cross(vel.w, Iv.w) + cross(vel.v, Iv.v), Ia.v + cross(vel.w, Iv.v)};
     }
+    // composite inertia and wrench of the subtree of dof j
+    auto sub = [&](T x) { return g_subtree_sum<T, TP>(x, j, lt); };
+    SI<T> Ic;
+    Ic.m = sub(I.m); Ic.h.x = sub(I.h.x); Ic.h.y = sub(I.h.y); Ic.h.z = sub(I.h.z);
+    Ic.I.xx = sub(I.I.xx); Ic.I.xy = sub(I.I.xy); Ic.I.xz = sub(I.I.xz); Ic.I.yy = sub(I.I.yy); Ic.I.yz = sub(I.I.yz); Ic.I.zz = sub(I.I.zz);
+    SV<T> W;
+    W.w.x = sub(F.w.x); W.w.y = sub(F.w.y); W.w.z = sub(F.w.z); W.v.x = sub(F.v.x); W.v.y = sub(F.v.y); W.v.z = sub(F.v.z);
+    const T bias = sdot(S, W);
+    const SV<T> f = si_mul(Ic, S);
+    // M[j][a] for the dofs a on the chain of j; mirrored through LDS
+    static_for<NV>([&](auto ai) {
+        constexpr int a = ai.value;
+        T mij;
+        if constexpr (TP::dof_type(a) == 0) mij = rbcast<a>(S.v.x) * f.v.x + rbcast<a>(S.v.y) * f.v.y + rbcast<a>(S.v.z) * f.v.z;
+        else mij = rbcast<a>(S.w.x) * f.w.x + rbcast<a>(S.w.y) * f.w.y + rbcast<a>(S.w.z) * f.w.z + rbcast<a>(S.v.x) * f.v.x + rbcast<a>(S.v.y) * f.v.y + rbcast<a>(S.v.z) * f.v.z;
+        mij = ((lt.anc >> a) & 1u) ? mij : T(0);
+        if (a == j) { mij += ln.armature; mdiag = mij; }
+        if (a <= j && isdof) { wb[Ld::MM + j * Ld::MS + a] = mij; wb[Ld::MM + a * Ld::MS + j] = mij; }
+    });
     g_sync<T>();
-    // ---- E: composite inertia and wrench of every subtree (body lanes sum over their descendants)
-    if (j >= 1 && j < nb) {
-        const uint32_t sub = ln.submask;
-        T acc[16];
-        for (int k = 0; k < 16; k++) acc[k] = T(0);
-        for (int c = 1; c < nb; c++) {
-            if (!((sub >> c) & 1u)) continue;
-            for (int k = 0; k < 10; k++) acc[k] += wb[Ld::IB + k * G_MAXB + c];
-            for (int k = 0; k < 6; k++) acc[10 + k] += wb[Ld::FW + k * G_MAXB + c];
-        }
-        for (int k = 0; k < 10; k++) wb[Ld::IC + k * G_MAXB + j] = acc[k];
-        for (int k = 0; k < 6; k++) wb[Ld::WC + k * G_MAXB + j] = acc[10 + k];
-    }
-    g_sync<T>();
-    // ---- F: bias force, row of the mass matrix, qfrc_smooth (dof lanes)
-    if (j < nv) {
-        const int b = ln.body;
-        const SV<T> S = {ld3(wb + Ld::SM + j, GL), ld3(wb + Ld::SM + 3 * GL + j, GL)};
-        const SV<T> W = {ld3(wb + Ld::WC + b, G_MAXB), ld3(wb + Ld::WC + 3 * G_MAXB + b, G_MAXB)};
-        const T bias = sdot(S, W);
-        SI<T> Ic;
-        DL_LDS T* ic = wb + Ld::IC + b;
-        Ic.m = ic[0]; Ic.h = ld3(ic + G_MAXB, G_MAXB);
-        Ic.I.xx = ic[4 * G_MAXB]; Ic.I.xy = ic[5 * G_MAXB]; Ic.I.xz = ic[6 * G_MAXB]; Ic.I.yy = ic[7 * G_MAXB]; Ic.I.yz = ic[8 * G_MAXB]; Ic.I.zz = ic[9 * G_MAXB];
-        const SV<T> f = si_mul(Ic, S);
-        const int depth = ln.depth;
-        for (int d = 0; d <= depth; d++) {
-            const int a = chain_at(ln.chain, d);
-            const SV<T> Sa = {ld3(wb + Ld::SM + a, GL), ld3(wb + Ld::SM + 3 * GL + a, GL)};
-            T mij = sdot(Sa, f);
-            if (a == j) mij += ln.armature;
-            wb[Ld::MM + j * Ld::MS + a] = mij;
-            wb[Ld::MM + a * Ld::MS + j] = mij;
-        }
-        wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = -ln.damping * v - bias + ctrl_force;
-    } else {
-        wb[Ld::VEC + Ld::V_SMOOTH * GL + j] = T(0);
-        wb[Ld::MM + j * Ld::MS + j] = T(1);          // padding rows/columns: identity
-    }
-    g_sync<T>();
+#pragma unroll
+    for (int a = 0; a < GL; a++) mrow[a] = (a < NV && isdof) ? wb[Ld::MM + j * Ld::MS + a] : T(0);
+    return isdof ? -ln.damping * v - bias + ctrl_force : T(0);
 }
-
-// value of lane K of the row in every lane: ONE DPP instruction (row_newbcast:K, gfx90a+), usually folded
-// into the consuming VALU instruction
-template <int K> __device__ __forceinline__ float rbcast(float x) { return dpp_f<0x150 + K>(x); }
-template <int K> __device__ __forceinline__ double rbcast(double x) { return dpp_f<0x150 + K>(x); }
 
 // 1/sqrt(x): float = v_rsq_f32 + one Newton step (<= 1 ulp-ish, no denormal fix-ups); double = exact path
 __device__ __forceinline__ float dl_rsqrt(float x) {
@@ -444,7 +506,7 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
 // [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
 // Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
 template <typename T>
-__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T q, int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
+__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
     using Ld = GLds;
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
@@ -536,34 +598,30 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, int grp, T 
         }
     }
     g_sync<T>();            // BFR (aliased with JC) is dead from here on
-    // ---- per contact: D, K*imp*dist for its 4 pyramid rows, contact-frame Jacobian over the body's chain
-    for (int pass = 0; pass < 2; pass++) {
-        const int c = j + GL * pass;
-        if (c < ncon) {
-            DL_LDS T* cn = wb + Ld::CON + c;
-            const V3<T> p = mk<T>(cn[0], cn[G_MAXCON], cn[2 * G_MAXCON]);
-            const T tx = cn[3 * G_MAXCON], ty = cn[4 * G_MAXCON], mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
-            const int body = (int)cn[7 * G_MAXCON];
-            const T imp = impedance(m.solimp, dist);
-            const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
-            const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag / imp);
-            const T D = T(1) / R, kd = m.solK * imp * dist;
-            const int r = nlim + 4 * c;
-            for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
-            DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
-            for (int a = 0; a < 3 * GL; a++) jc[a] = T(0);
-            const int last = g.si[GShared::I_BODY_LAST + body];
-            const int depth = (g.si[GShared::I_PROPS + last] >> 8) & 15;
-            const uint64_t bch = (uint64_t)(uint32_t)g.si[GShared::I_CHAIN_LO + last] | ((uint64_t)(uint32_t)g.si[GShared::I_CHAIN_HI + last] << 32);
-            for (int d = 0; d <= depth; d++) {
-                const int a = chain_at(bch, d);
-                const V3<T> ax = ld3(wb + Ld::AX + a, GL);
-                V3<T> w;
-                if ((g.si[GShared::I_PROPS + a] & 1) == 0) w = ax;
-                else w = cross(ax, p - ld3(wb + Ld::AX + 3 * GL + a, GL));
-                jc[a] = w.z; jc[GL + a] = tx * w.x + ty * w.y; jc[2 * GL + a] = -ty * w.x + tx * w.y;
-            }
-        }
+    // ---- per contact: D, K*imp*dist for its 4 pyramid rows (lane c)
+    for (int c = j; c < ncon; c += GL) {
+        DL_LDS T* cn = wb + Ld::CON + c;
+        const T mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
+        const int body = (int)cn[7 * G_MAXCON];
+        const T imp = impedance(m.solimp, dist);
+        const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
+        const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag / imp);
+        const T D = T(1) / R, kd = m.solK * imp * dist;
+        const int r = nlim + 4 * c;
+        for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
+    }
+    // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
+    // every contact from its joint axis / anchor in registers; dofs that do not move the contact's body write zeros
+    for (int c = 0; c < ncon; c++) {
+        DL_LDS T* cn = wb + Ld::CON + c;
+        const V3<T> p = mk<T>(cn[0], cn[G_MAXCON], cn[2 * G_MAXCON]);
+        const T tx = cn[3 * G_MAXCON], ty = cn[4 * G_MAXCON];
+        const int body = (int)cn[7 * G_MAXCON];
+        const bool moves = (lt.bodies >> body) & 1u;
+        V3<T> w = ln.type == 0 ? kin.axis : cross(kin.axis, p - kin.pos);
+        if (!moves) w = mk<T>(0, 0, 0);
+        DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
+        jc[j] = w.z; jc[GL + j] = tx * w.x + ty * w.y; jc[2 * GL + j] = -ty * w.x + tx * w.y;
     }
     g_sync<T>();
     nlim_out = nlim; ncon_out = ncon;
@@ -609,8 +667,9 @@ __device__ __forceinline__ T g_apply(const GCtx<T>& g, int nlim, int ncon, int m
 // changes state).  It is written with selects so that the 4 walkers of a wave do not serialise on it.
 // TIMED: accumulate shader-clock cycles per section into tacc[8] (diagnostics build of k_forward_g16 only):
 // 0 smooth dynamics, 1 constraints, 2 rows/J^T f/Hessian, 3 factor + solve, 4 J dir / M dir, 5 line search + step, 6 #iterations of the wave
-template <typename T, int N, bool TIMED = false>
-__device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ctrl_force, T warm, int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr) {
+template <typename T, typename TP, bool TIMED = false>
+__device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm, int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr) {
+    constexpr int N = TP::NV;
     using Ld = GLds;
     long long t_last = 0;
     if constexpr (TIMED) t_last = (long long)__builtin_readcyclecounter();
@@ -620,16 +679,13 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, int grp, T q, T v, T ct
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    g_smooth_dynamics<T>(g, q, v, ctrl_force);
-    const T smooth = wb[Ld::VEC + Ld::V_SMOOTH * GL + j];
-    T mrow[GL];
-#pragma unroll
-    for (int a = 0; a < GL; a++) mrow[a] = wb[Ld::MM + j * Ld::MS + a];
-    const T mdiag = wb[Ld::MM + j * Ld::MS + j];
+    GKin<T> kin;
+    T mrow[GL], mdiag;
+    const T smooth = g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, kin, mrow, mdiag);
     tick(0);
     int nlim, ncon, my_lim;
     T lim_sign;
-    g_make_constraints<T>(g, grp, q, nlim, ncon, my_lim, lim_sign);
+    g_make_constraints<T>(g, lt, kin, grp, q, nlim, ncon, my_lim, lim_sign);
     const int nefc = nlim + 4 * ncon;
     ncon_o = ncon; nefc_o = nefc;
     DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * G_MAXROW;

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     }
     int nc, ne, ni;
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const T a = g_forward<T, TopoStraight::NV, TIMED>(g, grp, q, v, force, wm, nc, ne, ni, tacc);
+    GLaneTopo<T> lt;
+    g_lane_topo<T, TopoStraight>(j, lt);
+    const T a = g_forward<T, TopoStraight, TIMED>(g, lt, grp, q, v, force, wm, nc, ne, ni, tacc);
     if constexpr (TIMED) { if (lane == 0) for (int k = 0; k < 8; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k]; }
     if (valid && j < nv) qacc[(size_t)j * n + w] = a;
     if (valid && j == 0) { if (ncon) ncon[w] = nc; if (nefc) nefc[w] = ne; if (niter) niter[w] = ni; }
@@ -128,6 +130,8 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     DL_LDS T* wb = g.wb;
     const int nv = m->nv, nu = m->nu;
     const bool isdof = j < nv;
+    GLaneTopo<T> lt;
+    g_lane_topo<T, TPS>(j, lt);
     T q = T(0), v = T(0), warm = T(0);
     if (isdof) { q = st.qpos[(size_t)j * n + w]; v = st.qvel[(size_t)j * n + w]; warm = st.warm[(size_t)j * n + w]; }
     int32_t cur[DL_CUR_WORDS];
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 int nc, ne, ni;
-                const T acc = g_forward<T, TPS::NV>(g, grp, qs, vs, force, warm, nc, ne, ni);
+                const T acc = g_forward<T, TPS>(g, lt, grp, qs, vs, force, warm, nc, ne, ni);
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
                 if (st.dbgf && valid && ni >= m->iterations) {
                     st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)warm;
@@ -272,9 +276,10 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
                 q = c.table[(size_t)j * c.total_len + base];
                 v = c.table[(size_t)(nv + j) * c.total_len + base];
             }
-            g_kinematics<T>(g, q, v);
+            { GKin<T> kin; g_fk<T, TPS>(g, lt, q, kin); }
             comz = g_lowest_site<T>(g);
-            if (j == 2) { q -= comz; wb[GLds::Q + 2] = q; }
+            if (j == 2) q -= comz;
+            if (isdof) { wb[GLds::Q + j] = q; wb[GLds::V + j] = v; }
             warm = T(0);
             cursor_next<T, TPS>(c, cur);
             g_sync<T>();
