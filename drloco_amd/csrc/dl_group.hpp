@@ -32,7 +32,7 @@ constexpr int G_JC_STRIDE = 49; // 3*16 + 1: contact lanes reading their Jacobia
 // model as data (host-built from dl_model_desc), read through the constant address space
 template <typename T> struct GModel {
     int32_t nv, nb, nu, ngeom, nsite, frame_skip, iterations, ls_iterations, ncand, root_last_dof;
-    T timestep, gravity_z, solK, solB, solimp[5], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, root_z0;
+    T timestep, gravity_z, solK, solB, solimp[5], solimp_inv[3], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, root_z0;
     int32_t dof_body[GL], dof_type[GL], dof_axis[GL], dof_first[GL], dof_limited[GL], dof_depth[GL], dof_is_last[GL];
     int32_t chain[GL][G_MAXCHAIN];
     T dof_sign[GL], qpos0[GL], range_lo[GL], range_hi[GL], damping[GL], armature[GL], dof_invw[GL];
@@ -103,9 +103,14 @@ template <typename T> struct GLane {
     int type, axis, first, body, depth, is_last, limited, act;
     T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
     uint64_t chain;                                   // own chain, nibble-packed
-    // body lane (j in 1..nb-1)
+    // inertial parameters of the body of this dof
     T mass, ipos[3], inertia[3];
     uint32_t submask;
+    // the two collision candidates of this lane (capsule end points / box corners in contact order, c = j and j + 16)
+    // as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
+    // to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
+    int cinfo[2];                                      // bit0 valid, 1 box, 2-4 sub index, 5-7 body
+    T cpl[2][3], crad[2], cal[2][3], crl[2][3], cmu[2];
 };
 
 template <typename T>
@@ -122,6 +127,28 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
     const int b = ln.body;                            // inertial parameters of the body this dof belongs to
     ln.mass = m.body_mass[b]; ln.submask = m.body_submask[b];
     for (int k = 0; k < 3; k++) { ln.ipos[k] = m.body_ipos[b][k]; ln.inertia[k] = m.body_inertia[b][k]; }
+    for (int pass = 0; pass < 2; pass++) {
+        const int c = j + GL * pass;
+        const bool ok = c < m.ncand;
+        const int ge = ok ? m.cand_geom[c] : 0, sub = ok ? m.cand_sub[c] : 0;
+        const bool box = m.geom_type[ge] != 0;
+        ln.cinfo[pass] = (ok ? 1 : 0) | (box ? 2 : 0) | (sub << 2) | (m.geom_body[ge] << 5);
+        const DL_CONST T* mat = m.geom_mat[ge];
+        T rel[3];
+        if (box) {
+            const T sx = (sub & 1) ? m.geom_size[ge][0] : -m.geom_size[ge][0];
+            const T sy = (sub & 2) ? m.geom_size[ge][1] : -m.geom_size[ge][1];
+            const T sz = (sub & 4) ? m.geom_size[ge][2] : -m.geom_size[ge][2];
+            for (int k = 0; k < 3; k++) { rel[k] = mat[3 * k] * sx + mat[3 * k + 1] * sy + mat[3 * k + 2] * sz; ln.cal[pass][k] = T(0); ln.crl[pass][k] = rel[k]; }
+            ln.crad[pass] = T(0);
+        } else {
+            const T hs = sub == 0 ? m.geom_size[ge][1] : -m.geom_size[ge][1];
+            for (int k = 0; k < 3; k++) { ln.cal[pass][k] = mat[3 * k + 2]; rel[k] = hs * mat[3 * k + 2]; ln.crl[pass][k] = T(0); }
+            ln.crad[pass] = m.geom_size[ge][0];
+        }
+        for (int k = 0; k < 3; k++) ln.cpl[pass][k] = m.geom_pos[ge][k] + rel[k];
+        ln.cmu[pass] = m.geom_mu[ge];
+    }
 }
 
 // fill the shared model block (all 64 lanes of the wave cooperate); call once, then __syncthreads()
@@ -141,15 +168,6 @@ __device__ __forceinline__ void g_fill_shared(const DL_CONST GModel<T>& m, DL_LD
         si[GShared::I_BODY_LAST + b] = m.body_last_dof[b];
         stt[GShared::T_BODY_INVW + b] = m.body_invw[b];
         for (int k = 0; k < 3; k++) stt[GShared::T_BODY_POS + 3 * b + k] = m.body_pos[b][k];
-    } else if (lane >= 32) {
-        const int c = lane - 32;                      // 32 candidate slots
-        const bool ok = c < m.ncand;
-        const int ge = ok ? m.cand_geom[c] : 0;
-        si[GShared::I_CAND + c] = (ok ? 1 : 0) | (m.geom_type[ge] << 1) | ((ok ? m.cand_sub[c] : 0) << 2) | (m.geom_body[ge] << 5);
-        DL_LDS T* cd = stt + GShared::T_CAND + c * GShared::CAND_W;
-        for (int k = 0; k < 3; k++) { cd[k] = m.geom_pos[ge][k]; cd[12 + k] = m.geom_size[ge][k]; }
-        for (int k = 0; k < 9; k++) cd[3 + k] = m.geom_mat[ge][k];
-        cd[15] = m.geom_mu[ge];
     }
 }
 
@@ -456,6 +474,35 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     return isdof ? -ln.damping * v - bias + ctrl_force : T(0);
 }
 
+// d += bcast_K(a) * b  (SIGN = +1)  or  d -= bcast_K(a) * b  (SIGN = -1).  float: ONE instruction, v_fmac_f32_dpp with the
+// row broadcast folded into src0 (the compiler only folds DPP into add/mul).  The DPP read of `a` needs two wait states
+// after the VALU write of `a`; inline asm is opaque to the hazard recogniser, so callers fence with g_dpp_ready(a).
+template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(float& d, float a, float b) {
+    if constexpr (SIGN > 0) asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
+    else asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
+}
+template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
+    if constexpr (SIGN > 0) d += rbcast<K>(a) * b; else d -= rbcast<K>(a) * b;
+}
+__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
+__device__ __forceinline__ void g_dpp_ready(double&) {}
+
+// 1/x: float = v_rcp_f32 + one Newton step; double = exact division
+__device__ __forceinline__ float dl_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * fmaf(-x, r, 2.0f);
+}
+__device__ __forceinline__ double dl_rcp(double x) { return 1.0 / x; }
+// [3P] solimp sigmoid (getimpedance) with the three reciprocals of the constants taken once (GModel::solimp_inv)
+template <typename T> __device__ __forceinline__ T g_impedance(const DL_CONST GModel<T>& m, T pos) {
+    const T x = dl_abs(pos) * m.solimp_inv[0];
+    T y;
+    if (m.solimp[4] == T(1)) y = x;
+    else y = (x <= m.solimp[3]) ? x * x * m.solimp_inv[1] : T(1) - (T(1) - x) * (T(1) - x) * m.solimp_inv[2];
+    const T imp = m.solimp[0] + y * (m.solimp[1] - m.solimp[0]);
+    return x >= T(1) ? m.solimp[1] : (x <= T(0) ? m.solimp[0] : imp);
+}
+
 // 1/sqrt(x): float = v_rsq_f32 + one Newton step (<= 1 ulp-ish, no denormal fix-ups); double = exact path
 __device__ __forceinline__ float dl_rsqrt(float x) {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -471,13 +518,14 @@ template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], 
         constexpr int k = kk.value;
         const T dkk = dl_max(rbcast<k>(hd), floor_);
         const T inv = dl_rsqrt(dkk);
-        const T lik = h[k] * inv;                             // lanes j > k: L[j][k]; other lanes: unused
+        T lik = h[k] * inv;                                   // lanes j > k: L[j][k]; other lanes: unused
         h[k] = lik;
         if (j == k) invd = inv;
         hd -= lik * lik;                                      // lanes j > k
+        g_dpp_ready(lik);
         static_for<N - 1 - k>([&](auto aa) {
             constexpr int a = k + 1 + aa.value;
-            h[a] -= lik * rbcast<a>(lik);                     // row j, column a (only a < j matters)
+            fmac_bcast<a, -1>(h[a], lik, lik);                // row j, column a (only a < j matters): h[a] -= L[a][k] L[j][k]
         });
     });
 }
@@ -487,9 +535,10 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
     T acc = b, yj = T(0);
     static_for<N>([&](auto kk) {
         constexpr int k = kk.value;
-        const T yloc = acc * invd;                            // valid in lane k
+        T yloc = acc * invd;                                  // valid in lane k
         if (j == k) yj = yloc;
-        acc -= l[k] * rbcast<k>(yloc);                        // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
+        g_dpp_ready(yloc);
+        fmac_bcast<k, -1>(acc, yloc, l[k]);                   // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
     });
     // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k]
     T x = T(0);
@@ -528,52 +577,37 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
     if (lim) {
         const int r = __popc(lmask & ((1u << j) - 1u));
         my_lim = r;
-        const T imp = impedance(m.solimp, lim_dist);
-        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw / imp);
-        wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = T(1) / R;
+        const T imp = g_impedance(m, lim_dist);
+        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
+        wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = dl_rcp(R);
         wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = m.solK * imp * lim_dist;
         wb[Ld::LIMC + r] = T(j | (lim_lo ? 0 : 32));
     }
-    // ---- contact candidates: two passes of 16 (capsule ends and box corners in geom order)
+    // ---- contact candidates: two passes of 16 (capsule ends and box corners in geom order); a candidate is a
+    // constant body-local point (GLane), so the test is one frame transform + the floor distance
     bool act[2];
     V3<T> cp[2];
     T cdist[2], ctx[2], cty[2];
     int cinf[2];
+#pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const int c = j + GL * pass;
-        act[pass] = false; cp[pass] = mk<T>(0, 0, 0); cdist[pass] = T(0); ctx[pass] = T(0); cty[pass] = T(1);
-        const int cinfo = g.si[GShared::I_CAND + c];
+        const int cinfo = ln.cinfo[pass];
         cinf[pass] = cinfo;
-        const DL_LDS T* cd = g.st + GShared::T_CAND + c * GShared::CAND_W;
-        if (cinfo & 1) {
-            const int sub = (cinfo >> 2) & 7, b = (cinfo >> 5) & 7;
-            DL_LDS T* f = wb + Ld::BFR + b;
-            const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
-            const V3<T> gp = pos + cd[0] * X + cd[1] * Y + cd[2] * Z;
-            const DL_LDS T* gm = cd + 3;
-            if (((cinfo >> 1) & 1) == 0) {
-                const V3<T> ax = gm[2] * X + gm[5] * Y + gm[8] * Z;
-                const T rad = cd[12], half = cd[13];
-                T tx = ax.x, ty = ax.y;
-                const T n2 = tx * tx + ty * ty;
-                if (n2 < T(1e-30)) { tx = T(1); ty = T(0); } else { const T inv = T(1) / dl_sqrt(n2); tx *= inv; ty *= inv; }
-                const V3<T> cc = gp + (sub == 0 ? half : -half) * ax;
-                const T dist = rootz + cc.z - rad;
-                act[pass] = dist < T(0);
-                cp[pass] = mk<T>(cc.x, cc.y, cc.z - (rad + T(0.5) * dist));
-                cdist[pass] = dist; ctx[pass] = tx; cty[pass] = ty;
-            } else {
-                const V3<T> ex = gm[0] * X + gm[3] * Y + gm[6] * Z, ey = gm[1] * X + gm[4] * Y + gm[7] * Z, ez = gm[2] * X + gm[5] * Y + gm[8] * Z;
-                const T sx = (sub & 1) ? cd[12] : -cd[12];
-                const T sy = (sub & 2) ? cd[13] : -cd[13];
-                const T sz = (sub & 4) ? cd[14] : -cd[14];
-                const V3<T> corner = sx * ex + sy * ey + sz * ez;
-                const T dist = rootz + gp.z + corner.z;
-                act[pass] = dist < T(0) && !(corner.z > T(0));
-                cp[pass] = mk<T>(gp.x + corner.x, gp.y + corner.y, gp.z + corner.z - T(0.5) * dist);
-                cdist[pass] = dist; ctx[pass] = T(0); cty[pass] = T(1);
-            }
-        }
+        const int b = (cinfo >> 5) & 7;
+        DL_LDS T* f = wb + Ld::BFR + b;
+        const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
+        const V3<T> pt = pos + ln.cpl[pass][0] * X + ln.cpl[pass][1] * Y + ln.cpl[pass][2] * Z;
+        const T relz = ln.crl[pass][0] * X.z + ln.crl[pass][1] * Y.z + ln.crl[pass][2] * Z.z;
+        T tx = ln.cal[pass][0] * X.x + ln.cal[pass][1] * Y.x + ln.cal[pass][2] * Z.x;
+        T ty = ln.cal[pass][0] * X.y + ln.cal[pass][1] * Y.y + ln.cal[pass][2] * Z.y;
+        const T n2 = tx * tx + ty * ty;
+        const bool box = (cinfo >> 1) & 1;
+        if (n2 < T(1e-30)) { tx = box ? T(0) : T(1); ty = box ? T(1) : T(0); } else { const T inv = dl_rsqrt(n2); tx *= inv; ty *= inv; }
+        const T rad = ln.crad[pass];
+        const T dist = rootz + pt.z - rad;
+        act[pass] = (cinfo & 1) && dist < T(0) && !(relz > T(0));
+        cp[pass] = mk<T>(pt.x, pt.y, pt.z - (rad + T(0.5) * dist));
+        cdist[pass] = dist; ctx[pass] = tx; cty[pass] = ty;
     }
     // box rule: only the first four qualifying corners of a box make contacts (mjc_PlaneBox)
     uint32_t cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
@@ -593,7 +627,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
             const int slot = __popc(cm & ((1u << c) - 1u));
             DL_LDS T* cn = wb + Ld::CON + slot;
             cn[0] = cp[pass].x; cn[G_MAXCON] = cp[pass].y; cn[2 * G_MAXCON] = cp[pass].z;
-            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = g.st[GShared::T_CAND + c * GShared::CAND_W + 15];
+            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = ln.cmu[pass];
             cn[6 * G_MAXCON] = cdist[pass]; cn[7 * G_MAXCON] = T((cinf[pass] >> 5) & 7);
         }
     }
@@ -603,10 +637,10 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         DL_LDS T* cn = wb + Ld::CON + c;
         const T mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
         const int body = (int)cn[7 * G_MAXCON];
-        const T imp = impedance(m.solimp, dist);
+        const T imp = g_impedance(m, dist);
         const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
-        const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag / imp);
-        const T D = T(1) / R, kd = m.solK * imp * dist;
+        const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
+        const T D = dl_rcp(R), kd = m.solK * imp * dist;
         const int r = nlim + 4 * c;
         for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
     }
@@ -746,7 +780,9 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
                 const T w11 = mu * mu * (dD[0] + dD[1]), w22 = mu * mu * (dD[2] + dD[3]);
                 const T t0 = w00 * jn + w01 * j1 + w02 * j2, t1 = w01 * jn + w11 * j1, t2 = w02 * jn + w22 * j2;
                 hd += jn * t0 + j1 * t1 + j2 * t2;
-                static_for<N>([&](auto ai) { constexpr int a = ai.value; h[a] += rbcast<a>(jn) * t0 + rbcast<a>(j1) * t1 + rbcast<a>(j2) * t2; });
+                T bn = jn, b1 = j1, b2 = j2;
+                g_dpp_ready(bn); g_dpp_ready(b1); g_dpp_ready(b2);
+                static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(h[a], bn, t0); fmac_bcast<a, 1>(h[a], b1, t1); fmac_bcast<a, 1>(h[a], b2, t2); });
             }
         }
         g_sync<T>();

@@ -117,6 +117,7 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
     g.solK = (T)(1.0 / std::fmax(1e-15, dmax * dmax * tc * tc * dr * dr));
     g.solB = (T)(2.0 / std::fmax(1e-15, dmax * tc));
     for (int k = 0; k < 5; k++) g.solimp[k] = (T)d.solimp[k];
+    g.solimp_inv[0] = (T)(1.0 / d.solimp[2]); g.solimp_inv[1] = (T)(1.0 / d.solimp[3]); g.solimp_inv[2] = (T)(1.0 / (1.0 - d.solimp[3]));
     g.meaninertia = (T)d.meaninertia; g.tolerance = (T)d.tolerance; g.ls_tolerance = (T)d.ls_tolerance;
     if (sizeof(T) == 4) { g.tolerance = (T)std::fmax(d.tolerance, 1e-6); g.ls_reltol = (T)1e-5; g.tol_rel = (T)1e-6; } else { g.ls_reltol = (T)0; g.tol_rel = (T)0; }
     g.root_z0 = (T)d.body_pos[1][2];

@@ -109,10 +109,13 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
 // one control step with 16 lanes per walker (straight walker): action map, 5 x RK4 mj_step through
 // g_forward, cursor / observation / reward / termination / Monitor, and the vec-env auto reset of finished
 // walkers (RSI draw, mocap lookup, foot-site kinematics, first observation) in the same launch.
-template <typename T>
+template <typename T, bool TIMED = false>
 __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
                                                      float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
-                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode) {
+                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode, long long* tim = nullptr) {
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_begin = 0;
+    if constexpr (TIMED) t_begin = (long long)__builtin_readcyclecounter();
     using TPS = TopoStraight;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 int nc, ne, ni;
-                const T acc = g_forward<T, TPS>(g, lt, grp, qs, vs, force, warm, nc, ne, ni);
+                const T acc = g_forward<T, TPS, TIMED>(g, lt, grp, qs, vs, force, warm, nc, ne, ni, tacc);
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
                 if (st.dbgf && valid && ni >= m->iterations) {
                     st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)warm;
@@ -297,6 +300,10 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
         for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
     }
     if (valid && isdof) { st.qpos[(size_t)j * n + w] = q; st.qvel[(size_t)j * n + w] = v; st.warm[(size_t)j * n + w] = warm; }
+    if constexpr (TIMED) {
+        tacc[7] = (long long)__builtin_readcyclecounter() - t_begin;
+        if (lane == 0) for (int k = 0; k < 8; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k];
+    }
 }
 
 // row primitives of dl_group.hpp on known data (tests/test_gpu_parity.py::test_row_primitives)
@@ -516,6 +523,7 @@ struct dl_env_s {
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
     virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
+    virtual int step_timed(const float*, float*, float*, uint8_t*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -716,6 +724,18 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         }
         return fail(DL_E_INVAL, "dl_debug_forward_timed: float32 straight walker only");
     }
+    int step_timed(const float* act, float* obs, float* rew, uint8_t* done, long long* tim, hipStream_t s) override {
+        if (!gmd || !act || !obs || !rew || !done || !tim) return fail(DL_E_INVAL, "dl_debug_step_timed: needs the 16-lane kernels and all arrays");
+        if constexpr (TP::ENV_KIND == 0 && sizeof(T) == 4) {
+            static bool attr = false;
+            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T))))); attr = true; }
+            hipLaunchKernelGGL((k_env_step_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
+                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, tim);
+            HIPCHK(hipGetLastError());
+            return DL_OK;
+        }
+        return fail(DL_E_INVAL, "dl_debug_step_timed: float32 straight walker only");
+    }
     int capstate(float* out, hipStream_t s) override {
         if (!st.dbgf || !out) return fail(DL_E_INVAL, "dl_debug_capstate: enable the counters first");
         HIPCHK(hipMemcpyAsync(out, st.dbgf, (size_t)48 * n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -820,6 +840,11 @@ int dl_debug_counters(dl_handle h, int32_t* out, int32_t clear, void* stream) {
 int dl_debug_forward_timed(dl_handle h, const void* ctrl, void* qacc, long long* tim, void* stream) {
     NEED(h);
     return h->forward_timed(ctrl, qacc, tim, (hipStream_t)stream);
+}
+/* one control step (16-lane f32 kernels) with per-section cycle counts: tim int64[8, ceil(N/4)] device; [7] = whole kernel */
+int dl_debug_step_timed(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* done, long long* tim, void* stream) {
+    NEED(h);
+    return h->step_timed(actions, obs, rew, done, tim, (hipStream_t)stream);
 }
 /* in: float[128] device, out: float[256] device (see k_selftest) */
 int dl_debug_selftest(const float* in, float* out, void* stream) {

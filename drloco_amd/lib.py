@@ -71,6 +71,7 @@ _EXTRA = {
     'dl_debug_capstate': (C.c_int, [_V, _P, _P]),
     'dl_debug_selftest': (C.c_int, [_P, _P, _P]),
     'dl_debug_forward_timed': (C.c_int, [_V, _P, _P, _P, _P]),
+    'dl_debug_step_timed': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -38,3 +38,17 @@ print('iters: mean %.2f  hist %s' % (ni.mean(), np.bincount(ni)[:12]))
 print('nefc: mean %.1f  hist(0,1-8,9-16,17-32,33+) %s' % (ne.mean(), [int((ne == 0).sum()), int(((ne > 0) & (ne <= 8)).sum()), int(((ne > 8) & (ne <= 16)).sum()), int(((ne > 16) & (ne <= 32)).sum()), int((ne > 32).sum())]))
 w = ni.reshape(-1, 4).max(1)
 print('per wave max iters: mean %.2f' % w.mean())
+
+# ---- the same sections inside whole control steps of the rollout (20 evaluations each)
+acts2 = torch.clamp(0.5 * torch.randn(30, n, 8, device='cuda', generator=g), -1, 1)
+tot = np.zeros((8, nb))
+for t in range(30):
+    lib.check(env._lib.dl_debug_step_timed(env._h, _ptr(acts2[t]), _ptr(env.obs), _ptr(env.rew), _ptr(env.done), _ptr(tim), _stream()))
+    torch.cuda.synchronize()
+    tot += tim.cpu().numpy().astype(np.float64)
+tot /= 30
+whole = tot[7]
+print(f'control step: per wave cycles mean {whole.mean():.0f} median {np.median(whole):.0f} max {whole.max():.0f} (the launch lasts as long as its slowest wave); wave iterations per step mean {tot[6].mean():.1f} max {tot[6].max():.0f}')
+for k in range(6):
+    print(f'  {names[k]:22s} mean {tot[k].mean():9.0f}  ({100 * tot[k].mean() / whole.mean():5.1f} %)  slowest wave {tot[k][whole.argmax()]:9.0f}')
+print(f'  {"outside the evaluations":22s} mean {(whole - tot[:6].sum(0)).mean():9.0f}  ({100 * (whole - tot[:6].sum(0)).mean() / whole.mean():5.1f} %)')
