@@ -154,7 +154,7 @@ def main():
                          'note': 'the fused dynamics kernel is FP32-VALU/latency bound (SURVEY.md 8d); HBM fraction is reported as the contract asks'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(64, 256)
+            out['cpu_baseline'] = cpu_baseline(256, 512)       # ~12 s of CPU work on one host core
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -209,6 +209,27 @@ template <typename T> __device__ __forceinline__ void g_sync() {
 }
 
 // ------------------------------------------------------------------------------------------
+// Uniform model scalars of the hot path, read ONCE per kernel and pinned in VGPRs (the empty asm makes the values
+// opaque: the compiler would otherwise re-issue the scalar loads inside the solver loops and wait for each --
+// s_waitcnt lgkmcnt(0) also drains the LDS queue).  VGPRs are plentiful at one wave per SIMD.
+template <typename T> struct GConst {
+    T body_pos[G_MAXB][3], root_z0, gravity_z, solK, solB, solimp[5], solimp_inv[3], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, scale, nvf;
+    int iterations, ls_iterations;
+};
+template <typename T> __device__ __forceinline__ void g_pin(T& x) { asm volatile("" : "+v"(x)); }
+template <typename T>
+__device__ __forceinline__ void g_load_const(const DL_CONST GModel<T>& m, GConst<T>& c) {
+    for (int b = 0; b < G_MAXB; b++) for (int k = 0; k < 3; k++) { c.body_pos[b][k] = b < m.nb ? m.body_pos[b][k] : T(0); g_pin(c.body_pos[b][k]); }
+    c.root_z0 = m.root_z0; c.gravity_z = m.gravity_z; c.solK = m.solK; c.solB = m.solB; c.meaninertia = m.meaninertia;
+    c.tolerance = m.tolerance; c.ls_tolerance = m.ls_tolerance; c.ls_reltol = m.ls_reltol; c.tol_rel = m.tol_rel;
+    c.nvf = T(m.nv); c.scale = T(1) / (m.meaninertia * c.nvf);
+    for (int k = 0; k < 5; k++) { c.solimp[k] = m.solimp[k]; g_pin(c.solimp[k]); }
+    for (int k = 0; k < 3; k++) { c.solimp_inv[k] = m.solimp_inv[k]; g_pin(c.solimp_inv[k]); }
+    c.iterations = m.iterations; c.ls_iterations = m.ls_iterations;
+    g_pin(c.root_z0); g_pin(c.gravity_z); g_pin(c.solK); g_pin(c.solB); g_pin(c.meaninertia); g_pin(c.tolerance); g_pin(c.ls_tolerance);
+    g_pin(c.ls_reltol); g_pin(c.tol_rel); g_pin(c.nvf); g_pin(c.scale); g_pin(c.iterations); g_pin(c.ls_iterations);
+}
+
 template <typename T> struct GCtx {
     DL_LDS T* wb;                        // walker's LDS region
     const DL_CONST GModel<T>* m;         // uniform scalars only on the hot path
@@ -216,6 +237,7 @@ template <typename T> struct GCtx {
     DL_LDS int* si;                      // shared model block (ints)
     DL_LDS T* st;                        // shared model block (reals)
     const GLane<T>* ln;                  // this lane's preloaded model data
+    const GConst<T>* c;                  // pinned uniform scalars
 };
 __device__ __forceinline__ int chain_at(uint64_t ch, int d) { return (int)((ch >> (4 * d)) & 15u); }
 
@@ -342,14 +364,14 @@ __device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T
     T s = T(0), c = T(1);
     if (j < TP::NV && ln.type == 1) dl_sincos(ln.sign * dq, s, c);
     V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
-    T rootz = m.root_z0;
+    T rootz = g.c->root_z0;
     static_for<TP::NV>([&](auto ai) {
         constexpr int a = ai.value;
         const bool in = (lt.anc >> a) & 1u;
         if constexpr (GTopo<TP>::dof_first(a) && TP::dof_body(a) != 1) {
             constexpr int b = TP::dof_body(a);
             const T f = in ? T(1) : T(0);
-            const T bx = f * m.body_pos[b][0], by = f * m.body_pos[b][1], bz = f * m.body_pos[b][2];
+            const T bx = f * g.c->body_pos[b][0], by = f * g.c->body_pos[b][1], bz = f * g.c->body_pos[b][2];
             pos = pos + bx * X + by * Y + bz * Z;
         }
         if constexpr (TP::dof_type(a) == 1) {
@@ -427,7 +449,7 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     const SV<T> cJ = {cross(vel.w, vJ.w), cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
     SV<T> acc;
     acc.w.x = g_chain_sum<T, TP>(cJ.w.x, j, lt); acc.w.y = g_chain_sum<T, TP>(cJ.w.y, j, lt); acc.w.z = g_chain_sum<T, TP>(cJ.w.z, j, lt);
-    acc.v.x = g_chain_sum<T, TP>(cJ.v.x, j, lt); acc.v.y = g_chain_sum<T, TP>(cJ.v.y, j, lt); acc.v.z = g_chain_sum<T, TP>(cJ.v.z, j, lt) - m.gravity_z;
+    acc.v.x = g_chain_sum<T, TP>(cJ.v.x, j, lt); acc.v.y = g_chain_sum<T, TP>(cJ.v.y, j, lt); acc.v.z = g_chain_sum<T, TP>(cJ.v.z, j, lt) - g.c->gravity_z;
     // spatial inertia and inertial wrench of the body whose last dof this is (zero on the other lanes)
     SI<T> I;
     {
@@ -494,7 +516,7 @@ __device__ __forceinline__ float dl_rcp(float x) {
 }
 __device__ __forceinline__ double dl_rcp(double x) { return 1.0 / x; }
 // [3P] solimp sigmoid (getimpedance) with the three reciprocals of the constants taken once (GModel::solimp_inv)
-template <typename T> __device__ __forceinline__ T g_impedance(const DL_CONST GModel<T>& m, T pos) {
+template <typename T> __device__ __forceinline__ T g_impedance(const GConst<T>& m, T pos) {
     const T x = dl_abs(pos) * m.solimp_inv[0];
     T y;
     if (m.solimp[4] == T(1)) y = x;
@@ -577,10 +599,10 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
     if (lim) {
         const int r = __popc(lmask & ((1u << j) - 1u));
         my_lim = r;
-        const T imp = g_impedance(m, lim_dist);
+        const T imp = g_impedance(*g.c, lim_dist);
         const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
         wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = dl_rcp(R);
-        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = m.solK * imp * lim_dist;
+        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = g.c->solK * imp * lim_dist;
         wb[Ld::LIMC + r] = T(j | (lim_lo ? 0 : 32));
     }
     // ---- contact candidates: two passes of 16 (capsule ends and box corners in geom order); a candidate is a
@@ -637,10 +659,10 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         DL_LDS T* cn = wb + Ld::CON + c;
         const T mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
         const int body = (int)cn[7 * G_MAXCON];
-        const T imp = g_impedance(m, dist);
+        const T imp = g_impedance(*g.c, dist);
         const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
         const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
-        const T D = dl_rcp(R), kd = m.solK * imp * dist;
+        const T D = dl_rcp(R), kd = g.c->solK * imp * dist;
         const int r = nlim + 4 * c;
         for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
     }
@@ -727,7 +749,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
     DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
     // jar = J a - aref at a = warm start:  K imp r (stored by g_make_constraints) + J (B v + a)
-    (void)g_apply<T, N>(g, nlim, ncon, my_lim, lim_sign, m.solB * v + warm, mrow);
+    (void)g_apply<T, N>(g, nlim, ncon, my_lim, lim_sign, g.c->solB * v + warm, mrow);
     g_sync<T>();
     for (int r = j; r < nefc; r += GL) { rJA[r] += rJV[r]; rTM[r] = T(0); }     // TMP: per-row "active" flags of the Hessian
     T qacc = warm, Ma = T(0);
@@ -735,7 +757,8 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     T h[GL], hd = mdiag;       // row j of H = M + sum_active D row^T row (off-diagonal part) and its diagonal
 #pragma unroll
     for (int a = 0; a < GL; a++) h[a] = mrow[a];
-    const T nvf = T(m.nv), scale = T(1) / (m.meaninertia * nvf);
+    const GConst<T>& cs = *g.c;
+    const T nvf = cs.nvf, scale = cs.scale;
     bool alive = true;         // this walker still iterates (identical in the 16 lanes of the row)
     int iter = 0;
     g_sync<T>();
@@ -792,7 +815,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         {
             const T gn = gsum(grad * grad), gmag = gsum(dl_abs(Ma) + dl_abs(smooth) + dl_abs(fcon));
             // float32: the gradient carries rounding noise proportional to the magnitude of its terms
-            if (!(scale * dl_sqrt(gn) >= m.tolerance + m.tol_rel * scale * gmag) || iter >= m.iterations) alive = false;   // also stops on NaN
+            if (!(scale * dl_sqrt(gn) >= cs.tolerance + cs.tol_rel * scale * gmag) || iter >= cs.iterations) alive = false;   // also stops on NaN
         }
         tick(2);
         if (!__any(alive)) break;
@@ -812,10 +835,10 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         tick(4);
         // ---- exact line search along dir
         const T g1s = gsum(dir * (Ma - smooth)), g2 = gsum(T(0.5) * dir * Md), d0 = gsum(dir * grad), snorm = dl_sqrt(gsum(dir * dir));
-        const T gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * nvf + m.ls_reltol * dl_abs(d0);
+        const T gtol = cs.tolerance * cs.ls_tolerance * snorm * cs.meaninertia * nvf + cs.ls_reltol * dl_abs(d0);
         T alpha = T(1), lo = T(0), hi = T(1e30), best_a = T(0), best_dc = T(0), best_mag = T(0), res_a = T(0), res_dc = T(0), res_mag = T(0);
         bool done = !alive || !(snorm >= T(1e-15));
-        const int maxit = m.ls_iterations;
+        const int maxit = cs.ls_iterations;
         int it = 0;
         while (__any(!done)) {
             T pc = T(0), pd1 = T(0), pd2 = T(0);
@@ -849,7 +872,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
                 for (int r = j; r < nefc; r += GL) rJA[r] += res_a * rJV[r];
                 iter++;
                 // mj_solNewton's improvement test (float32: relative to the magnitude of the terms of the cost difference)
-                if (!(scale * -res_dc >= m.tolerance + m.tol_rel * scale * res_mag) || nefc == 0) alive = false;
+                if (!(scale * -res_dc >= cs.tolerance + cs.tol_rel * scale * res_mag) || nefc == 0) alive = false;
             }
         }
         g_sync<T>();

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     GLane<T> ln;
     g_load_lane<T>(*m, j, ln);
     __syncthreads();
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln};
+    GConst<T> cst;
+    g_load_const<T>(*m, cst);
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln, &cst};
     const int nv = m->nv;
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < nv) {
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     GLane<T> ln;
     g_load_lane<T>(*m, j, ln);
     __syncthreads();
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln};
+    GConst<T> cst;
+    g_load_const<T>(*m, cst);
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln, &cst};
     DL_LDS T* wb = g.wb;
     const int nv = m->nv, nu = m->nu;
     const bool isdof = j < nv;
