@@ -27,7 +27,6 @@ constexpr int G_MAXB = 8;       // bodies incl. world
 constexpr int G_MAXCAND = 32;   // collision candidate points
 constexpr int G_MAXCON = 20;    // >= 18
 constexpr int G_MAXROW = 80;
-constexpr int G_JC_STRIDE = 49; // 3*16 + 1: contact lanes reading their Jacobian hit different banks
 
 // model as data (host-built from dl_model_desc), read through the constant address space
 template <typename T> struct GModel {
@@ -50,32 +49,21 @@ template <typename T> struct GModel {
 
 // per-walker LDS layout (in elements of T)
 struct GLds {
-    static constexpr int Q = 0, V = Q + GL, SC = V + GL;             // sin[16], cos[16]
-    static constexpr int AX = SC + 2 * GL;                           // axis(3) anchor(3): [6][16]
-    static constexpr int SM = AX + 6 * GL;                           // motion subspace [6][16]
-    static constexpr int VEC = SM + 6 * GL;                          // vectors [NVEC][16]
-    static constexpr int V_SMOOTH = 0, V_QSM = 1, V_X = 2, V_MX = 3, V_FC = 4, NVEC = 5;
+    static constexpr int Q = 0, V = Q + GL;                          // q, v staged for the observation writer
     static constexpr int MS = GL + 1;                                // row stride of M (odd: row-wise and column-wise access are both conflict-free)
-    static constexpr int MM = VEC + NVEC * GL;                       // M [16 rows][MS]
+    static constexpr int MM = V + GL;                                // M [16 rows][MS]: mirror of the lower triangle
     static constexpr int CON = MM + GL * MS;                         // contacts [8][G_MAXCON]: px py pz tx ty mu dist body
-    static constexpr int ROW = CON + 8 * G_MAXCON;                   // rows [4][G_MAXROW]: D, JAREF, JV, TMP
+    static constexpr int ROW = CON + 8 * G_MAXCON;                   // rows [4][G_MAXROW]: D, JAREF, JV, TMP; contact c owns rows 4c..4c+3 (16-byte groups), limits follow
     static constexpr int R_D = 0, R_JAREF = 1, R_JV = 2, R_TMP = 3;
-    static constexpr int LIMC = ROW + 4 * G_MAXROW;                  // limit codes [8]
-    static constexpr int FC = LIMC + 8;                              // contact forces in the contact frame [G_MAXCON][3]
-    static constexpr int MISC = FC + 3 * G_MAXCON;                   // rootz, counts ... [8]
-    static constexpr int JC = MISC + 8;                              // contact Jacobians [G_MAXCON][G_JC_STRIDE]
-    // dynamics temporaries (dead once the constraints are built) share the space of JC
-    static constexpr int BFR = JC;                                   // body frames [12][8]
-    static constexpr int IB = BFR + 12 * G_MAXB;                     // body inertia [10][8]
-    static constexpr int TW = IB + 10 * G_MAXB;                      // twist + acc [12][8]
-    static constexpr int FW = TW + 12 * G_MAXB;                      // body wrench [6][8]
-    static constexpr int IC = FW + 6 * G_MAXB;                       // composite inertia [10][8]
-    static constexpr int WC = IC + 10 * G_MAXB;                      // composite wrench [6][8]
-    static constexpr int DYN_END = WC + 6 * G_MAXB;
-    static constexpr int JC_END = JC + G_MAXCON * G_JC_STRIDE;
-    static constexpr int TOTAL_RAW = JC_END > DYN_END ? JC_END : DYN_END;
+    static constexpr int FC_W = 12;                                  // per contact: Fn F1 F2 flip | w00 w01 w02 w11 | w22 - - -
+    static constexpr int FC = ROW + 4 * G_MAXROW;                    // contact-frame force and Hessian weights [G_MAXCON][FC_W]
+    static constexpr int MISC = FC + FC_W * G_MAXCON;                // rootz ... [8]
+    static constexpr int JC = MISC + 8;                              // contact Jacobians, dof-lane major [G_MAXCON][16 lanes][4]: normal, tangent 1, tangent 2, -
+    static constexpr int BFR = JC;                                   // body frames [12][8] (dead once the contacts exist) share the space of JC
+    static constexpr int TOTAL_RAW = JC + G_MAXCON * GL * 4;
     // walker regions are offset by 16 (mod 32) words so that the two rows of a half-wave use disjoint banks
     static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
+    static_assert(CON % 4 == 0 && ROW % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && G_MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
 };
 
 // model data needed with per-lane (non-uniform) indices inside the inner loops is staged once per
@@ -93,9 +81,7 @@ struct GShared {
     static constexpr int T_QPOS0 = 0;                 // [16]
     static constexpr int T_BODY_POS = 16;             // [8][3]
     static constexpr int T_BODY_INVW = 40;            // [8]
-    static constexpr int T_CAND = 48;                 // [32][CAND_W]: pos(3) mat(9) size(3) mu
-    static constexpr int CAND_W = 17;                 // 16 values, padded to an odd stride (bank spread)
-    static constexpr int T_END = T_CAND + 32 * CAND_W;
+    static constexpr int T_END = 48;
     template <typename T> static constexpr int bytes() { return ((I_END * 4 + T_END * (int)sizeof(T) + 255) / 256) * 256; }
 };
 
@@ -242,6 +228,20 @@ template <typename T> struct GCtx {
 __device__ __forceinline__ int chain_at(uint64_t ch, int d) { return (int)((ch >> (4 * d)) & 15u); }
 
 template <typename T> __device__ __forceinline__ V3<T> ld3(DL_LDS T* p, int stride) { return {p[0], p[stride], p[2 * stride]}; }
+// four consecutive, 16-byte aligned LDS words as one ds_read_b128 / ds_write_b128 (float); plain accesses for double
+template <typename T> struct Q4 { T a, b, c, d; };
+__device__ __forceinline__ Q4<float> ld4(const DL_LDS float* p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = *(const DL_LDS f4*)p;
+    return {v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(DL_LDS float* p, float a, float b, float c, float d) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+    *(DL_LDS f4*)p = v;
+}
+__device__ __forceinline__ Q4<double> ld4(const DL_LDS double* p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void st4(DL_LDS double* p, double a, double b, double c, double d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
 // rotate the frame (X,Y,Z) about its own coordinate axis `idx` by the angle with (s, c)
 template <typename T> __device__ __forceinline__ void rot_axis(V3<T>& X, V3<T>& Y, V3<T>& Z, int idx, T s, T c) {
@@ -596,15 +596,6 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
     const uint32_t lmask = (uint32_t)((__ballot(lim) >> (GL * grp)) & 0xFFFFull);
     const int nlim = __popc(lmask);
     my_lim = -1; lim_sign = lim_lo ? T(1) : T(-1);
-    if (lim) {
-        const int r = __popc(lmask & ((1u << j) - 1u));
-        my_lim = r;
-        const T imp = g_impedance(*g.c, lim_dist);
-        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
-        wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = dl_rcp(R);
-        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = g.c->solK * imp * lim_dist;
-        wb[Ld::LIMC + r] = T(j | (lim_lo ? 0 : 32));
-    }
     // ---- contact candidates: two passes of 16 (capsule ends and box corners in geom order); a candidate is a
     // constant body-local point (GLane), so the test is one frame transform + the floor distance
     bool act[2];
@@ -654,7 +645,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         }
     }
     g_sync<T>();            // BFR (aliased with JC) is dead from here on
-    // ---- per contact: D, K*imp*dist for its 4 pyramid rows (lane c)
+    // ---- rows: contact c owns rows 4c..4c+3 (D and K*imp*dist, written by lane c), limit rows follow in dof order
     for (int c = j; c < ncon; c += GL) {
         DL_LDS T* cn = wb + Ld::CON + c;
         const T mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
@@ -663,8 +654,16 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
         const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
         const T D = dl_rcp(R), kd = g.c->solK * imp * dist;
-        const int r = nlim + 4 * c;
-        for (int s4 = 0; s4 < 4; s4++) { wb[Ld::ROW + Ld::R_D * G_MAXROW + r + s4] = D; wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r + s4] = kd; }
+        st4(wb + Ld::ROW + Ld::R_D * G_MAXROW + 4 * c, D, D, D, D);
+        st4(wb + Ld::ROW + Ld::R_JAREF * G_MAXROW + 4 * c, kd, kd, kd, kd);
+    }
+    if (lim) {
+        const int r = 4 * ncon + __popc(lmask & ((1u << j) - 1u));
+        my_lim = r;
+        const T imp = g_impedance(*g.c, lim_dist);
+        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
+        wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = dl_rcp(R);
+        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = g.c->solK * imp * lim_dist;
     }
     // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
     // every contact from its joint axis / anchor in registers; dofs that do not move the contact's body write zeros
@@ -676,8 +675,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         const bool moves = (lt.bodies >> body) & 1u;
         V3<T> w = ln.type == 0 ? kin.axis : cross(kin.axis, p - kin.pos);
         if (!moves) w = mk<T>(0, 0, 0);
-        DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
-        jc[j] = w.z; jc[GL + j] = tx * w.x + ty * w.y; jc[2 * GL + j] = -ty * w.x + tx * w.y;
+        st4(wb + Ld::JC + (c * GL + j) * 4, w.z, tx * w.x + ty * w.y, -ty * w.x + tx * w.y, T(0));
     }
     g_sync<T>();
     nlim_out = nlim; ncon_out = ncon;
@@ -687,24 +685,23 @@ template <typename T> struct GEps;
 template <> struct GEps<float> { static constexpr float value = 1.1920929e-7f; };
 template <> struct GEps<double> { static constexpr double value = 2.220446049250313e-16; };
 
-// rows JV = J x for the walker and (M x)_j; x_j lives in lane j.  The broadcasts of x serve both products.
-// Limit rows are written by the lane of their dof, contact rows by lane c (c, c + 16, ... < ncon).
+// rows JV = J x for the walker and (M x)_j; x_j lives in lane j.  M x: row broadcasts of x against the lane's row of M.
+// J x: the limit row of a dof is +-x_j; per contact the three contact-frame components are row sums of the lane's own
+// Jacobian column times x_j, expanded to the four pyramid rows by lanes 0..3.
 template <typename T, int N>
-__device__ __forceinline__ T g_apply(const GCtx<T>& g, int nlim, int ncon, int my_lim, T lim_sign, T x, const T (&mrow)[GL]) {
+__device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T lim_sign, T x, const T (&mrow)[GL]) {
     using Ld = GLds;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    T xa[N];
-    T mx = T(0);
-    static_for<N>([&](auto ai) { constexpr int a = ai.value; xa[a] = rbcast<a>(x); mx += mrow[a] * xa[a]; });
+    T mx = T(0), xb = x;
+    g_dpp_ready(xb);
+    static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(mx, xb, mrow[a]); });
     if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * G_MAXROW + my_lim] = lim_sign * x;
-    for (int c = j; c < ncon; c += GL) {
-        DL_LDS T* jc = wb + Ld::JC + c * G_JC_STRIDE;
-        T vn = T(0), v1 = T(0), v2 = T(0);
-        static_for<N>([&](auto ai) { constexpr int a = ai.value; vn += jc[a] * xa[a]; v1 += jc[GL + a] * xa[a]; v2 += jc[2 * GL + a] * xa[a]; });
+    for (int c = 0; c < ncon; c++) {
+        const Q4<T> jt = ld4(wb + Ld::JC + (c * GL + j) * 4);
+        const T vn = gsum(jt.a * x), v1 = gsum(jt.b * x), v2 = gsum(jt.c * x);
         const T mu = wb[Ld::CON + 5 * G_MAXCON + c];
-        DL_LDS T* jv = wb + Ld::ROW + Ld::R_JV * G_MAXROW + nlim + 4 * c;
-        jv[0] = vn + mu * v1; jv[1] = vn - mu * v1; jv[2] = vn + mu * v2; jv[3] = vn - mu * v2;
+        if (j < 4) wb[Ld::ROW + Ld::R_JV * G_MAXROW + 4 * c + j] = vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
     }
     return mx;
 }
@@ -749,7 +746,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
     DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
     // jar = J a - aref at a = warm start:  K imp r (stored by g_make_constraints) + J (B v + a)
-    (void)g_apply<T, N>(g, nlim, ncon, my_lim, lim_sign, g.c->solB * v + warm, mrow);
+    (void)g_apply<T, N>(g, ncon, my_lim, lim_sign, g.c->solB * v + warm, mrow);
     g_sync<T>();
     for (int r = j; r < nefc; r += GL) { rJA[r] += rJV[r]; rTM[r] = T(0); }     // TMP: per-row "active" flags of the Hessian
     T qacc = warm, Ma = T(0);
@@ -764,52 +761,55 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     g_sync<T>();
     tick(1);
     for (;;) {
-        // ---- row forces and cost at the current point
-        T c = T(0);
-        for (int r = j; r < nefc; r += GL) {
-            const T jar = rJA[r], D = rD[r];
-            const bool on = jar < T(0);
-            rJV[r] = on ? -D * jar : T(0);
-            if (on) c += T(0.5) * D * jar * jar;
-        }
-        g_sync<T>();
-        // ---- J^T f, and the Hessian rows of constraint rows whose state flipped
-        T fcon = T(0);
+        // ---- rows are processed by their owners: force, cost and active-set flips of a limit row by the lane of its
+        // dof, of the four pyramid rows of contact c by lane c, which leaves the contact-frame force and the weights of
+        // the rank-3 Hessian update for the dof lanes
+        T c = T(0), fcon = T(0);
         if (my_lim >= 0) {
-            const bool on = rJA[my_lim] < T(0), was = rTM[my_lim] != T(0);
-            fcon = lim_sign * rJV[my_lim];
-            if (on != was && alive) hd += on ? rD[my_lim] : -rD[my_lim];
+            const T jar = rJA[my_lim], D = rD[my_lim];
+            const bool on = jar < T(0), was = rTM[my_lim] != T(0);
+            if (on) { c = T(0.5) * D * jar * jar; fcon = -lim_sign * D * jar; }
+            if (on != was && alive) hd += on ? D : -D;
+            rTM[my_lim] = on ? T(1) : T(0);
         }
-        for (int cc = 0; cc < ncon; cc++) {
-            const int r0 = nlim + 4 * cc;
-            const T mu = wb[Ld::CON + 5 * G_MAXCON + cc], D = rD[r0];
-            T f4[4], dD[4];
+        for (int cc = j; cc < ncon; cc += GL) {
+            const Q4<T> ja = ld4(rJA + 4 * cc), tm = ld4(rTM + 4 * cc);
+            const T D = rD[4 * cc], mu = wb[Ld::CON + 5 * G_MAXCON + cc];
+            const T jar[4] = {ja.a, ja.b, ja.c, ja.d}, was[4] = {tm.a, tm.b, tm.c, tm.d};
+            T f4[4], dD[4], onf[4];
             bool anyflip = false;
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
-                f4[s4] = rJV[r0 + s4];
-                const bool on = rJA[r0 + s4] < T(0), was = rTM[r0 + s4] != T(0);
-                dD[s4] = (on == was) ? T(0) : (on ? D : -D);
-                anyflip = anyflip || (on != was);
+                const bool on = jar[s4] < T(0), w = was[s4] != T(0);
+                f4[s4] = on ? -D * jar[s4] : T(0);
+                if (on) c += T(0.5) * D * jar[s4] * jar[s4];
+                dD[s4] = (on == w) ? T(0) : (on ? D : -D);
+                anyflip = anyflip || (on != w);
+                onf[s4] = on ? T(1) : T(0);
             }
-            DL_LDS T* jc = wb + Ld::JC + cc * G_JC_STRIDE;
-            const T jn = jc[j], j1 = jc[GL + j], j2 = jc[2 * GL + j];
-            const T Fn = f4[0] + f4[1] + f4[2] + f4[3], F1 = mu * (f4[0] - f4[1]), F2 = mu * (f4[2] - f4[3]);
-            fcon += jn * Fn + j1 * F1 + j2 * F2;
-            if (anyflip && alive) {
-                // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
-                const T w00 = dD[0] + dD[1] + dD[2] + dD[3];
-                const T w01 = mu * (dD[0] - dD[1]), w02 = mu * (dD[2] - dD[3]);
-                const T w11 = mu * mu * (dD[0] + dD[1]), w22 = mu * mu * (dD[2] + dD[3]);
-                const T t0 = w00 * jn + w01 * j1 + w02 * j2, t1 = w01 * jn + w11 * j1, t2 = w02 * jn + w22 * j2;
-                hd += jn * t0 + j1 * t1 + j2 * t2;
-                T bn = jn, b1 = j1, b2 = j2;
+            // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
+            DL_LDS T* fc = wb + Ld::FC + Ld::FC_W * cc;
+            st4(fc, f4[0] + f4[1] + f4[2] + f4[3], mu * (f4[0] - f4[1]), mu * (f4[2] - f4[3]), anyflip ? T(1) : T(0));
+            st4(fc + 4, dD[0] + dD[1] + dD[2] + dD[3], mu * (dD[0] - dD[1]), mu * (dD[2] - dD[3]), mu * mu * (dD[0] + dD[1]));
+            fc[8] = mu * mu * (dD[2] + dD[3]);
+            st4(rTM + 4 * cc, onf[0], onf[1], onf[2], onf[3]);
+        }
+        g_sync<T>();
+        // ---- J^T f and the Hessian rows (dof lanes; the lane's Jacobian column of contact cc is one 16-byte read)
+        for (int cc = 0; cc < ncon; cc++) {
+            const DL_LDS T* fc = wb + Ld::FC + Ld::FC_W * cc;
+            const Q4<T> F = ld4(fc), jt = ld4(wb + Ld::JC + (cc * GL + j) * 4);
+            fcon += jt.a * F.a + jt.b * F.b + jt.c * F.c;
+            if (F.d != T(0) && alive) {
+                const Q4<T> W = ld4(fc + 4);
+                const T w22 = fc[8];
+                const T t0 = W.a * jt.a + W.b * jt.b + W.c * jt.c, t1 = W.b * jt.a + W.d * jt.b, t2 = W.c * jt.a + w22 * jt.c;
+                hd += jt.a * t0 + jt.b * t1 + jt.c * t2;
+                T bn = jt.a, b1 = jt.b, b2 = jt.c;
                 g_dpp_ready(bn); g_dpp_ready(b1); g_dpp_ready(b2);
                 static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(h[a], bn, t0); fmac_bcast<a, 1>(h[a], b1, t1); fmac_bcast<a, 1>(h[a], b2, t2); });
             }
         }
-        g_sync<T>();
-        for (int r = j; r < nefc; r += GL) rTM[r] = (rJA[r] < T(0)) ? T(1) : T(0);
         const T pc0 = gsum(c);
         const T grad = Ma - smooth - fcon;
         {
@@ -830,7 +830,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
             dir = -g_chol_solve<T, N>(l, invd, grad, j);
         }
         tick(3);
-        const T Md = g_apply<T, N>(g, nlim, ncon, my_lim, lim_sign, dir, mrow);      // rows JV = J dir
+        const T Md = g_apply<T, N>(g, ncon, my_lim, lim_sign, dir, mrow);      // rows JV = J dir
         g_sync<T>();
         tick(4);
         // ---- exact line search along dir

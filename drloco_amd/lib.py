@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libdrloco_hip.so')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
-_SOURCES = ['dl_kernels.hip', 'dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp']
+_SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.h')))
 
 _lib = None
 
