@@ -184,6 +184,21 @@ template <typename T> __device__ __forceinline__ T gsum(T x) {
     x += dpp_f<0x121>(x);
     return x;
 }
+// the same reduction for NV values at once: the NV dependent DPP chains are interleaved, which hides the two wait
+// states every DPP read of a freshly written VGPR costs
+template <int NV, typename T> __device__ __forceinline__ void gsum_n(T (&x)[NV]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < NV; i++) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+    for (int i = 0; i < NV; i++) x[i] += dpp_f<0x128>(x[i]);
+#pragma unroll
+    for (int i = 0; i < NV; i++) x[i] += dpp_f<0x124>(x[i]);
+#pragma unroll
+    for (int i = 0; i < NV; i++) x[i] += dpp_f<0x122>(x[i]);
+#pragma unroll
+    for (int i = 0; i < NV; i++) x[i] += dpp_f<0x121>(x[i]);
+}
 __device__ __forceinline__ bool gany(bool p) { return gsum(p ? 1.0f : 0.0f) > 0.0f; }
 
 // A workgroup is ONE wave and a wave's LDS operations execute in order, so lanes exchange data through LDS
@@ -677,6 +692,10 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         if (!moves) w = mk<T>(0, 0, 0);
         st4(wb + Ld::JC + (c * GL + j) * 4, w.z, tx * w.x + ty * w.y, -ty * w.x + tx * w.y, T(0));
     }
+    if (ncon < G_MAXCON) {          // contacts are processed in pairs: a neutral record closes an odd count
+        st4(wb + Ld::JC + (ncon * GL + j) * 4, T(0), T(0), T(0), T(0));
+        if (j == 0) { st4(wb + Ld::FC + Ld::FC_W * ncon, T(0), T(0), T(0), T(0)); wb[Ld::CON + 5 * G_MAXCON + ncon] = T(0); }
+    }
     g_sync<T>();
     nlim_out = nlim; ncon_out = ncon;
 }
@@ -697,11 +716,17 @@ __device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T l
     g_dpp_ready(xb);
     static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(mx, xb, mrow[a]); });
     if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * G_MAXROW + my_lim] = lim_sign * x;
-    for (int c = 0; c < ncon; c++) {
-        const Q4<T> jt = ld4(wb + Ld::JC + (c * GL + j) * 4);
-        const T vn = gsum(jt.a * x), v1 = gsum(jt.b * x), v2 = gsum(jt.c * x);
-        const T mu = wb[Ld::CON + 5 * G_MAXCON + c];
-        if (j < 4) wb[Ld::ROW + Ld::R_JV * G_MAXROW + 4 * c + j] = vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
+    // two contacts per trip (the Jacobian record after the last contact is zero): six interleaved row sums
+    for (int c = 0; c < ncon; c += 2) {
+        const Q4<T> ja = ld4(wb + Ld::JC + (c * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c + 1) * GL + j) * 4);
+        const T mua = wb[Ld::CON + 5 * G_MAXCON + c], mub = wb[Ld::CON + 5 * G_MAXCON + c + 1];
+        T r[6] = {ja.a * x, ja.b * x, ja.c * x, jb.a * x, jb.b * x, jb.c * x};
+        gsum_n<6>(r);
+        if (j < 8) {
+            const bool second = j >= 4;
+            const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? mub : mua;
+            if (!second || c + 1 < ncon) wb[Ld::ROW + Ld::R_JV * G_MAXROW + 4 * c + j] = vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
+        }
     }
     return mx;
 }
@@ -796,24 +821,32 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         }
         g_sync<T>();
         // ---- J^T f and the Hessian rows (dof lanes; the lane's Jacobian column of contact cc is one 16-byte read)
-        for (int cc = 0; cc < ncon; cc++) {
-            const DL_LDS T* fc = wb + Ld::FC + Ld::FC_W * cc;
-            const Q4<T> F = ld4(fc), jt = ld4(wb + Ld::JC + (cc * GL + j) * 4);
-            fcon += jt.a * F.a + jt.b * F.b + jt.c * F.c;
-            if (F.d != T(0) && alive) {
-                const Q4<T> W = ld4(fc + 4);
-                const T w22 = fc[8];
-                const T t0 = W.a * jt.a + W.b * jt.b + W.c * jt.c, t1 = W.b * jt.a + W.d * jt.b, t2 = W.c * jt.a + w22 * jt.c;
-                hd += jt.a * t0 + jt.b * t1 + jt.c * t2;
-                T bn = jt.a, b1 = jt.b, b2 = jt.c;
-                g_dpp_ready(bn); g_dpp_ready(b1); g_dpp_ready(b2);
-                static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(h[a], bn, t0); fmac_bcast<a, 1>(h[a], b1, t1); fmac_bcast<a, 1>(h[a], b2, t2); });
+        for (int c2 = 0; c2 < ncon; c2 += 2) {
+            const DL_LDS T* fca = wb + Ld::FC + Ld::FC_W * c2;
+            const Q4<T> Fa = ld4(fca), Fb = ld4(fca + Ld::FC_W), ja = ld4(wb + Ld::JC + (c2 * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c2 + 1) * GL + j) * 4);
+            fcon += ja.a * Fa.a + ja.b * Fa.b + ja.c * Fa.c + jb.a * Fb.a + jb.b * Fb.b + jb.c * Fb.c;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const Q4<T>& F = half ? Fb : Fa;
+                const Q4<T>& jt = half ? jb : ja;
+                if (F.d != T(0) && alive) {
+                    const DL_LDS T* fc = fca + half * Ld::FC_W;
+                    const Q4<T> W = ld4(fc + 4);
+                    const T w22 = fc[8];
+                    const T t0 = W.a * jt.a + W.b * jt.b + W.c * jt.c, t1 = W.b * jt.a + W.d * jt.b, t2 = W.c * jt.a + w22 * jt.c;
+                    hd += jt.a * t0 + jt.b * t1 + jt.c * t2;
+                    T bn = jt.a, b1 = jt.b, b2 = jt.c;
+                    g_dpp_ready(bn); g_dpp_ready(b1); g_dpp_ready(b2);
+                    static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(h[a], bn, t0); fmac_bcast<a, 1>(h[a], b1, t1); fmac_bcast<a, 1>(h[a], b2, t2); });
+                }
             }
         }
-        const T pc0 = gsum(c);
         const T grad = Ma - smooth - fcon;
+        T r3[3] = {c, grad * grad, dl_abs(Ma) + dl_abs(smooth) + dl_abs(fcon)};
+        gsum_n<3>(r3);
+        const T pc0 = r3[0];
         {
-            const T gn = gsum(grad * grad), gmag = gsum(dl_abs(Ma) + dl_abs(smooth) + dl_abs(fcon));
+            const T gn = r3[1], gmag = r3[2];
             // float32: the gradient carries rounding noise proportional to the magnitude of its terms
             if (!(scale * dl_sqrt(gn) >= cs.tolerance + cs.tol_rel * scale * gmag) || iter >= cs.iterations) alive = false;   // also stops on NaN
         }
@@ -834,7 +867,9 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         g_sync<T>();
         tick(4);
         // ---- exact line search along dir
-        const T g1s = gsum(dir * (Ma - smooth)), g2 = gsum(T(0.5) * dir * Md), d0 = gsum(dir * grad), snorm = dl_sqrt(gsum(dir * dir));
+        T r4[4] = {dir * (Ma - smooth), T(0.5) * dir * Md, dir * grad, dir * dir};
+        gsum_n<4>(r4);
+        const T g1s = r4[0], g2 = r4[1], d0 = r4[2], snorm = dl_sqrt(r4[3]);
         const T gtol = cs.tolerance * cs.ls_tolerance * snorm * cs.meaninertia * nvf + cs.ls_reltol * dl_abs(d0);
         T alpha = T(1), lo = T(0), hi = T(1e30), best_a = T(0), best_dc = T(0), best_mag = T(0), res_a = T(0), res_dc = T(0), res_mag = T(0);
         bool done = !alive || !(snorm >= T(1e-15));
@@ -846,7 +881,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
                 const T jv = rJV[r], xx = rJA[r] + alpha * jv;
                 if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jv; pd2 += D * jv * jv; }
             }
-            pc = gsum(pc); pd1 = gsum(pd1); pd2 = gsum(pd2);
+            { T r3[3] = {pc, pd1, pd2}; gsum_n<3>(r3); pc = r3[0]; pd1 = r3[1]; pd2 = r3[2]; }
             const T d1 = g1s + T(2) * alpha * g2 + pd1, d2 = T(2) * g2 + pd2;
             const T dc = alpha * g1s + alpha * alpha * g2 + (pc - pc0);
             const T mag = dl_abs(alpha * g1s) + alpha * alpha * g2 + pc + pc0;
