@@ -271,6 +271,36 @@ template <typename T> __device__ __forceinline__ void rot_axis(V3<T>& X, V3<T>& 
 template <int K> __device__ __forceinline__ float rbcast(float x) { return dpp_f<0x150 + K>(x); }
 template <int K> __device__ __forceinline__ double rbcast(double x) { return dpp_f<0x150 + K>(x); }
 
+// d += bcast_K(a) * b  (SIGN = +1)  or  d -= bcast_K(a) * b  (SIGN = -1).  float: ONE instruction, v_fmac_f32_dpp with the
+// row broadcast folded into src0 (the compiler only folds DPP into add/mul).  The DPP read of `a` needs two wait states
+// after the VALU write of `a`; inline asm is opaque to the hazard recogniser, so callers fence with g_dpp_ready(a).
+template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(float& d, float a, float b) {
+    if constexpr (SIGN > 0) asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
+    else asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
+}
+template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
+    if constexpr (SIGN > 0) d += rbcast<K>(a) * b; else d -= rbcast<K>(a) * b;
+}
+// d += dpp<CTRL>(a) * b for the row shifts of the segmented scans (lanes without a source lane read 0)
+#define DL_FMAC_DPP_CASE(code, text) \
+    if constexpr (CTRL == code) asm("v_fmac_f32_dpp %0, %1, %2 " text " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(d) : "v"(a), "v"(b));
+template <int CTRL> __device__ __forceinline__ void fmac_dpp(float& d, float a, float b) {
+    DL_FMAC_DPP_CASE(0x111, "row_shr:1") DL_FMAC_DPP_CASE(0x112, "row_shr:2") DL_FMAC_DPP_CASE(0x114, "row_shr:4") DL_FMAC_DPP_CASE(0x118, "row_shr:8")
+    DL_FMAC_DPP_CASE(0x101, "row_shl:1") DL_FMAC_DPP_CASE(0x102, "row_shl:2") DL_FMAC_DPP_CASE(0x104, "row_shl:4") DL_FMAC_DPP_CASE(0x108, "row_shl:8")
+}
+#undef DL_FMAC_DPP_CASE
+template <int CTRL> __device__ __forceinline__ void fmac_dpp(double& d, double a, double b) { d += dpp_f<CTRL>(a) * b; }
+__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
+// one wait for a whole group of values that are about to be read through DPP
+template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) {
+    if constexpr (NV == 6) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+    else if constexpr (NV == 16) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+    else { for (int i = 0; i < NV; i++) asm volatile("s_nop 1" : "+v"(x[i])); }
+}
+template <int NV> __device__ __forceinline__ void g_dpp_ready_n(double (&)[NV]) {}
+__device__ __forceinline__ void g_dpp_ready(double&) {}
+
+
 
 // ------------------------------------------------------------------------------------------
 // Compile-time topology for the lane-per-dof layout.  The dof order of a model is topological and mostly
@@ -322,35 +352,71 @@ template <typename T, typename TP> __device__ __forceinline__ void g_lane_topo(i
 #pragma unroll
     for (int k = 0; k < 4; k++) { lt.ms[k] = (j - (1 << k) >= lt.rs) ? T(1) : T(0); lt.ns[k] = (j + (1 << k) <= re) ? T(1) : T(0); }
 }
-// x_j <- sum over the dofs a on the root -> j chain of x_a
-template <typename T, typename TP> __device__ __forceinline__ T g_chain_sum(T x, int j, const GLaneTopo<T>& lt) {
+// x_j <- sum over the dofs a on the root -> j chain of x_a, for NVAL values at once (one v_fmac_f32_dpp per value
+// and scan step)
+template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_chain_sum_n(T (&x)[NVAL], int j, const GLaneTopo<T>& lt) {
     constexpr int MR = GTopo<TP>::max_run();
-    x += lt.ms[0] * dpp_f<0x111>(x);
-    if constexpr (MR > 2) x += lt.ms[1] * dpp_f<0x112>(x);
-    if constexpr (MR > 4) x += lt.ms[2] * dpp_f<0x114>(x);
-    if constexpr (MR > 8) x += lt.ms[3] * dpp_f<0x118>(x);
+    g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+    for (int i = 0; i < NVAL; i++) fmac_dpp<0x111>(x[i], x[i], lt.ms[0]);
+    if constexpr (MR > 2) {
+        g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) fmac_dpp<0x112>(x[i], x[i], lt.ms[1]);
+    }
+    if constexpr (MR > 4) {
+        g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) fmac_dpp<0x114>(x[i], x[i], lt.ms[2]);
+    }
+    if constexpr (MR > 8) {
+        g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) fmac_dpp<0x118>(x[i], x[i], lt.ms[3]);
+    }
     static_for<TP::NV>([&](auto ri) {
         constexpr int r = ri.value;
-        if constexpr (r > 0 && GTopo<TP>::run_start(r)) { constexpr int P = TP::dof_parent(r); x += (lt.rs == r ? T(1) : T(0)) * rbcast<P>(x); }
+        if constexpr (r > 0 && GTopo<TP>::run_start(r)) {
+            constexpr int P = TP::dof_parent(r);
+            const T f = lt.rs == r ? T(1) : T(0);
+            g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+            for (int i = 0; i < NVAL; i++) fmac_bcast<P, 1>(x[i], x[i], f);
+        }
     });
-    return x;
 }
 // x_j <- sum over the dofs d of the subtree of j (j on the root -> d chain) of x_d
-template <typename T, typename TP> __device__ __forceinline__ T g_subtree_sum(T x, int j, const GLaneTopo<T>& lt) {
+template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_subtree_sum_n(T (&x)[NVAL], int j, const GLaneTopo<T>& lt) {
     constexpr int MR = GTopo<TP>::max_run();
-    x += lt.ns[0] * dpp_f<0x101>(x);
-    if constexpr (MR > 2) x += lt.ns[1] * dpp_f<0x102>(x);
-    if constexpr (MR > 4) x += lt.ns[2] * dpp_f<0x104>(x);
-    if constexpr (MR > 8) x += lt.ns[3] * dpp_f<0x108>(x);
+    g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+    for (int i = 0; i < NVAL; i++) fmac_dpp<0x101>(x[i], x[i], lt.ns[0]);
+    if constexpr (MR > 2) {
+        g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) fmac_dpp<0x102>(x[i], x[i], lt.ns[1]);
+    }
+    if constexpr (MR > 4) {
+        g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) fmac_dpp<0x104>(x[i], x[i], lt.ns[2]);
+    }
+    if constexpr (MR > 8) {
+        g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) fmac_dpp<0x108>(x[i], x[i], lt.ns[3]);
+    }
     static_for<TP::NV>([&](auto ri) {
         constexpr int r = TP::NV - 1 - ri.value;           // deepest runs first
         if constexpr (r > 0 && GTopo<TP>::run_start(r)) {
             constexpr int P = TP::dof_parent(r);
             constexpr uint32_t ancP = GTopo<TP>::tab.anc[P];
-            x += (((ancP >> j) & 1u) ? T(1) : T(0)) * rbcast<r>(x);
+            const T f = ((ancP >> j) & 1u) ? T(1) : T(0);
+            g_dpp_ready_n<NVAL>(x);
+#pragma unroll
+            for (int i = 0; i < NVAL; i++) fmac_bcast<r, 1>(x[i], x[i], f);
         }
     });
-    return x;
 }
 // rotate the frame (X,Y,Z) about its own coordinate axis IDX (compile time) by the angle with (s, c)
 template <int IDX, typename T> __device__ __forceinline__ void rot_axis_c(V3<T>& X, V3<T>& Y, V3<T>& Z, T s, T c) {
@@ -456,15 +522,15 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     if (!isdof) { S.w = mk<T>(0, 0, 0); S.v = mk<T>(0, 0, 0); }
     const T qd = isdof ? v : T(0);
     const SV<T> vJ = {qd * S.w, qd * S.v};
-    SV<T> vel;
-    vel.w.x = g_chain_sum<T, TP>(vJ.w.x, j, lt); vel.w.y = g_chain_sum<T, TP>(vJ.w.y, j, lt); vel.w.z = g_chain_sum<T, TP>(vJ.w.z, j, lt);
-    vel.v.x = g_chain_sum<T, TP>(vJ.v.x, j, lt); vel.v.y = g_chain_sum<T, TP>(vJ.v.y, j, lt); vel.v.z = g_chain_sum<T, TP>(vJ.v.z, j, lt);
+    T sv[6] = {vJ.w.x, vJ.w.y, vJ.w.z, vJ.v.x, vJ.v.y, vJ.v.z};
+    g_chain_sum_n<T, TP, 6>(sv, j, lt);
+    const SV<T> vel = {mk<T>(sv[0], sv[1], sv[2]), mk<T>(sv[3], sv[4], sv[5])};
     // velocity-product acceleration: sum over the chain of (twist of the parent) x (joint velocity); the twist of
     // the parent is vel - vJ and vJ x vJ = 0
     const SV<T> cJ = {cross(vel.w, vJ.w), cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
-    SV<T> acc;
-    acc.w.x = g_chain_sum<T, TP>(cJ.w.x, j, lt); acc.w.y = g_chain_sum<T, TP>(cJ.w.y, j, lt); acc.w.z = g_chain_sum<T, TP>(cJ.w.z, j, lt);
-    acc.v.x = g_chain_sum<T, TP>(cJ.v.x, j, lt); acc.v.y = g_chain_sum<T, TP>(cJ.v.y, j, lt); acc.v.z = g_chain_sum<T, TP>(cJ.v.z, j, lt) - g.c->gravity_z;
+    T sa[6] = {cJ.w.x, cJ.w.y, cJ.w.z, cJ.v.x, cJ.v.y, cJ.v.z};
+    g_chain_sum_n<T, TP, 6>(sa, j, lt);
+    const SV<T> acc = {mk<T>(sa[0], sa[1], sa[2]), mk<T>(sa[3], sa[4], sa[5] - g.c->gravity_z)};
     // spatial inertia and inertial wrench of the body whose last dof this is (zero on the other lanes)
     SI<T> I;
     {
@@ -487,20 +553,22 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
         F = {Ia.w + cross(vel.w, Iv.w) + cross(vel.v, Iv.v), Ia.v + cross(vel.w, Iv.v)};
     }
     // composite inertia and wrench of the subtree of dof j
-    auto sub = [&](T x) { return g_subtree_sum<T, TP>(x, j, lt); };
+    T cs16[16] = {I.m, I.h.x, I.h.y, I.h.z, I.I.xx, I.I.xy, I.I.xz, I.I.yy, I.I.yz, I.I.zz, F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
+    g_subtree_sum_n<T, TP, 16>(cs16, j, lt);
     SI<T> Ic;
-    Ic.m = sub(I.m); Ic.h.x = sub(I.h.x); Ic.h.y = sub(I.h.y); Ic.h.z = sub(I.h.z);
-    Ic.I.xx = sub(I.I.xx); Ic.I.xy = sub(I.I.xy); Ic.I.xz = sub(I.I.xz); Ic.I.yy = sub(I.I.yy); Ic.I.yz = sub(I.I.yz); Ic.I.zz = sub(I.I.zz);
-    SV<T> W;
-    W.w.x = sub(F.w.x); W.w.y = sub(F.w.y); W.w.z = sub(F.w.z); W.v.x = sub(F.v.x); W.v.y = sub(F.v.y); W.v.z = sub(F.v.z);
+    Ic.m = cs16[0]; Ic.h = mk<T>(cs16[1], cs16[2], cs16[3]);
+    Ic.I.xx = cs16[4]; Ic.I.xy = cs16[5]; Ic.I.xz = cs16[6]; Ic.I.yy = cs16[7]; Ic.I.yz = cs16[8]; Ic.I.zz = cs16[9];
+    const SV<T> W = {mk<T>(cs16[10], cs16[11], cs16[12]), mk<T>(cs16[13], cs16[14], cs16[15])};
     const T bias = sdot(S, W);
     const SV<T> f = si_mul(Ic, S);
     // M[j][a] for the dofs a on the chain of j; mirrored through LDS
+    T Sr[6] = {S.w.x, S.w.y, S.w.z, S.v.x, S.v.y, S.v.z};
+    g_dpp_ready_n<6>(Sr);
     static_for<NV>([&](auto ai) {
         constexpr int a = ai.value;
-        T mij;
-        if constexpr (TP::dof_type(a) == 0) mij = rbcast<a>(S.v.x) * f.v.x + rbcast<a>(S.v.y) * f.v.y + rbcast<a>(S.v.z) * f.v.z;
-        else mij = rbcast<a>(S.w.x) * f.w.x + rbcast<a>(S.w.y) * f.w.y + rbcast<a>(S.w.z) * f.w.z + rbcast<a>(S.v.x) * f.v.x + rbcast<a>(S.v.y) * f.v.y + rbcast<a>(S.v.z) * f.v.z;
+        T mij = T(0);
+        if constexpr (TP::dof_type(a) == 1) { fmac_bcast<a, 1>(mij, Sr[0], f.w.x); fmac_bcast<a, 1>(mij, Sr[1], f.w.y); fmac_bcast<a, 1>(mij, Sr[2], f.w.z); }
+        fmac_bcast<a, 1>(mij, Sr[3], f.v.x); fmac_bcast<a, 1>(mij, Sr[4], f.v.y); fmac_bcast<a, 1>(mij, Sr[5], f.v.z);
         mij = ((lt.anc >> a) & 1u) ? mij : T(0);
         if (a == j) { mij += ln.armature; mdiag = mij; }
         if (a <= j && isdof) { wb[Ld::MM + j * Ld::MS + a] = mij; wb[Ld::MM + a * Ld::MS + j] = mij; }
@@ -510,19 +578,6 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     for (int a = 0; a < GL; a++) mrow[a] = (a < NV && isdof) ? wb[Ld::MM + j * Ld::MS + a] : T(0);
     return isdof ? -ln.damping * v - bias + ctrl_force : T(0);
 }
-
-// d += bcast_K(a) * b  (SIGN = +1)  or  d -= bcast_K(a) * b  (SIGN = -1).  float: ONE instruction, v_fmac_f32_dpp with the
-// row broadcast folded into src0 (the compiler only folds DPP into add/mul).  The DPP read of `a` needs two wait states
-// after the VALU write of `a`; inline asm is opaque to the hazard recogniser, so callers fence with g_dpp_ready(a).
-template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(float& d, float a, float b) {
-    if constexpr (SIGN > 0) asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
-    else asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
-}
-template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
-    if constexpr (SIGN > 0) d += rbcast<K>(a) * b; else d -= rbcast<K>(a) * b;
-}
-__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
-__device__ __forceinline__ void g_dpp_ready(double&) {}
 
 // 1/x: float = v_rcp_f32 + one Newton step; double = exact division
 __device__ __forceinline__ float dl_rcp(float x) {
