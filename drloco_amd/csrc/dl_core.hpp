@@ -220,8 +220,8 @@ template <typename T> struct DevCfg {
     T rew_w[3], rew_scale, alive_bonus, com_z_min, inv_ctrl_freq;
     int32_t ep_dur_max, mirror_policy, env_index_base;
     uint64_t seed;
-    int32_t n_steps, total_len, stride;
-    const T* table;            // [2*NV][total_len]
+    int32_t n_steps, total_len, stride, n_rows;
+    const T* table;            // sample-major [total_len][2*NV]: the 2*NV reference values of one mocap sample are contiguous
     const int32_t* step_off;   // [n_steps+1]
     const int32_t* step_is_left;
     const T* step_vel;

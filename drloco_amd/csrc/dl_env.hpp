@@ -52,15 +52,18 @@ template <typename T> DL_HD void rsi_draw(const DevCfg<T>& c, uint32_t genv, uin
     pos = (int)(((uint64_t)hi * (uint64_t)len) >> 32);
 }
 
+// reference value `row` of mocap sample `col` (device table is sample-major, see DevCfg)
+template <typename T> DL_HD T ref_at(const DevCfg<T>& c, int row, int col) { return c.table[(size_t)col * c.n_rows + row]; }
+
 template <typename T, typename TP>
 DL_HD void ref_lookup(const DevCfg<T>& c, const int32_t (&cur)[DL_CUR_WORDS], T comz_off, T (&qr)[TP::NV], T (&vr)[TP::NV]) {
     const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
     static_for<TP::NV>([&](auto ji) {
         constexpr int j = ji.value;
-        qr[j] = c.table[(size_t)j * c.total_len + base];
-        vr[j] = c.table[(size_t)(TP::NV + j) * c.total_len + base];
+        qr[j] = ref_at(c, j, base);
+        vr[j] = ref_at(c, TP::NV + j, base);
     });
-    if (cur[DL_CUR_HAS_DIST]) qr[0] += c.table[c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1];   // quirk Q1
+    if (cur[DL_CUR_HAS_DIST]) qr[0] += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1);   // quirk Q1
     else qr[2] -= comz_off;
 }
 

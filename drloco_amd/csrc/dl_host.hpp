@@ -85,7 +85,14 @@ template <typename T> inline void fill_dev_cfg(const dl_config& c, const dl_refs
     o.rew_scale = (T)c.rew_scale; o.alive_bonus = (T)c.alive_bonus; o.com_z_min = (T)c.com_z_min;
     o.inv_ctrl_freq = (T)(1.0 / c.ctrl_freq);
     o.ep_dur_max = c.ep_dur_max; o.mirror_policy = c.mirror_policy; o.env_index_base = c.env_index_base; o.seed = c.seed;
-    o.n_steps = r.n_steps; o.total_len = r.total_len; o.stride = r.stride;
+    o.n_steps = r.n_steps; o.total_len = r.total_len; o.stride = r.stride; o.n_rows = r.n_rows;
+}
+
+// dl_refs_desc.table is row-major [n_rows][total_len]; the kernels read it sample-major [total_len][n_rows]
+inline void transpose_refs(const dl_refs_desc& r, std::vector<double>& out) {
+    out.resize((size_t)r.n_rows * r.total_len);
+    for (int row = 0; row < r.n_rows; row++)
+        for (int col = 0; col < r.total_len; col++) out[(size_t)col * r.n_rows + row] = r.table[(size_t)row * r.total_len + col];
 }
 
 // float64 prefix sums of the two desired-velocity rows (rows nv, nv+1 of the table): [2][total_len+1]

@@ -69,12 +69,22 @@ __global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP>* __rest
     if (niter) niter[i] = info >> 16;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.  The SoA
+// state rows put 16 consecutive walkers into one 64-byte line, i.e. 4 consecutive walker groups share their lines:
+// map workgroup i to walker group (i % 8) * (G / 8) + i / 8 so that neighbouring groups run on the SAME XCD and a
+// line is fetched into one L2 only.  (G not a multiple of 8: identity.)
+__device__ __forceinline__ int g_block_of_workgroup(int wg, int nwg) {
+    constexpr int XCDS = 8;
+    if (nwg % XCDS) return wg;
+    return (wg % XCDS) * (nwg / XCDS) + wg / XCDS;
+}
+
 // forward dynamics with 16 lanes per walker (dl_group.hpp): 4 walkers per 64-lane workgroup
 template <typename T, bool TIMED = false>
 __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict__ gm, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, long long* tim = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
-    const int w = blockIdx.x * GW + grp;
+    const int w = g_block_of_workgroup(blockIdx.x, gridDim.x) * GW + grp;
     const bool valid = w < n;
     const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     using TPS = TopoStraight;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
-    const int w0 = blockIdx.x * GW + grp;
+    const int w0 = g_block_of_workgroup(blockIdx.x, gridDim.x) * GW + grp;
     const bool valid = w0 < n;
     const int w = valid ? w0 : n - 1;
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
@@ -236,9 +246,9 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             T dp = T(0), dvv = T(0), dc = T(0);
             if (isdof) {
                 const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
-                T qr = c.table[(size_t)j * c.total_len + base];
-                const T vr = c.table[(size_t)(nv + j) * c.total_len + base];
-                if (cur[DL_CUR_HAS_DIST]) { if (j == 0) qr += c.table[c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1]; }
+                T qr = ref_at(c, j, base);
+                const T vr = ref_at(c, nv + j, base);
+                if (cur[DL_CUR_HAS_DIST]) { if (j == 0) qr += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1); }
                 else if (j == 2) qr -= comz;
                 const T d1 = q - qr, d2 = v - vr;
                 if (j < 3) dc = d1 * d1; else { dp = d1 * d1; dvv = d2 * d2; }
@@ -280,8 +290,8 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             cur[DL_CUR_I_STEP] = s0; cur[DL_CUR_RSI_STEP] = s0; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s0; cur[DL_CUR_POS] = p0; cur[DL_CUR_HAS_DIST] = 0;
             if (isdof) {
                 const int base = c.step_off[cur[DL_CUR_READ_STEP]] + p0;
-                q = c.table[(size_t)j * c.total_len + base];
-                v = c.table[(size_t)(nv + j) * c.total_len + base];
+                q = ref_at(c, j, base);
+                v = ref_at(c, nv + j, base);
             }
             { GKin<T> kin; g_fk<T, TPS>(g, lt, q, kin); }
             comz = g_lowest_site<T>(g);
@@ -584,7 +594,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         T* table; double* stage; T* svel; int32_t *soff, *sleft;
         if ((rc = dalloc(&table, tn))) return rc;
         if ((rc = dalloc(&stage, tn))) return rc;
-        HIPCHK(hipMemcpy(stage, r.table, tn * sizeof(double), hipMemcpyHostToDevice));
+        {
+            std::vector<double> tr;
+            transpose_refs(r, tr);              // sample-major: one walker's 2*nv reference values are contiguous
+            HIPCHK(hipMemcpy(stage, tr.data(), tn * sizeof(double), hipMemcpyHostToDevice));
+        }
         k_copy_cast<T><<<(unsigned)((tn + 255) / 256), 256>>>(table, stage, tn);
         HIPCHK(hipDeviceSynchronize());            // `stage` is reused below
         if ((rc = dalloc(&svel, r.n_steps))) return rc;

@@ -30,7 +30,11 @@ template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_
     fill_dev_cfg<T>(*cfg, *r, e->c);
     size_t tn = (size_t)r->n_rows * r->total_len;
     e->table.resize(tn);
-    for (size_t k = 0; k < tn; k++) e->table[k] = (T)r->table[k];
+    {
+        std::vector<double> tr;
+        transpose_refs(*r, tr);
+        for (size_t k = 0; k < tn; k++) e->table[k] = (T)tr[k];
+    }
     e->step_off.assign(r->step_off, r->step_off + r->n_steps + 1);
     e->is_left.assign(r->step_is_left, r->step_is_left + r->n_steps);
     e->step_vel.resize(r->n_steps);
