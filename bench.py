@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--rollout-len', type=int, default=512)
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
+    ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -93,6 +94,10 @@ def main():
     vn.reset()
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = torch.ones(n, dtype=torch.uint8, device=dev)
+    policy = None
+    if args.policy:
+        from drloco_amd.policy import HipPolicy
+        policy = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=512, seed=99, index_base=rank * n)
 
     def rollout():
         # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
@@ -102,6 +107,8 @@ def main():
         buf.episode_starts[0].copy_(last_done)
         for t in range(T):
             nxt = t + 1 < T
+            if policy is not None:      # collect_rollouts: actions, values, log_probs = policy.forward(obs) -> straight into the buffer
+                policy.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
             vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t],
                             done_out=buf.episode_starts[t + 1] if nxt else last_done)
         buf.compute_returns_and_advantage(last_values, last_done)
@@ -147,7 +154,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'straight_walking 3D walker, {n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
-                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}'},
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,

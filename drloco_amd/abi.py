@@ -60,6 +60,11 @@ class Config(C.Structure):
     ]
 
 
+class PolicyParams(C.Structure):
+    _fields_ = [('w1', C.c_void_p), ('b1', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p), ('wa', C.c_void_p), ('ba', C.c_void_p),
+                ('wv', C.c_void_p), ('bv', C.c_void_p), ('log_std', C.c_void_p), ('obs_dim', _i), ('hidden', _i), ('act_dim', _i)]
+
+
 def loco3d_config(**kw):
     """Defaults for MimicWalker165cm65kg: CTRL_FREQ 100 (config.py:20); the policy-mirroring modification
     must be off because Loco3dReferenceTrajectories has no is_step_left."""

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "dl_host.hpp"
+#include "dl_policy.hpp"
 
 using namespace dl;
 
@@ -947,6 +948,20 @@ int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done
     const size_t ne = (size_t)B * D;
     hipLaunchKernelGGL(k_vn_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, rew, done, (const double*)obs_mean, (const double*)obs_var, obs_count,
                        ret, (const double*)ret_var, ret_count, B, D, eps, clip_obs, clip_rew, flags, obs_out, rew_out);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                      int32_t deterministic, float* actions, float* values, float* log_probs, void* stream) {
+    if (!p || !obs || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward: bad arguments");
+    if (!p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->wa || !p->ba || !p->wv || !p->bv || !p->log_std) return fail(DL_E_INVAL, "dl_policy_forward: NULL parameter array");
+    if (p->hidden <= 0 || p->hidden % 64 || p->hidden > 64 * POL_MAXT || p->obs_dim <= 0 || p->act_dim <= 0 || p->act_dim > 15)
+        return fail(DL_E_INVAL, "dl_policy_forward: hidden must be a multiple of 64 and <= 512, act_dim <= 15");
+    const size_t lds = ((size_t)2 * POL_ROWS * (p->hidden + 4) + 4 * 16 * 16) * sizeof(float);
+    static size_t lds_set = 0;
+    if (lds > lds_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set = lds; }
+    hipLaunchKernelGGL(k_policy_forward, dim3((n + POL_ROWS - 1) / POL_ROWS), dim3(256), lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic,
+                       actions, values, log_probs);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

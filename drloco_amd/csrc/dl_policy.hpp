@@ -1,0 +1,168 @@
+// dl_policy.hpp -- the policy forward pass of the rollout loop as one fused kernel.
+//
+// Restates SB3 1.0 ActorCriticPolicy.forward for the reference's CustomActorCriticPolicy
+// (/root/reference/drloco/custom/policies.py:13-51; constructed at drloco/train.py:105-118):
+//     latent  = tanh(W2 tanh(W1 obs + b1) + b2)          policy_net and value_net are built from the SAME layer
+//                                                         objects (:33-41), i.e. one shared trunk
+//     mean    = Wa latent + ba,  value = Wv latent + bv
+//     action  = mean + exp(log_std) * eps,  eps ~ N(0, 1)   (DiagGaussianDistribution.sample)
+//     log_prob = sum_a( -eps_a^2 / 2 - log_std_a - log(2 pi) / 2 )
+// This is the one genuinely GEMM-shaped piece of the path: [N,29]x[29,512], [N,512]x[512,512], [N,512]x[512,9].
+// One workgroup (4 waves) owns 16 walkers; the three layers run back to back on v_mfma_f32_16x16x4f32 (float32 in,
+// float32 accumulate -- parity with the float32 torch module to ~1e-6), the activations never leave LDS.
+//   A operand (activations): lane l supplies row l % 16, the reduction index is permuted so that a lane's four k
+//     values of a 16-wide k block are contiguous: one ds_read_b128 feeds four MFMAs;
+//   B operand (weights, torch layout [out][in]): lane l supplies output column n0 + l % 16 with the same four k:
+//     one global_load_dwordx4 per tile and k block, 64 contiguous bytes per weight row and wave;
+//   layer 2: each wave owns hidden/4 output columns (up to 8 accumulator tiles); heads: the reduction is split over
+//     the four waves and summed through LDS.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "drloco_hip.h"
+
+namespace dl {
+
+typedef float pf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pol_tanh(float x) {
+    // 1 - 2 / (exp(2x) + 1); |error| < 2e-7 absolute
+    const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+    const float e = __expf(2.0f * xc);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ uint64_t pol_mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// counter-based standard normal keyed by (seed, step counter, global walker index, action index): the sampled
+// actions do not depend on how the walkers are sharded over GPUs
+__device__ __forceinline__ float pol_gauss(uint64_t seed, uint64_t counter, uint32_t genv, uint32_t a) {
+    const uint64_t r = pol_mix(seed ^ pol_mix(counter * 0x100000001B3ull + (((uint64_t)genv << 8) | a)));
+    const float u1 = ((uint32_t)(r >> 40) + 1u) * (1.0f / 16777216.0f);       // (0, 1]
+    const float u2 = (uint32_t)(r & 0xFFFFFFu) * (1.0f / 16777216.0f);         // [0, 1)
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+
+constexpr int POL_ROWS = 16;       // walkers per workgroup
+constexpr int POL_MAXT = 8;        // accumulator tiles per wave in the hidden layer (hidden <= 512)
+
+__global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
+                                                        uint64_t seed, uint64_t counter, int index_base, int deterministic,
+                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = p.hidden, D = p.obs_dim, A = p.act_dim, LDH = H + 4;
+    float* h1 = sm;
+    float* h2 = sm + POL_ROWS * LDH;
+    float* part = h2 + POL_ROWS * LDH;            // [4][16][16] partial head tiles, then [16][16] log-prob terms
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
+    const int row0 = blockIdx.x * POL_ROWS;
+    const int ncw = H / 4, n0w = wave * ncw, ntw = ncw / 16;
+    // ---- layer 1: [16, D] x [D, H]
+    {
+        const int r = row0 + lm;
+        for (int t = 0; t < ntw; t++) {
+            const int ncol = n0w + t * 16 + lm;
+            pf4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < (D + 15) / 16; kb++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int k = kb * 16 + lk * 4 + s;
+                    const float a = (k < D && r < n) ? obs[(size_t)r * D + k] : 0.0f;
+                    const float b = (k < D) ? p.w1[(size_t)ncol * D + k] : 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+                }
+            }
+            const float bias = p.b1[ncol];
+#pragma unroll
+            for (int i = 0; i < 4; i++) h1[(4 * lk + i) * LDH + ncol] = pol_tanh(acc[i] + bias);
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: [16, H] x [H, H]; the weight rows of this wave's tiles stream from L2 one k block ahead
+    {
+        pf4 acc[POL_MAXT];
+#pragma unroll
+        for (int t = 0; t < POL_MAXT; t++) acc[t] = pf4{0.f, 0.f, 0.f, 0.f};
+        const float* wbase = p.w2 + (size_t)(n0w + lm) * H + lk * 4;
+        pf4 bnext[POL_MAXT];
+#pragma unroll
+        for (int t = 0; t < POL_MAXT; t++) if (t < ntw) bnext[t] = *(const pf4*)(wbase + (size_t)t * 16 * H);
+        const int nkb = H / 16;
+        for (int kb = 0; kb < nkb; kb++) {
+            const pf4 a4 = *(const pf4*)&h1[lm * LDH + kb * 16 + lk * 4];
+            pf4 b4[POL_MAXT];
+#pragma unroll
+            for (int t = 0; t < POL_MAXT; t++) b4[t] = bnext[t];
+            if (kb + 1 < nkb) {
+#pragma unroll
+                for (int t = 0; t < POL_MAXT; t++) if (t < ntw) bnext[t] = *(const pf4*)(wbase + (size_t)t * 16 * H + (kb + 1) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < POL_MAXT; t++) {
+                if (t < ntw) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < POL_MAXT; t++) {
+            if (t < ntw) {
+                const int ncol = n0w + t * 16 + lm;
+                const float bias = p.b2[ncol];
+#pragma unroll
+                for (int i = 0; i < 4; i++) h2[(4 * lk + i) * LDH + ncol] = pol_tanh(acc[t][i] + bias);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- heads: one 16 x 16 tile (columns 0..A-1 action means, column A the value); reduction split over the waves
+    {
+        pf4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int kper = H / 4;
+        const float* wrow = lm < A ? p.wa + (size_t)lm * H : (lm == A ? p.wv : nullptr);
+        for (int kb = 0; kb < kper / 16; kb++) {
+            const int k0 = wave * kper + kb * 16 + lk * 4;
+            const pf4 a4 = *(const pf4*)&h2[lm * LDH + k0];
+            const pf4 b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) part[(wave * 16 + 4 * lk + i) * 16 + lm] = acc[i];
+    }
+    __syncthreads();
+    // ---- epilogue: sample, log-probability, value
+    float lp = 0.0f;
+    const int row = tid >> 4, col = tid & 15, r = row0 + row;
+    if (tid < 256) {
+        const float v = part[(0 * 16 + row) * 16 + col] + part[(1 * 16 + row) * 16 + col] + part[(2 * 16 + row) * 16 + col] + part[(3 * 16 + row) * 16 + col];
+        if (r < n) {
+            if (col < A) {
+                const float mean = v + p.ba[col], ls = p.log_std[col];
+                const float e = deterministic ? 0.0f : (eps ? eps[(size_t)r * A + col] : pol_gauss(seed, counter, (uint32_t)(index_base + r), (uint32_t)col));
+                actions[(size_t)r * A + col] = mean + __expf(ls) * e;
+                lp = -0.5f * e * e - ls - 0.91893853320467274178f;
+            } else if (col == A) values[r] = v + p.bv[0];
+        }
+    }
+    __syncthreads();
+    part[tid] = lp;
+    __syncthreads();
+    if (col == 0 && r < n) {
+        float s = 0.0f;
+        for (int a = 0; a < A; a++) s += part[row * 16 + a];
+        logp[r] = s;
+    }
+}
+
+}  // namespace dl

@@ -1,0 +1,73 @@
+"""HipPolicy: the forward pass of the reference's CustomActorCriticPolicy (drloco/custom/policies.py:13-51, built at
+drloco/train.py:105-118) as one fused MFMA kernel (`dl_policy_forward`), for GPU-resident rollouts.
+
+The parameters stay ordinary torch tensors (the PPO update and its optimiser remain PyTorch): `HipPolicy` only reads
+them.  `forward(obs)` mirrors SB3 1.0 `ActorCriticPolicy.forward`: (actions, values, log_probs)."""
+import ctypes as C
+import math
+
+import torch
+
+from . import abi, lib
+from .vec_env import _ptr, _stream
+
+
+class HipPolicy:
+    def __init__(self, obs_dim=29, act_dim=8, hidden=512, log_std_init=-0.75, device='cuda', seed=0, index_base=0):
+        """Fresh parameters with torch's nn.Linear default initialisation (the reference's CustomHiddenLayers builds
+        plain nn.Linear layers; SB3 then applies its orthogonal init -- load trained weights with `load_state`)."""
+        self._lib = lib.load()
+        g = torch.Generator(device='cpu'); g.manual_seed(seed)
+
+        def linear(o, i):
+            bound = 1.0 / math.sqrt(i)
+            w = (torch.rand(o, i, generator=g) * 2 - 1) * bound
+            b = (torch.rand(o, generator=g) * 2 - 1) * bound
+            return w.to(device).contiguous(), b.to(device).contiguous()
+        self.obs_dim, self.act_dim, self.hidden = obs_dim, act_dim, hidden
+        self.w1, self.b1 = linear(hidden, obs_dim)
+        self.w2, self.b2 = linear(hidden, hidden)
+        self.wa, self.ba = linear(act_dim, hidden)
+        self.wv, self.bv = linear(1, hidden)
+        self.log_std = torch.full((act_dim,), float(log_std_init), device=device)
+        self.seed, self.counter, self.index_base = int(seed), 0, int(index_base)
+
+    def load_state(self, w1, b1, w2, b2, wa, ba, wv, bv, log_std):
+        """Take the tensors of a trained torch policy: mlp_extractor.policy_net[0], [2] (shared with value_net),
+        action_net, value_net, log_std."""
+        f = lambda t: t.detach().to(device=self.w1.device, dtype=torch.float32).contiguous()
+        self.w1, self.b1, self.w2, self.b2, self.wa, self.ba, self.wv, self.bv, self.log_std = map(f, (w1, b1, w2, b2, wa, ba, wv, bv, log_std))
+        self.hidden, self.obs_dim = self.w1.shape
+        self.act_dim = self.wa.shape[0]
+
+    def _params(self):
+        p = abi.PolicyParams()
+        for name in ('w1', 'b1', 'w2', 'b2', 'wa', 'ba', 'wv', 'bv', 'log_std'):
+            setattr(p, name, getattr(self, name).data_ptr())
+        p.obs_dim, p.hidden, p.act_dim = self.obs_dim, self.hidden, self.act_dim
+        return p
+
+    def forward(self, obs, deterministic=False, eps=None, actions_out=None, values_out=None, log_probs_out=None):
+        """obs: float32 cuda [N, obs_dim] (normalised).  eps: optional standard-normal draws [N, act_dim]; by default
+        a counter-based stream keyed by (seed, call counter, global walker index).  The outputs may be
+        rollout-buffer slots."""
+        n = obs.shape[0]
+        dev = obs.device
+        a = torch.empty(n, self.act_dim, device=dev) if actions_out is None else actions_out
+        v = torch.empty(n, device=dev) if values_out is None else values_out
+        lp = torch.empty(n, device=dev) if log_probs_out is None else log_probs_out
+        p = self._params()
+        lib.check(self._lib.dl_policy_forward(C.byref(p), _ptr(obs), n, _ptr(eps), self.seed, self.counter, self.index_base,
+                                              int(deterministic), _ptr(a), _ptr(v), _ptr(lp), _stream()))
+        self.counter += 1
+        return a, v, lp
+
+    def torch_reference(self, obs, eps):
+        """The same computation with torch ops (tests only)."""
+        h = torch.tanh(torch.nn.functional.linear(obs, self.w1, self.b1))
+        h = torch.tanh(torch.nn.functional.linear(h, self.w2, self.b2))
+        mean = torch.nn.functional.linear(h, self.wa, self.ba)
+        value = torch.nn.functional.linear(h, self.wv, self.bv)[:, 0]
+        actions = mean + torch.exp(self.log_std) * eps
+        logp = (-0.5 * eps ** 2 - self.log_std - 0.5 * math.log(2 * math.pi)).sum(1)
+        return actions, value, logp

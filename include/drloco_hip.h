@@ -264,6 +264,26 @@ int dl_adv_stats(const float* adv, int64_t n, double* out3, void* stream);
 /* a = (a - mean)/(std_unbiased + 1e-8) from the (all-reduced) sums. */
 int dl_adv_normalize(float* adv, int64_t n, const double* sums3, void* stream);
 
+/* ---- policy forward pass of the rollout loop ----
+ * Parameters of the reference's CustomActorCriticPolicy (drloco/custom/policies.py:13-51) in torch's nn.Linear
+ * layout [out][in], float32, DEVICE pointers: shared trunk obs_dim -> hidden -> hidden (tanh), action_net
+ * hidden -> act_dim, value_net hidden -> 1, log_std[act_dim].  hidden: multiple of 64, <= 512; act_dim <= 15. */
+typedef struct dl_policy_params {
+    const float* w1; const float* b1;   /* [hidden, obs_dim], [hidden] */
+    const float* w2; const float* b2;   /* [hidden, hidden], [hidden] */
+    const float* wa; const float* ba;   /* [act_dim, hidden], [act_dim] */
+    const float* wv; const float* bv;   /* [1, hidden], [1] */
+    const float* log_std;               /* [act_dim] */
+    int32_t obs_dim, hidden, act_dim;
+} dl_policy_params;
+/* SB3 1.0 ActorCriticPolicy.forward for n observations (already normalised): actions float[n, act_dim]
+ * (unclipped, as the rollout buffer stores them), values float[n], log_probs float[n].
+ * eps: float[n, act_dim] standard-normal draws, or NULL = counter-based stream keyed by (seed, counter, index_base +
+ * row, action index); deterministic != 0 returns the mean action (evaluation). */
+int dl_policy_forward(const dl_policy_params* params, const float* obs, int32_t n, const float* eps,
+                      uint64_t seed, uint64_t counter, int32_t index_base, int32_t deterministic,
+                      float* actions, float* values, float* log_probs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

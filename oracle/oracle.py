@@ -223,3 +223,18 @@ def rsi_draw(seed, global_env, episode, step_off):
     s = C.c_int32(); p = C.c_int32()
     lib().dlo_rsi_draw(C.c_uint64(seed), C.c_uint32(global_env), C.c_uint32(episode), C.c_int32(len(so) - 1), _p(so, C.c_int32), C.byref(s), C.byref(p))
     return s.value, p.value
+
+
+def policy_forward(w1, b1, w2, b2, wa, ba, wv, bv, log_std, obs, eps):
+    """float64 numpy restatement of SB3 1.0 ActorCriticPolicy.forward for the reference's CustomActorCriticPolicy
+    (/root/reference/drloco/custom/policies.py:13-51: one tanh trunk shared by policy_net and value_net;
+    action_net / value_net heads; DiagGaussianDistribution sample + log_prob).  Returns (latent, actions, values, log_probs)."""
+    f = lambda a: np.asarray(a, np.float64)
+    h = np.tanh(f(obs) @ f(w1).T + f(b1))
+    lat = np.tanh(h @ f(w2).T + f(b2))
+    mean = lat @ f(wa).T + f(ba)
+    val = (lat @ f(wv).T + f(bv))[:, 0]
+    e = f(eps)
+    act = mean + np.exp(f(log_std)) * e
+    logp = (-0.5 * e ** 2 - f(log_std) - 0.5 * np.log(2 * np.pi)).sum(1)
+    return lat, act, val, logp

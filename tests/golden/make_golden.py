@@ -18,6 +18,8 @@ Fixtures:
   G5_actions.npz         _rescale_actions + mirror_action
   G6_terminate_early.npz do_terminate_early truth table
   G7_monitor.npz         Monitor smoothing traces
+  G10_policy_trunk.npz   CustomHiddenLayers (drloco/custom/policies.py:13-51): weights, inputs, latent outputs
+                         (`python tests/golden/make_golden.py policy` regenerates only this one)
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -249,7 +251,35 @@ def make_loco3d_golden(mimic_env_mod, hypers, rng):
     np.savez_compressed(os.path.join(OUT, 'G9_loco3d.npz'), **g)
 
 
+def make_policy_golden():
+    """CustomHiddenLayers of the reference with a small hidden size (the fixture stays a few KB): the trunk that
+    policy_net and value_net SHARE (both Sequentials are built from the same layer objects, policies.py:33-41)."""
+    _install_stubs()
+    sys.modules['stable_baselines3.common.policies'] = _StubModule('stable_baselines3.common.policies')
+    sys.path.insert(0, REF)
+    import torch as th
+    from drloco.config import hypers
+    hypers.hid_layer_sizes = [64, 64]
+    hypers.activation_fns = [th.nn.Tanh] * 2
+    from drloco.custom import policies
+    th.manual_seed(0)
+    net = policies.CustomHiddenLayers(29)
+    assert net.policy_net[0] is net.value_net[0] and net.policy_net[2] is net.value_net[2]       # shared parameters
+    x = th.randn(37, 29)
+    with th.no_grad():
+        lat_pi, lat_vf = net(x)
+    assert th.equal(lat_pi, lat_vf)
+    np.savez_compressed(os.path.join(OUT, 'G10_policy_trunk.npz'), x=x.numpy(), latent=lat_pi.numpy(),
+                        w1=net.policy_net[0].weight.detach().numpy(), b1=net.policy_net[0].bias.detach().numpy(),
+                        w2=net.policy_net[2].weight.detach().numpy(), b2=net.policy_net[2].bias.detach().numpy(),
+                        shared=np.array(1), latent_dim_pi=np.array(net.latent_dim_pi), latent_dim_vf=np.array(net.latent_dim_vf))
+    print('G10_policy_trunk.npz written')
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'policy':
+        make_policy_golden()
+        return
     refs_mod, walker_mod, monitor_mod, utils, hypers, MujocoException = _import_reference()
     import drloco.mujoco.mimic_env as mimic_env_mod
     mimic_env_mod.pause_mujoco_viewer_on_start = False

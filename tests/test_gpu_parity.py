@@ -606,3 +606,68 @@ def test_G9_loco3d_trace_on_device(torch_cuda):
         st = env.get_state()
         assert st['cursor'][abi.DL_CUR_POS, 0] == g['s_pos'][t]
         np.testing.assert_allclose(st['walked'][0], g['s_walked'][t], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# policy forward: fused MFMA kernel behind dl_policy_forward
+def test_policy_forward_matches_reference_trunk(torch_cuda, oracle):
+    """Golden G10 (the reference's own CustomHiddenLayers): the latent is read out through one-hot action heads."""
+    import torch
+    from drloco_amd.policy import HipPolicy
+    with np.load(os.path.join(GOLDEN, 'G10_policy_trunk.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32), device='cuda')
+    pol = HipPolicy(obs_dim=29, act_dim=8, hidden=64)
+    x = t(g['x'])
+    for chunk in range(8):
+        wa = np.zeros((8, 64), np.float32); wa[np.arange(8), chunk * 8 + np.arange(8)] = 1
+        wv = np.zeros((1, 64), np.float32); wv[0, chunk] = 1
+        pol.load_state(t(g['w1']), t(g['b1']), t(g['w2']), t(g['b2']), t(wa), t(np.zeros(8)), t(wv), t(np.zeros(1)), t(np.full(8, -0.75)))
+        a, v, lp = pol.forward(x, deterministic=True)
+        np.testing.assert_allclose(a.cpu().numpy(), g['latent'][:, chunk * 8:chunk * 8 + 8], atol=3e-6)
+        np.testing.assert_allclose(v.cpu().numpy(), g['latent'][:, chunk], atol=3e-6)
+
+
+@pytest.mark.parametrize('n,hidden', [(4096, 512), (1000, 512), (37, 256), (1, 64)])
+def test_policy_forward_matches_float64(torch_cuda, oracle, n, hidden):
+    import torch
+    from drloco_amd.policy import HipPolicy
+    pol = HipPolicy(obs_dim=29, act_dim=8, hidden=hidden, seed=n)
+    gen = torch.Generator(device='cuda'); gen.manual_seed(n)
+    obs = torch.clamp(torch.randn(n, 29, device='cuda', generator=gen) * 2, -10, 10)
+    eps = torch.randn(n, 8, device='cuda', generator=gen)
+    a, v, lp = pol.forward(obs, eps=eps)
+    c = lambda x: x.cpu().numpy()
+    _, a0, v0, lp0 = oracle.policy_forward(c(pol.w1), c(pol.b1), c(pol.w2), c(pol.b2), c(pol.wa), c(pol.ba), c(pol.wv), c(pol.bv), c(pol.log_std), c(obs), c(eps))
+    np.testing.assert_allclose(c(a), a0, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(c(v), v0, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(c(lp), lp0, atol=2e-5, rtol=1e-5)
+    a2, v2, lp2 = pol.torch_reference(obs, eps)
+    np.testing.assert_allclose(c(a), c(a2), atol=2e-5, rtol=1e-5)
+
+
+def test_policy_sampling_stream(torch_cuda):
+    """eps = NULL: counter-based Gaussian stream -- standard normal, reproducible, invariant to sharding."""
+    import torch
+    from drloco_amd.policy import HipPolicy
+    n = 4096
+    pol = HipPolicy(hidden=128, seed=7)
+    obs = torch.randn(n, 29, device='cuda')
+    mean, _, _ = pol.forward(obs, deterministic=True)
+    pol.counter = 5
+    a, v, lp = pol.forward(obs)
+    z = ((a - mean) / torch.exp(pol.log_std)).cpu().numpy()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 3).mean()) < 0.05 and np.abs(z).max() < 6
+    np.testing.assert_allclose(lp.cpu().numpy(), (-0.5 * z ** 2 + 0.75 - 0.5 * np.log(2 * np.pi)).sum(1), atol=1e-3)
+    pol.counter = 5
+    a2, _, _ = pol.forward(obs)
+    assert torch.equal(a, a2)                                   # same (seed, counter) -> same draws
+    a3, _, _ = pol.forward(obs)
+    assert not torch.equal(a, a3)                               # the counter advanced
+    shard = HipPolicy(hidden=128, seed=7, index_base=1024)
+    shard.load_state(pol.w1, pol.b1, pol.w2, pol.b2, pol.wa, pol.ba, pol.wv, pol.bv, pol.log_std)
+    shard.counter = 5
+    a4, _, _ = shard.forward(obs[1024:2048].contiguous())
+    assert torch.equal(a4, a[1024:2048])
+    with pytest.raises(Exception):
+        HipPolicy(hidden=100).forward(obs)                      # hidden must be a multiple of 64

@@ -287,3 +287,16 @@ def test_G9_loco3d_step_trace(oracle):
         assert abs(rew[0] - g['s_rew'][t]) <= 5e-16 * abs(g['s_rew'][t])
         st = env.get_state()
         assert st['cursor'][abi.DL_CUR_POS, 0] == g['s_pos'][t] and st['walked'][0] == g['s_walked'][t]
+
+
+def test_G10_policy_trunk(oracle):
+    """The numpy restatement of the policy forward reproduces the reference's CustomHiddenLayers (shared trunk)."""
+    with np.load(os.path.join(GOLDEN, 'G10_policy_trunk.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    assert int(g['shared']) == 1 and int(g['latent_dim_pi']) == 64
+    A = 8
+    wa = np.zeros((A, 64)); wv = np.zeros((1, 64))
+    lat, act, val, logp = oracle.policy_forward(g['w1'], g['b1'], g['w2'], g['b2'], wa, np.zeros(A), wv, np.zeros(1), np.full(A, -0.75),
+                                                g['x'], np.zeros((len(g['x']), A)))
+    np.testing.assert_allclose(lat, g['latent'], atol=2e-6)          # torch float32 vs numpy float64
+    assert np.allclose(logp, A * (0.75 - 0.5 * np.log(2 * np.pi)))
