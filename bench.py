@@ -76,8 +76,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
 
@@ -115,7 +117,7 @@ def main():
         buf.normalize_advantages()                   # all-reduce of [sum, sum^2, n] when world > 1
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,7 +133,7 @@ def main():
     tot_ms, launches = C.c_double(), C.c_int32()
     lib.check(venv._lib.dl_profile_read(venv._h, C.byref(tot_ms), C.byref(launches)))
     lib.check(venv._lib.dl_profile(venv._h, 0))
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -163,7 +165,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(256, 512)       # ~12 s of CPU work on one host core
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,17 +1,19 @@
-// dl_group.hpp -- "16 lanes per walker" formulation of the forward dynamics (device only).
+// dl_group.hpp -- "16 lanes per walker" formulation of the forward dynamics (device only): the product path.
 //
 // The lane-per-walker kernels (dl_core.hpp) leave 15/16 of the chip idle at the benchmark size
 // (4096 walkers = 64 waves on 1024 SIMDs) and their run time is the serial instruction stream of
-// one walker.  Here a walker is spread over a 16-lane DPP row: lane j owns degree of freedom j
-// (and, for j < 8, body j; for the solver also constraint rows j, j+16, ...), four walkers share a
-// wave, 4096 walkers are 1024 waves -- one per SIMD.  Communication inside a walker:
-//   * LDS, laid out so that the 16 lanes of a row hit 16 different banks ([field][16]);
-//   * DPP row rotations for all-reduce sums and broadcasts (full-rate VALU, no LDS round trip);
-//   * a workgroup is one wave, so __syncthreads() is only an LDS wait + compiler fence.
-// The kinematic tree is DATA here (chain tables in GModel), not a compile-time constant.
+// one walker.  Here a walker is spread over a 16-lane DPP row: lane j owns degree of freedom j (and the
+// body whose last dof it is, the collision candidates j and j + 16, contact j, its own limit row), four
+// walkers share a wave, 4096 walkers are 1024 waves -- one per SIMD.  At one wave per SIMD nothing hides
+// latency, so the design goal is few instructions and few dependent round trips:
+//   * the dynamics run in registers; lanes exchange data through DPP (row_newbcast broadcasts, row_shr /
+//     row_shl segmented scans over the dof tree, row_ror sums), mostly folded into v_fmac_f32_dpp;
+//   * LDS holds only what is indexed dynamically (contacts, constraint rows, contact Jacobians, body frames
+//     for the collision stage), in 16-byte groups; a workgroup is one wave, so LDS needs no barrier;
+//   * the kinematic tree is a compile-time constant (GTopo<TopoStraight>), all numeric parameters are data.
 //
-// Arithmetic and results follow dl_core.hpp (same model, same solver phases); parity tests compare
-// both device paths with the CPU oracle.
+// Results follow dl_core.hpp / the CPU restatement (same model, same minimiser); the parity tests run both device
+// paths against the CPU oracle.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,7 +24,6 @@ namespace dl {
 
 constexpr int GL = 16;          // lanes per walker
 constexpr int GW = 4;           // walkers per wave
-constexpr int G_MAXCHAIN = 12;  // longest root->dof chain
 constexpr int G_MAXB = 8;       // bodies incl. world
 constexpr int G_MAXCAND = 32;   // collision candidate points
 constexpr int G_MAXCON = 20;    // >= 18
@@ -32,13 +33,10 @@ constexpr int G_MAXROW = 80;
 template <typename T> struct GModel {
     int32_t nv, nb, nu, ngeom, nsite, frame_skip, iterations, ls_iterations, ncand, root_last_dof;
     T timestep, gravity_z, solK, solB, solimp[5], solimp_inv[3], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, root_z0;
-    int32_t dof_body[GL], dof_type[GL], dof_axis[GL], dof_first[GL], dof_limited[GL], dof_depth[GL], dof_is_last[GL];
-    int32_t chain[GL][G_MAXCHAIN];
+    int32_t dof_body[GL], dof_type[GL], dof_axis[GL], dof_limited[GL];
     T dof_sign[GL], qpos0[GL], range_lo[GL], range_hi[GL], damping[GL], armature[GL], dof_invw[GL];
     int32_t dof_act[GL];                       // actuator index driving this dof, or -1
     T ctrl_lo[GL], ctrl_hi[GL], force_lo[GL], force_hi[GL], gear[GL];   // indexed by dof
-    int32_t body_last_dof[G_MAXB];
-    uint32_t body_submask[G_MAXB];             // bodies in the subtree of b (incl. b)
     T body_pos[G_MAXB][3], body_mass[G_MAXB], body_ipos[G_MAXB][3], body_inertia[G_MAXB][3], body_invw[G_MAXB];
     int32_t cand_geom[G_MAXCAND], cand_sub[G_MAXCAND];
     int32_t geom_body[G_MAXB], geom_type[G_MAXB];
@@ -66,32 +64,20 @@ struct GLds {
     static_assert(CON % 4 == 0 && ROW % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && G_MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
 };
 
-// model data needed with per-lane (non-uniform) indices inside the inner loops is staged once per
-// kernel in LDS (shared by the 4 walkers of the wave); everything a lane needs about ITS OWN dof /
-// body / collision candidates is preloaded into registers (GLane).  No vector-memory table lookups
-// remain on the critical path.
+// model data that is indexed dynamically inside the loops (by the body of a contact) is staged once per kernel in
+// LDS, shared by the 4 walkers of the wave; everything a lane needs about ITS OWN dof / body / collision
+// candidates is preloaded into registers (GLane), uniform scalars are pinned in VGPRs (GConst).
 struct GShared {
-    // int region
-    static constexpr int I_PROPS = 0;                 // [16] bit0 type, 1-2 axis, 3 negative axis, 4 first dof of body, 5-7 body, 8-11 depth, 12 last dof of body
-    static constexpr int I_CHAIN_LO = 16, I_CHAIN_HI = 32;   // [16] packed chains: nibble d = d-th dof on the root->dof path
-    static constexpr int I_BODY_LAST = 48;            // [8]
-    static constexpr int I_CAND = 56;                 // [32] bit0 valid, 1 type (box), 2-4 sub, 5-7 body
-    static constexpr int I_END = 88;
-    // T region (offsets in T elements, after the int region)
-    static constexpr int T_QPOS0 = 0;                 // [16]
-    static constexpr int T_BODY_POS = 16;             // [8][3]
-    static constexpr int T_BODY_INVW = 40;            // [8]
-    static constexpr int T_END = 48;
-    template <typename T> static constexpr int bytes() { return ((I_END * 4 + T_END * (int)sizeof(T) + 255) / 256) * 256; }
+    static constexpr int T_BODY_INVW = 0;             // [8]
+    static constexpr int T_END = 8;
+    template <typename T> static constexpr int bytes() { return ((T_END * (int)sizeof(T) + 255) / 256) * 256; }
 };
 
 template <typename T> struct GLane {
-    int type, axis, first, body, depth, is_last, limited, act;
+    int type, axis, body, limited, act;
     T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
-    uint64_t chain;                                   // own chain, nibble-packed
     // inertial parameters of the body of this dof
     T mass, ipos[3], inertia[3];
-    uint32_t submask;
     // the two collision candidates of this lane (capsule end points / box corners in contact order, c = j and j + 16)
     // as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
     // to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
@@ -102,16 +88,12 @@ template <typename T> struct GLane {
 template <typename T>
 __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, GLane<T>& ln) {
     const int jj = j < m.nv ? j : 0;
-    ln.type = m.dof_type[jj]; ln.axis = m.dof_axis[jj]; ln.first = m.dof_first[jj]; ln.body = m.dof_body[jj]; ln.depth = m.dof_depth[jj];
-    ln.is_last = m.dof_is_last[jj]; ln.limited = m.dof_limited[jj]; ln.act = m.dof_act[jj];
+    ln.type = m.dof_type[jj]; ln.axis = m.dof_axis[jj]; ln.body = m.dof_body[jj]; ln.limited = m.dof_limited[jj]; ln.act = m.dof_act[jj];
     ln.sign = m.dof_sign[jj]; ln.qpos0 = m.qpos0[jj]; ln.range_lo = m.range_lo[jj]; ln.range_hi = m.range_hi[jj];
     ln.damping = m.damping[jj]; ln.armature = m.armature[jj]; ln.invw = m.dof_invw[jj];
     ln.ctrl_lo = m.ctrl_lo[jj]; ln.ctrl_hi = m.ctrl_hi[jj]; ln.force_lo = m.force_lo[jj]; ln.force_hi = m.force_hi[jj]; ln.gear = m.gear[jj];
-    uint64_t ch = 0;
-    for (int d = 0; d < G_MAXCHAIN; d++) ch |= (uint64_t)(m.chain[jj][d] & 15) << (4 * d);
-    ln.chain = ch;
     const int b = ln.body;                            // inertial parameters of the body this dof belongs to
-    ln.mass = m.body_mass[b]; ln.submask = m.body_submask[b];
+    ln.mass = m.body_mass[b];
     for (int k = 0; k < 3; k++) { ln.ipos[k] = m.body_ipos[b][k]; ln.inertia[k] = m.body_inertia[b][k]; }
     for (int pass = 0; pass < 2; pass++) {
         const int c = j + GL * pass;
@@ -137,24 +119,10 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
     }
 }
 
-// fill the shared model block (all 64 lanes of the wave cooperate); call once, then __syncthreads()
+// fill the shared model block; call once, then __syncthreads()
 template <typename T>
-__device__ __forceinline__ void g_fill_shared(const DL_CONST GModel<T>& m, DL_LDS int* si, DL_LDS T* stt, int lane) {
-    if (lane < GL) {
-        const int a = lane < m.nv ? lane : 0;
-        si[GShared::I_PROPS + lane] = m.dof_type[a] | (m.dof_axis[a] << 1) | ((m.dof_sign[a] < T(0)) ? 8 : 0) | (m.dof_first[a] << 4) | (m.dof_body[a] << 5) |
-                                      (m.dof_depth[a] << 8) | (m.dof_is_last[a] << 12);
-        uint64_t ch = 0;
-        for (int d = 0; d < G_MAXCHAIN; d++) ch |= (uint64_t)(m.chain[a][d] & 15) << (4 * d);
-        si[GShared::I_CHAIN_LO + lane] = (int)(uint32_t)ch;
-        si[GShared::I_CHAIN_HI + lane] = (int)(uint32_t)(ch >> 32);
-        stt[GShared::T_QPOS0 + lane] = m.qpos0[a];
-    } else if (lane < GL + G_MAXB) {
-        const int b = lane - GL;
-        si[GShared::I_BODY_LAST + b] = m.body_last_dof[b];
-        stt[GShared::T_BODY_INVW + b] = m.body_invw[b];
-        for (int k = 0; k < 3; k++) stt[GShared::T_BODY_POS + 3 * b + k] = m.body_pos[b][k];
-    }
+__device__ __forceinline__ void g_fill_shared(const DL_CONST GModel<T>& m, DL_LDS T* stt, int lane) {
+    if (lane < G_MAXB) stt[GShared::T_BODY_INVW + lane] = m.body_invw[lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -235,13 +203,10 @@ template <typename T> struct GCtx {
     DL_LDS T* wb;                        // walker's LDS region
     const DL_CONST GModel<T>* m;         // uniform scalars only on the hot path
     int j;                               // lane in the row
-    DL_LDS int* si;                      // shared model block (ints)
-    DL_LDS T* st;                        // shared model block (reals)
+    DL_LDS T* st;                        // shared model block
     const GLane<T>* ln;                  // this lane's preloaded model data
     const GConst<T>* c;                  // pinned uniform scalars
 };
-__device__ __forceinline__ int chain_at(uint64_t ch, int d) { return (int)((ch >> (4 * d)) & 15u); }
-
 template <typename T> __device__ __forceinline__ V3<T> ld3(DL_LDS T* p, int stride) { return {p[0], p[stride], p[2 * stride]}; }
 // four consecutive, 16-byte aligned LDS words as one ds_read_b128 / ds_write_b128 (float); plain accesses for double
 template <typename T> struct Q4 { T a, b, c, d; };
@@ -257,14 +222,6 @@ __device__ __forceinline__ void st4(DL_LDS float* p, float a, float b, float c, 
 }
 __device__ __forceinline__ Q4<double> ld4(const DL_LDS double* p) { return {p[0], p[1], p[2], p[3]}; }
 __device__ __forceinline__ void st4(DL_LDS double* p, double a, double b, double c, double d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
-
-// rotate the frame (X,Y,Z) about its own coordinate axis `idx` by the angle with (s, c)
-template <typename T> __device__ __forceinline__ void rot_axis(V3<T>& X, V3<T>& Y, V3<T>& Z, int idx, T s, T c) {
-    const V3<T> A = idx == 0 ? Y : (idx == 1 ? Z : X);
-    const V3<T> B = idx == 0 ? Z : (idx == 1 ? X : Y);
-    const V3<T> A2 = c * A + s * B, B2 = c * B - s * A;
-    if (idx == 0) { Y = A2; Z = B2; } else if (idx == 1) { Z = A2; X = B2; } else { X = A2; Y = B2; }
-}
 
 // value of lane K of the row in every lane: ONE DPP instruction (row_newbcast:K, gfx90a+), usually folded
 // into the consuming VALU instruction

@@ -132,40 +132,18 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
     for (int b = 0; b < d.nbody; b++) {
         for (int k = 0; k < 3; k++) { g.body_pos[b][k] = (T)d.body_pos[b][k]; g.body_ipos[b][k] = (T)d.body_ipos[b][k]; g.body_inertia[b][k] = (T)d.body_inertia[b][k]; }
         g.body_mass[b] = (T)d.body_mass[b]; g.body_invw[b] = (T)d.body_invweight0[b][0];
-        g.body_last_dof[b] = -1;
-        uint32_t sub = 0;
-        for (int c = 1; c < d.nbody; c++) { int a = c; while (a > 0 && a != b) a = d.body_parent[a]; if (a == b && b > 0) sub |= 1u << c; }
-        g.body_submask[b] = sub;
     }
-    // dofs: parent dof = previous dof of the same body, else last dof of the nearest ancestor body that has dofs
-    int dof_parent[GL];
     for (int j = 0; j < d.nv; j++) {
-        const int b = d.jnt_body[j];
-        g.dof_body[j] = b; g.dof_type[j] = d.jnt_type[j]; g.dof_limited[j] = d.jnt_limited[j];
+        g.dof_body[j] = d.jnt_body[j]; g.dof_type[j] = d.jnt_type[j]; g.dof_limited[j] = d.jnt_limited[j];
         int ax = -1; double sg = 0;
         for (int k = 0; k < 3; k++) if (std::fabs(d.jnt_axis[j][k]) > 0.5) { ax = k; sg = d.jnt_axis[j][k] > 0 ? 1 : -1; }
         g.dof_axis[j] = ax; g.dof_sign[j] = (T)sg;
         g.qpos0[j] = (T)d.jnt_qpos0[j]; g.range_lo[j] = (T)d.jnt_range[j][0]; g.range_hi[j] = (T)d.jnt_range[j][1];
         g.damping[j] = (T)d.jnt_damping[j]; g.armature[j] = (T)d.jnt_armature[j]; g.dof_invw[j] = (T)d.dof_invweight0[j];
-        g.dof_first[j] = (j == 0 || d.jnt_body[j - 1] != b) ? 1 : 0;
-        g.dof_is_last[j] = (j == d.nv - 1 || d.jnt_body[j + 1] != b) ? 1 : 0;
-        if (g.dof_is_last[j]) g.body_last_dof[b] = j;
         g.dof_act[j] = -1;
-        if (!g.dof_first[j]) dof_parent[j] = j - 1;
-        else {
-            int a = d.body_parent[b], p = -1;
-            while (a > 0 && p < 0) { for (int k = d.nv - 1; k >= 0; k--) if (d.jnt_body[k] == a) { p = k; break; } a = d.body_parent[a]; }
-            dof_parent[j] = p;
-        }
     }
-    for (int j = 0; j < d.nv; j++) {
-        int tmp[G_MAXCHAIN], n = 0, a = j;
-        while (a >= 0) { if (n >= G_MAXCHAIN) { why = "kinematic chain too long for the 16-lane kernels"; return false; } tmp[n++] = a; a = dof_parent[a]; }
-        g.dof_depth[j] = n - 1;
-        for (int k = 0; k < n; k++) g.chain[j][k] = tmp[n - 1 - k];
-    }
-    g.root_last_dof = g.body_last_dof[1];
-    for (int b = 1; b < d.nbody; b++) if (g.body_last_dof[b] < 0) { why = "every body needs at least one joint"; return false; }
+    g.root_last_dof = -1;
+    for (int j = 0; j < d.nv; j++) if (d.jnt_body[j] == 1) g.root_last_dof = j;
     for (int a = 0; a < d.nu; a++) {
         const int j = d.act_dof[a];
         g.dof_act[j] = a;

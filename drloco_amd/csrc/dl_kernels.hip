@@ -89,15 +89,14 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     const bool valid = w < n;
     const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    DL_LDS int* si = (DL_LDS int*)smem;
-    DL_LDS T* stt = (DL_LDS T*)(smem + GShared::I_END * 4);
-    g_fill_shared<T>(*m, si, stt, lane);
+    DL_LDS T* stt = (DL_LDS T*)smem;
+    g_fill_shared<T>(*m, stt, lane);
     GLane<T> ln;
     g_load_lane<T>(*m, j, ln);
     __syncthreads();
     GConst<T> cst;
     g_load_const<T>(*m, cst);
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln, &cst};
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst};
     const int nv = m->nv;
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < nv) {
@@ -136,15 +135,14 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     const bool valid = w0 < n;
     const int w = valid ? w0 : n - 1;
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    DL_LDS int* si = (DL_LDS int*)smem;
-    DL_LDS T* stt = (DL_LDS T*)(smem + GShared::I_END * 4);
-    g_fill_shared<T>(*m, si, stt, lane);
+    DL_LDS T* stt = (DL_LDS T*)smem;
+    g_fill_shared<T>(*m, stt, lane);
     GLane<T> ln;
     g_load_lane<T>(*m, j, ln);
     __syncthreads();
     GConst<T> cst;
     g_load_const<T>(*m, cst);
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, si, stt, &ln, &cst};
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst};
     DL_LDS T* wb = g.wb;
     const int nv = m->nv, nu = m->nu;
     const bool isdof = j < nv;
