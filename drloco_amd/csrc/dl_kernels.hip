@@ -337,6 +337,22 @@ template <typename T> __global__ void k_copy_cast(T* dst, const double* src, siz
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (T)src[i];
 }
+// MimicEnv.do_terminate_early (mimic_env.py:652-702; straight walker, 3 trunk joints) for every walker:
+// flags[i] = {any, COM height < 0.75, trunk angle (sagittal outside [-0.05, 0.3] or frontal deviation from the reference > 0.2), |COM y| > 0.2}
+template <typename T>
+__global__ void k_terminate_early(const DevCfg<T> c, const DevState<T> st, int32_t* flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = st.n;
+    if (i >= n) return;
+    int32_t cur[DL_CUR_WORDS];
+#pragma unroll
+    for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + i];
+    const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
+    const T q1 = st.qpos[(size_t)1 * n + i], q2 = st.qpos[(size_t)2 * n + i], q3 = st.qpos[(size_t)3 * n + i], q4 = st.qpos[(size_t)4 * n + i];
+    const bool low = q2 < T(0.75), drunk = dl_abs(q1) > T(0.2);
+    const bool front = dl_abs(q3 - ref_at(c, 3, base)) > T(0.2), sag = q4 > T(0.3) || q4 < T(-0.05);
+    const bool trunk = sag || front;
+    flags[4 * (size_t)i] = low || trunk || drunk; flags[4 * (size_t)i + 1] = low; flags[4 * (size_t)i + 2] = trunk; flags[4 * (size_t)i + 3] = drunk;
+}
 __global__ void k_mon_snapshot(const double* mon, int word, double* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = mon[(size_t)word * n + i];
@@ -532,6 +548,7 @@ struct dl_env_s {
     virtual int set_state(const void*, const void*, const void*, const int32_t*, const double*, hipStream_t) = 0;
     virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
+    virtual int terminate_early(int32_t* flags, hipStream_t) = 0;
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
@@ -719,6 +736,13 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
+    int terminate_early(int32_t* flags, hipStream_t s) override {
+        if (!flags) return fail(DL_E_INVAL, "dl_terminate_early: flags must not be NULL");
+        if (TP::ENV_KIND != 0) return fail(DL_E_INVAL, "dl_terminate_early: defined for the straight walker only (mimic_env.py:654)");
+        hipLaunchKernelGGL((k_terminate_early<T>), dim3((n + 255) / 256), dim3(256), 0, s, c, st, flags);
+        HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
     int snapshot(int word, double* out, hipStream_t s) override {
         hipLaunchKernelGGL(k_mon_snapshot, dim3((n + 255) / 256), dim3(256), 0, s, (const double*)st.mon, word, out, n);
         HIPCHK(hipGetLastError());
@@ -874,6 +898,10 @@ int dl_debug_selftest(const float* in, float* out, void* stream) {
 int dl_debug_capstate(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->capstate(out, (hipStream_t)stream);
+}
+int dl_terminate_early(dl_handle h, int32_t* flags, void* stream) {
+    NEED(h);
+    return h->terminate_early(flags, (hipStream_t)stream);
 }
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) {
     NEED(h);

@@ -173,6 +173,8 @@ class HipVecEnv:
             return [None] * self.num_envs
         if method_name == 'get_walked_distance':
             return list(self.get_walked_distance())
+        if method_name == 'do_terminate_early':
+            return [tuple(r) for r in self.do_terminate_early()]
         raise NotImplementedError(method_name)
 
     # ---- MimicEnv surface used by the evaluation loop (drloco/common/callback.py:285-314) ----
@@ -183,6 +185,13 @@ class HipVecEnv:
 
     def is_evaluation_on(self):
         return getattr(self, '_eval', False)
+
+    def do_terminate_early(self):
+        """MimicEnv.do_terminate_early (mimic_env.py:652-702) for all walkers: bool [N, 4] =
+        (terminate_early, com_height_too_low, trunk_ang_exceeded, is_drunk)."""
+        flags = torch.empty(self.num_envs, 4, dtype=torch.int32, device=self.device)
+        lib.check(self._lib.dl_terminate_early(self._h, _ptr(flags), _stream()))
+        return flags.cpu().numpy().astype(bool)
 
     def get_walked_distance(self):
         walked = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)

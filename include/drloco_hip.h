@@ -214,6 +214,11 @@ int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qa
 int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc,
                int32_t* niter, void* stream);
 
+/* MimicEnv.do_terminate_early (mimic_env.py:652-702; the reference defines it but its call in step() is commented
+ * out, :113-118) at the current state of every walker: flags int32[N, 4] device =
+ * {terminate, COM height too low (< 0.75), trunk angle exceeded, |COM y| > 0.2}.  Straight walker only. */
+int dl_terminate_early(dl_handle h, int32_t* flags, void* stream);
+
 /* Monitor attributes (drloco/mujoco/monitor_wrapper.py:88-133) kept per walker on device.
  * name: one of ep_len_smoothed, ep_ret_smoothed, mean_reward_smoothed, moved_distance,
  * mean_ep_pos_rew_smoothed, mean_ep_vel_rew_smoothed, mean_ep_com_rew_smoothed,

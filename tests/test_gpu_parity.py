@@ -496,6 +496,34 @@ def test_vecnormalize_save_load_and_attrs(torch_cuda, model, refs, tmp_path):
     assert vn.normalize_obs(vn.get_original_obs()).shape == (96, 29)
 
 
+def test_terminate_early_on_device(torch_cuda, oracle, model, refs):
+    """MimicEnv.do_terminate_early for every walker: golden G6 states (the reference's own truth table) and
+    random states against the oracle."""
+    from drloco_amd.vec_env import HipVecEnv
+    with np.load(os.path.join(GOLDEN, 'G6_terminate_early.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    K = len(g['flags'])
+    for precision in (32, 64):
+        env = HipVecEnv(num_envs=K, precision=precision, model=model, refs=refs)
+        cur = np.zeros((abi.DL_CUR_WORDS, K), np.int32)
+        cur[abi.DL_CUR_I_STEP] = cur[abi.DL_CUR_RSI_STEP] = cur[abi.DL_CUR_READ_STEP] = g['i_step']
+        cur[abi.DL_CUR_POS] = g['pos']; cur[abi.DL_CUR_COUNT] = 1
+        env.set_state(qpos=g['qpos'].T, qvel=np.zeros((14, K)), cursor=cur)
+        assert np.array_equal(env.do_terminate_early(), g['flags'].astype(bool))
+    n = 512
+    dev, orc = make_pair(oracle, model, refs, n, 64)
+    dev.reset(); orc.reset()
+    rng = np.random.default_rng(4)
+    st = orc.get_state()
+    st['qpos'][1] += 0.15 * rng.standard_normal(n); st['qpos'][2] -= 0.3 * rng.random(n)
+    st['qpos'][3] += 0.15 * rng.standard_normal(n); st['qpos'][4] += 0.2 * rng.standard_normal(n)
+    for e in (dev, orc):
+        e.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=st['warm'], cursor=st['cursor'], walked=st['walked'])
+    want = np.array([orc.terminate_early(i) for i in range(n)]).astype(bool)
+    got = dev.do_terminate_early()
+    assert np.array_equal(got, want) and want[:, 1].any() and want[:, 2].any() and want[:, 3].any() and not want[:, 0].all()
+
+
 @LANES
 def test_evaluation_mode_matches_oracle(torch_cuda, oracle, model, refs, lanes):
     """activate_evaluation -> deterministic init states (quirk Q3), through the eval-loop surface."""
