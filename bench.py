@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--rollout-len', type=int, default=512)
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
+    ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -96,6 +97,16 @@ def main():
     vn.reset()
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = torch.ones(n, dtype=torch.uint8, device=dev)
+    push_phase = push_force = None
+    if args.randomize:
+        import numpy as np
+        gidx = np.arange(rank * n, (rank + 1) * n)
+        u = lambda salt: np.array([np.random.default_rng((int(i), salt)).random() for i in gidx])     # seed = global walker index
+        venv.set_randomization(0.8 + 0.4 * u(1), 0.5 + 0.6 * u(2))
+        ang = 2 * np.pi * u(3)
+        push_force = torch.as_tensor(np.stack([50 * np.cos(ang), 50 * np.sin(ang), 0 * ang], 1), dtype=torch.float32, device=dev)
+        push_phase = torch.as_tensor((400 * u(4)).astype(np.int64), device=dev)
+        step_counter = [0]
     policy = None
     if args.policy:
         from drloco_amd.policy import HipPolicy
@@ -109,6 +120,10 @@ def main():
         buf.episode_starts[0].copy_(last_done)
         for t in range(T):
             nxt = t + 1 < T
+            if push_force is not None:  # 0.1 s = 20 control steps of push every 2 s = 400 control steps
+                on = ((step_counter[0] + push_phase) % 400 < 20).to(torch.float32).unsqueeze(1)
+                lib.check(venv._lib.dl_set_push(venv._h, C.c_void_p((push_force * on).contiguous().data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                step_counter[0] += 1
             if policy is not None:      # collect_rollouts: actions, values, log_probs = policy.forward(obs) -> straight into the buffer
                 policy.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
             vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t],
@@ -156,7 +171,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'straight_walking 3D walker, {n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
-                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated'},
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated',
+                       'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,

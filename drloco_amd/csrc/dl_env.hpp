@@ -33,6 +33,7 @@ template <typename T> struct DevState {
     int32_t* inj_rsi;        // [2][N]: injected RSI draw for all later resets (step < 0: none); test hook
     T* work;                 // [4*NV][N] staging of the RK4 bookkeeping
     int32_t n;
+    T* rnd;                  // [5][N] or NULL: per-walker mass scale, floor friction, push force on the torso (x, y, z)
     float* dbgf;             // [3*16][N] or NULL: stage input (q, v, warmstart) of the last evaluation that hit the iteration cap
     int32_t* dbg;            // [4][N] or NULL: solver diagnostics of the 16-lane step kernel (sum iters, max iters, sum rows, diverged)
 };

@@ -40,7 +40,7 @@ template <typename T> struct GModel {
     T body_pos[G_MAXB][3], body_mass[G_MAXB], body_ipos[G_MAXB][3], body_inertia[G_MAXB][3], body_invw[G_MAXB];
     int32_t cand_geom[G_MAXCAND], cand_sub[G_MAXCAND];
     int32_t geom_body[G_MAXB], geom_type[G_MAXB];
-    T geom_pos[G_MAXB][3], geom_mat[G_MAXB][9], geom_size[G_MAXB][3], geom_mu[G_MAXB];
+    T geom_pos[G_MAXB][3], geom_mat[G_MAXB][9], geom_size[G_MAXB][3], geom_friction[G_MAXB], floor_friction;
     int32_t site_body[8];
     T site_pos[8][3];
 };
@@ -115,7 +115,7 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
             ln.crad[pass] = m.geom_size[ge][0];
         }
         for (int k = 0; k < 3; k++) ln.cpl[pass][k] = m.geom_pos[ge][k] + rel[k];
-        ln.cmu[pass] = m.geom_mu[ge];
+        ln.cmu[pass] = m.geom_friction[ge];          // the contact uses max(geom, floor) with the walker's floor friction
     }
 }
 
@@ -199,6 +199,11 @@ __device__ __forceinline__ void g_load_const(const DL_CONST GModel<T>& m, GConst
     g_pin(c.ls_reltol); g_pin(c.tol_rel); g_pin(c.nvf); g_pin(c.scale); g_pin(c.iterations); g_pin(c.ls_iterations);
 }
 
+// build-defined dynamics randomisation of one walker (the reference's dynamics_randomization is a stub,
+// drloco/mujoco/mimic_env.py:492-524; BASELINE config 5): scale of all body masses / inertias, sliding friction of
+// the floor, world-frame push force at the torso's centre of mass ([3P] xfrc_applied)
+template <typename T> struct GWalk { T mscale, floor_mu; V3<T> push; bool pushed; };
+
 template <typename T> struct GCtx {
     DL_LDS T* wb;                        // walker's LDS region
     const DL_CONST GModel<T>* m;         // uniform scalars only on the hot path
@@ -206,6 +211,7 @@ template <typename T> struct GCtx {
     DL_LDS T* st;                        // shared model block
     const GLane<T>* ln;                  // this lane's preloaded model data
     const GConst<T>* c;                  // pinned uniform scalars
+    const GWalk<T>* wk;                  // this walker's randomisation
 };
 template <typename T> __device__ __forceinline__ V3<T> ld3(DL_LDS T* p, int stride) { return {p[0], p[stride], p[2 * stride]}; }
 // four consecutive, 16-byte aligned LDS words as one ds_read_b128 / ds_write_b128 (float); plain accesses for double
@@ -490,11 +496,13 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     const SV<T> acc = {mk<T>(sa[0], sa[1], sa[2]), mk<T>(sa[3], sa[4], sa[5] - g.c->gravity_z)};
     // spatial inertia and inertial wrench of the body whose last dof this is (zero on the other lanes)
     SI<T> I;
+    V3<T> com;                // centre of mass of the lane's body (relative to the root origin)
     {
-        const T mass = (isdof && lt.last) ? ln.mass : T(0);
-        const T i0 = (isdof && lt.last) ? ln.inertia[0] : T(0), i1 = (isdof && lt.last) ? ln.inertia[1] : T(0), i2 = (isdof && lt.last) ? ln.inertia[2] : T(0);
+        const T ms = (isdof && lt.last) ? g.wk->mscale : T(0);
+        const T mass = ms * ln.mass, i0 = ms * ln.inertia[0], i1 = ms * ln.inertia[1], i2 = ms * ln.inertia[2];
         const V3<T>&X = k.X, &Y = k.Y, &Z = k.Z;
         const V3<T> c = k.pos + ln.ipos[0] * X + ln.ipos[1] * Y + ln.ipos[2] * Z;
+        com = c;
         const T cc = dot(c, c);
         I.m = mass; I.h = mass * c;
         I.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
@@ -533,7 +541,14 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     g_sync<T>();
 #pragma unroll
     for (int a = 0; a < GL; a++) mrow[a] = (a < NV && isdof) ? wb[Ld::MM + j * Ld::MS + a] : T(0);
-    return isdof ? -ln.damping * v - bias + ctrl_force : T(0);
+    // [3P] xfrc_applied on the torso (body 1): J^T of a world-frame force at its centre of mass
+    T push_q = T(0);
+    if (g.wk->pushed) {
+        constexpr int RL = TP::body_last_dof(1);
+        const V3<T> pc = mk<T>(rbcast<RL>(com.x), rbcast<RL>(com.y), rbcast<RL>(com.z));
+        if ((lt.bodies >> 1) & 1u) push_q = dot(S.w, cross(pc, g.wk->push)) + dot(S.v, g.wk->push);
+    }
+    return isdof ? -ln.damping * v - bias + ctrl_force + push_q : T(0);
 }
 
 // 1/x: float = v_rcp_f32 + one Newton step; double = exact division
@@ -667,7 +682,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
             const int slot = __popc(cm & ((1u << c) - 1u));
             DL_LDS T* cn = wb + Ld::CON + slot;
             cn[0] = cp[pass].x; cn[G_MAXCON] = cp[pass].y; cn[2 * G_MAXCON] = cp[pass].z;
-            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = ln.cmu[pass];
+            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = dl_max(ln.cmu[pass], g.wk->floor_mu);
             cn[6 * G_MAXCON] = cdist[pass]; cn[7 * G_MAXCON] = T((cinf[pass] >> 5) & 7);
         }
     }

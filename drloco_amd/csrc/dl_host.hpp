@@ -156,11 +156,12 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
         g.geom_body[ge] = d.geom_body[ge]; g.geom_type[ge] = d.geom_type[ge];
         for (int k = 0; k < 3; k++) { g.geom_pos[ge][k] = (T)d.geom_pos[ge][k]; g.geom_size[ge][k] = (T)d.geom_size[ge][k]; }
         for (int k = 0; k < 9; k++) g.geom_mat[ge][k] = (T)d.geom_mat[ge][k];
-        g.geom_mu[ge] = (T)(d.geom_friction[ge] > d.floor_friction ? d.geom_friction[ge] : d.floor_friction);
+        g.geom_friction[ge] = (T)d.geom_friction[ge];
         const int cnt = d.geom_type[ge] == DL_GEOM_CAPSULE ? 2 : 8;
         for (int k = 0; k < cnt; k++) { if (nc >= G_MAXCAND) { why = "too many collision candidates"; return false; } g.cand_geom[nc] = ge; g.cand_sub[nc] = k; nc++; }
     }
     g.ncand = nc;
+    g.floor_friction = (T)d.floor_friction;
     for (int s = 0; s < d.nsite; s++) { g.site_body[s] = d.site_body[s]; for (int k = 0; k < 3; k++) g.site_pos[s][k] = (T)d.site_pos[s][k]; }
     return true;
 }

@@ -96,7 +96,14 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     __syncthreads();
     GConst<T> cst;
     g_load_const<T>(*m, cst);
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst};
+    GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
+    if (st.rnd) {
+        const size_t ws = (size_t)(wi);
+        wk.mscale = st.rnd[ws]; wk.floor_mu = st.rnd[(size_t)n + ws];
+        wk.push = mk<T>(st.rnd[(size_t)2 * n + ws], st.rnd[(size_t)3 * n + ws], st.rnd[(size_t)4 * n + ws]);
+        wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
+    }
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst, &wk};
     const int nv = m->nv;
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < nv) {
@@ -142,7 +149,14 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     __syncthreads();
     GConst<T> cst;
     g_load_const<T>(*m, cst);
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst};
+    GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
+    if (st.rnd) {
+        const size_t ws = (size_t)(w);
+        wk.mscale = st.rnd[ws]; wk.floor_mu = st.rnd[(size_t)n + ws];
+        wk.push = mk<T>(st.rnd[(size_t)2 * n + ws], st.rnd[(size_t)3 * n + ws], st.rnd[(size_t)4 * n + ws]);
+        wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
+    }
+    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst, &wk};
     DL_LDS T* wb = g.wb;
     const int nv = m->nv, nu = m->nu;
     const bool isdof = j < nv;
@@ -332,6 +346,10 @@ __global__ __launch_bounds__(64) void k_selftest(const float* in, float* out) {
 template <typename T> __global__ void k_fill(T* p, T val, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = val;
+}
+template <typename T> __global__ void k_copy_strided(T* dst, const float* src, int n, int stride, int offset) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (T)src[(size_t)i * stride + offset];
 }
 template <typename T> __global__ void k_copy_cast(T* dst, const double* src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,6 +567,7 @@ struct dl_env_s {
     virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
     virtual int terminate_early(int32_t* flags, hipStream_t) = 0;
+    virtual int randomize(const float* mass_scale, const float* floor_friction, const float* push, bool set_push, hipStream_t) = 0;
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
@@ -582,6 +601,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     T *inj_q = nullptr, *inj_v = nullptr;
     int32_t* inj_flags = nullptr;
     bool inj_armed = false;
+    double floor_friction_model = 0;
     float* scratch_obs = nullptr;
 
     ~EnvImpl() override { for (void* p : allocs) (void)hipFree(p); }
@@ -598,6 +618,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         HIPCHK(hipSetDevice(device));
         fill_dev_model<T, TP>(d, m);
         fill_dev_cfg<T>(cfg, r, c);
+        floor_friction_model = d.floor_friction;
         {
             int rc0;
             if ((rc0 = dalloc(&md, 1))) return rc0;
@@ -733,6 +754,26 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             return DL_OK;
         }
         hipLaunchKernelGGL((k_forward<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+        HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    int randomize(const float* mass_scale, const float* floor_friction, const float* push, bool set_push, hipStream_t s) override {
+        if (!(variant == 1 && gmd)) return fail(DL_E_INVAL, "dynamics randomisation / pushes are implemented by the 16-lane kernels (lanes_per_walker = 16)");
+        const unsigned g256 = (unsigned)((n + 255) / 256);
+        if (!st.rnd) {
+            int rc;
+            if ((rc = dalloc(&st.rnd, (size_t)5 * n))) return rc;
+            k_fill<T><<<g256, 256, 0, s>>>(st.rnd, T(1), (size_t)n);
+            k_fill<T><<<g256, 256, 0, s>>>(st.rnd + n, (T)floor_friction_model, (size_t)n);
+        }
+        if (mass_scale) k_copy_strided<T><<<g256, 256, 0, s>>>(st.rnd, mass_scale, n, 1, 0);
+        if (floor_friction) k_copy_strided<T><<<g256, 256, 0, s>>>(st.rnd + n, floor_friction, n, 1, 0);
+        if (set_push) {
+            for (int k = 0; k < 3; k++) {
+                if (push) k_copy_strided<T><<<g256, 256, 0, s>>>(st.rnd + (size_t)(2 + k) * n, push, n, 3, k);
+                else k_fill<T><<<g256, 256, 0, s>>>(st.rnd + (size_t)(2 + k) * n, T(0), (size_t)n);
+            }
+        }
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
@@ -898,6 +939,14 @@ int dl_debug_selftest(const float* in, float* out, void* stream) {
 int dl_debug_capstate(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->capstate(out, (hipStream_t)stream);
+}
+int dl_set_randomization(dl_handle h, const float* mass_scale, const float* floor_friction, void* stream) {
+    NEED(h);
+    return h->randomize(mass_scale, floor_friction, nullptr, false, (hipStream_t)stream);
+}
+int dl_set_push(dl_handle h, const float* force, void* stream) {
+    NEED(h);
+    return h->randomize(nullptr, nullptr, force, true, (hipStream_t)stream);
 }
 int dl_terminate_early(dl_handle h, int32_t* flags, void* stream) {
     NEED(h);

@@ -53,6 +53,8 @@ _SIGNATURES = {
     'dl_get_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
     'dl_set_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
     'dl_forward': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
+    'dl_set_randomization': (C.c_int, [_V, _P, _P, _P]),
+    'dl_set_push': (C.c_int, [_V, _P, _P]),
     'dl_terminate_early': (C.c_int, [_V, _P, _P]),
     'dl_stats_snapshot': (C.c_int, [_V, C.c_char_p, _P, _P]),
     'dl_profile': (C.c_int, [_V, _I]),

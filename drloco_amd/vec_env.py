@@ -186,6 +186,20 @@ class HipVecEnv:
     def is_evaluation_on(self):
         return getattr(self, '_eval', False)
 
+    def set_randomization(self, mass_scale=None, floor_friction=None):
+        """MimicEnv.dynamics_randomization (a stub in the reference, mimic_env.py:492-524) for body masses/inertias
+        (one scale per walker) and the floor friction; arrays of length N or None."""
+        f = lambda a: None if a is None else torch.as_tensor(np.asarray(a, np.float32), device=self.device).contiguous()
+        ms, fr = f(mass_scale), f(floor_friction)
+        lib.check(self._lib.dl_set_randomization(self._h, _ptr(ms), _ptr(fr), _stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def set_push(self, force=None):
+        """World-frame force [N, 3] on the torso's centre of mass (xfrc_applied) for the following steps; None clears it."""
+        f = None if force is None else torch.as_tensor(np.asarray(force, np.float32), device=self.device).contiguous()
+        lib.check(self._lib.dl_set_push(self._h, _ptr(f), _stream()))
+        torch.cuda.current_stream().synchronize()
+
     def do_terminate_early(self):
         """MimicEnv.do_terminate_early (mimic_env.py:652-702) for all walkers: bool [N, 4] =
         (terminate_early, com_height_too_low, trunk_ang_exceeded, is_drunk)."""

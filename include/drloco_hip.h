@@ -214,6 +214,15 @@ int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qa
 int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc,
                int32_t* niter, void* stream);
 
+/* MimicEnv.dynamics_randomization (mimic_env.py:492-524): a stub in the reference that only lists the intended fields.
+ * Built here for the fields BASELINE config 5 names: one scale per walker for all body masses and inertias
+ * (body_mass, body_inertia) and the sliding friction of the floor (geom_friction; a contact uses the larger of the
+ * two geoms' coefficients).  float[N] device arrays, NULL = leave unchanged.  16-lane kernels only. */
+int dl_set_randomization(dl_handle h, const float* mass_scale, const float* floor_friction, void* stream);
+/* [3P] xfrc_applied on the torso: world-frame force float[N, 3] (device) acting at the torso's centre of mass during
+ * every following mj_step until changed; NULL = no force.  16-lane kernels only. */
+int dl_set_push(dl_handle h, const float* force, void* stream);
+
 /* MimicEnv.do_terminate_early (mimic_env.py:652-702; the reference defines it but its call in step() is commented
  * out, :113-118) at the current state of every walker: flags int32[N, 4] device =
  * {terminate, COM height too low (< 0.75), trunk angle exceeded, |COM y| > 0.2}.  Straight walker only. */

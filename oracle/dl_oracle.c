@@ -93,6 +93,7 @@ static void chol_solve(int n, const double L[NV][NV], const double* b, double* x
 typedef struct {
     dl_model_desc m;
     unsigned char anc[NB][NV]; /* dof j moves body b */
+    double xfrc[3];            /* [3P] xfrc_applied on the torso (body 1): world-frame force at its centre of mass */
 } model_t;
 
 typedef struct {
@@ -120,6 +121,7 @@ typedef struct {
 static void model_init(model_t* mm, const dl_model_desc* m) {
     mm->m = *m;
     memset(mm->anc, 0, sizeof mm->anc);
+    memset(mm->xfrc, 0, sizeof mm->xfrc);
     for (int b = 1; b < m->nbody; b++)
         for (int j = 0; j < m->nv; j++) {
             int a = b;
@@ -619,6 +621,12 @@ static void forward(const model_t* mm, const double* q, const double* v, const d
         d->actuator[m->act_dof[a]] += m->act_gear[a] * f;
     }
     for (int j = 0; j < nv; j++) d->smooth[j] = d->passive[j] - d->bias[j] + d->actuator[j];
+    if (mm->xfrc[0] != 0 || mm->xfrc[1] != 0 || mm->xfrc[2] != 0) {
+        /* mj_xfrcAccumulate: qfrc_applied += Jp(com of body 1)^T F */
+        double jp[3][NV], jr[3][NV];
+        jac(mm, d, d->xipos[1], 1, jp, jr);
+        for (int j = 0; j < nv; j++) d->smooth[j] += jp[0][j] * mm->xfrc[0] + jp[1][j] * mm->xfrc[1] + jp[2][j] * mm->xfrc[2];
+    }
     chol_solve(nv, d->LM, d->smooth, d->qacc_smooth);
     solve(mm, warm, d);
 }
@@ -728,6 +736,9 @@ typedef struct {
     int inject_exc, inject_state, inject_rsi, inj_rsi_step, inj_rsi_pos;
     double last_ctrl[DL_MAX_ACT];
     double inj_q[NV], inj_v[NV];
+    /* build-defined dynamics randomisation (the reference's dynamics_randomization is a stub, mimic_env.py:492-524) */
+    double mass_scale, floor_mu, xfrc[3];
+    int randomized;
 } walker_t;
 
 struct dlo_env_s {
@@ -911,6 +922,20 @@ static double lowest_site(dlo_env* e, const double* q) {
     return low;
 }
 
+/* the model a walker is simulated with: the shared one, or a copy with its body masses / inertias scaled, its own
+ * floor friction and its current push force */
+static const model_t* walker_model(const dlo_env* e, const walker_t* w, model_t* tmp) {
+    if (!w->randomized) return &e->mm;
+    *tmp = e->mm;
+    for (int b = 1; b < tmp->m.nbody; b++) {
+        tmp->m.body_mass[b] *= w->mass_scale;
+        for (int k = 0; k < 3; k++) tmp->m.body_inertia[b][k] *= w->mass_scale;
+    }
+    tmp->m.floor_friction = w->floor_mu;
+    memcpy(tmp->xfrc, w->xfrc, sizeof tmp->xfrc);
+    return tmp;
+}
+
 /* MujocoEnv.reset + MimicEnv.reset_model (mimic_env.py:526-572), RSI (straight_walk_trajecs.py:460-474) */
 static void reset_walker(dlo_env* e, int i, int inj_step, int inj_pos, double* obs) {
     walker_t* w = &e->w[i];
@@ -942,7 +967,7 @@ static void reset_walker(dlo_env* e, int i, int inj_step, int inj_pos, double* o
     w->q[2] -= low;
     w->comz_off = low;
     /* set_state -> mj_forward: qacc of the initial state becomes the warmstart */
-    forward(&e->mm, w->q, w->v, NULL, NULL, 0, &e->d);
+    { model_t tmp; forward(walker_model(e, w, &tmp), w->q, w->v, NULL, NULL, 0, &e->d); }
     memcpy(w->warm, e->d.qacc, m->nv * sizeof(double));
     /* :562 get_imitation_reward() for the sanity assert leaves the components at exactly 1 */
     w->pos_rew = w->vel_rew = w->com_rew = 1.0;
@@ -1020,7 +1045,9 @@ void dlo_step(dlo_env* e, const double* actions, double* obs, double* rew, uint8
             memcpy(w->v, w->inj_v, nv * sizeof(double));
             w->inject_state = 0;
         } else {
-            for (int k = 0; k < m->frame_skip && !exc; k++) exc = mj_step_rk4(&e->mm, w->q, w->v, ctrl, w->warm, m->timestep, 0, &e->d);
+            model_t tmp;
+            const model_t* mw = walker_model(e, w, &tmp);
+            for (int k = 0; k < m->frame_skip && !exc; k++) exc = mj_step_rk4(mw, w->q, w->v, ctrl, w->warm, m->timestep, 0, &e->d);
         }
         double tor = 0;
         for (int a = 0; a < nu; a++) {
@@ -1089,7 +1116,7 @@ void dlo_forward(dlo_env* e, const double* ctrl, double* qacc, int32_t* ncon, in
     for (int i = 0; i < n; i++) {
         double u[DL_MAX_ACT];
         for (int a = 0; a < nu; a++) u[a] = ctrl ? ctrl[(size_t)a * n + i] : 0;
-        forward(&e->mm, e->w[i].q, e->w[i].v, u, e->w[i].warm, 0, &e->d);
+        { model_t tmp; forward(walker_model(e, &e->w[i], &tmp), e->w[i].q, e->w[i].v, u, e->w[i].warm, 0, &e->d); }
         for (int j = 0; j < nv; j++) qacc[(size_t)j * n + i] = e->d.qacc[j];
         if (ncon) ncon[i] = e->d.ncon;
         if (nefc) nefc[i] = e->d.nefc;
@@ -1143,6 +1170,17 @@ int dlo_stats_snapshot(dlo_env* e, const char* name, double* out) {
         else return -1;
     }
     return 0;
+}
+
+/* per-walker dynamics randomisation / push force; NULL leaves a field unchanged */
+void dlo_set_randomization(dlo_env* e, const double* mass_scale, const double* floor_friction, const double* xfrc) {
+    for (int i = 0; i < e->n; i++) {
+        walker_t* w = &e->w[i];
+        if (!w->randomized) { w->mass_scale = 1.0; w->floor_mu = e->mm.m.floor_friction; w->xfrc[0] = w->xfrc[1] = w->xfrc[2] = 0; w->randomized = 1; }
+        if (mass_scale) w->mass_scale = mass_scale[i];
+        if (floor_friction) w->floor_mu = floor_friction[i];
+        if (xfrc) memcpy(w->xfrc, xfrc + 3 * (size_t)i, 3 * sizeof(double));
+    }
 }
 
 /* do_terminate_early (mimic_env.py:652-702): [any, com height, trunk angle, com-y] */

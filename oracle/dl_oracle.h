@@ -69,6 +69,9 @@ void dlo_monitor_feed(dlo_env* e, int32_t i, double rew, int32_t done, double po
                       double com, double tor, double walked);
 /* reference lookup at the current cursor: q_ref[nv], v_ref[nv] of walker i */
 void dlo_ref_lookup(dlo_env* e, int32_t i, double* qref, double* vref);
+/* build-defined stress test (BASELINE config 5): per-walker body mass/inertia scale, floor friction, push force on the
+ * torso (world frame, double[N,3]); NULL leaves a field unchanged */
+void dlo_set_randomization(dlo_env* e, const double* mass_scale, const double* floor_friction, const double* xfrc);
 /* do_terminate_early (mimic_env.py:652-702), unused by step(): flags[4] */
 void dlo_terminate_early(dlo_env* e, int32_t i, int32_t* flags);
 

@@ -194,6 +194,11 @@ class OracleEnv:
         lib().dlo_ref_lookup(self.h, C.c_int32(i), _p(q), _p(v))
         return q, v
 
+    def set_randomization(self, mass_scale=None, floor_friction=None, xfrc=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+        ms, fr, xf = f(mass_scale), f(floor_friction), f(xfrc)
+        lib().dlo_set_randomization(self.h, _p(ms), _p(fr), _p(xf))
+
     def terminate_early(self, i):
         f = np.zeros(4, np.int32)
         lib().dlo_terminate_early(self.h, C.c_int32(i), _p(f, C.c_int32))

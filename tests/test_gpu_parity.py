@@ -496,6 +496,52 @@ def test_vecnormalize_save_load_and_attrs(torch_cuda, model, refs, tmp_path):
     assert vn.normalize_obs(vn.get_original_obs()).shape == (96, 29)
 
 
+def test_randomization_and_push(torch_cuda, oracle, model, refs):
+    """BASELINE config 5 (build-defined: the reference's dynamics_randomization is a stub): per-walker mass scale,
+    floor friction and push force through the 16-lane kernels against the oracle."""
+    from drloco_amd import lib as L
+    n = 512
+    rng = np.random.default_rng(9)
+    ms = rng.uniform(0.8, 1.2, n); fr = rng.uniform(0.5, 1.1, n)
+    push = np.zeros((n, 3)); k = rng.random(n) < 0.5
+    ang = rng.uniform(0, 2 * np.pi, n); push[k, 0] = 50 * np.cos(ang[k]); push[k, 1] = 50 * np.sin(ang[k])
+    ms, fr, push = (x.astype(np.float32).astype(np.float64) for x in (ms, fr, push))      # the ABI takes float32 arrays
+    q, v, w, u = random_states(model, n, 5)
+    for precision, tol in ((64, 1e-9), (32, 5e-3)):
+        dev, orc = make_pair(oracle, model, refs, n, precision, lanes_per_walker=16)
+        for e in (dev, orc):
+            e.set_state(qpos=q, qvel=v, warm=w)
+        dev.set_randomization(ms, fr); dev.set_push(push)
+        orc.set_randomization(ms, fr, push)
+        qa, nc, ne, _ = orc.forward(u); qb, nc2, ne2, _ = dev.forward(u)
+        assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2) and nc.max() >= 6
+        err = np.abs(qa - qb) / (1 + np.abs(qa))
+        assert err.max() < tol, (precision, err.max())
+    # the randomisation really changes the dynamics
+    dev0, orc0 = make_pair(oracle, model, refs, n, 64, lanes_per_walker=16)
+    orc0.set_state(qpos=q, qvel=v, warm=w)
+    qa0, _, _, _ = orc0.forward(u)
+    assert np.abs(qa0 - qa).max() > 1.0
+    # whole control steps incl. auto-resets (float64 kernels track the oracle)
+    dev, orc = make_pair(oracle, model, refs, 128, 64, lanes_per_walker=16)
+    dev.set_randomization(ms[:128], fr[:128]); orc.set_randomization(ms[:128], fr[:128])
+    np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
+    for t in range(60):
+        if t % 20 == 5:
+            dev.set_push(push[:128]); orc.set_randomization(xfrc=push[:128])
+        if t % 20 == 12:
+            dev.set_push(None); orc.set_randomization(xfrc=np.zeros((128, 3)))
+        a = np.clip(0.5 * rng.standard_normal((128, 8)), -1, 1).astype(np.float32)
+        o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2), t
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(r2, r1, atol=1e-6)
+    # the lane-per-walker kernels refuse instead of silently ignoring the request
+    one = make_pair(oracle, model, refs, 8, 32, lanes_per_walker=1)[0]
+    with pytest.raises(L.DrlocoError, match='16-lane'):
+        one.set_randomization(np.ones(8), np.ones(8))
+
+
 def test_terminate_early_on_device(torch_cuda, oracle, model, refs):
     """MimicEnv.do_terminate_early for every walker: golden G6 states (the reference's own truth table) and
     random states against the oracle."""
