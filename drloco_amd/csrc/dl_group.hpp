@@ -253,6 +253,19 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp(float& d, float a, 
 }
 #undef DL_FMAC_DPP_CASE
 template <int CTRL> __device__ __forceinline__ void fmac_dpp(double& d, double a, double b) { d += dpp_f<CTRL>(a) * b; }
+// x += dpp<CTRL>(x) * b with x as destination AND DPP source of the same instruction (no register copy)
+#define DL_FMAC_SELF_CASE(code, text) \
+    if constexpr (CTRL == code) asm("v_fmac_f32_dpp %0, %0, %1 " text " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x) : "v"(b));
+template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, float b) {
+    DL_FMAC_SELF_CASE(0x111, "row_shr:1") DL_FMAC_SELF_CASE(0x112, "row_shr:2") DL_FMAC_SELF_CASE(0x114, "row_shr:4") DL_FMAC_SELF_CASE(0x118, "row_shr:8")
+    DL_FMAC_SELF_CASE(0x101, "row_shl:1") DL_FMAC_SELF_CASE(0x102, "row_shl:2") DL_FMAC_SELF_CASE(0x104, "row_shl:4") DL_FMAC_SELF_CASE(0x108, "row_shl:8")
+}
+#undef DL_FMAC_SELF_CASE
+template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(double& x, double b) { x += dpp_f<CTRL>(x) * b; }
+template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) {
+    asm("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
+}
+template <int K> __device__ __forceinline__ void fmac_bcast_self(double& x, double b) { x += rbcast<K>(x) * b; }
 __device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
 // one wait for a whole group of values that are about to be read through DPP
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) {
@@ -321,21 +334,21 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_c
     constexpr int MR = GTopo<TP>::max_run();
     g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-    for (int i = 0; i < NVAL; i++) fmac_dpp<0x111>(x[i], x[i], lt.ms[0]);
+    for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x111>(x[i], lt.ms[0]);
     if constexpr (MR > 2) {
         g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) fmac_dpp<0x112>(x[i], x[i], lt.ms[1]);
+        for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x112>(x[i], lt.ms[1]);
     }
     if constexpr (MR > 4) {
         g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) fmac_dpp<0x114>(x[i], x[i], lt.ms[2]);
+        for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x114>(x[i], lt.ms[2]);
     }
     if constexpr (MR > 8) {
         g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) fmac_dpp<0x118>(x[i], x[i], lt.ms[3]);
+        for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x118>(x[i], lt.ms[3]);
     }
     static_for<TP::NV>([&](auto ri) {
         constexpr int r = ri.value;
@@ -344,7 +357,7 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_c
             const T f = lt.rs == r ? T(1) : T(0);
             g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-            for (int i = 0; i < NVAL; i++) fmac_bcast<P, 1>(x[i], x[i], f);
+            for (int i = 0; i < NVAL; i++) fmac_bcast_self<P>(x[i], f);
         }
     });
 }
@@ -353,21 +366,21 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_s
     constexpr int MR = GTopo<TP>::max_run();
     g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-    for (int i = 0; i < NVAL; i++) fmac_dpp<0x101>(x[i], x[i], lt.ns[0]);
+    for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x101>(x[i], lt.ns[0]);
     if constexpr (MR > 2) {
         g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) fmac_dpp<0x102>(x[i], x[i], lt.ns[1]);
+        for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x102>(x[i], lt.ns[1]);
     }
     if constexpr (MR > 4) {
         g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) fmac_dpp<0x104>(x[i], x[i], lt.ns[2]);
+        for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x104>(x[i], lt.ns[2]);
     }
     if constexpr (MR > 8) {
         g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) fmac_dpp<0x108>(x[i], x[i], lt.ns[3]);
+        for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x108>(x[i], lt.ns[3]);
     }
     static_for<TP::NV>([&](auto ri) {
         constexpr int r = TP::NV - 1 - ri.value;           // deepest runs first
@@ -377,7 +390,7 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_s
             const T f = ((ancP >> j) & 1u) ? T(1) : T(0);
             g_dpp_ready_n<NVAL>(x);
 #pragma unroll
-            for (int i = 0; i < NVAL; i++) fmac_bcast<r, 1>(x[i], x[i], f);
+            for (int i = 0; i < NVAL; i++) fmac_bcast_self<r>(x[i], f);
         }
     });
 }

@@ -496,6 +496,36 @@ def test_vecnormalize_save_load_and_attrs(torch_cuda, model, refs, tmp_path):
     assert vn.normalize_obs(vn.get_original_obs()).shape == (96, 29)
 
 
+def test_config0_four_envs_2048_steps(torch_cuda, oracle, model, refs):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case: 4 envs, one 2048-step rollout.  The float64
+    16-lane kernels track the oracle over the whole rollout (every episode end re-synchronises through RSI), and the
+    GAE over the collected rewards is the oracle's."""
+    import torch
+    from drloco_amd.rollout import HipRolloutBuffer
+    n, T = 4, 2048
+    dev, orc = make_pair(oracle, model, refs, n, 64, seed=33)
+    rng = np.random.default_rng(33)
+    np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
+    rew = np.zeros((T, n), np.float32); starts = np.zeros((T, n), np.uint8); last = np.ones(n, np.uint8)
+    ndone = 0
+    for t in range(T):
+        a = np.clip(0.3 * rng.standard_normal((n, 8)), -1, 1).astype(np.float32)
+        o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2), t
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(r2, r1, atol=1e-6)
+        rew[t] = r2; starts[t] = last; last = d2.astype(np.uint8); ndone += int(d2.sum())
+    assert ndone >= 8
+    assert np.array_equal(orc.get_state()['cursor'], dev.get_state()['cursor'])
+    buf = HipRolloutBuffer(T, n, 29, 8, 'cuda', gamma=0.995, gae_lambda=0.95)
+    val = rng.standard_normal((T, n)).astype(np.float32); lv = rng.standard_normal(n).astype(np.float32)
+    buf.rewards.copy_(torch.as_tensor(rew)); buf.values.copy_(torch.as_tensor(val)); buf.episode_starts.copy_(torch.as_tensor(starts))
+    adv, ret = buf.compute_returns_and_advantage(torch.as_tensor(lv, device='cuda'), torch.as_tensor(last, device='cuda'))
+    a0, r0 = oracle.gae(rew, val, starts, lv, last, 0.995, 0.95)
+    np.testing.assert_allclose(adv.cpu().numpy(), a0, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ret.cpu().numpy(), r0, rtol=2e-6, atol=2e-6)
+
+
 def test_randomization_and_push(torch_cuda, oracle, model, refs):
     """BASELINE config 5 (build-defined: the reference's dynamics_randomization is a stub): per-walker mass scale,
     floor friction and push force through the 16-lane kernels against the oracle."""
