@@ -13,7 +13,8 @@
 //   A operand (activations): lane l supplies row l % 16, the reduction index is permuted so that a lane's four k
 //     values of a 16-wide k block are contiguous: one ds_read_b128 feeds four MFMAs;
 //   B operand (weights, torch layout [out][in]): lane l supplies output column n0 + l % 16 with the same four k:
-//     one global_load_dwordx4 per tile and k block, 64 contiguous bytes per weight row and wave;
+//     one global_load_dwordx4 per tile and k block; two k blocks (one 128-byte line per weight row) per step, in two
+//     ping-pong register sets loaded by inline asm one step ahead of the 64 MFMAs that consume them;
 //   layer 2: each wave owns hidden/4 output columns (up to 8 accumulator tiles); heads: the reduction is split over
 //     the four waves and summed through LDS.
 #pragma once
@@ -51,69 +52,112 @@ __device__ __forceinline__ float pol_gauss(uint64_t seed, uint64_t counter, uint
 constexpr int POL_ROWS = 16;       // walkers per workgroup
 constexpr int POL_MAXT = 8;        // accumulator tiles per wave in the hidden layer (hidden <= 512)
 
+// NTW = accumulator tiles per wave in the hidden layer: hidden = 64 * NTW (compile time, so that the tile loops are
+// straight-line code)
+template <int NTW>
 __global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                         uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                         float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int H = p.hidden, D = p.obs_dim, A = p.act_dim, LDH = H + 4;
+    constexpr int H = 64 * NTW, LDH = H + 4, ntw = NTW;
+    const int D = p.obs_dim, A = p.act_dim;
     float* h1 = sm;
     float* h2 = sm + POL_ROWS * LDH;
     float* part = h2 + POL_ROWS * LDH;            // [4][16][16] partial head tiles, then [16][16] log-prob terms
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
     const int row0 = blockIdx.x * POL_ROWS;
-    const int ncw = H / 4, n0w = wave * ncw, ntw = ncw / 16;
-    // ---- layer 1: [16, D] x [D, H]
+    constexpr int ncw = H / 4;
+    const int n0w = wave * ncw;
+    // ---- layer 1: [16, D] x [D, H].  D is small (29): all operand loads of the wave are issued before the first MFMA
+    // (one memory latency for the layer instead of one per tile)
     {
         const int r = row0 + lm;
-        for (int t = 0; t < ntw; t++) {
+        constexpr int KB1 = 3;                                      // obs_dim <= 48 (checked by the host): 29 (straight walker), 47 (165 cm walker)
+        float a1[KB1 * 4], b1v[NTW][KB1 * 4];
+#pragma unroll
+        for (int q = 0; q < KB1 * 4; q++) {
+            const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
+            a1[q] = (k < D && r < n) ? obs[(size_t)r * D + k] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
             const int ncol = n0w + t * 16 + lm;
-            pf4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kb = 0; kb < (D + 15) / 16; kb++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int k = kb * 16 + lk * 4 + s;
-                    const float a = (k < D && r < n) ? obs[(size_t)r * D + k] : 0.0f;
-                    const float b = (k < D) ? p.w1[(size_t)ncol * D + k] : 0.0f;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-                }
+            for (int q = 0; q < KB1 * 4; q++) {
+                const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
+                b1v[t][q] = (k < D) ? p.w1[(size_t)ncol * D + k] : 0.0f;
             }
-            const float bias = p.b1[ncol];
+        }
 #pragma unroll
-            for (int i = 0; i < 4; i++) h1[(4 * lk + i) * LDH + ncol] = pol_tanh(acc[i] + bias);
+        for (int t = 0; t < NTW; t++) {
+            if (t < ntw) {
+                const int ncol = n0w + t * 16 + lm;
+                pf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < KB1 * 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1v[t][q], acc, 0, 0, 0);
+                const float bias = p.b1[ncol];
+#pragma unroll
+                for (int i = 0; i < 4; i++) h1[(4 * lk + i) * LDH + ncol] = pol_tanh(acc[i] + bias);
+            }
         }
     }
     __syncthreads();
     // ---- layer 2: [16, H] x [H, H]; the weight rows of this wave's tiles stream from L2 one k block ahead
     {
-        pf4 acc[POL_MAXT];
+        pf4 acc[NTW];
 #pragma unroll
-        for (int t = 0; t < POL_MAXT; t++) acc[t] = pf4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; t++) acc[t] = pf4{0.f, 0.f, 0.f, 0.f};
         const float* wbase = p.w2 + (size_t)(n0w + lm) * H + lk * 4;
-        pf4 bnext[POL_MAXT];
+        // two k blocks (32 k = one 128-byte line per weight row) per step: both halves of every line a wave touches are
+        // consumed together.  Explicit ping-pong register sets: the loads of the next step are issued BEFORE the 64 MFMAs
+        // of the current one (with one buffer the compiler reuses the registers and every step waits a full L2 latency).
+        const int npair = H / 32;                 // even for every supported hidden size
+        // The loads are inline asm: LLVM sinks ordinary loads below the MFMA block to their uses (IR-level, sched_barrier
+        // does not help), which serialises every step behind a full memory latency.  The compiler does not know that the
+        // asm outputs are still in flight, so the wait is explicit and carries the registers as operands (the MFMAs depend
+        // on the waited values).
+        auto load_set = [&](pf4 (&b)[NTW][2], int kp) {
 #pragma unroll
-        for (int t = 0; t < POL_MAXT; t++) if (t < ntw) bnext[t] = *(const pf4*)(wbase + (size_t)t * 16 * H);
-        const int nkb = H / 16;
-        for (int kb = 0; kb < nkb; kb++) {
-            const pf4 a4 = *(const pf4*)&h1[lm * LDH + kb * 16 + lk * 4];
-            pf4 b4[POL_MAXT];
-#pragma unroll
-            for (int t = 0; t < POL_MAXT; t++) b4[t] = bnext[t];
-            if (kb + 1 < nkb) {
-#pragma unroll
-                for (int t = 0; t < POL_MAXT; t++) if (t < ntw) bnext[t] = *(const pf4*)(wbase + (size_t)t * 16 * H + (kb + 1) * 16);
+            for (int t = 0; t < NTW; t++) {
+                const float* q = wbase + (size_t)t * 16 * H + kp * 32;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[t][0]) : "v"(q) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(b[t][1]) : "v"(q) : "memory");
             }
+        };
+        auto wait_set = [&](pf4 (&b)[NTW][2], bool newer_in_flight) {
+            // loads return in order: allow the 2 * NTW loads of the other set to stay in flight
+            if (newer_in_flight) {
+                if constexpr (NTW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if constexpr (NTW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (NTW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int t = 0; t < POL_MAXT; t++) {
-                if (t < ntw) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
-                }
-            }
+            for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(b[t][0]), "+v"(b[t][1]));
+        };
+        auto compute = [&](const pf4 (&b4)[NTW][2], int kp) {
+            const pf4 a4a = *(const pf4*)&h1[lm * LDH + kp * 32 + lk * 4], a4b = *(const pf4*)&h1[lm * LDH + kp * 32 + 16 + lk * 4];
+            // k step outermost: consecutive MFMAs go to different accumulator tiles (no back-to-back dependent issue)
+#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b4[t][H2].C, acc[t], 0, 0, 0);
+            DL_POL_KSTEP(a4a.x, 0, x) DL_POL_KSTEP(a4a.y, 0, y) DL_POL_KSTEP(a4a.z, 0, z) DL_POL_KSTEP(a4a.w, 0, w)
+            DL_POL_KSTEP(a4b.x, 1, x) DL_POL_KSTEP(a4b.y, 1, y) DL_POL_KSTEP(a4b.z, 1, z) DL_POL_KSTEP(a4b.w, 1, w)
+#undef DL_POL_KSTEP
+        };
+        pf4 bs0[NTW][2], bs1[NTW][2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the compiler's own loads may be counted against the sets
+        load_set(bs0, 0);
+        for (int kp = 0; kp < npair; kp += 2) {
+            load_set(bs1, kp + 1);
+            wait_set(bs0, true);
+            compute(bs0, kp);
+            const bool more = kp + 2 < npair;
+            if (more) load_set(bs0, kp + 2);
+            wait_set(bs1, more);
+            compute(bs1, kp + 1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < POL_MAXT; t++) {
+        for (int t = 0; t < NTW; t++) {
             if (t < ntw) {
                 const int ncol = n0w + t * 16 + lm;
                 const float bias = p.b2[ncol];

@@ -281,7 +281,7 @@ int dl_adv_normalize(float* adv, int64_t n, const double* sums3, void* stream);
 /* ---- policy forward pass of the rollout loop ----
  * Parameters of the reference's CustomActorCriticPolicy (drloco/custom/policies.py:13-51) in torch's nn.Linear
  * layout [out][in], float32, DEVICE pointers: shared trunk obs_dim -> hidden -> hidden (tanh), action_net
- * hidden -> act_dim, value_net hidden -> 1, log_std[act_dim].  hidden: multiple of 64, <= 512; act_dim <= 15. */
+ * hidden -> act_dim, value_net hidden -> 1, log_std[act_dim].  hidden: multiple of 64, <= 512; obs_dim <= 48; act_dim <= 15. */
 typedef struct dl_policy_params {
     const float* w1; const float* b1;   /* [hidden, obs_dim], [hidden] */
     const float* w2; const float* b2;   /* [hidden, hidden], [hidden] */
