@@ -130,6 +130,8 @@ def main():
                             done_out=buf.episode_starts[t + 1] if nxt else last_done)
         buf.compute_returns_and_advantage(last_values, last_done)
         buf.normalize_advantages()                   # all-reduce of [sum, sum^2, n] when world > 1
+        if use_dist:
+            vn.sync_moments()                        # one all-reduce of the moment increments per rollout: every rank normalises alike
 
     def barrier():
         if use_dist:

@@ -303,6 +303,28 @@ class _WalkerView:
         raise AttributeError(name)
 
 
+def merge_moments_across_ranks(mean, var, count, mean0, var0, count0, group=None):
+    """Exact cross-rank merge of running moments (collective C3).  Every rank holds
+    (mean, var, count) = the state agreed at the last merge (mean0, var0, count0) advanced by its OWN batches.  The
+    increments [n, sum, sum of squares] since that state are all-reduced and added to it, which gives the moments a
+    single process would have after seeing every rank's batches (one all-reduce of 2 D + 1 doubles).  Tensors are
+    float64 (count: 1 element) on any device; updated in place, returns nothing."""
+    import torch.distributed as dist
+    n0, n1 = count0, count
+    inc = torch.cat([(n1 * mean - n0 * mean0).reshape(-1), (n1 * (var + mean * mean) - n0 * (var0 + mean0 * mean0)).reshape(-1), (n1 - n0).reshape(-1)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(inc, group=group)
+    d = mean.numel()
+    n = n0 + inc[2 * d]
+    s = n0 * mean0 + inc[:d].reshape(mean.shape)
+    q = n0 * (var0 + mean0 * mean0) + inc[d:2 * d].reshape(mean.shape)
+    new_mean = s / n
+    mean.copy_(new_mean)
+    var.copy_(torch.clamp(q / n - new_mean * new_mean, min=0))
+    count.copy_(n.reshape(count.shape))
+    mean0.copy_(mean); var0.copy_(var); count0.copy_(count)
+
+
 class RunningMeanStd:
     """SB3 1.0 RunningMeanStd with device-resident float64 moments."""
 
@@ -312,6 +334,10 @@ class RunningMeanStd:
         self._mean = torch.zeros(d, dtype=torch.float64, device=device)
         self._var = torch.ones(d, dtype=torch.float64, device=device)
         self._count = torch.full((1,), epsilon, dtype=torch.float64, device=device)
+        self._sync = (self._mean.clone(), self._var.clone(), self._count.clone())     # state at the last cross-rank merge
+
+    def sync(self, group=None):
+        merge_moments_across_ranks(self._mean, self._var, self._count, *self._sync, group=group)
 
     @property
     def mean(self):
@@ -332,6 +358,7 @@ class RunningMeanStd:
         self._mean.copy_(torch.as_tensor(np.asarray(s['mean'], np.float64).reshape(-1)))
         self._var.copy_(torch.as_tensor(np.asarray(s['var'], np.float64).reshape(-1)))
         self._count.fill_(float(s['count']))
+        self._sync = (self._mean.clone(), self._var.clone(), self._count.clone())
 
 
 class HipVecNormalize:
@@ -381,6 +408,12 @@ class HipVecNormalize:
             _ptr(self.ret), _ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, d,
             self.gamma, self.epsilon, self.clip_obs, self.clip_reward, flags, _ptr(obs_out), _ptr(rew_out), _ptr(self._vn_work), _stream()))
         return obs_out, rew_out, done, term
+
+    def sync_moments(self, process_group=None):
+        """Data-parallel runs: make the observation / return moments of all ranks those of the union of their batches
+        (call between rollouts; every rank then normalises identically, as the single-process reference does)."""
+        self.obs_rms.sync(process_group)
+        self.ret_rms.sync(process_group)
 
     def step_async(self, actions):
         self._actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.venv.device)

@@ -75,3 +75,50 @@ def test_sharded_rollout_and_advnorm_allreduce(tmp_path):
         assert np.array_equal(z['cursor'], cur[:, sl])
         assert np.array_equal(z['adv'], adv[:, sl])
         np.testing.assert_allclose(z['norm'], want_norm[:, sl], rtol=1e-9, atol=1e-9)
+
+
+def _moments_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from drloco_amd.vec_env import merge_moments_across_ranks
+    from oracle import oracle as O
+    D = 5
+    rng = np.random.default_rng(100)                   # the same data on every rank; each consumes its slice
+    mean = np.zeros(D); var = np.ones(D); cnt = 1e-4
+    tm = torch.zeros(D, dtype=torch.float64); tv = torch.ones(D, dtype=torch.float64); tc = torch.full((1,), 1e-4, dtype=torch.float64)
+    sync = (tm.clone(), tv.clone(), tc.clone())
+    for rollout in range(3):
+        for t in range(4):
+            x = rng.standard_normal((world, 16, D)) * np.arange(1, D + 1) + rollout
+            cnt = O.moments_update(mean, var, cnt, x[rank])
+        tm.copy_(torch.as_tensor(mean)); tv.copy_(torch.as_tensor(var)); tc.fill_(cnt)
+        merge_moments_across_ranks(tm, tv, tc, *sync)
+        mean[:] = tm.numpy(); var[:] = tv.numpy(); cnt = float(tc.item())
+    np.savez(os.path.join(tmp, f'mom{rank}.npz'), mean=mean, var=var, cnt=cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_moment_merge_across_ranks(tmp_path):
+    """C3: after a merge every rank holds the moments one process would have computed from all ranks' batches."""
+    world, port = 2, 30041 + os.getpid() % 500
+    mp.spawn(_moments_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    D = 5
+    rng = np.random.default_rng(100)
+    xs = []
+    for rollout in range(3):
+        for t in range(4):
+            xs.append((rng.standard_normal((world, 16, D)) * np.arange(1, D + 1) + rollout).reshape(-1, D))
+    allx = np.concatenate(xs)
+    n = 1e-4 + len(allx)
+    # the prior (mean 0, var 1, count 1e-4) enters once
+    want_mean = allx.sum(0) / n
+    want_var = ((allx ** 2).sum(0) + 1e-4 * 1.0) / n - want_mean ** 2
+    for r in range(world):
+        z = np.load(tmp_path / f'mom{r}.npz')
+        np.testing.assert_allclose(z['mean'], want_mean, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(z['var'], want_var, rtol=1e-9)
+        assert abs(float(z['cnt']) - n) < 1e-9
