@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""PPO on the MI355X hot path, end to end on one GPU -- a caller of the drop-in surface (the learner stays PyTorch,
+as in the reference's train.py; this script is an example, not part of the library).
+
+It follows drloco/train.py:77-139 with the reference's hyperparameters (drloco/config/hypers.py): batch 16 384
+samples per update, minibatch 2 048, 4 epochs, gamma 0.995, lambda 0.95, clip range 0.15 (also for the value
+function), entropy coefficient -0.0075, learning rate 5e-4 -> 1e-6 (LinearDecay), log_std_init -0.75, 2 x 512 tanh
+trunk shared by policy and value heads (drloco/custom/policies.py), Adam eps 1e-5, gradient clipping 0.5.
+The default is 128 walkers x 128-step rollouts (the reference: 8 x 2048); rollouts of only a few steps -- e.g.
+4096 walkers x 4 steps for the same batch -- learn to stand longer but not to walk, use --batch 262144 --minibatch 16384
+with thousands of walkers.  Everything of the rollout runs through the C-ABI:
+dl_policy_forward -> dl_step -> dl_vecnormalize_step -> dl_gae; torch autograd only evaluates the PPO loss.
+
+  python examples/train_ppo.py --mio 8          # the reference's budget: 8 M env-steps, ~35 s on one MI355X, walks 23 m per episode
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from drloco_amd.policy import HipPolicy
+from drloco_amd.rollout import HipRolloutBuffer
+from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+
+
+def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True):
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(seed)
+    venv = HipVecEnv(num_envs=n_envs, seed=seed)
+    vn = HipVecNormalize(venv, norm_reward=norm_reward)
+    T = batch // n_envs
+    buf = HipRolloutBuffer(T, n_envs, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
+    pol = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=512, log_std_init=-0.75, seed=seed)
+    names = ('w1', 'b1', 'w2', 'b2', 'wa', 'ba', 'wv', 'bv', 'log_std')
+    # SB3's orthogonal initialisation (gain sqrt(2) trunk, 0.01 action head, 1 value head)
+    for n_, g in (('w1', math.sqrt(2)), ('w2', math.sqrt(2)), ('wa', 0.01), ('wv', 1.0)):
+        torch.nn.init.orthogonal_(getattr(pol, n_), gain=g)
+    for n_ in ('b1', 'b2', 'ba', 'bv'):
+        getattr(pol, n_).zero_()
+    params = [getattr(pol, n_).requires_grad_(True) for n_ in names]
+    opt = torch.optim.Adam(params, lr=5e-4, eps=1e-5)
+    clip, ent_coef, vf_coef = 0.15, -0.0075, 0.5
+    total = int(mio * 1e6)
+    n_updates = max(1, total // batch)
+    vn.reset()
+    obs = vn.norm_obs_t.clone()
+    start = torch.ones(n_envs, dtype=torch.uint8, device=dev)
+    last_done = torch.zeros(n_envs, dtype=torch.uint8, device=dev)
+    scratch_obs = torch.empty_like(obs)
+    hist = []
+    t0 = time.perf_counter()
+    for upd in range(n_updates):
+        lr = max(5e-4 + (upd / n_updates) * (1e-6 - 5e-4), 1e-6)             # LinearDecay(5e-4 -> 1e-6)
+        for gp in opt.param_groups:
+            gp['lr'] = lr
+        # ---- collect_rollouts
+        with torch.no_grad():
+            buf.observations[0].copy_(obs); buf.episode_starts[0].copy_(start)
+            for t in range(T):
+                nxt = t + 1 < T
+                pol.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
+                vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else scratch_obs, rew_out=buf.rewards[t],
+                                done_out=buf.episode_starts[t + 1] if nxt else last_done)
+            obs.copy_(scratch_obs); start.copy_(last_done)
+            _, last_values, _ = pol.forward(obs, deterministic=True)
+            buf.compute_returns_and_advantage(last_values, last_done)
+        # ---- PPO.train
+        b_obs = buf.observations.reshape(-1, venv.obs_dim); b_act = buf.actions.reshape(-1, venv.nu)
+        b_adv = buf.advantages.reshape(-1); b_ret = buf.returns.reshape(-1); b_val = buf.values.reshape(-1); b_lp = buf.log_probs.reshape(-1)
+        for ep in range(epochs):
+            perm = torch.randperm(batch, device=dev)
+            for i in range(0, batch, minibatch):
+                idx = perm[i:i + minibatch]
+                o, a = b_obs[idx], b_act[idx]
+                h = torch.tanh(torch.nn.functional.linear(o, pol.w1, pol.b1))
+                h = torch.tanh(torch.nn.functional.linear(h, pol.w2, pol.b2))
+                mean = torch.nn.functional.linear(h, pol.wa, pol.ba)
+                value = torch.nn.functional.linear(h, pol.wv, pol.bv)[:, 0]
+                std = torch.exp(pol.log_std)
+                logp = (-0.5 * ((a - mean) / std) ** 2 - pol.log_std - 0.5 * math.log(2 * math.pi)).sum(1)
+                entropy = (0.5 + 0.5 * math.log(2 * math.pi) + pol.log_std).sum()
+                adv = b_adv[idx]
+                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+                ratio = torch.exp(logp - b_lp[idx])
+                pg_loss = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+                v_pred = b_val[idx] + torch.clamp(value - b_val[idx], -clip, clip)
+                v_loss = torch.nn.functional.mse_loss(b_ret[idx], v_pred)
+                loss = pg_loss + ent_coef * (-entropy) + vf_coef * v_loss
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(params, 0.5)
+                opt.step()
+        if upd % log_every == 0 or upd == n_updates - 1:
+            torch.cuda.synchronize()
+            ep_len = torch.tensor(venv.get_attr('ep_len_smoothed')).mean().item()
+            mean_rew = torch.tensor(venv.get_attr('mean_reward_smoothed')).mean().item()
+            dist_ = torch.tensor(venv.get_attr('moved_distance')).mean().item()
+            el = time.perf_counter() - t0
+            hist.append(dict(update=upd, env_steps=(upd + 1) * batch, ep_len=ep_len, mean_step_reward=mean_rew, moved_distance=dist_, seconds=el))
+            if not quiet:
+                print(f'update {upd:5d}  env-steps {(upd + 1) * batch / 1e6:6.2f} M  ep_len {ep_len:7.1f}  step reward {mean_rew:.3f}  '
+                      f'walked {dist_:5.2f} m  lr {lr:.2e}  {el:6.1f} s  ({(upd + 1) * batch / el / 1e3:.0f} k env-steps/s incl. learning)', flush=True)
+    return hist
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--mio', type=float, default=2.0, help='million env-steps (the reference trains 8)')
+    ap.add_argument('--envs', type=int, default=128, help='parallel walkers (the reference: 8)')
+    ap.add_argument('--batch', type=int, default=16384, help='samples per update = envs x rollout steps (the reference: 16 384)')
+    ap.add_argument('--minibatch', type=int, default=2048)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--no-norm-reward', action='store_true', help='VecNormalize(norm_reward=False)')
+    args = ap.parse_args()
+    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward)

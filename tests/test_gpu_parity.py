@@ -775,3 +775,18 @@ def test_policy_sampling_stream(torch_cuda):
     assert torch.equal(a4, a[1024:2048])
     with pytest.raises(Exception):
         HipPolicy(hidden=100).forward(obs)                      # hidden must be a multiple of 64
+
+
+def test_ppo_learns_on_the_device_path(torch_cuda):
+    """End-to-end sanity of the whole path as a caller sees it (examples/train_ppo.py: the reference's PPO
+    hyperparameters, policy forward / env step / VecNormalize / GAE through the C-ABI, torch autograd for the loss):
+    1.3 M env-steps are enough to triple the episode length and the imitation reward of the initial policy."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('train_ppo', os.path.join(root, 'examples', 'train_ppo.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    hist = mod.train(mio=1.3, n_envs=128, seed=0, log_every=10, quiet=True)
+    first = next(h for h in hist if h['ep_len'] > 0)
+    last = hist[-1]
+    assert last['ep_len'] > 300 and last['ep_len'] > 2.5 * first['ep_len'], (first, last)
+    assert last['mean_step_reward'] > 0.5 and last['moved_distance'] > 2.0, last
