@@ -435,47 +435,43 @@ __global__ void k_reward_finish(float* rew, double* ret, const uint8_t* done, co
 }
 
 // ---- VecNormalize.step_wait fused into two launches -------------------------------------------------------
-// k_vn_reduce: grid = VN_BLOCKS + 1.  Blocks [0, VN_BLOCKS) read slabs of x[B, D] with coalesced loads (thread t
-// always meets column t % D) and leave per-column partial sums of (x - K) and (x - K)^2, K = the running mean
-// (shift against cancellation); the last block to arrive merges them into (mean, var) with RunningMeanStd's Chan
-// update.  Block VN_BLOCKS advances the discounted returns ret = ret*gamma + r and merges their moments.
-// The counts are read here and advanced by k_vn_apply (stream order), so every merge sees the old count.
+// k_vn_reduce: grid = VN_BLOCKS.  Every block reads a slab of x[B, D] with coalesced loads (thread t always meets
+// column t % D) and a slice of the discounted returns (ret = ret*gamma + r is advanced here) and leaves per-column
+// partial sums of (x - K) and (x - K)^2, K = the running mean (shift against cancellation); the returns are column D.
+// The last block to arrive merges them into (mean, var) with RunningMeanStd's Chan update.  The counts are read here
+// and advanced by k_vn_apply (stream order), so every merge sees the old count.
 constexpr int VN_BLOCKS = 32;
 __global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
                                                    double* ret, double* ret_mean, double* ret_var, const double* ret_count,
                                                    int B, int D, double gamma, int flags, double* work, unsigned* arrive) {
     __shared__ double sh[2][256];
+    __shared__ double sh2[4];
     __shared__ bool is_last;
-    const int t = threadIdx.x;
-    if ((int)blockIdx.x == VN_BLOCKS) {
-        if (!(flags & 4)) return;
+    const int t = threadIdx.x, W = D + 1;
+    // ---- observations: per-column partial sums of this block's rows
+    if (flags & 1) {
+        const int rpb = blockDim.x / D, nthr = rpb * D;       // rows per pass of this block
+        double s = 0, ss = 0;
+        const int col = t % D, rsub = t / D;
+        if (t < nthr) {
+            const double K = mean[col];
+            for (int row = blockIdx.x * rpb + rsub; row < B; row += VN_BLOCKS * rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
+        }
+        sh[0][t] = s; sh[1][t] = ss;
+        __syncthreads();
+        if (t < D) {
+            for (int r = 1; r < rpb; r++) { s += sh[0][r * D + t]; ss += sh[1][r * D + t]; }
+            work[((size_t)blockIdx.x * W + t) * 2] = s; work[((size_t)blockIdx.x * W + t) * 2 + 1] = ss;
+        }
+    }
+    // ---- discounted returns: advance this block's slice, partial sums as column D
+    if (flags & 4) {
+        const int chunk = (B + VN_BLOCKS - 1) / VN_BLOCKS, lo = blockIdx.x * chunk, hi = lo + chunk < B ? lo + chunk : B;
         const double K = *ret_mean;
         double s = 0, ss = 0;
-        for (int i = t; i < B; i += blockDim.x) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; const double d = r - K; s += d; ss += d * d; }
-        __shared__ double sh2[4];
+        for (int i = lo + t; i < hi; i += blockDim.x) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; const double d = r - K; s += d; ss += d * d; }
         s = block_sum(s, sh2); ss = block_sum(ss, sh2);
-        if (t == 0) {
-            const double bm = K + s / B, bv = ss / B - (s / B) * (s / B);
-            const double cnt = *ret_count, tot = cnt + B, delta = bm - *ret_mean;
-            const double M2 = *ret_var * cnt + bv * B + delta * delta * cnt * B / tot;
-            *ret_mean = *ret_mean + delta * B / tot;
-            *ret_var = M2 / tot;
-        }
-        return;
-    }
-    if (!(flags & 1)) return;
-    const int rpb = blockDim.x / D, nthr = rpb * D;       // rows per pass of this block
-    double s = 0, ss = 0;
-    const int col = t % D, rsub = t / D;
-    if (t < nthr) {
-        const double K = mean[col];
-        for (int row = blockIdx.x * rpb + rsub; row < B; row += VN_BLOCKS * rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
-    }
-    sh[0][t] = s; sh[1][t] = ss;
-    __syncthreads();
-    if (t < D) {
-        for (int r = 1; r < rpb; r++) { s += sh[0][r * D + t]; ss += sh[1][r * D + t]; }
-        work[((size_t)blockIdx.x * D + t) * 2] = s; work[((size_t)blockIdx.x * D + t) * 2 + 1] = ss;
+        if (t == 0) { work[((size_t)blockIdx.x * W + D) * 2] = s; work[((size_t)blockIdx.x * W + D) * 2 + 1] = ss; }
     }
     __threadfence();
     __syncthreads();
@@ -483,14 +479,17 @@ __global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, 
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    if (t < D) {
+    const bool do_obs = t < D && (flags & 1), do_ret = t == D && (flags & 4);
+    if (do_obs || do_ret) {
         double S = 0, SS = 0;
-        for (int b = 0; b < VN_BLOCKS; b++) { S += __builtin_nontemporal_load(&work[((size_t)b * D + t) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * D + t) * 2 + 1]); }
-        const double K = mean[t], bm = K + S / B, bv = SS / B - (S / B) * (S / B);
-        const double cnt = *count, tot = cnt + B, delta = bm - K;
-        const double M2 = var[t] * cnt + bv * B + delta * delta * cnt * B / tot;
-        mean[t] = K + delta * B / tot;
-        var[t] = M2 / tot;
+        for (int b = 0; b < VN_BLOCKS; b++) { S += __builtin_nontemporal_load(&work[((size_t)b * W + t) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * W + t) * 2 + 1]); }
+        double* m = do_obs ? mean + t : ret_mean;
+        double* v = do_obs ? var + t : ret_var;
+        const double K = *m, bm = K + S / B, bv = SS / B - (S / B) * (S / B);
+        const double cnt = do_obs ? *count : *ret_count, tot = cnt + B, delta = bm - K;
+        const double M2 = *v * cnt + bv * B + delta * delta * cnt * B / tot;
+        *m = K + delta * B / tot;
+        *v = M2 / tot;
     }
     if (t == 0) *arrive = 0;
 }
@@ -515,13 +514,32 @@ __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, c
     }
 }
 
-// RolloutBuffer.compute_returns_and_advantage: one lane per walker, reverse scan over T
+// RolloutBuffer.compute_returns_and_advantage: one lane per walker, reverse scan over T (same float32 operation
+// order as SB3's loop).  The inputs of the next GAE_U steps do not depend on the recurrence: they are loaded as a
+// block before the dependent chain runs, so the scan pays one memory latency per GAE_U steps instead of one per step.
+constexpr int GAE_U = 16;
 __global__ void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const float* __restrict__ last_val,
                       const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N, float* adv, float* ret) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float last = 0.f, nnt = 1.0f - (float)last_done[i], nv = last_val[i];
-    for (int t = T - 1; t >= 0; t--) {
+    int t = T - 1;
+    for (; t >= GAE_U - 1; t -= GAE_U) {
+        float r[GAE_U], v[GAE_U], s[GAE_U];
+#pragma unroll
+        for (int u = 0; u < GAE_U; u++) { const size_t o = (size_t)(t - u) * N + i; r[u] = rew[o]; v[u] = val[o]; s[u] = (float)ep_start[o]; }
+#pragma unroll
+        for (int u = 0; u < GAE_U; u++) {
+            const size_t o = (size_t)(t - u) * N + i;
+            const float delta = r[u] + gamma * nv * nnt - v[u];
+            last = delta + gamma * lam * nnt * last;
+            adv[o] = last;
+            ret[o] = last + v[u];
+            nnt = 1.0f - s[u];
+            nv = v[u];
+        }
+    }
+    for (; t >= 0; t--) {
         const size_t o = (size_t)t * N + i;
         const float vt = val[o];
         const float delta = rew[o] + gamma * nv * nnt - vt;
@@ -1016,9 +1034,9 @@ int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done
     if (!obs || !rew || !done || !obs_mean || !obs_var || !obs_count || !ret || !ret_mean || !ret_var || !ret_count || !obs_out || !rew_out || !workspace || B <= 0 || D <= 0 || D > 128)
         return fail(DL_E_INVAL, "dl_vecnormalize_step: bad arguments");
     double* work = (double*)workspace;
-    unsigned* arrive = (unsigned*)(work + (size_t)2 * VN_BLOCKS * D);
+    unsigned* arrive = (unsigned*)(work + (size_t)2 * VN_BLOCKS * (D + 1));
     if (flags & 5)
-        hipLaunchKernelGGL(k_vn_reduce, dim3(VN_BLOCKS + 1), dim3(256), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
+        hipLaunchKernelGGL(k_vn_reduce, dim3(VN_BLOCKS), dim3(256), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
                            (const double*)ret_count, B, D, gamma, flags, work, arrive);
     const size_t ne = (size_t)B * D;
     hipLaunchKernelGGL(k_vn_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, rew, done, (const double*)obs_mean, (const double*)obs_var, obs_count,

@@ -377,7 +377,7 @@ class HipVecNormalize:
         self.ret = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)
         self.norm_obs_t = torch.zeros_like(venv.obs)
         self.norm_rew_t = torch.zeros_like(venv.rew)
-        self._vn_work = torch.zeros(2 * 32 * venv.obs_dim + 2, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
+        self._vn_work = torch.zeros(2 * 32 * (venv.obs_dim + 1) + 2, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
 
     # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
     @property

@@ -261,7 +261,7 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
  * moments (training), 8 normalise rewards.  obs/rew are not modified (get_original_obs / get_original_reward);
  * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
  * zero-initialised once by the caller and owned by this call sequence. */
-#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * (D) + 2))
+#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * ((D) + 1) + 2))
 int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean,
                          double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                          double* ret_count, int32_t B, int32_t D, double gamma, double eps, double clip_obs,

@@ -290,7 +290,7 @@ def test_sb3_reductions(torch_cuda, oracle):
         tc2 = torch.full((1,), 1e-4, dtype=torch.float64, device='cuda')
         trm = torch.zeros(1, dtype=torch.float64, device='cuda'); trv = torch.ones(1, dtype=torch.float64, device='cuda')
         trc = torch.full((1,), 1e-4, dtype=torch.float64, device='cuda'); tret = torch.zeros(B2, dtype=torch.float64, device='cuda')
-        work = torch.zeros(2 * 32 * D2 + 2, dtype=torch.float64, device='cuda')
+        work = torch.zeros(2 * 32 * (D2 + 1) + 2, dtype=torch.float64, device='cuda')
         for it in range(4):
             x = (rng.standard_normal((B2, D2)) * rng.uniform(0.1, 5, D2) + rng.uniform(-20, 20, D2)).astype(np.float32)
             r = rng.uniform(0, 1.2, B2).astype(np.float32); dn = (rng.random(B2) < 0.1).astype(np.uint8)
