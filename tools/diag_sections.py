@@ -49,6 +49,7 @@ for t in range(30):
 tot /= 30
 whole = tot[7]
 print(f'control step: per wave cycles mean {whole.mean():.0f} median {np.median(whole):.0f} max {whole.max():.0f} (the launch lasts as long as its slowest wave); wave iterations per step mean {tot[6].mean():.1f} max {tot[6].max():.0f}')
+print('  wave-time percentiles (cycles): ' + '  '.join(f'p{q} {np.percentile(whole, q):.0f}' for q in (10, 50, 90, 99, 100)))
 for k in range(6):
     print(f'  {names[k]:22s} mean {tot[k].mean():9.0f}  ({100 * tot[k].mean() / whole.mean():5.1f} %)  slowest wave {tot[k][whole.argmax()]:9.0f}')
 print(f'  {"outside the evaluations":22s} mean {(whole - tot[:6].sum(0)).mean():9.0f}  ({100 * (whole - tot[:6].sum(0)).mean() / whole.mean():5.1f} %)')
