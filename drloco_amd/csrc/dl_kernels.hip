@@ -514,47 +514,71 @@ __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, c
     }
 }
 
-// RolloutBuffer.compute_returns_and_advantage: one lane per walker, reverse scan over T (same float32 operation
-// order as SB3's loop).  The inputs of the next GAE_U steps do not depend on the recurrence: they are loaded as a
-// block before the dependent chain runs, so the scan pays one memory latency per GAE_U steps instead of one per step.
-constexpr int GAE_U = 16;
-__global__ void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const float* __restrict__ last_val,
-                      const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N, float* adv, float* ret) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// RolloutBuffer.compute_returns_and_advantage.  The recurrence A_t = delta_t + c_t A_{t+1} (c_t = gamma lambda (1 - start_{t+1}))
+// is affine in A_{t+1}, so the T axis is cut into GAE_CHUNKS pieces that run in parallel (N x GAE_CHUNKS lanes instead of N:
+// a [512, 4096] buffer is 512 waves instead of 64):
+//   k_gae_local   per (walker, chunk): scan the chunk with A_in = 0, which yields its offset a; its slope b = prod c_t;
+//   k_gae_apply   per (walker, chunk): A_in of the chunk by composing the (a, b) of the later chunks (<= GAE_CHUNKS - 1 steps), then
+//                 A_t = A_t(local) + B_t A_in with the running product B_t, returns = A + V.
+// Inputs are read twice (40 B per sample instead of 20) in exchange for 8x the parallelism.  Float32; the grouping of the
+// operations differs from SB3's single loop by rounding only (<= 1e-6 relative, tests/test_gpu_parity.py::test_sb3_reductions).
+constexpr int GAE_CHUNKS = 8;
+__global__ void k_gae_local(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const float* __restrict__ last_val,
+                            const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N, int clen, float* adv, float* ab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (i >= N) return;
-    float last = 0.f, nnt = 1.0f - (float)last_done[i], nv = last_val[i];
-    int t = T - 1;
-    for (; t >= GAE_U - 1; t -= GAE_U) {
-        float r[GAE_U], v[GAE_U], s[GAE_U];
-#pragma unroll
-        for (int u = 0; u < GAE_U; u++) { const size_t o = (size_t)(t - u) * N + i; r[u] = rew[o]; v[u] = val[o]; s[u] = (float)ep_start[o]; }
-#pragma unroll
-        for (int u = 0; u < GAE_U; u++) {
-            const size_t o = (size_t)(t - u) * N + i;
-            const float delta = r[u] + gamma * nv * nnt - v[u];
-            last = delta + gamma * lam * nnt * last;
-            adv[o] = last;
-            ret[o] = last + v[u];
-            nnt = 1.0f - s[u];
-            nv = v[u];
-        }
-    }
-    for (; t >= 0; t--) {
+    const int t1 = T - 1 - k * clen, t0 = t1 - clen + 1 > 0 ? t1 - clen + 1 : 0;      // chunk k covers t1 down to t0 (chunk 0 is the latest)
+    if (t1 < 0) { ab[((size_t)k * N + i) * 2] = 0.f; ab[((size_t)k * N + i) * 2 + 1] = 1.f; return; }
+    // value / non-terminal flag of step t1 + 1
+    float nv, nnt;
+    if (t1 == T - 1) { nv = last_val[i]; nnt = 1.0f - (float)last_done[i]; }
+    else { const size_t o1 = (size_t)(t1 + 1) * N + i; nv = val[o1]; nnt = 1.0f - (float)ep_start[o1]; }
+    float last = 0.f, b = 1.f;
+    for (int t = t1; t >= t0; t--) {
         const size_t o = (size_t)t * N + i;
         const float vt = val[o];
         const float delta = rew[o] + gamma * nv * nnt - vt;
-        last = delta + gamma * lam * nnt * last;
+        const float c = gamma * lam * nnt;
+        last = delta + c * last;
+        b *= c;
         adv[o] = last;
-        ret[o] = last + vt;
         nnt = 1.0f - (float)ep_start[o];
         nv = vt;
+    }
+    ab[((size_t)k * N + i) * 2] = last; ab[((size_t)k * N + i) * 2 + 1] = b;
+}
+__global__ void k_gae_apply(const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const uint8_t* __restrict__ last_done, float gamma, float lam,
+                            int T, int N, int clen, const float* __restrict__ ab, float* adv, float* ret) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i >= N) return;
+    const int t1 = T - 1 - k * clen, t0 = t1 - clen + 1 > 0 ? t1 - clen + 1 : 0;
+    if (t1 < 0) return;
+    // advantage entering this chunk = A at the first step of chunk k - 1, ...: compose the later chunks from the latest on
+    float ain = 0.f;
+    for (int kk = 0; kk < k; kk++) ain = ab[((size_t)kk * N + i) * 2] + ab[((size_t)kk * N + i) * 2 + 1] * ain;
+    float nnt = (t1 == T - 1) ? 1.0f - (float)last_done[i] : 1.0f - (float)ep_start[(size_t)(t1 + 1) * N + i];
+    float B = 1.f;
+    for (int t = t1; t >= t0; t--) {
+        const size_t o = (size_t)t * N + i;
+        B *= gamma * lam * nnt;
+        const float a = adv[o] + B * ain;
+        adv[o] = a;
+        ret[o] = a + val[o];
+        nnt = 1.0f - (float)ep_start[o];
     }
 }
 
 __global__ __launch_bounds__(256) void k_adv_stats(const float* __restrict__ a, long long n, double* out3) {
     __shared__ double sh[4];
     double s = 0, s2 = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { const double x = a[i]; s += x; s2 += x * x; }
+    const long long n4 = n / 4, stride = (long long)gridDim.x * blockDim.x;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 x = a4[i];
+        s += (double)x.x + (double)x.y + (double)x.z + (double)x.w;
+        s2 += (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z + (double)x.w * x.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) { const double x = a[4 * n4 + threadIdx.x]; s += x; s2 += x * x; }
     s = block_sum(s, sh);
     s2 = block_sum(s2, sh);
     if (threadIdx.x == 0) { atomicAdd(&out3[0], s); atomicAdd(&out3[1], s2); if (blockIdx.x == 0) atomicAdd(&out3[2], (double)n); }
@@ -1071,15 +1095,32 @@ int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, co
 }
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val, const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv, float* ret, void* stream) {
     if (!rew || !val || !ep_start || !last_val || !last_done || !adv || !ret || T <= 0 || N <= 0) return fail(DL_E_INVAL, "dl_gae: bad arguments");
-    hipLaunchKernelGGL(k_gae, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew, val, ep_start, last_val, last_done, gamma, lam, T, N, adv, ret);
+    const int clen = (T + GAE_CHUNKS - 1) / GAE_CHUNKS;
+    // (offset, slope) of every chunk and walker: a per-device scratch buffer owned by the library, grown on demand
+    // (calls are stream-ordered and a device is driven by one host thread, see the header)
+    static float* ws[64] = {nullptr};
+    static size_t ws_n[64] = {0};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(DL_E_INVAL, "dl_gae: device ordinal out of range");
+    const size_t need = (size_t)2 * GAE_CHUNKS * N;
+    if (ws_n[dev] < need) {
+        if (ws[dev]) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(ws[dev])); ws[dev] = nullptr; ws_n[dev] = 0; }
+        HIPCHK(hipMalloc((void**)&ws[dev], need * sizeof(float)));
+        ws_n[dev] = need;
+    }
+    float* ab = ws[dev];
+    hipLaunchKernelGGL(k_gae_local, dim3((N + 63) / 64, GAE_CHUNKS), dim3(64), 0, (hipStream_t)stream, rew, val, ep_start, last_val, last_done, gamma, lam, T, N, clen, adv, ab);
+    hipLaunchKernelGGL(k_gae_apply, dim3((N + 63) / 64, GAE_CHUNKS), dim3(64), 0, (hipStream_t)stream, val, ep_start, last_done, gamma, lam, T, N, clen, (const float*)ab, adv, ret);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
 int dl_adv_stats(const float* adv, int64_t n, double* out3, void* stream) {
     if (!adv || !out3 || n <= 0) return fail(DL_E_INVAL, "dl_adv_stats: bad arguments");
     HIPCHK(hipMemsetAsync(out3, 0, 3 * sizeof(double), (hipStream_t)stream));
-    long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adv_stats, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, adv, (long long)n, out3);
     HIPCHK(hipGetLastError());
     return DL_OK;

@@ -313,7 +313,7 @@ def test_sb3_reductions(torch_cuda, oracle):
             np.testing.assert_allclose(ro.cpu().numpy(), rn, atol=1e-6)
             np.testing.assert_allclose(tret.cpu().numpy(), ret, rtol=1e-12, atol=1e-12)
             assert torch.equal(xt2.cpu(), torch.as_tensor(x))          # inputs untouched
-    # GAE against the oracle's float32 scan (bit-exact: same operation order)
+    # GAE against the oracle's float32 scan (the device scan runs 8 chunks of the T axis in parallel: same result up to rounding)
     T, N = 64, 512
     buf = HipRolloutBuffer(T, N, 29, 8, 'cuda', gamma=0.995, gae_lambda=0.95)
     rew = rng.uniform(0, 1.2, (T, N)).astype(np.float32); val = rng.standard_normal((T, N)).astype(np.float32)
@@ -323,6 +323,16 @@ def test_sb3_reductions(torch_cuda, oracle):
     a0, r0 = oracle.gae(rew, val, es, lv, ld, 0.995, 0.95)
     np.testing.assert_allclose(adv.cpu().numpy(), a0, rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(ret.cpu().numpy(), r0, rtol=2e-6, atol=2e-6)
+    # ragged shapes: rollouts shorter than / not divisible by the number of parallel chunks of the scan
+    for T2, N2 in ((1, 5), (3, 70), (7, 64), (13, 64), (100, 33)):
+        b2 = HipRolloutBuffer(T2, N2, 29, 8, 'cuda', gamma=0.995, gae_lambda=0.95)
+        rew2 = rng.uniform(0, 1.2, (T2, N2)).astype(np.float32); val2 = rng.standard_normal((T2, N2)).astype(np.float32)
+        es2 = (rng.random((T2, N2)) < 0.2).astype(np.uint8); lv2 = rng.standard_normal(N2).astype(np.float32); ld2 = (rng.random(N2) < 0.3).astype(np.uint8)
+        b2.rewards.copy_(torch.as_tensor(rew2)); b2.values.copy_(torch.as_tensor(val2)); b2.episode_starts.copy_(torch.as_tensor(es2))
+        adv2, ret2 = b2.compute_returns_and_advantage(torch.as_tensor(lv2, device='cuda'), torch.as_tensor(ld2, device='cuda'))
+        a2, r2 = oracle.gae(rew2, val2, es2, lv2, ld2, 0.995, 0.95)
+        np.testing.assert_allclose(adv2.cpu().numpy(), a2, rtol=2e-6, atol=2e-6, err_msg=f'T={T2} N={N2}')
+        np.testing.assert_allclose(ret2.cpu().numpy(), r2, rtol=2e-6, atol=2e-6)
     # closed form: constant reward, zero values, no episode starts -> geometric sums
     buf.rewards.fill_(1.0); buf.values.zero_(); buf.episode_starts.zero_()
     adv, _ = buf.compute_returns_and_advantage(torch.zeros(N, device='cuda'), torch.zeros(N, dtype=torch.uint8, device='cuda'))
