@@ -191,16 +191,26 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     if (__any(simulate)) {
         const T h = m->timestep;
         const int fs = m->frame_skip;
+        T acc_s2_prev = T(0);
 #pragma unroll 1
         for (int kf = 0; kf < fs; kf++) {
             // mj_checkPos / mj_checkVel
             if (simulate && !exc && gany(isdof && (dl_bad(q) || dl_bad(v)))) exc = true;
             const T q0 = q, v0 = v;
             T dq = T(0), dv = T(0), qs = q, vs = v;
+            T acc_s0 = warm;
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 int nc, ne, ni;
-                const T acc = g_forward<T, TPS, TIMED>(g, lt, grp, qs, vs, force, warm, nc, ne, ni, tacc);
+                // starting point of the Newton iteration (the minimiser does not depend on it): the last solution (MuJoCo's
+                // qacc_warmstart), linearly extrapolated where the next stage lies half a time step further: stage 1 from
+                // (stage 2 of the previous mj_step, stage 0), stage 3 from (stage 0, stage 2)
+                T start = warm;
+                if (stage == 1 && kf > 0) start = warm + (warm - acc_s2_prev);
+                else if (stage == 3) start = warm + (warm - acc_s0);
+                const T acc = g_forward<T, TPS, TIMED>(g, lt, grp, qs, vs, force, start, nc, ne, ni, tacc);
+                if (stage == 0) acc_s0 = acc;
+                if (stage == 2) acc_s2_prev = acc;
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
                 if (st.dbgf && valid && ni >= m->iterations) {
                     st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)warm;
