@@ -53,6 +53,27 @@ class RefTable:
         d._keepalive = self
         return d
 
+    def mirrored(self):
+        """StraightWalkingTrajectories._mirror_refs (straight_walk_trajecs.py:72-94,128-139) on the converted table:
+        every left step becomes the preceding right step with the right/left leg rows exchanged and the lateral
+        quantities negated (COM y, trunk rotation about x and z, frontal hip angle -- positions and velocities).  In
+        the straight walker's row order (mimic_walker3d.py:11-23): qpos = [com x y z, trunk rot x y z,
+        hip sagittal/frontal, knee, ankle (right), the same (left)], velocities likewise.  Step velocities and the
+        left-step flags keep the values computed from the recorded data (the reference mirrors after computing them)."""
+        if self.table.shape[0] != 28:
+            raise ValueError('mirroring is defined for the straight walker\'s step-segmented table')
+        half = list(range(6)) + list(range(10, 14)) + list(range(6, 10))
+        perm = half + [14 + r for r in half]
+        neg = [1, 3, 5, 7, 11]
+        neg = neg + [14 + r for r in neg]
+        steps = [self.table[:, self.step_off[i]:self.step_off[i + 1]] for i in range(self.n_steps)]
+        for i in np.nonzero(self.step_is_left)[0]:
+            m = steps[i - 1][perm, :].copy()
+            m[neg, :] *= -1
+            steps[i] = m
+        off = np.concatenate([[0], np.cumsum([s.shape[1] for s in steps])])
+        return RefTable(np.concatenate(steps, axis=1), off, self.step_is_left, self.step_vel, self.stride)
+
     def save(self, path):
         np.savez_compressed(path, table=self.table, step_off=self.step_off, step_is_left=self.step_is_left,
                             step_vel=self.step_vel, stride=np.int32(self.stride))
@@ -70,8 +91,10 @@ def _sequential_mean(row):
     return acc / len(row)
 
 
-def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200):
-    """Trajecs_Constant_Speed_400Hz.mat -> RefTable."""
+def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200, mirror_refs=False):
+    """Trajecs_Constant_Speed_400Hz.mat -> RefTable.  mirror_refs: StraightWalkingTrajectories(mirror_refs=True)
+    (straight_walk_trajecs.py:98-116): applied after the step velocities and the left-step indices were computed from
+    the recorded data, exactly as the reference orders it."""
     import scipy.io as spio
     steps = spio.loadmat(mat_path, squeeze_me=True)['Data'].flatten()
     if steps[0].shape[0] != 38:
@@ -91,7 +114,8 @@ def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200):
     for s in steps:
         if not s[0, 0] < 0.005:
             raise ValueError('COM-x of every step must start at 0 (straight_walk_trajecs.py:343)')
-    return RefTable(table, off, is_left, vel, int(stride))
+    ref = RefTable(table, off, is_left, vel, int(stride))
+    return ref.mirrored() if mirror_refs else ref
 
 
 # loco3d: rows of angJoi / angDJoi used by MimicWalker165cm65kg (mimic_walker_165cm_65kg.py:6-15,
@@ -100,14 +124,21 @@ def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200):
 LOCO3D_ROWS = [3, 5, 4, 1, 0, 2, 21, 20, 22, 6, 7, 8, 9, 10, 13, 14, 15, 16, 17]
 
 
-def convert_loco3d_mat(mat_path, sample_freq=500, control_freq=100):
+def convert_loco3d_mat(mat_path, sample_freq=500, control_freq=100, adaptations=None):
     """loco3d_guoping.mat (angJoi, angDJoi: (37, L)) -> RefTable with one continuous trajectory."""
     import scipy.io as spio
     d = spio.loadmat(mat_path, squeeze_me=True)
-    return loco3d_table(np.asarray(d['angJoi'], np.float64), np.asarray(d['angDJoi'], np.float64), sample_freq, control_freq)
+    return loco3d_table(np.asarray(d['angJoi'], np.float64), np.asarray(d['angDJoi'], np.float64), sample_freq, control_freq, adaptations)
 
 
-def loco3d_table(ang, ang_vel, sample_freq=500, control_freq=100):
+def loco3d_table(ang, ang_vel, sample_freq=500, control_freq=100, adaptations=None):
+    """adaptations: BaseReferenceTrajectories.adapt_trajectories (base_ref_trajecs.py:105-118) -- {row of angJoi/angDJoi:
+    scalar}; position and velocity of that row are scaled (the reference's walkers pass an empty dict)."""
+    if adaptations:
+        ang, ang_vel = np.array(ang, np.float64), np.array(ang_vel, np.float64)
+        for row, scalar in adaptations.items():
+            ang[row, :] *= scalar
+            ang_vel[row, :] *= scalar
     stride = sample_freq / control_freq
     if stride != int(stride):
         raise ValueError('sample frequency must be an integer multiple of the control frequency')

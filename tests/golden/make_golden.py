@@ -18,6 +18,8 @@ Fixtures:
   G5_actions.npz         _rescale_actions + mirror_action
   G6_terminate_early.npz do_terminate_early truth table
   G7_monitor.npz         Monitor smoothing traces
+  G11_mocap_options.npz  StraightWalkingTrajectories(mirror_refs=True) table + cursor trace; adapt_trajectories on the
+                         synthetic loco3d table (`python tests/golden/make_golden.py mocap` regenerates only this one)
   G10_policy_trunk.npz   CustomHiddenLayers (drloco/custom/policies.py:13-51): weights, inputs, latent outputs
                          (`python tests/golden/make_golden.py policy` regenerates only this one)
 
@@ -276,9 +278,60 @@ def make_policy_golden():
     print('G10_policy_trunk.npz written')
 
 
+def make_mocap_options_golden():
+    """G11: the two load-time options of the reference-trajectory classes that G1/G9 do not exercise."""
+    import tempfile
+    import scipy.io as spio
+    refs_mod, walker_mod, monitor_mod, utils, hypers, _ = _import_reference()
+    qpos_rows, qvel_rows = list(walker_mod.qpos_indices), list(walker_mod.qvel_indices)
+    refs = refs_mod.StraightWalkingTrajectories(qpos_rows, qvel_rows, mirror_refs=True)
+    rows = qpos_rows + qvel_rows
+    full = [np.asarray(s[rows, :], dtype=np.float64) for s in refs.data]
+    # the first six steps in full, every step by per-row sums (keeps the fixture small)
+    g = dict(m_table6=np.concatenate(full[:6], axis=1), m_rowsum=np.stack([f.sum(axis=1) for f in full]),
+             m_rowabs=np.stack([np.abs(f).sum(axis=1) for f in full]),
+             m_step_len=np.array([s.shape[1] for s in refs.data], dtype=np.int32),
+             m_left=np.array(refs.left_step_indices, dtype=np.int32),
+             m_step_vel=np.asarray(refs.step_velocities, dtype=np.float64))
+    # a cursor trace across a right -> (mirrored) left rollover
+    set_refs_cursor(refs, 4, 200)
+    T = 120
+    g['m_start'] = np.array([4, 200])
+    g['m_q'] = np.zeros((T, 14)); g['m_v'] = np.zeros((T, 14)); g['m_cur'] = np.zeros((T, 2), np.int32)
+    for t in range(T):
+        refs.next()
+        g['m_q'][t], g['m_v'][t] = np.asarray(refs.get_qpos(), float), np.asarray(refs.get_qvel(), float)
+        g['m_cur'][t] = refs._i_step, refs._pos
+    # adapt_trajectories through Loco3dReferenceTrajectories on a small synthetic table in the reference's .mat schema
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from drloco_amd import mocap as my_mocap
+    import drloco.config.config as cfgl
+    L, seed = 500, 5
+    ang, vel = my_mocap.synthetic_loco3d(L=L, seed=seed)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, 'mocaps', 'loco3d'))
+    spio.savemat(os.path.join(tmp, 'mocaps', 'loco3d', 'loco3d_guoping.mat'),
+                 {'angJoi': ang, 'angDJoi': vel, 'rowNameIK': np.array([f'row{i}' for i in range(37)], dtype=object)})
+    cfgl.CTRL_FREQ = 100
+    import drloco.ref_trajecs.loco3d_trajecs as l3
+    l3.get_project_path = lambda: tmp + '/'
+    from drloco.mujoco import mimic_walker_165cm_65kg as w165
+    adapt = {6: 1.1, 9: 0.9, 13: 1.1, 16: 0.9, 4: 0.95}
+    r3 = l3.Loco3dReferenceTrajectories(w165.ref_trajecs_qpos_indices, w165.ref_trajecs_qvel_indices, adapt)
+    g['a_L'], g['a_seed'] = np.array(L), np.array(seed)
+    g['a_rows'], g['a_scalars'] = np.array(list(adapt.keys())), np.array(list(adapt.values()))
+    g['a_q'] = np.asarray(r3._qpos_full[w165.ref_trajecs_qpos_indices, :], dtype=np.float64)
+    g['a_v'] = np.asarray(r3._qvel_full[w165.ref_trajecs_qvel_indices, :], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'G11_mocap_options.npz'), **g)
+    print('wrote G11_mocap_options.npz')
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'policy':
         make_policy_golden()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'mocap':
+        make_mocap_options_golden()
         return
     refs_mod, walker_mod, monitor_mod, utils, hypers, MujocoException = _import_reference()
     import drloco.mujoco.mimic_env as mimic_env_mod

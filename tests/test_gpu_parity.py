@@ -800,3 +800,40 @@ def test_ppo_learns_on_the_device_path(torch_cuda):
     last = hist[-1]
     assert last['ep_len'] > 300 and last['ep_len'] > 2.5 * first['ep_len'], (first, last)
     assert last['mean_step_reward'] > 0.5 and last['moved_distance'] > 2.0, last
+
+
+def test_batched_evaluation_matches_the_serial_loop(torch_cuda, model, refs):
+    """evaluate_walking (20 deterministic-init episodes as 20 walkers of one handle) against the reference's own loop
+    shape (callback.py:294-317: ONE walker, episodes one after the other through the VecEnv API)."""
+    import torch
+    from drloco_amd.evaluation import evaluate_walking, make_eval_env
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize, vec_env
+    train = vec_env(num_envs=64, seed=3, model=model, refs=refs)
+    train.reset()
+    rng = np.random.default_rng(1)
+    for t in range(40):                                         # some moments to normalise with
+        train.step(np.clip(0.5 * rng.standard_normal((64, 8)), -1, 1))
+    pol = HipPolicy(hidden=128, seed=11)
+    res = evaluate_walking(make_eval_env(train), pol)
+    assert len(res['ep_durs']) == 20 and min(res['ep_durs']) >= 2 and max(res['ep_durs']) <= 3000
+    # serial: a 1-walker handle, evaluation on, frozen copy of the moments
+    one = HipVecNormalize(HipVecEnv(num_envs=1, seed=3, model=model, refs=refs), training=False, norm_reward=False)
+    one.obs_rms.load_state(train.obs_rms.state()); one.ret_rms.load_state(train.ret_rms.state())
+    one.venv.envs[0].env.activate_evaluation()
+    obs = one.reset()
+    for k in range(6):
+        ep_dur, walked, rewards = 0, 0.0, []
+        while True:
+            ep_dur += 1
+            a, _, _ = pol.forward(torch.as_tensor(obs, device='cuda'), deterministic=True)
+            obs, reward, done, info = one.step(a.cpu().numpy())
+            if done[0]:
+                break
+            walked = one.venv.envs[0].env.get_walked_distance()
+            rewards.append(one.get_original_reward()[0])
+        assert ep_dur == res['ep_durs'][k], (k, ep_dur, res['ep_durs'][k])
+        assert walked == pytest.approx(res['moved_distances'][k], rel=1e-6, abs=1e-9)
+        assert np.mean(rewards) == pytest.approx(res['mean_rewards'][k], rel=1e-5)
+    assert res['count_stable_walks'] == 0 and not res['is_stable_humanlike_walking']     # a random policy does not walk
+    assert res['mean_walked_distance'] == pytest.approx(np.mean(res['moved_distances']))

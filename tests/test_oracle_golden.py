@@ -300,3 +300,41 @@ def test_G10_policy_trunk(oracle):
                                                 g['x'], np.zeros((len(g['x']), A)))
     np.testing.assert_allclose(lat, g['latent'], atol=2e-6)          # torch float32 vs numpy float64
     assert np.allclose(logp, A * (0.75 - 0.5 * np.log(2 * np.pi)))
+
+
+def test_G11_mirrored_refs(oracle, model, refs):
+    """StraightWalkingTrajectories(mirror_refs=True): the table RefTable.mirrored() builds, and the oracle's cursor /
+    lookup driven on it across a right -> mirrored-left rollover."""
+    g = load('G11_mocap_options.npz')
+    m = refs.mirrored()
+    assert np.array_equal(m.step_len, g['m_step_len'])
+    assert np.array_equal(np.nonzero(m.step_is_left)[0], g['m_left']) and np.array_equal(m.step_vel, g['m_step_vel'])
+    assert np.array_equal(m.table[:, :m.step_off[6]], g['m_table6'])
+    for i in range(m.n_steps):
+        blk = m.table[:, m.step_off[i]:m.step_off[i + 1]]
+        np.testing.assert_allclose(blk.sum(axis=1), g['m_rowsum'][i], rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(np.abs(blk).sum(axis=1), g['m_rowabs'][i], rtol=1e-13, atol=1e-12)
+    # left steps really are mirrored right steps: the lateral COM position flips sign
+    assert np.array_equal(m.table[1, m.step_off[1]:m.step_off[2]], -m.table[1, m.step_off[0]:m.step_off[1]])
+    env = make_env(oracle, model, m, n=1, ep_dur_max=10 ** 9)
+    env.set_state(cursor=cursor(int(g['m_start'][0]), int(g['m_start'][1])))
+    q_up = np.array(model.jnt_qpos0[:14])
+    for t in range(len(g['m_q'])):
+        env.inject_state(0, q_up, np.zeros(14))
+        env.step(np.zeros((1, 8)))
+        st = env.get_state()['cursor']
+        assert (st[abi.DL_CUR_I_STEP, 0], st[abi.DL_CUR_POS, 0]) == tuple(g['m_cur'][t]), t
+        qr, vr = env.ref_lookup(0)
+        assert np.array_equal(qr, g['m_q'][t]) and np.array_equal(vr, g['m_v'][t]), t
+    assert len(set(g['m_cur'][:, 0])) > 1
+
+
+def test_G11_adapt_trajectories():
+    """BaseReferenceTrajectories.adapt_trajectories through Loco3dReferenceTrajectories (synthetic table, reference schema)."""
+    from drloco_amd import mocap
+    g = load('G11_mocap_options.npz')
+    ang, vel = mocap.synthetic_loco3d(L=int(g['a_L']), seed=int(g['a_seed']))
+    t = mocap.loco3d_table(ang, vel, adaptations=dict(zip(g['a_rows'].tolist(), g['a_scalars'].tolist())))
+    assert np.array_equal(t.table[:19], g['a_q']) and np.array_equal(t.table[19:], g['a_v'])
+    plain = mocap.loco3d_table(ang, vel)
+    assert not np.array_equal(plain.table, t.table)
