@@ -1,0 +1,158 @@
+"""Checkpoint formats either side of the path: what `utils.save_model` writes and
+`utils.load_env` / `PPO.load` read (drloco/common/utils.py:175-192,234-240; callback.py:280-291).
+
+  envs/env_<ckpt>       [3P SB3 1.0] `VecNormalize.save`: `pickle.dump(self)` with `__getstate__` dropping venv,
+                        class_attributes and ret -- an object of class
+                        stable_baselines3.common.vec_env.vec_normalize.VecNormalize whose obs_rms / ret_rms are
+                        stable_baselines3.common.running_mean_std.RunningMeanStd(mean, var, count) and whose
+                        observation_space / action_space are gym Boxes.
+  models/model_<ckpt>.zip  [3P SB3 1.0] zip archive: `data` (json of the constructor arguments), `policy.pth`
+                        (`th.save(policy.state_dict())`), `policy.optimizer.pth`, `pytorch_variables.pth`,
+                        `_stable_baselines3_version`.  For the reference's CustomActorCriticPolicy
+                        (drloco/custom/policies.py:13-80) the state dict holds log_std, mlp_extractor.policy_net.{0,2}.*
+                        (the SAME modules appear again as mlp_extractor.value_net.{0,2}.*), action_net.*, value_net.*.
+
+Neither SB3 nor gym is installed here, so both layouts are restated from SB3 1.0's published source and are
+**unpinned by a reference artefact**: the reader below is tolerant (any class it cannot import becomes a plain attribute
+bag), the writer emits the SB3 class paths so that an SB3 installation unpickles real objects.
+"""
+import io
+import json
+import pickle
+import sys
+import types
+import zipfile
+
+import numpy as np
+import torch
+
+_VN_CLASS = ('stable_baselines3.common.vec_env.vec_normalize', 'VecNormalize')
+_RMS_CLASS = ('stable_baselines3.common.running_mean_std', 'RunningMeanStd')
+
+
+class _Bag:
+    """Stand-in for a class that cannot be imported while reading a pickle."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):      # (dict, slots)
+            state = {**(state[0] or {}), **state[1]}
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__['_state'] = state
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            return type(name, (_Bag,), {'__module__': module})
+
+
+def read_vecnormalize(path):
+    """-> dict(obs_rms, ret_rms, clip_obs, clip_reward, gamma, epsilon, norm_obs, norm_reward, training) from either
+    the SB3 object pickle or this package's own dict pickle (HipVecNormalize.save)."""
+    with open(path, 'rb') as f:
+        obj = _TolerantUnpickler(f).load()
+    if isinstance(obj, dict):
+        return obj
+    d = obj.__dict__
+    rms = lambda r: dict(mean=np.asarray(r.mean, np.float64), var=np.asarray(r.var, np.float64), count=float(r.count))
+    return dict(obs_rms=rms(d['obs_rms']), ret_rms=rms(d['ret_rms']), clip_obs=float(d['clip_obs']), clip_reward=float(d['clip_reward']),
+                gamma=float(d['gamma']), epsilon=float(d['epsilon']), norm_obs=bool(d.get('norm_obs', True)),
+                norm_reward=bool(d.get('norm_reward', True)), training=bool(d.get('training', True)))
+
+
+def _sb3_class(module, name):
+    """The real class when SB3 is importable, otherwise a placeholder registered under the SB3 module path so that
+    pickle writes `module.name` as the global."""
+    try:
+        __import__(module)
+        return getattr(sys.modules[module], name), False
+    except Exception:
+        parts = module.split('.')
+        for i in range(1, len(parts) + 1):
+            sys.modules.setdefault('.'.join(parts[:i]), types.ModuleType('.'.join(parts[:i])))
+        cls = type(name, (object,), {'__module__': module})
+        setattr(sys.modules[module], name, cls)
+        return cls, True
+
+
+def _drop_placeholders():
+    for m in [m for m in sys.modules if m.split('.')[0] == 'stable_baselines3' and not hasattr(sys.modules[m], '__file__')]:
+        del sys.modules[m]
+
+
+def write_vecnormalize_sb3(vn, path):
+    """HipVecNormalize -> the SB3 1.0 object pickle (state after `__getstate__`; the spaces are left to `set_venv`,
+    which takes them from the wrapped venv on load)."""
+    vn_cls, fake1 = _sb3_class(*_VN_CLASS)
+    rms_cls, fake2 = _sb3_class(*_RMS_CLASS)
+
+    def rms(r):
+        o = rms_cls.__new__(rms_cls)
+        o.__dict__.update(mean=np.array(r.mean, np.float64), var=np.array(r.var, np.float64), count=float(r.count))
+        return o
+    o = vn_cls.__new__(vn_cls)
+    o.__dict__.update(num_envs=vn.num_envs, obs_rms=rms(vn.obs_rms), ret_rms=rms(vn.ret_rms), clip_obs=vn.clip_obs, clip_reward=vn.clip_reward,
+                      gamma=vn.gamma, epsilon=vn.epsilon, training=vn.training, norm_obs=vn.norm_obs, norm_reward=vn.norm_reward,
+                      old_obs=np.array([]), old_reward=np.array([]))
+    try:
+        with open(path, 'wb') as f:
+            pickle.dump(o, f)
+    finally:
+        if fake1 or fake2:
+            _drop_placeholders()
+
+
+# ---- model.zip ---------------------------------------------------------------------------------
+_KEYS = dict(w1='mlp_extractor.policy_net.0.weight', b1='mlp_extractor.policy_net.0.bias', w2='mlp_extractor.policy_net.2.weight',
+             b2='mlp_extractor.policy_net.2.bias', wa='action_net.weight', ba='action_net.bias', wv='value_net.weight', bv='value_net.bias',
+             log_std='log_std')
+
+
+def read_policy_zip(path):
+    """SB3 model.zip -> the nine tensors HipPolicy.load_state takes.  Only the reference's shared-trunk
+    CustomActorCriticPolicy maps onto the fused kernel; separate pi/vf trunks (SB3's MlpPolicy with
+    net_arch=[dict(pi=..., vf=...)], the reference's non-default branch, train.py:106-108) are refused."""
+    with zipfile.ZipFile(path) as z:
+        sd = torch.load(io.BytesIO(z.read('policy.pth')), map_location='cpu', weights_only=True)
+    for a, b in (('mlp_extractor.policy_net.0.weight', 'mlp_extractor.value_net.0.weight'), ('mlp_extractor.policy_net.2.weight', 'mlp_extractor.value_net.2.weight')):
+        if a not in sd:
+            raise ValueError(f'{path}: no {a} in policy.pth -- not a CustomActorCriticPolicy checkpoint')
+        if b in sd and not torch.equal(sd[a], sd[b]):
+            raise ValueError(f'{path}: policy and value trunks differ; the fused policy kernel implements the shared trunk only')
+    if any(k.startswith('mlp_extractor.policy_net.4') for k in sd):
+        raise ValueError(f'{path}: more than two hidden layers')
+    return {k: sd[v] for k, v in _KEYS.items()}
+
+
+def load_policy_zip(path, **kw):
+    from .policy import HipPolicy
+    t = read_policy_zip(path)
+    pol = HipPolicy(obs_dim=t['w1'].shape[1], act_dim=t['wa'].shape[0], hidden=t['w1'].shape[0], **kw)
+    pol.load_state(**t)
+    return pol
+
+
+def write_policy_zip(policy, path, data=None):
+    """Tensors of a HipPolicy (or any object with w1..log_std) -> model.zip with the SB3 1.0 member names."""
+    sd = {}
+    for k, name in _KEYS.items():
+        sd[name] = getattr(policy, k).detach().cpu()
+    for layer in ('0', '2'):       # the shared modules appear under both names in the reference's state dict
+        for p in ('weight', 'bias'):
+            sd[f'mlp_extractor.value_net.{layer}.{p}'] = sd[f'mlp_extractor.policy_net.{layer}.{p}']
+    buf = io.BytesIO(); torch.save(sd, buf)
+    empty = io.BytesIO(); torch.save({}, empty)
+    meta = dict(policy_class='CustomActorCriticPolicy', policy_kwargs=dict(log_std_init=float(getattr(policy, 'log_std')[0])))
+    meta.update(data or {})
+    with zipfile.ZipFile(path, 'w') as z:
+        z.writestr('data', json.dumps(meta, indent=4))
+        z.writestr('policy.pth', buf.getvalue())
+        z.writestr('pytorch_variables.pth', empty.getvalue())
+        z.writestr('_stable_baselines3_version', '1.0')

@@ -472,7 +472,11 @@ class HipVecNormalize:
         self.venv.close()
 
     # utils.save_model / load_env (drloco/common/utils.py:175-192,234-240) keep the running moments
-    def save(self, path):
+    def save(self, path, sb3_format=False):
+        """sb3_format: write SB3 1.0's object pickle (drloco_amd.checkpoint) instead of this package's plain dict."""
+        if sb3_format:
+            from .checkpoint import write_vecnormalize_sb3
+            return write_vecnormalize_sb3(self, path)
         with open(path, 'wb') as f:
             pickle.dump(dict(obs_rms=self.obs_rms.state(), ret_rms=self.ret_rms.state(), clip_obs=self.clip_obs,
                              clip_reward=self.clip_reward, gamma=self.gamma, epsilon=self.epsilon,
@@ -480,8 +484,9 @@ class HipVecNormalize:
 
     @staticmethod
     def load(path, venv):
-        with open(path, 'rb') as f:
-            s = pickle.load(f)
+        """Reads this package's dict pickle or an SB3 1.0 `VecNormalize.save` file (e.g. one written by the reference)."""
+        from .checkpoint import read_vecnormalize
+        s = read_vecnormalize(path)
         vn = HipVecNormalize(venv, norm_obs=s['norm_obs'], norm_reward=s['norm_reward'], clip_obs=s['clip_obs'],
                              clip_reward=s['clip_reward'], gamma=s['gamma'], epsilon=s['epsilon'])
         vn.obs_rms.load_state(s['obs_rms'])

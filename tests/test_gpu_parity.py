@@ -495,6 +495,20 @@ def test_vecnormalize_save_load_and_attrs(torch_cuda, model, refs, tmp_path):
     np.testing.assert_allclose(vn2.obs_rms.mean, vn.obs_rms.mean)
     np.testing.assert_allclose(vn2.ret_rms.var, vn.ret_rms.var)
     assert vn2.obs_rms.count == pytest.approx(vn.obs_rms.count)
+    # the SB3 1.0 layouts of utils.save_model's two files (drloco_amd.checkpoint)
+    p3 = str(tmp_path / 'env_3')
+    vn.save(p3, sb3_format=True)
+    vn3 = HipVecNormalize.load(p3, HipVecEnv(num_envs=4, model=model, refs=refs))
+    np.testing.assert_array_equal(vn3.obs_rms.var, vn.obs_rms.var)
+    assert vn3.ret_rms.count == vn.ret_rms.count and vn3.norm_reward == vn.norm_reward
+    import torch
+    from drloco_amd import checkpoint
+    from drloco_amd.policy import HipPolicy
+    pol = HipPolicy(hidden=128, seed=2)
+    checkpoint.write_policy_zip(pol, str(tmp_path / 'model_3.zip'))
+    pol2 = checkpoint.load_policy_zip(str(tmp_path / 'model_3.zip'))
+    x = torch.randn(40, 29, device='cuda')
+    assert all(torch.equal(a, b) for a, b in zip(pol.forward(x, deterministic=True), pol2.forward(x, deterministic=True)))
     lens = vn.get_attr('ep_lens')
     assert len(lens) == 96 and sum(len(x) for x in lens) > 0
     for name in ('ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance',

@@ -132,3 +132,46 @@ def test_kernel_source_on_host_matches_oracle_loco3d(emu, oracle):
         np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6)
         np.testing.assert_allclose(r2, r1, atol=1e-6)
     assert np.array_equal(o.get_state()['cursor'], e.get_state()['cursor'])
+
+
+def test_checkpoint_formats_round_trip(tmp_path):
+    """drloco_amd.checkpoint: the SB3 1.0 layouts of utils.save_model's two files (restated; SB3 is not installed,
+    so the reader's tolerance for un-importable classes is what makes a reference-written file readable here)."""
+    import pickle
+    import types
+    import zipfile
+    import torch
+    from drloco_amd import checkpoint as ck
+    rng = np.random.default_rng(0)
+    rms = lambda shape: types.SimpleNamespace(mean=rng.standard_normal(shape), var=rng.uniform(0.5, 2, shape), count=12345.5)
+    vn = types.SimpleNamespace(num_envs=8, obs_rms=rms((29,)), ret_rms=rms(()), clip_obs=10.0, clip_reward=10.0, gamma=0.99,
+                               epsilon=1e-8, training=True, norm_obs=True, norm_reward=False)
+    p = str(tmp_path / 'env_17')
+    ck.write_vecnormalize_sb3(vn, p)
+    raw = open(p, 'rb').read()
+    assert b'stable_baselines3.common.vec_env.vec_normalize' in raw and b'RunningMeanStd' in raw
+    assert 'stable_baselines3' not in sys.modules                       # the placeholder modules are gone again
+    with pytest.raises(Exception):
+        pickle.loads(raw)                                               # plain pickle needs SB3 ...
+    s = ck.read_vecnormalize(p)                                         # ... the tolerant reader does not
+    assert np.array_equal(s['obs_rms']['mean'], vn.obs_rms.mean) and s['ret_rms']['var'] == vn.ret_rms.var
+    assert s['obs_rms']['count'] == 12345.5 and s['norm_reward'] is False and s['gamma'] == 0.99
+    # model.zip
+    t = lambda *sh: torch.as_tensor(rng.standard_normal(sh), dtype=torch.float32)
+    pol = types.SimpleNamespace(w1=t(64, 29), b1=t(64), w2=t(64, 64), b2=t(64), wa=t(8, 64), ba=t(8), wv=t(1, 64), bv=t(1), log_std=torch.full((8,), -0.75))
+    z = str(tmp_path / 'model_17.zip')
+    ck.write_policy_zip(pol, z)
+    assert {'data', 'policy.pth', 'pytorch_variables.pth', '_stable_baselines3_version'} <= set(zipfile.ZipFile(z).namelist())
+    back = ck.read_policy_zip(z)
+    for k in ('w1', 'b1', 'w2', 'b2', 'wa', 'ba', 'wv', 'bv', 'log_std'):
+        assert torch.equal(back[k], getattr(pol, k))
+    # separate policy / value trunks cannot be mapped onto the shared-trunk kernel
+    import io
+    sd = torch.load(io.BytesIO(zipfile.ZipFile(z).read('policy.pth')), weights_only=True)
+    sd['mlp_extractor.value_net.0.weight'] = sd['mlp_extractor.value_net.0.weight'] + 1
+    buf = io.BytesIO(); torch.save(sd, buf)
+    z2 = str(tmp_path / 'sep.zip')
+    with zipfile.ZipFile(z2, 'w') as zz:
+        zz.writestr('policy.pth', buf.getvalue())
+    with pytest.raises(ValueError):
+        ck.read_policy_zip(z2)
