@@ -587,26 +587,30 @@ __device__ __forceinline__ float dl_rsqrt(float x) {
 }
 __device__ __forceinline__ double dl_rsqrt(double x) { return 1.0 / sqrt(x); }
 
-// dense Cholesky of the N x N matrix whose row j is held in lane j: strictly-lower entries in h[0..j-1], the
-// diagonal separately in hd.  Afterwards h[a] (a < j) is row j of the factor and invd = 1 / L[j][j].  Column k
-// is gathered with row broadcasts (one DPP each).  Pivots are floored (mju_cholFactor's mjMINVAL guard).
+// dense Cholesky of the symmetric N x N matrix whose FULL row j is held in lane j (h[a], a != j; the diagonal separately
+// in hd).  Column k of the factor is gathered with row broadcasts (one DPP each).  The trailing update runs over the whole
+// row, and lanes j <= k take no part in step k (their l_jk is 0), so afterwards lane j holds
+//   h[a], a < j:  L[j][a]                       (row j of the factor), and
+//   h[a], a > j:  L[a][j] * L[j][j]             (column j of the factor, unscaled: the symmetric trailing matrix at step j),
+// invd = 1 / L[j][j].  Having both the row and the column in the lane makes BOTH triangular solves broadcast-type
+// (one v_fmac_f32_dpp per step, no cross-lane reduction).  Pivots are floored (mju_cholFactor's mjMINVAL guard).
 template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], T hd, T& invd, int j, T floor_) {
     static_for<N>([&](auto kk) {
         constexpr int k = kk.value;
         const T dkk = dl_max(rbcast<k>(hd), floor_);
         const T inv = dl_rsqrt(dkk);
-        T lik = h[k] * inv;                                   // lanes j > k: L[j][k]; other lanes: unused
-        h[k] = lik;
+        T lik = (j > k) ? h[k] * inv : T(0);                  // lanes j > k: L[j][k]
+        h[k] = (j > k) ? lik : h[k];
         if (j == k) invd = inv;
         hd -= lik * lik;                                      // lanes j > k
         g_dpp_ready(lik);
         static_for<N - 1 - k>([&](auto aa) {
             constexpr int a = k + 1 + aa.value;
-            fmac_bcast<a, -1>(h[a], lik, lik);                // row j, column a (only a < j matters): h[a] -= L[a][k] L[j][k]
+            fmac_bcast<a, -1>(h[a], lik, lik);                // lanes j > k, all columns a > k: h[a] -= L[a][k] L[j][k]
         });
     });
 }
-// solve (L L^T) x = b with row j of L in lane j; b_j in, x_j out
+// solve (L L^T) x = b with the factor as g_chol leaves it; b_j in, x_j out
 template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T invd, T b, int j) {
     // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k]
     T acc = b, yj = T(0);
@@ -617,12 +621,17 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
         g_dpp_ready(yloc);
         fmac_bcast<k, -1>(acc, yloc, l[k]);                   // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
     });
-    // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k]
-    T x = T(0);
+    // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k] with L[i][k] = l_k[i] / L[k][k] from lane k's own registers:
+    // t_k = sum_{i>k} l_k[i] x_i accumulates as the x_i become final (highest first)
+    T x = T(0), t = T(0);
     static_for<N>([&](auto kk) {
         constexpr int k = N - 1 - kk.value;
-        const T s = gsum((j > k) ? l[k] * x : T(0));          // x_j is final for j > k
-        if (j == k) x = (yj - s) * invd;
+        T xloc = (yj - invd * t) * invd;                      // final in lane k
+        if (j == k) x = xloc;
+        if constexpr (k > 0) {
+            g_dpp_ready(xloc);
+            fmac_bcast<k, 1>(t, xloc, l[k]);                  // lanes j < k
+        }
     });
     return x;
 }
@@ -906,6 +915,15 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         const T Md = g_apply<T, N>(g, ncon, my_lim, lim_sign, dir, mrow);      // rows JV = J dir
         g_sync<T>();
         tick(4);
+        // ---- the common case: the full Newton step leaves the active set as it is.  The cost is quadratic on that
+        // set, so a + dir is its exact minimiser (gradient zero up to rounding): no line search, no further pass over
+        // the rows.  Checked per walker; the line search below only runs if some walker of the wave still needs it.
+        {
+            bool flips = !(dir == dir);
+            for (int r = j; r < nefc; r += GL) flips = flips || ((rJA[r] + rJV[r] < T(0)) != (rTM[r] != T(0)));
+            if (alive && !gany(flips)) { qacc += dir; iter++; alive = false; }
+        }
+        if (!__any(alive)) { tick(5); break; }
         // ---- exact line search along dir
         T r4[4] = {dir * (Ma - smooth), T(0.5) * dir * Md, dir * grad, dir * dir};
         gsum_n<4>(r4);
@@ -928,7 +946,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
             it++;
             if (!done) {
                 if (d1 < T(0)) lo = alpha; else hi = alpha;
-                const T cand = alpha - d1 / d2;
+                const T cand = alpha - d1 * dl_rcp(d2);
                 const T mid = hi < T(1e29) ? T(0.5) * (lo + hi) : T(2) * alpha;
                 const T next = (cand > lo && cand < hi) ? cand : mid;
                 // converged: derivative below tolerance, or the iterate no longer moves at working precision

@@ -12,6 +12,9 @@ Differences from the reference loop, on purpose:
   * the evaluation copy of VecNormalize does not keep training its moments (the reference's reloaded copy does,
     because SB3's `VecNormalize.load` leaves `training=True`; serial moment updates cannot be reproduced by a
     batch and the effect is a drift of the 20 episodes' normalisation, not a property anyone relies on);
+  * every episode starts from a fresh `count_steps_same_vel` (the reference's counter only ever increments and
+    survives resets, straight_walk_trajecs.py:124,336, so in its serial loop the desired-velocity observation of
+    episode k depends on how many step rollovers episodes 0..k-1 contained -- history a batch does not have);
   * the per-step reward is the raw reward (`get_original_reward`), which equals the reference's
     `reward * sqrt(ret_rms.var + 1e-8)` un-normalisation whenever the normalised reward was not clipped.
 """
