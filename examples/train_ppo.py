@@ -27,7 +27,7 @@ from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 
-def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True):
+def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False):
     dev = torch.device('cuda', 0)
     torch.manual_seed(seed)
     venv = HipVecEnv(num_envs=n_envs, seed=seed)
@@ -104,6 +104,15 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
             if not quiet:
                 print(f'update {upd:5d}  env-steps {(upd + 1) * batch / 1e6:6.2f} M  ep_len {ep_len:7.1f}  step reward {mean_rew:.3f}  '
                       f'walked {dist_:5.2f} m  lr {lr:.2e}  {el:6.1f} s  ({(upd + 1) * batch / el / 1e3:.0f} k env-steps/s incl. learning)', flush=True)
+    if evaluate:
+        # TrainingMonitor.eval_walking (drloco/common/callback.py:272-390): 20 deterministic episodes, here as one batch
+        from drloco_amd.evaluation import evaluate_walking, make_eval_env
+        res = evaluate_walking(make_eval_env(vn), pol)
+        hist[-1]['evaluation'] = res
+        if not quiet:
+            print(f"evaluation (20 deterministic episodes): mean distance {res['mean_walked_distance']:.1f} m, min {res['min_walked_distance']:.1f} m, "
+                  f"mean episode length {res['mean_episode_duration'] * 3000:.0f}, stable walks {res['count_stable_walks']}/20, "
+                  f"mean step reward (normalised) {res['mean_reward_means']:.2f}")
     return hist
 
 
@@ -116,4 +125,4 @@ if __name__ == '__main__':
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-norm-reward', action='store_true', help='VecNormalize(norm_reward=False)')
     args = ap.parse_args()
-    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward)
+    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward, evaluate=True)

@@ -809,11 +809,16 @@ def test_ppo_learns_on_the_device_path(torch_cuda):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location('train_ppo', os.path.join(root, 'examples', 'train_ppo.py'))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    hist = mod.train(mio=1.3, n_envs=128, seed=0, log_every=10, quiet=True)
+    hist = mod.train(mio=1.3, n_envs=128, seed=0, log_every=10, quiet=True, evaluate=True)
     first = next(h for h in hist if h['ep_len'] > 0)
     last = hist[-1]
     assert last['ep_len'] > 300 and last['ep_len'] > 2.5 * first['ep_len'], (first, last)
     assert last['mean_step_reward'] > 0.5 and last['moved_distance'] > 2.0, last
+    # the batched evaluation of the trained policy (drloco_amd.evaluation): the deterministic policy does at least as
+    # well as the exploring one did on average
+    ev = last['evaluation']
+    assert len(ev['ep_durs']) == 20 and ev['mean_episode_duration'] * 3000 > 0.5 * last['ep_len'], (ev, last)
+    assert ev['mean_walked_distance'] > 1.0 and -0.2 <= ev['mean_reward_means'] <= 1.0, ev
 
 
 def test_batched_evaluation_matches_the_serial_loop(torch_cuda, model, refs):
@@ -823,7 +828,7 @@ def test_batched_evaluation_matches_the_serial_loop(torch_cuda, model, refs):
     auto-reset (solver warm start 0) while batched walker k starts through dl_reset (warm start from a forward
     evaluation): the initial state is the same -- asserted on the first observation -- but float32 trajectories of a
     falling walker separate chaotically after that, so their lengths are NOT compared (the batch's statistics for a
-    policy that walks are checked end to end by test_ppo_learns_on_the_device_path's caller, examples/train_ppo.py)."""
+    trained policy are checked in test_ppo_learns_on_the_device_path)."""
     import torch
     from drloco_amd.evaluation import evaluate_walking, make_eval_env
     from drloco_amd.policy import HipPolicy
