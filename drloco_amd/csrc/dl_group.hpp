@@ -590,39 +590,47 @@ __device__ __forceinline__ double dl_rsqrt(double x) { return 1.0 / sqrt(x); }
 // dense Cholesky of the symmetric N x N matrix whose FULL row j is held in lane j (h[a], a != j; the diagonal separately
 // in hd).  Column k of the factor is gathered with row broadcasts (one DPP each).  The trailing update runs over the whole
 // row, and lanes j <= k take no part in step k (their l_jk is 0), so afterwards lane j holds
-//   h[a], a < j:  L[j][a]                       (row j of the factor), and
+//   lo[a], a < j: L[j][a]                       (row j of the factor; zero for a >= j), and
 //   h[a], a > j:  L[a][j] * L[j][j]             (column j of the factor, unscaled: the symmetric trailing matrix at step j),
 // invd = 1 / L[j][j].  Having both the row and the column in the lane makes BOTH triangular solves broadcast-type
 // (one v_fmac_f32_dpp per step, no cross-lane reduction).  Pivots are floored (mju_cholFactor's mjMINVAL guard).
-template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], T hd, T& invd, int j, T floor_) {
+// pivot reciprocal square root: float = bare v_rsq_f32 (1 ulp; the factor only shapes the Newton direction and its 91
+// float32 trailing updates round far more than that), double = exact path
+__device__ __forceinline__ float dl_rsqrt_pivot(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double dl_rsqrt_pivot(double x) { return 1.0 / sqrt(x); }
+
+// In: h = full row j of the matrix (h[j] unused), hd = its diagonal.  Out: lo[k] = L[j][k] for k < j and 0 otherwise;
+// h[a] for a > j = L[a][j] * L[j][j]; invd.  A lane's pivot is final once the steps k < j are done (l_jk = 0 for k >= j),
+// so invd is taken once at the end from the lane's own hd -- the same bits every lane used at step j.
+template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], T (&lo)[GL], T hd, T& invd, int j, T floor_) {
     static_for<N>([&](auto kk) {
         constexpr int k = kk.value;
-        const T dkk = dl_max(rbcast<k>(hd), floor_);
-        const T inv = dl_rsqrt(dkk);
-        T lik = (j > k) ? h[k] * inv : T(0);                  // lanes j > k: L[j][k]
-        h[k] = (j > k) ? lik : h[k];
-        if (j == k) invd = inv;
-        hd -= lik * lik;                                      // lanes j > k
+        const T inv = dl_rsqrt_pivot(dl_max(rbcast<k>(hd), floor_));
+        T lik = h[k] * ((j > k) ? inv : T(0));                // lanes j > k: L[j][k]
+        lo[k] = lik;
+        hd -= lik * lik;
         g_dpp_ready(lik);
         static_for<N - 1 - k>([&](auto aa) {
             constexpr int a = k + 1 + aa.value;
             fmac_bcast<a, -1>(h[a], lik, lik);                // lanes j > k, all columns a > k: h[a] -= L[a][k] L[j][k]
         });
     });
+    invd = dl_rsqrt_pivot(dl_max(hd, floor_));
 }
 // solve (L L^T) x = b with the factor as g_chol leaves it; b_j in, x_j out
-template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (&l)[GL], T invd, T b, int j) {
-    // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k]
-    T acc = b, yj = T(0);
-    static_for<N>([&](auto kk) {
+template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (&lo)[GL], const T (&up)[GL], T invd, T b, int j) {
+    // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k].  lo[k] is zero in the lanes j <= k, so a lane's accumulator
+    // is final after step j - 1 and y_j is read off after the loop
+    T acc = b;
+    static_for<N - 1>([&](auto kk) {
         constexpr int k = kk.value;
-        T yloc = acc * invd;                                  // valid in lane k
-        if (j == k) yj = yloc;
+        T yloc = acc * invd;                                  // y_k in lane k
         g_dpp_ready(yloc);
-        fmac_bcast<k, -1>(acc, yloc, l[k]);                   // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
+        fmac_bcast<k, -1>(acc, yloc, lo[k]);                  // lanes j > k: b_j - sum_{a<=k} L[j][a] y_a
     });
-    // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k] with L[i][k] = l_k[i] / L[k][k] from lane k's own registers:
-    // t_k = sum_{i>k} l_k[i] x_i accumulates as the x_i become final (highest first)
+    const T yj = acc * invd;
+    // backward: x_k = (y_k - sum_{i>k} L[i][k] x_i) / L[k][k] with L[i][k] = up_k[i] / L[k][k] from lane k's own registers:
+    // t_k = sum_{i>k} up_k[i] x_i accumulates as the x_i become final (highest first)
     T x = T(0), t = T(0);
     static_for<N>([&](auto kk) {
         constexpr int k = N - 1 - kk.value;
@@ -630,7 +638,7 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
         if (j == k) x = xloc;
         if constexpr (k > 0) {
             g_dpp_ready(xloc);
-            fmac_bcast<k, 1>(t, xloc, l[k]);                  // lanes j < k
+            fmac_bcast<k, 1>(t, xloc, up[k]);                 // lanes j < k (t of the other lanes is no longer read)
         }
     });
     return x;
@@ -905,11 +913,11 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         // ---- Newton direction
         T dir;
         {
-            T l[GL], invd = T(1);
+            T up[GL], lo[GL], invd = T(1);
 #pragma unroll
-            for (int a = 0; a < GL; a++) l[a] = h[a];
-            g_chol<T, N>(l, hd, invd, j, T(1e-10));
-            dir = -g_chol_solve<T, N>(l, invd, grad, j);
+            for (int a = 0; a < GL; a++) { up[a] = h[a]; lo[a] = T(0); }
+            g_chol<T, N>(up, lo, hd, invd, j, T(1e-10));
+            dir = -g_chol_solve<T, N>(lo, up, invd, grad, j);
         }
         tick(3);
         const T Md = g_apply<T, N>(g, ncon, my_lim, lim_sign, dir, mrow);      // rows JV = J dir

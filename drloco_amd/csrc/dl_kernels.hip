@@ -132,7 +132,7 @@ template <typename T, bool TIMED = false>
 __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
                                                      float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
                                                      const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode, long long* tim = nullptr) {
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        // TIMED: 0-6 g_forward's sections, 7 whole kernel, 8 before the physics, 9 after it
     long long t_begin = 0;
     if constexpr (TIMED) t_begin = (long long)__builtin_readcyclecounter();
     using TPS = TopoStraight;
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
         force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
     }
     const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
+    if constexpr (TIMED) tacc[8] = (long long)__builtin_readcyclecounter() - t_begin;
     // ---- physics
     bool exc = false;
     const int flag = inj_flags ? inj_flags[w] : 0;
@@ -226,6 +227,8 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             if (simulate && !exc) { q = q0 + h * dq; v = v0 + h * dv; }
         }
     }
+    long long t_phys_end = 0;
+    if constexpr (TIMED) t_phys_end = (long long)__builtin_readcyclecounter();
     // ---- environment logic
     const double tor_mean = (double)tor_sum / nu;
     double walked = st.walked[w];
@@ -338,8 +341,9 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     }
     if (valid && isdof) { st.qpos[(size_t)j * n + w] = q; st.qvel[(size_t)j * n + w] = v; st.warm[(size_t)j * n + w] = warm; }
     if constexpr (TIMED) {
-        tacc[7] = (long long)__builtin_readcyclecounter() - t_begin;
-        if (lane == 0) for (int k = 0; k < 8; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k];
+        const long long t_end = (long long)__builtin_readcyclecounter();
+        tacc[7] = t_end - t_begin; tacc[9] = t_end - t_phys_end;
+        if (lane == 0) for (int k = 0; k < 10; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k];
     }
 }
 
@@ -975,7 +979,7 @@ int dl_debug_forward_timed(dl_handle h, const void* ctrl, void* qacc, long long*
     NEED(h);
     return h->forward_timed(ctrl, qacc, tim, (hipStream_t)stream);
 }
-/* one control step (16-lane f32 kernels) with per-section cycle counts: tim int64[8, ceil(N/4)] device; [7] = whole kernel */
+/* one control step (16-lane f32 kernels) with per-section cycle counts: tim int64[10, ceil(N/4)] device; [7] = whole kernel, [8] before / [9] after the physics */
 int dl_debug_step_timed(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* done, long long* tim, void* stream) {
     NEED(h);
     return h->step_timed(actions, obs, rew, done, tim, (hipStream_t)stream);

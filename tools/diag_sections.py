@@ -20,7 +20,7 @@ for t in range(args.warm):
     env.step_tensors(acts[t])
 ctrl = (300 * torch.clamp(0.5 * torch.randn(8, n, device='cuda', generator=g), -1, 1)).contiguous()
 nb = (n + 3) // 4
-tim = torch.zeros(8, nb, dtype=torch.int64, device='cuda')
+tim = torch.zeros(10, nb, dtype=torch.int64, device='cuda')
 qacc = torch.zeros(14, n, device='cuda')
 names = ['smooth dynamics', 'constraints', 'rows, J^T f, Hessian', 'factor + solve', 'J dir / M dir', 'line search + step', '(iterations)', '-']
 for rep in range(3):
@@ -28,7 +28,7 @@ for rep in range(3):
     e0.record()
     lib.check(env._lib.dl_debug_forward_timed(env._h, _ptr(ctrl), _ptr(qacc), _ptr(tim), _stream()))
     e1.record(); torch.cuda.synchronize()
-    t = tim.cpu().numpy().astype(np.float64)
+    t = tim.cpu().numpy().astype(np.float64)[:8]
 tot = t[:6].sum(0)
 print(f'kernel {e0.elapsed_time(e1) * 1e3:.1f} us; per wave: total cycles mean {tot.mean():.0f} median {np.median(tot):.0f} max {tot.max():.0f}; wave iterations mean {t[6].mean():.2f} max {t[6].max():.0f}')
 for k in range(6):
@@ -41,7 +41,7 @@ print('per wave max iters: mean %.2f' % w.mean())
 
 # ---- the same sections inside whole control steps of the rollout (20 evaluations each)
 acts2 = torch.clamp(0.5 * torch.randn(30, n, 8, device='cuda', generator=g), -1, 1)
-tot = np.zeros((8, nb))
+tot = np.zeros((10, nb))
 for t in range(30):
     lib.check(env._lib.dl_debug_step_timed(env._h, _ptr(acts2[t]), _ptr(env.obs), _ptr(env.rew), _ptr(env.done), _ptr(tim), _stream()))
     torch.cuda.synchronize()
@@ -53,3 +53,4 @@ print('  wave-time percentiles (cycles): ' + '  '.join(f'p{q} {np.percentile(who
 for k in range(6):
     print(f'  {names[k]:22s} mean {tot[k].mean():9.0f}  ({100 * tot[k].mean() / whole.mean():5.1f} %)  slowest wave {tot[k][whole.argmax()]:9.0f}')
 print(f'  {"outside the evaluations":22s} mean {(whole - tot[:6].sum(0)).mean():9.0f}  ({100 * (whole - tot[:6].sum(0)).mean() / whole.mean():5.1f} %)')
+print(f'    of which: before the physics (model/state/action loads) {tot[8].mean():9.0f}   after it (cursor, reward, observation, Monitor, reset, stores) {tot[9].mean():9.0f}   inside the RK4 loop {(whole - tot[:6].sum(0) - tot[8] - tot[9]).mean():9.0f}')
