@@ -11,7 +11,10 @@ One "step" of this benchmark = ONE 512-step rollout of all walkers of a rank:
                      termination + Monitor statistics + auto-reset/RSI) -> raw obs/reward, done flags
                      into the next episode_starts slot of the rollout buffer,
                      dl_vecnormalize_step (moments update + observation/reward normalisation) -> the
-                     rollout buffer's observations[t+1] / rewards[t] slots (3 launches per control step);
+                     rollout buffer's observations[t+1] / rewards[t] slots (3 launches per control step; with
+                     pre-generated actions nothing on the main stream waits for the normalised observation, so
+                     these two launches run on a side HIP stream while dl_step of t+1 executes -- ping-pong raw
+                     buffers, HIP events both ways; --no-overlap or --policy keeps everything on one stream);
   per rollout        GAE(lambda) return/advantage scan, advantage statistics + normalisation
                      (RCCL all-reduce of 3 doubles when N > 1 -- the only collective).
 Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) (seed 4321 + rank), values are synthetic,
@@ -61,6 +64,8 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
+    ap.add_argument('--profile-every', type=int, default=16, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
+    ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -95,6 +100,8 @@ def main():
     buf.values.copy_(torch.randn(T, n, device=dev, generator=gen))
     last_values = torch.randn(n, device=dev, generator=gen)
     vn.reset()
+    if not args.policy and not args.no_overlap:
+        vn.enable_overlap()      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = torch.ones(n, dtype=torch.uint8, device=dev)
     push_phase = push_force = None
@@ -128,6 +135,7 @@ def main():
                 policy.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
             vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t],
                             done_out=buf.episode_starts[t + 1] if nxt else last_done)
+        vn.flush()
         buf.compute_returns_and_advantage(last_values, last_done)
         buf.normalize_advantages()                   # all-reduce of [sum, sum^2, n] when world > 1
         if use_dist:
@@ -140,7 +148,7 @@ def main():
 
     for _ in range(args.warmup):
         rollout()
-    lib.check(venv._lib.dl_profile(venv._h, 1))
+    lib.check(venv._lib.dl_profile(venv._h, args.profile_every))    # HIP events around every k-th launch of the step kernel
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -174,10 +182,11 @@ def main():
             'config': {'workload': f'straight_walking 3D walker, {n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated',
+                       'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, overlapped with the next env step',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
-                         'launches': launches.value, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,
+                         'launches': launches.value, 'sampled_every': args.profile_every, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,
                          'note': 'the fused dynamics kernel is FP32-VALU/latency bound (SURVEY.md 8d); HBM fraction is reported as the contract asks'},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -630,16 +630,20 @@ struct dl_env_s {
     virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
     virtual int step_timed(const float*, float*, float*, uint8_t*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
-    bool prof = false;
+    int prof = 0;                // 0 off, k > 0: bracket every k-th launch (events between kernels cost a few us of launch gap each)
+    int prof_tick = 0;
+    bool prof_open = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     void prof_begin(hipStream_t s) {
-        if (!prof) return;
+        prof_open = false;
+        if (!prof || (prof_tick++ % prof) != 0) return;
+        prof_open = true;
         if (ev_used + 2 > ev.size()) { hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return; ev.push_back(a); ev.push_back(b); }
         (void)hipEventRecord(ev[ev_used], s);
     }
     void prof_end(hipStream_t s) {
-        if (!prof || ev_used + 2 > ev.size()) return;
+        if (!prof_open || ev_used + 2 > ev.size()) return;
         (void)hipEventRecord(ev[ev_used + 1], s);
         ev_used += 2;
     }
@@ -1021,7 +1025,8 @@ int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) 
 
 int dl_profile(dl_handle h, int32_t enable) {
     NEED(h);
-    h->prof = enable != 0;
+    h->prof = enable > 0 ? enable : 0;
+    h->prof_tick = 0;
     h->ev_used = 0;
     return DL_OK;
 }

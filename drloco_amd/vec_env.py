@@ -107,15 +107,18 @@ class HipVecEnv:
         lib.check(self._lib.dl_reset(self._h, _ptr(m), _ptr(s), _ptr(p), _ptr(self.obs), _stream()))
         return self.obs
 
-    def step_tensors(self, actions, done_out=None):
+    def step_tensors(self, actions, done_out=None, obs_out=None, rew_out=None):
         """actions: float32 cuda tensor [N, nu]; returns device tensors (obs, rew, done, term_obs).
-        done_out: optional uint8 [N] destination for the done flags (e.g. the next episode_starts slot)."""
+        done_out: optional uint8 [N] destination for the done flags (e.g. the next episode_starts slot);
+        obs_out / rew_out: optional destinations of the raw observation / reward (default: self.obs / self.rew)."""
         a = actions.to(device=self.device, dtype=torch.float32).contiguous()
         assert a.shape == (self.num_envs, self.nu)
         done = self.done if done_out is None else done_out
-        lib.check(self._lib.dl_step(self._h, _ptr(a), _ptr(self.obs), _ptr(self.rew), _ptr(done),
+        obs = self.obs if obs_out is None else obs_out
+        rew = self.rew if rew_out is None else rew_out
+        lib.check(self._lib.dl_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done),
                                     _ptr(self.term_obs), _ptr(self.rew_terms), _stream()))
-        return self.obs, self.rew, done, self.term_obs
+        return obs, rew, done, self.term_obs
 
     def step_async(self, actions):
         self._actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device)
@@ -378,14 +381,21 @@ class HipVecNormalize:
         self.norm_obs_t = torch.zeros_like(venv.obs)
         self.norm_rew_t = torch.zeros_like(venv.rew)
         self._vn_work = torch.zeros(2 * 32 * (venv.obs_dim + 1) + 2, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
+        self._ov = None                                   # overlap state (enable_overlap)
 
     # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
     @property
     def old_obs(self):
+        if self._ov is not None and self._ov['last'] is not None:
+            self.flush()
+            return self._ov['raw'][self._ov['last']][0]
         return self.venv.obs
 
     @property
     def old_rew(self):
+        if self._ov is not None and self._ov['last'] is not None:
+            self.flush()
+            return self._ov['raw'][self._ov['last']][1]
         return self.venv.rew
 
     def _normalize_obs_inplace(self, x):
@@ -393,21 +403,86 @@ class HipVecNormalize:
         lib.check(self._lib.dl_normalize_obs(_ptr(x), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), n, x.shape[1],
                                              self.epsilon, self.clip_obs, _stream()))
 
-    def step_tensors(self, actions, obs_out=None, rew_out=None, done_out=None):
-        """One control step + VecNormalize.step_wait, everything on the device: dl_step, then the two launches
-        of dl_vecnormalize_step.  obs_out / rew_out / done_out may be rollout-buffer slots (float32 [N, obs],
-        float32 [N], uint8 [N]); by default the results land in norm_obs_t / norm_rew_t / venv.done."""
-        obs, rew, done, term = self.venv.step_tensors(actions, done_out=done_out)
+    def _vn_launch(self, obs, rew, done, obs_out, rew_out):
         n, d = obs.shape
-        obs_out = self.norm_obs_t if obs_out is None else obs_out
-        rew_out = self.norm_rew_t if rew_out is None else rew_out
         flags = (1 if (self.norm_obs and self.training) else 0) | (2 if self.norm_obs else 0) | \
                 (4 if (self.norm_reward and self.training) else 0) | (8 if self.norm_reward else 0)
         lib.check(self._lib.dl_vecnormalize_step(
             _ptr(obs), _ptr(rew), _ptr(done), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
             _ptr(self.ret), _ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, d,
             self.gamma, self.epsilon, self.clip_obs, self.clip_reward, flags, _ptr(obs_out), _ptr(rew_out), _ptr(self._vn_work), _stream()))
+
+    def step_tensors(self, actions, obs_out=None, rew_out=None, done_out=None):
+        """One control step + VecNormalize.step_wait, everything on the device: dl_step, then the two launches
+        of dl_vecnormalize_step.  obs_out / rew_out / done_out may be rollout-buffer slots (float32 [N, obs],
+        float32 [N], uint8 [N]); by default the results land in norm_obs_t / norm_rew_t / venv.done.
+        With `enable_overlap()` the normalisation of step t runs on a side stream while the main stream already
+        simulates step t + 1 (see there)."""
+        obs_out = self.norm_obs_t if obs_out is None else obs_out
+        rew_out = self.norm_rew_t if rew_out is None else rew_out
+        if self._ov is None:
+            obs, rew, done, term = self.venv.step_tensors(actions, done_out=done_out)
+            self._vn_launch(obs, rew, done, obs_out, rew_out)
+            return obs_out, rew_out, done, term
+        ov = self._ov
+        C = ov['chunk']
+        k = ov['k']                                          # slot in the ring of 2 C raw-buffer sets
+        main = torch.cuda.current_stream()
+        if k % C == 0 and ov['read'][k // C] is not None:
+            main.wait_event(ov['read'][k // C])             # the normalisations that last read this half of the ring
+        raw_obs, raw_rew = ov['raw'][k]
+        done = ov['done'][k] if done_out is None else done_out
+        _, _, done, term = self.venv.step_tensors(actions, done_out=done, obs_out=raw_obs, rew_out=raw_rew)
+        ov['pending'].append((k, done, obs_out, rew_out))
+        ov['last'] = k
+        ov['k'] = (k + 1) % (2 * C)
+        if (k + 1) % C == 0:
+            self._submit_pending()
         return obs_out, rew_out, done, term
+
+    def _submit_pending(self):
+        """Hand the steps simulated since the last hand-over to the side stream: ONE event pair per chunk (event packets
+        between the env-step kernels cost launch gap)."""
+        ov = self._ov
+        if not ov['pending']:
+            return
+        main, side = torch.cuda.current_stream(), ov['stream']
+        half = ov['pending'][0][0] // ov['chunk']
+        ov['stepped'][half].record(main)
+        side.wait_event(ov['stepped'][half])
+        with torch.cuda.stream(side):
+            for k, done, obs_out, rew_out in ov['pending']:
+                self._vn_launch(ov['raw'][k][0], ov['raw'][k][1], done, obs_out, rew_out)
+            ov['read'][half] = ov['readev'][half]
+            ov['read'][half].record(side)
+        ov['pending'] = []
+
+    def enable_overlap(self, chunk=8):
+        """Software pipelining for callers whose next actions do not depend on this step's normalised observation
+        (fixed-action rollouts such as BASELINE configs[1]; NOT a policy in the loop): dl_step writes its raw
+        observation / reward into a ring of 2 x `chunk` buffer sets, and after every `chunk` steps their
+        dl_vecnormalize_step launches are issued on a side HIP stream, where they run while the main stream keeps
+        simulating.  Same kernels, same order of moment updates, same results; the outputs of step_tensors are complete
+        only after `flush()` (call it before anything on the main stream reads them: GAE, the policy, a copy to the host)."""
+        dev = self.venv.device
+        ev = lambda: torch.cuda.Event()
+        self._ov = dict(stream=torch.cuda.Stream(device=dev), chunk=int(chunk), k=0, last=None, pending=[], read=[None, None], readev=[ev(), ev()],
+                        stepped=[ev(), ev()],
+                        raw=[(torch.zeros_like(self.venv.obs), torch.zeros_like(self.venv.rew)) for _ in range(2 * chunk)],
+                        done=[torch.zeros_like(self.venv.done) for _ in range(2 * chunk)])
+
+    def flush(self):
+        """Issue what is still pending and make the main stream wait for the side stream."""
+        if self._ov is not None:
+            if self._ov['pending']:
+                # a partial chunk: continue with the other half of the ring afterwards
+                C, k = self._ov['chunk'], self._ov['k']
+                self._submit_pending()
+                self._ov['k'] = ((k + C - 1) // C * C) % (2 * C)
+            main = torch.cuda.current_stream()
+            for e in self._ov['read']:
+                if e is not None:
+                    main.wait_event(e)
 
     def sync_moments(self, process_group=None):
         """Data-parallel runs: make the observation / return moments of all ranks those of the union of their batches
@@ -420,6 +495,7 @@ class HipVecNormalize:
 
     def step_wait(self):
         obs, rew, done, term = self.step_tensors(self._actions)
+        self.flush()
         done_h = done.cpu().numpy().astype(bool)
         infos = [{} for _ in range(self.num_envs)]
         self.venv._ep_len += 1

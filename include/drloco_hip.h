@@ -234,9 +234,11 @@ int dl_terminate_early(dl_handle h, int32_t* flags, void* stream);
  * mean_abs_ep_torque_smoothed.  out: double[N] device. */
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream);
 
-/* Measurement hooks (no reference counterpart): when enabled, every launch of the dominant
- * kernel (the fused env-step kernel) is bracketed by HIP events on its launch stream;
- * dl_profile_read waits for them and returns the summed duration and the launch count. */
+/* Measurement hooks (no reference counterpart): enable = k > 0 brackets every k-th launch of the
+ * dominant kernel (the fused env-step kernel) by HIP events on its launch stream (k = 1: every
+ * launch; event packets between kernels widen the launch gap by a few microseconds each, so a
+ * throughput run samples); 0 switches it off.  dl_profile_read waits for the events and returns
+ * the summed duration and the number of bracketed launches. */
 int dl_profile(dl_handle h, int32_t enable);
 int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches);
 

@@ -870,3 +870,31 @@ def test_batched_evaluation_matches_the_serial_loop(torch_cuda, model, refs):
             assert 2 <= ep_dur <= 3000          # lengths of chaotic falls are not comparable step for step (190 vs 244 observed)
     assert res['count_stable_walks'] == 0 and not res['is_stable_humanlike_walking']     # a random policy does not walk
     assert res['mean_walked_distance'] == pytest.approx(np.mean(res['moved_distances']))
+
+
+def test_overlapped_vecnormalize_is_identical(torch_cuda, model, refs):
+    """HipVecNormalize.enable_overlap(): the normalisation of step t on a side stream under the simulation of step t + 1
+    gives bit-identical buffers and moments."""
+    import torch
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    n, T = 512, 130
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    acts = torch.clamp(0.6 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
+    out = []
+    for overlap in (False, True):
+        vn = HipVecNormalize(HipVecEnv(num_envs=n, seed=9, model=model, refs=refs))
+        vn.reset()
+        if overlap:
+            vn.enable_overlap()
+        obs = torch.zeros(T, n, 29, device='cuda'); rew = torch.zeros(T, n, device='cuda'); done = torch.zeros(T, n, dtype=torch.uint8, device='cuda')
+        for t in range(T):
+            vn.step_tensors(acts[t], obs_out=obs[t], rew_out=rew[t], done_out=done[t] if t % 2 else None)
+            if t % 2 == 0:
+                vn.flush(); done[t].copy_(vn._ov['done'][vn._ov['last']] if overlap else vn.venv.done)
+        vn.flush()
+        torch.cuda.synchronize()
+        out.append((obs.cpu(), rew.cpu(), done.cpu(), vn.obs_rms.mean.copy(), vn.ret_rms.var.copy(), vn.get_original_obs().copy()))
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert a[2].sum() > 0          # episodes ended inside the window
