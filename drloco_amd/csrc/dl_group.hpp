@@ -50,14 +50,17 @@ struct GLds {
     static constexpr int Q = 0, V = Q + GL;                          // q, v staged for the observation writer
     static constexpr int MS = GL + 1;                                // row stride of M (odd: row-wise and column-wise access are both conflict-free)
     static constexpr int MM = V + GL;                                // M [16 rows][MS]: mirror of the lower triangle
-    static constexpr int CON = MM + GL * MS;                         // contacts [8][G_MAXCON]: px py pz tx ty mu dist body
-    static constexpr int ROW = CON + 8 * G_MAXCON;                   // rows [4][G_MAXROW]: D, JAREF, JV, TMP; contact c owns rows 4c..4c+3 (16-byte groups), limits follow
+    static constexpr int CON_W = 12;                                 // contact record: (px py pz body) (tx ty mu dist) (diagApprox - - -): three 16-byte groups
+    static constexpr int C_P = 0, C_BODY = 3, C_TX = 4, C_TY = 5, C_MU = 6, C_DIST = 7, C_DIAG = 8;
+    static constexpr int CON = MM + GL * MS;                         // contacts [G_MAXCON][CON_W]
+    static constexpr int ROW = CON + CON_W * G_MAXCON;               // rows [4][G_MAXROW]: D, JAREF, JV, TMP; contact c owns rows 4c..4c+3 (16-byte groups), limits follow
     static constexpr int R_D = 0, R_JAREF = 1, R_JV = 2, R_TMP = 3;
     static constexpr int FC_W = 12;                                  // per contact: Fn F1 F2 flip | w00 w01 w02 w11 | w22 - - -
     static constexpr int FC = ROW + 4 * G_MAXROW;                    // contact-frame force and Hessian weights [G_MAXCON][FC_W]
     static constexpr int MISC = FC + FC_W * G_MAXCON;                // rootz ... [8]
     static constexpr int JC = MISC + 8;                              // contact Jacobians, dof-lane major [G_MAXCON][16 lanes][4]: normal, tangent 1, tangent 2, -
-    static constexpr int BFR = JC;                                   // body frames [12][8] (dead once the contacts exist) share the space of JC
+    static constexpr int BFR_W = 12;                                 // body frame record: X (3) Y (3) Z (3) pos (3) = three 16-byte groups
+    static constexpr int BFR = JC;                                   // body frames [8][BFR_W] (dead once the contacts exist) share the space of JC
     static constexpr int TOTAL_RAW = JC + G_MAXCON * GL * 4;
     // walker regions are offset by 16 (mod 32) words so that the two rows of a half-wave use disjoint banks
     static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
@@ -82,7 +85,7 @@ template <typename T> struct GLane {
     // as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
     // to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
     int cinfo[2];                                      // bit0 valid, 1 box, 2-4 sub index, 5-7 body
-    T cpl[2][3], crad[2], cal[2][3], crl[2][3], cmu[2];
+    T cpl[2][3], crad[2], cal[2][3], crl[2][3], cmu[2], cinvw[2];   // cinvw: body_invweight0 of the candidate's body (diagApprox of its contact rows)
 };
 
 template <typename T>
@@ -116,6 +119,7 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
         }
         for (int k = 0; k < 3; k++) ln.cpl[pass][k] = m.geom_pos[ge][k] + rel[k];
         ln.cmu[pass] = m.geom_friction[ge];          // the contact uses max(geom, floor) with the walker's floor friction
+        ln.cinvw[pass] = m.body_invw[m.geom_body[ge]];
     }
 }
 
@@ -442,11 +446,8 @@ __device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T
     const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
     k.X = X; k.Y = Y; k.Z = Z; k.pos = pos; k.axis = ln.sign * col; k.rootz = rootz;
     if (j < TP::NV && lt.last) {
-        DL_LDS T* f = wb + Ld::BFR + ln.body;
-        f[0 * G_MAXB] = X.x; f[1 * G_MAXB] = X.y; f[2 * G_MAXB] = X.z;
-        f[3 * G_MAXB] = Y.x; f[4 * G_MAXB] = Y.y; f[5 * G_MAXB] = Y.z;
-        f[6 * G_MAXB] = Z.x; f[7 * G_MAXB] = Z.y; f[8 * G_MAXB] = Z.z;
-        f[9 * G_MAXB] = pos.x; f[10 * G_MAXB] = pos.y; f[11 * G_MAXB] = pos.z;
+        DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
+        st4(f, X.x, X.y, X.z, Y.x); st4(f + 4, Y.y, Y.z, Z.x, Z.y); st4(f + 8, Z.z, pos.x, pos.y, pos.z);
     }
     if (j == 0) wb[Ld::MISC + 0] = rootz;
     g_sync<T>();
@@ -463,8 +464,8 @@ __device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
     T low = T(1e30);
     if (j < m.nsite) {
         const int b = m.site_body[j];
-        DL_LDS T* f = wb + Ld::BFR + b;
-        const T pz = f[11 * G_MAXB] + m.site_pos[j][0] * f[2 * G_MAXB] + m.site_pos[j][1] * f[5 * G_MAXB] + m.site_pos[j][2] * f[8 * G_MAXB];
+        DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * b;
+        const T pz = f[11] + m.site_pos[j][0] * f[2] + m.site_pos[j][1] * f[5] + m.site_pos[j][2] * f[8];
         low = wb[Ld::MISC + 0] + pz;
     }
     low = dl_min(low, dpp_f<0x128>(low));
@@ -649,7 +650,7 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
 // [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
 // Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
 template <typename T>
-__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
+__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, T x0, int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
     using Ld = GLds;
     const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
@@ -679,8 +680,9 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         const int cinfo = ln.cinfo[pass];
         cinf[pass] = cinfo;
         const int b = (cinfo >> 5) & 7;
-        DL_LDS T* f = wb + Ld::BFR + b;
-        const V3<T> X = ld3(f, G_MAXB), Y = ld3(f + 3 * G_MAXB, G_MAXB), Z = ld3(f + 6 * G_MAXB, G_MAXB), pos = ld3(f + 9 * G_MAXB, G_MAXB);
+        DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * b;
+        const Q4<T> f0 = ld4(f), f1 = ld4(f + 4), f2 = ld4(f + 8);
+        const V3<T> X = mk<T>(f0.a, f0.b, f0.c), Y = mk<T>(f0.d, f1.a, f1.b), Z = mk<T>(f1.c, f1.d, f2.a), pos = mk<T>(f2.b, f2.c, f2.d);
         const V3<T> pt = pos + ln.cpl[pass][0] * X + ln.cpl[pass][1] * Y + ln.cpl[pass][2] * Z;
         const T relz = ln.crl[pass][0] * X.z + ln.crl[pass][1] * Y.z + ln.crl[pass][2] * Z.z;
         T tx = ln.cal[pass][0] * X.x + ln.cal[pass][1] * Y.x + ln.cal[pass][2] * Z.x;
@@ -706,52 +708,68 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
     }
     cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
     const int ncon = __popc(cm);
+    // (BFR is aliased with JC, which is first written after the next g_sync: the frame reads above are complete by then)
+    // ---- the lane of a candidate writes the contact record AND the contact's rows (rows 4c..4c+3: D, K imp r, cleared
+    // active flags): nothing about a contact waits for another lane
     for (int pass = 0; pass < 2; pass++) {
         const int c = j + GL * pass;
         if (act[pass]) {
             const int slot = __popc(cm & ((1u << c) - 1u));
-            DL_LDS T* cn = wb + Ld::CON + slot;
-            cn[0] = cp[pass].x; cn[G_MAXCON] = cp[pass].y; cn[2 * G_MAXCON] = cp[pass].z;
-            cn[3 * G_MAXCON] = ctx[pass]; cn[4 * G_MAXCON] = cty[pass]; cn[5 * G_MAXCON] = dl_max(ln.cmu[pass], g.wk->floor_mu);
-            cn[6 * G_MAXCON] = cdist[pass]; cn[7 * G_MAXCON] = T((cinf[pass] >> 5) & 7);
+            const T mu = dl_max(ln.cmu[pass], g.wk->floor_mu), dist = cdist[pass];
+            DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * slot;
+            st4(cn, cp[pass].x, cp[pass].y, cp[pass].z, T((cinf[pass] >> 5) & 7));
+            st4(cn + 4, ctx[pass], cty[pass], mu, dist);
+            const T imp = g_impedance(*g.c, dist);
+            const T diag = ln.cinvw[pass] * (T(1) + mu * mu);
+            const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
+            const T D = dl_rcp(R), kd = g.c->solK * imp * dist;
+            st4(wb + Ld::ROW + Ld::R_D * G_MAXROW + 4 * slot, D, D, D, D);
+            st4(wb + Ld::ROW + Ld::R_JAREF * G_MAXROW + 4 * slot, kd, kd, kd, kd);
+            st4(wb + Ld::ROW + Ld::R_TMP * G_MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
         }
     }
-    g_sync<T>();            // BFR (aliased with JC) is dead from here on
-    // ---- rows: contact c owns rows 4c..4c+3 (D and K*imp*dist, written by lane c), limit rows follow in dof order
-    for (int c = j; c < ncon; c += GL) {
-        DL_LDS T* cn = wb + Ld::CON + c;
-        const T mu = cn[5 * G_MAXCON], dist = cn[6 * G_MAXCON];
-        const int body = (int)cn[7 * G_MAXCON];
-        const T imp = g_impedance(*g.c, dist);
-        const T diag = g.st[GShared::T_BODY_INVW + body] * (T(1) + mu * mu);
-        const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
-        const T D = dl_rcp(R), kd = g.c->solK * imp * dist;
-        st4(wb + Ld::ROW + Ld::R_D * G_MAXROW + 4 * c, D, D, D, D);
-        st4(wb + Ld::ROW + Ld::R_JAREF * G_MAXROW + 4 * c, kd, kd, kd, kd);
+    // contacts are processed in pairs: a neutral record (world body: no dof moves it; mu = 0) closes an odd count
+    if (j == 0 && ncon < G_MAXCON) {
+        DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * ncon;
+        st4(cn, T(0), T(0), T(0), T(0)); st4(cn + 4, T(1), T(0), T(0), T(0));
+        st4(wb + Ld::FC + Ld::FC_W * ncon, T(0), T(0), T(0), T(0));
     }
+    // limit rows follow in dof order; jar = J a - aref at the start point x0 = B v + a:  K imp r + (+-x0_j)
     if (lim) {
         const int r = 4 * ncon + __popc(lmask & ((1u << j) - 1u));
         my_lim = r;
         const T imp = g_impedance(*g.c, lim_dist);
         const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
         wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = dl_rcp(R);
-        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = g.c->solK * imp * lim_dist;
+        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = g.c->solK * imp * lim_dist + lim_sign * x0;
+        wb[Ld::ROW + Ld::R_TMP * G_MAXROW + r] = T(0);
     }
+    g_sync<T>();
     // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
-    // every contact from its joint axis / anchor in registers; dofs that do not move the contact's body write zeros
-    for (int c = 0; c < ncon; c++) {
-        DL_LDS T* cn = wb + Ld::CON + c;
-        const V3<T> p = mk<T>(cn[0], cn[G_MAXCON], cn[2 * G_MAXCON]);
-        const T tx = cn[3 * G_MAXCON], ty = cn[4 * G_MAXCON];
-        const int body = (int)cn[7 * G_MAXCON];
-        const bool moves = (lt.bodies >> body) & 1u;
-        V3<T> w = ln.type == 0 ? kin.axis : cross(kin.axis, p - kin.pos);
-        if (!moves) w = mk<T>(0, 0, 0);
-        st4(wb + Ld::JC + (c * GL + j) * 4, w.z, tx * w.x + ty * w.y, -ty * w.x + tx * w.y, T(0));
-    }
-    if (ncon < G_MAXCON) {          // contacts are processed in pairs: a neutral record closes an odd count
-        st4(wb + Ld::JC + (ncon * GL + j) * 4, T(0), T(0), T(0), T(0));
-        if (j == 0) { st4(wb + Ld::FC + Ld::FC_W * ncon, T(0), T(0), T(0), T(0)); wb[Ld::CON + 5 * G_MAXCON + ncon] = T(0); }
+    // every contact from its joint axis / anchor in registers (dofs that do not move the contact's body write zeros),
+    // two contacts per trip; the same trip adds J x0 to the contacts' rows (six interleaved row sums, expanded to the
+    // pyramid rows by lanes 0..7), so the Jacobian is not read back for the start point
+    for (int c = 0; c < ncon; c += 2) {
+        const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * c;
+        const Q4<T> A0 = ld4(cn), B0 = ld4(cn + 4), A1 = ld4(cn + Ld::CON_W), B1 = ld4(cn + Ld::CON_W + 4);
+        DL_LDS T* rja = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW + 4 * c + j;
+        const bool writer = j < 4 || (j < 8 && c + 1 < ncon);
+        const T base = writer ? *rja : T(0);
+        V3<T> w0 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A0.a, A0.b, A0.c) - kin.pos);
+        V3<T> w1 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A1.a, A1.b, A1.c) - kin.pos);
+        if (!((lt.bodies >> (int)A0.d) & 1u)) w0 = mk<T>(0, 0, 0);
+        if (!((lt.bodies >> (int)A1.d) & 1u)) w1 = mk<T>(0, 0, 0);
+        const T j0n = w0.z, j0a = B0.a * w0.x + B0.b * w0.y, j0b = -B0.b * w0.x + B0.a * w0.y;
+        const T j1n = w1.z, j1a = B1.a * w1.x + B1.b * w1.y, j1b = -B1.b * w1.x + B1.a * w1.y;
+        st4(wb + Ld::JC + (c * GL + j) * 4, j0n, j0a, j0b, T(0));
+        st4(wb + Ld::JC + ((c + 1) * GL + j) * 4, j1n, j1a, j1b, T(0));
+        T r[6] = {j0n * x0, j0a * x0, j0b * x0, j1n * x0, j1a * x0, j1b * x0};
+        gsum_n<6>(r);
+        if (writer) {
+            const bool second = j >= 4;
+            const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? B1.c : B0.c;
+            *rja = base + vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
+        }
     }
     g_sync<T>();
     nlim_out = nlim; ncon_out = ncon;
@@ -776,7 +794,7 @@ __device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T l
     // two contacts per trip (the Jacobian record after the last contact is zero): six interleaved row sums
     for (int c = 0; c < ncon; c += 2) {
         const Q4<T> ja = ld4(wb + Ld::JC + (c * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c + 1) * GL + j) * 4);
-        const T mua = wb[Ld::CON + 5 * G_MAXCON + c], mub = wb[Ld::CON + 5 * G_MAXCON + c + 1];
+        const T mua = wb[Ld::CON + Ld::CON_W * c + Ld::C_MU], mub = wb[Ld::CON + Ld::CON_W * (c + 1) + Ld::C_MU];
         T r[6] = {ja.a * x, ja.b * x, ja.c * x, jb.a * x, jb.b * x, jb.c * x};
         gsum_n<6>(r);
         if (j < 8) {
@@ -820,17 +838,14 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     tick(0);
     int nlim, ncon, my_lim;
     T lim_sign;
-    g_make_constraints<T>(g, lt, kin, grp, q, nlim, ncon, my_lim, lim_sign);
+    // rows: D, jar = J a - aref at a = warm start (K imp r + J (B v + a)), cleared "active" flags (TMP) of the Hessian
+    g_make_constraints<T>(g, lt, kin, grp, q, (j < N) ? g.c->solB * v + warm : T(0), nlim, ncon, my_lim, lim_sign);
     const int nefc = nlim + 4 * ncon;
     ncon_o = ncon; nefc_o = nefc;
     DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * G_MAXROW;
     DL_LDS T* rJA = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW;
     DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
     DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
-    // jar = J a - aref at a = warm start:  K imp r (stored by g_make_constraints) + J (B v + a)
-    (void)g_apply<T, N>(g, ncon, my_lim, lim_sign, g.c->solB * v + warm, mrow);
-    g_sync<T>();
-    for (int r = j; r < nefc; r += GL) { rJA[r] += rJV[r]; rTM[r] = T(0); }     // TMP: per-row "active" flags of the Hessian
     T qacc = warm, Ma = T(0);
     static_for<N>([&](auto ai) { constexpr int a = ai.value; Ma += mrow[a] * rbcast<a>(qacc); });
     T h[GL], hd = mdiag;       // row j of H = M + sum_active D row^T row (off-diagonal part) and its diagonal
@@ -856,7 +871,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         }
         for (int cc = j; cc < ncon; cc += GL) {
             const Q4<T> ja = ld4(rJA + 4 * cc), tm = ld4(rTM + 4 * cc);
-            const T D = rD[4 * cc], mu = wb[Ld::CON + 5 * G_MAXCON + cc];
+            const T D = rD[4 * cc], mu = wb[Ld::CON + Ld::CON_W * cc + Ld::C_MU];
             const T jar[4] = {ja.a, ja.b, ja.c, ja.d}, was[4] = {tm.a, tm.b, tm.c, tm.d};
             T f4[4], dD[4], onf[4];
             bool anyflip = false;
