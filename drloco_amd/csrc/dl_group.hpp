@@ -941,9 +941,22 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         // ---- the common case: the full Newton step leaves the active set as it is.  The cost is quadratic on that
         // set, so a + dir is its exact minimiser (gradient zero up to rounding): no line search, no further pass over
         // the rows.  Checked per walker; the line search below only runs if some walker of the wave still needs it.
+        // The lane's rows (r = j, j + 16, j + 32) are taken into registers once: the check below, every trial of the line
+        // search and the final update then run without LDS round trips; rows beyond 48 (rare) stay in LDS.
+        constexpr int NS = 3;
+        T ja[NS], jv[NS], dd[NS];
         {
             bool flips = !(dir == dir);
-            for (int r = j; r < nefc; r += GL) flips = flips || ((rJA[r] + rJV[r] < T(0)) != (rTM[r] != T(0)));
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const int r = j + GL * s;
+                const bool ok = r < nefc;
+                const int rr = ok ? r : 0;
+                const T a_ = rJA[rr], v_ = rJV[rr], d_ = rD[rr], t_ = rTM[rr];
+                ja[s] = ok ? a_ : T(1); jv[s] = ok ? v_ : T(0); dd[s] = ok ? d_ : T(0);
+                flips = flips || (ok && ((a_ + v_ < T(0)) != (t_ != T(0))));
+            }
+            for (int r = j + GL * NS; r < nefc; r += GL) flips = flips || ((rJA[r] + rJV[r] < T(0)) != (rTM[r] != T(0)));
             if (alive && !gany(flips)) { qacc += dir; iter++; alive = false; }
         }
         if (!__any(alive)) { tick(5); break; }
@@ -958,9 +971,15 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         int it = 0;
         while (__any(!done)) {
             T pc = T(0), pd1 = T(0), pd2 = T(0);
-            for (int r = j; r < nefc; r += GL) {
-                const T jv = rJV[r], xx = rJA[r] + alpha * jv;
-                if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jv; pd2 += D * jv * jv; }
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const T xx = ja[s] + alpha * jv[s];
+                const T dx = (xx < T(0)) ? dd[s] * xx : T(0), dj = (xx < T(0)) ? dd[s] * jv[s] : T(0);
+                pc += T(0.5) * dx * xx; pd1 += dx * jv[s]; pd2 += dj * jv[s];
+            }
+            for (int r = j + GL * NS; r < nefc; r += GL) {
+                const T jvr = rJV[r], xx = rJA[r] + alpha * jvr;
+                if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jvr; pd2 += D * jvr * jvr; }
             }
             { T r3[3] = {pc, pd1, pd2}; gsum_n<3>(r3); pc = r3[0]; pd1 = r3[1]; pd2 = r3[2]; }
             const T d1 = g1s + T(2) * alpha * g2 + pd1, d2 = T(2) * g2 + pd2;
@@ -985,7 +1004,9 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
             if (res_a == T(0)) alive = false;                      // no improvement along a descent direction: converged to working precision
             else {
                 qacc += res_a * dir; Ma += res_a * Md;
-                for (int r = j; r < nefc; r += GL) rJA[r] += res_a * rJV[r];
+#pragma unroll
+                for (int s = 0; s < NS; s++) { const int r = j + GL * s; if (r < nefc) rJA[r] = ja[s] + res_a * jv[s]; }
+                for (int r = j + GL * NS; r < nefc; r += GL) rJA[r] += res_a * rJV[r];
                 iter++;
                 // mj_solNewton's improvement test (float32: relative to the magnitude of the terms of the cost difference)
                 if (!(scale * -res_dc >= cs.tolerance + cs.tol_rel * scale * res_mag) || nefc == 0) alive = false;
