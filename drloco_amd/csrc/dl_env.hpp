@@ -34,7 +34,8 @@ template <typename T> struct DevState {
     T* work;                 // [4*NV][N] staging of the RK4 bookkeeping
     int32_t n;
     T* rnd;                  // [5][N] or NULL: per-walker mass scale, floor friction, push force on the torso (x, y, z)
-    float* dbgf;             // [3*16][N] or NULL: stage input (q, v, warmstart) of the last evaluation that hit the iteration cap
+    float* dbgf;             // [3*16][N] or NULL: stage input (q, v, solver start) of the last evaluation with >= dbg_cap iterations
+    int dbg_cap;             // default: the iteration cap of the model (env DL_DEBUG_CAP_ITERS overrides; diagnostics)
     int32_t* dbg;            // [4][N] or NULL: solver diagnostics of the 16-lane step kernel (sum iters, max iters, sum rows, diverged)
 };
 

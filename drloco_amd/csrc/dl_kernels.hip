@@ -213,8 +213,8 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
                 if (stage == 0) acc_s0 = acc;
                 if (stage == 2) acc_s2_prev = acc;
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
-                if (st.dbgf && valid && ni >= m->iterations) {
-                    st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)warm;
+                if (st.dbgf && valid && ni >= st.dbg_cap) {
+                    st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)start;
                 }
                 if (simulate && !exc) warm = acc;
                 if (stage == 0 && simulate && !exc && gany(isdof && dl_bad(acc))) exc = true;     // mj_checkAcc
@@ -850,7 +850,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         return DL_OK;
     }
     int counters(int32_t* out, int clear, hipStream_t s) override {
-        if (!st.dbg) { int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; if ((rc = dalloc(&st.dbgf, (size_t)48 * n))) return rc; }
+        if (!st.dbg) {
+            int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; if ((rc = dalloc(&st.dbgf, (size_t)48 * n))) return rc;
+            const char* e = getenv("DL_DEBUG_CAP_ITERS");
+            st.dbg_cap = e ? atoi(e) : (int)m.iterations;
+        }
         if (out) HIPCHK(hipMemcpyAsync(out, st.dbg, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         if (clear) HIPCHK(hipMemsetAsync(st.dbg, 0, (size_t)4 * n * sizeof(int32_t), s));
         return DL_OK;
