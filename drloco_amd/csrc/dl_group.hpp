@@ -324,6 +324,8 @@ template <typename T> struct GLaneTopo {
     int rs;
     bool last;
     T ms[4], ns[4];          // 1/0: lane j - 2^k (j + 2^k) belongs to the same run
+    T ancf[GL];              // 1/0: dof a is on the root -> j chain.  Float masks in VGPRs: the boolean form lives in SGPR pairs,
+                             // which the step kernel has to spill (two v_readlane per use inside the evaluation)
 };
 template <typename T, typename TP> __device__ __forceinline__ void g_lane_topo(int j, GLaneTopo<T>& lt) {
     const auto& tb = GTopo<TP>::tab;
@@ -331,6 +333,8 @@ template <typename T, typename TP> __device__ __forceinline__ void g_lane_topo(i
     const int re = tb.re[j];
 #pragma unroll
     for (int k = 0; k < 4; k++) { lt.ms[k] = (j - (1 << k) >= lt.rs) ? T(1) : T(0); lt.ns[k] = (j + (1 << k) <= re) ? T(1) : T(0); }
+#pragma unroll
+    for (int a = 0; a < GL; a++) { lt.ancf[a] = ((lt.anc >> a) & 1u) ? T(1) : T(0); g_pin(lt.ancf[a]); }
 }
 // x_j <- sum over the dofs a on the root -> j chain of x_a, for NVAL values at once (one v_fmac_f32_dpp per value
 // and scan step)
@@ -424,20 +428,20 @@ __device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T
     const T dq = (j < TP::NV) ? q - ln.qpos0 : T(0);
     T s = T(0), c = T(1);
     if (j < TP::NV && ln.type == 1) dl_sincos(ln.sign * dq, s, c);
+    const T cm1 = c - T(1);
     V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
     T rootz = g.c->root_z0;
     static_for<TP::NV>([&](auto ai) {
         constexpr int a = ai.value;
-        const bool in = (lt.anc >> a) & 1u;
+        const T f = lt.ancf[a];                           // 1 where hinge / body a is on this lane's chain, else the identity
         if constexpr (GTopo<TP>::dof_first(a) && TP::dof_body(a) != 1) {
             constexpr int b = TP::dof_body(a);
-            const T f = in ? T(1) : T(0);
             const T bx = f * g.c->body_pos[b][0], by = f * g.c->body_pos[b][1], bz = f * g.c->body_pos[b][2];
             pos = pos + bx * X + by * Y + bz * Z;
         }
         if constexpr (TP::dof_type(a) == 1) {
-            const T sa = rbcast<a>(s), ca = rbcast<a>(c);
-            rot_axis_c<TP::dof_axis(a)>(X, Y, Z, in ? sa : T(0), in ? ca : T(1));
+            const T sa = rbcast<a>(s) * f, ca = T(1) + rbcast<a>(cm1) * f;
+            rot_axis_c<TP::dof_axis(a)>(X, Y, Z, sa, ca);
         } else if constexpr (TP::dof_axis(a) == 2) {
             rootz += T(TP::dof_sign(a)) * rbcast<a>(dq);
         }
@@ -548,7 +552,7 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
         T mij = T(0);
         if constexpr (TP::dof_type(a) == 1) { fmac_bcast<a, 1>(mij, Sr[0], f.w.x); fmac_bcast<a, 1>(mij, Sr[1], f.w.y); fmac_bcast<a, 1>(mij, Sr[2], f.w.z); }
         fmac_bcast<a, 1>(mij, Sr[3], f.v.x); fmac_bcast<a, 1>(mij, Sr[4], f.v.y); fmac_bcast<a, 1>(mij, Sr[5], f.v.z);
-        mij = ((lt.anc >> a) & 1u) ? mij : T(0);
+        mij *= lt.ancf[a];
         if (a == j) { mij += ln.armature; mdiag = mij; }
         if (a <= j && isdof) { wb[Ld::MM + j * Ld::MS + a] = mij; wb[Ld::MM + a * Ld::MS + j] = mij; }
     });
