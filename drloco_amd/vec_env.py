@@ -466,7 +466,9 @@ class HipVecNormalize:
         only after `flush()` (call it before anything on the main stream reads them: GAE, the policy, a copy to the host)."""
         dev = self.venv.device
         ev = lambda: torch.cuda.Event()
-        self._ov = dict(stream=torch.cuda.Stream(device=dev), chunk=int(chunk), k=0, last=None, pending=[], read=[None, None], readev=[ev(), ev()],
+        # high priority: its own hardware-queue pool (a default-priority stream may share the main stream's queue once other
+        # libraries -- RCCL -- have created streams) and the tiny launches are dispatched while the step kernel runs
+        self._ov = dict(stream=torch.cuda.Stream(device=dev, priority=-1), chunk=int(chunk), k=0, last=None, pending=[], read=[None, None], readev=[ev(), ev()],
                         stepped=[ev(), ev()],
                         raw=[(torch.zeros_like(self.venv.obs), torch.zeros_like(self.venv.rew)) for _ in range(2 * chunk)],
                         done=[torch.zeros_like(self.venv.done) for _ in range(2 * chunk)])
