@@ -67,15 +67,9 @@ struct GLds {
     static_assert(CON % 4 == 0 && ROW % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && G_MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
 };
 
-// model data that is indexed dynamically inside the loops (by the body of a contact) is staged once per kernel in
-// LDS, shared by the 4 walkers of the wave; everything a lane needs about ITS OWN dof / body / collision
-// candidates is preloaded into registers (GLane), uniform scalars are pinned in VGPRs (GConst).
-struct GShared {
-    static constexpr int T_BODY_INVW = 0;             // [8]
-    static constexpr int T_END = 8;
-    template <typename T> static constexpr int bytes() { return ((T_END * (int)sizeof(T) + 255) / 256) * 256; }
-};
-
+// everything a lane needs about ITS OWN dof / body / collision candidates (incl. the inverse weight of the candidates'
+// bodies) is preloaded into registers (GLane), uniform scalars are pinned in VGPRs (GConst); nothing of the model is
+// indexed dynamically inside the loops, so there is no shared model block in LDS.
 template <typename T> struct GLane {
     int type, axis, body, limited, act;
     T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
@@ -121,12 +115,6 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
         ln.cmu[pass] = m.geom_friction[ge];          // the contact uses max(geom, floor) with the walker's floor friction
         ln.cinvw[pass] = m.body_invw[m.geom_body[ge]];
     }
-}
-
-// fill the shared model block; call once, then __syncthreads()
-template <typename T>
-__device__ __forceinline__ void g_fill_shared(const DL_CONST GModel<T>& m, DL_LDS T* stt, int lane) {
-    if (lane < G_MAXB) stt[GShared::T_BODY_INVW + lane] = m.body_invw[lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -212,7 +200,6 @@ template <typename T> struct GCtx {
     DL_LDS T* wb;                        // walker's LDS region
     const DL_CONST GModel<T>* m;         // uniform scalars only on the hot path
     int j;                               // lane in the row
-    DL_LDS T* st;                        // shared model block
     const GLane<T>* ln;                  // this lane's preloaded model data
     const GConst<T>* c;                  // pinned uniform scalars
     const GWalk<T>* wk;                  // this walker's randomisation

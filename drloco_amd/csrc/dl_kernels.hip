@@ -89,11 +89,8 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     const bool valid = w < n;
     const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    DL_LDS T* stt = (DL_LDS T*)smem;
-    g_fill_shared<T>(*m, stt, lane);
     GLane<T> ln;
     g_load_lane<T>(*m, j, ln);
-    __syncthreads();
     GConst<T> cst;
     g_load_const<T>(*m, cst);
     GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
@@ -103,7 +100,7 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
         wk.push = mk<T>(st.rnd[(size_t)2 * n + ws], st.rnd[(size_t)3 * n + ws], st.rnd[(size_t)4 * n + ws]);
         wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
     }
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst, &wk};
+    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j, &ln, &cst, &wk};
     const int nv = m->nv;
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < nv) {
@@ -142,11 +139,8 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     const bool valid = w0 < n;
     const int w = valid ? w0 : n - 1;
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    DL_LDS T* stt = (DL_LDS T*)smem;
-    g_fill_shared<T>(*m, stt, lane);
     GLane<T> ln;
     g_load_lane<T>(*m, j, ln);
-    __syncthreads();
     GConst<T> cst;
     g_load_const<T>(*m, cst);
     GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
@@ -156,7 +150,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
         wk.push = mk<T>(st.rnd[(size_t)2 * n + ws], st.rnd[(size_t)3 * n + ws], st.rnd[(size_t)4 * n + ws]);
         wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
     }
-    GCtx<T> g{(DL_LDS T*)(smem + GShared::bytes<T>()) + (size_t)grp * GLds::TOTAL, m, j, stt, &ln, &cst, &wk};
+    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j, &ln, &cst, &wk};
     DL_LDS T* wb = g.wb;
     const int nv = m->nv, nu = m->nu;
     const bool isdof = j < nv;
@@ -741,8 +735,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             else {
                 if ((rc = dalloc(&gmd, 1))) return rc;
                 HIPCHK(hipMemcpy(gmd, &gmh, sizeof gmh, hipMemcpyHostToDevice));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)))));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)))));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T)))));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T)))));
             }
         } else if (cfg.lanes_per_walker == GL) return fail(DL_E_INVAL, "the 16-lane kernels support the straight walker (<= 16 dofs, <= 8 bodies)");
         else variant = 0;
@@ -769,7 +763,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (variant == 1 && gmd) {
             if constexpr (TP::ENV_KIND == 0) {
                 prof_begin(s);
-                hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
+                hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
                                    (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), eval_mode);
                 prof_end(s);
             }
@@ -809,7 +803,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
         if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
         if (variant == 1 && gmd) {
-            hipLaunchKernelGGL((k_forward_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+            hipLaunchKernelGGL((k_forward_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
@@ -863,8 +857,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (!gmd || !qacc || !tim) return fail(DL_E_INVAL, "dl_debug_forward_timed: needs the 16-lane kernels, qacc and tim");
         if constexpr (TP::ENV_KIND == 0 && sizeof(T) == 4) {
             static bool attr = false;
-            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T))))); attr = true; }
-            hipLaunchKernelGGL((k_forward_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, tim);
+            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T))))); attr = true; }
+            hipLaunchKernelGGL((k_forward_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, tim);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
@@ -874,8 +868,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (!gmd || !act || !obs || !rew || !done || !tim) return fail(DL_E_INVAL, "dl_debug_step_timed: needs the 16-lane kernels and all arrays");
         if constexpr (TP::ENV_KIND == 0 && sizeof(T) == 4) {
             static bool attr = false;
-            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T))))); attr = true; }
-            hipLaunchKernelGGL((k_env_step_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GShared::bytes<T>() + GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
+            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T))))); attr = true; }
+            hipLaunchKernelGGL((k_env_step_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
                                (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, tim);
             HIPCHK(hipGetLastError());
             return DL_OK;
