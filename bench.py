@@ -122,10 +122,15 @@ def main():
     def rollout():
         # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
         # (dl_step -> episode_starts[t+1]; dl_vecnormalize_step -> observations[t+1], rewards[t])
-        buf.reset()
-        buf.observations[0].copy_(last_obs)
-        buf.episode_starts[0].copy_(last_done)
-        for t in range(T):
+        if policy is not None and push_force is None:
+            buf.collect_rollouts(vn, policy, last_obs, last_done)     # dl_rollout_policy: the whole loop in one C-ABI call
+            T_loop = 0
+        else:
+            buf.reset()
+            buf.observations[0].copy_(last_obs)
+            buf.episode_starts[0].copy_(last_done)
+            T_loop = T
+        for t in range(T_loop):
             nxt = t + 1 < T
             if push_force is not None:  # 0.1 s = 20 control steps of push every 2 s = 400 control steps
                 on = ((step_counter[0] + push_phase) % 400 < 20).to(torch.float32).unsqueeze(1)

@@ -65,6 +65,13 @@ class PolicyParams(C.Structure):
                 ('wv', C.c_void_p), ('bv', C.c_void_p), ('log_std', C.c_void_p), ('obs_dim', _i), ('hidden', _i), ('act_dim', _i)]
 
 
+class VecNormState(C.Structure):
+    """dl_vecnorm_state (include/drloco_hip.h)."""
+    _fields_ = [('obs_mean', C.c_void_p), ('obs_var', C.c_void_p), ('obs_count', C.c_void_p), ('ret', C.c_void_p), ('ret_mean', C.c_void_p),
+                ('ret_var', C.c_void_p), ('ret_count', C.c_void_p), ('workspace', C.c_void_p), ('gamma', C.c_double), ('eps', C.c_double),
+                ('clip_obs', C.c_double), ('clip_rew', C.c_double), ('flags', _i)]
+
+
 def loco3d_config(**kw):
     """Defaults for MimicWalker165cm65kg: CTRL_FREQ 100 (config.py:20); the policy-mirroring modification
     must be off because Loco3dReferenceTrajectories has no is_step_left."""

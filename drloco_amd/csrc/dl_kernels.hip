@@ -896,7 +896,16 @@ extern "C" {
 
 const char* dl_last_error(void) { return g_err.c_str(); }
 int dl_abi_version(void) { return DL_ABI_VERSION; }
-int dl_abi_sizeof(int which) { return which == 0 ? (int)sizeof(dl_model_desc) : which == 1 ? (int)sizeof(dl_refs_desc) : (int)sizeof(dl_config); }
+int dl_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(dl_model_desc);
+        case 1: return (int)sizeof(dl_refs_desc);
+        case 2: return (int)sizeof(dl_config);
+        case 3: return (int)sizeof(dl_policy_params);
+        case 4: return (int)sizeof(dl_vecnorm_state);
+        default: return -1;
+    }
+}
 
 int dl_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_config* cfg, int32_t n_envs, int32_t device, dl_handle* out) {
     if (!model || !refs || !cfg || !out || n_envs <= 0) return fail(DL_E_INVAL, "dl_create: bad arguments");
@@ -1108,6 +1117,27 @@ int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, co
     }
 #undef DL_POL_LAUNCH
     HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
+                      float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
+                      float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, void* stream) {
+    NEED(h);
+    if (!pol || !vn || T <= 0 || !observations || !actions || !values || !log_probs || !rewards || !episode_starts || !next_obs || !next_done || !raw_obs || !raw_rew)
+        return fail(DL_E_INVAL, "dl_rollout_policy: bad arguments");
+    const size_t n = (size_t)h->n, od = (size_t)h->obs_dim, ad = (size_t)h->act_dim;
+    if (pol->obs_dim != h->obs_dim || pol->act_dim != h->act_dim) return fail(DL_E_INVAL, "dl_rollout_policy: the policy's observation / action sizes are not the environment's");
+    for (int t = 0; t < T; t++) {
+        const bool last = t + 1 == T;
+        int rc = dl_policy_forward(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, 0,
+                                   actions + t * n * ad, values + t * n, log_probs + t * n, stream);
+        if (rc) return rc;
+        uint8_t* done = last ? next_done : episode_starts + (t + 1) * n;
+        if ((rc = h->step(actions + t * n * ad, raw_obs, raw_rew, done, nullptr, nullptr, (hipStream_t)stream))) return rc;
+        rc = dl_vecnormalize_step(raw_obs, raw_rew, done, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od,
+                                  vn->gamma, vn->eps, vn->clip_obs, vn->clip_rew, vn->flags, last ? next_obs : observations + (t + 1) * n * od, rewards + t * n, vn->workspace, stream);
+        if (rc) return rc;
+    }
     return DL_OK;
 }
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val, const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv, float* ret, void* stream) {

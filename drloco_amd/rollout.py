@@ -31,6 +31,22 @@ class HipRolloutBuffer:
         self.episode_starts[t].copy_(episode_start); self.values[t].copy_(value); self.log_probs[t].copy_(log_prob)
         self.pos += 1
 
+    def collect_rollouts(self, vn, policy, last_obs, last_done):
+        """SB3 1.0 OnPolicyAlgorithm.collect_rollouts (the loop between two PPO updates) as ONE C-ABI call,
+        dl_rollout_policy: T x (policy forward -> env step -> VecNormalize) enqueued back to back, every result written
+        straight into this buffer.  vn: HipVecNormalize; policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]:
+        the normalised observation and episode-start flags that open this rollout -- overwritten with the ones that open
+        the next (SB3's _last_obs / _last_episode_starts)."""
+        self.reset()
+        self.observations[0].copy_(last_obs)
+        self.episode_starts[0].copy_(last_done)
+        p, st = policy._params(), vn.state_struct()
+        lib.check(self._lib.dl_rollout_policy(vn.venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), self.T,
+                                              _ptr(self.observations), _ptr(self.actions), _ptr(self.values), _ptr(self.log_probs), _ptr(self.rewards),
+                                              _ptr(self.episode_starts), _ptr(last_obs), _ptr(last_done), _ptr(vn.venv.obs), _ptr(vn.venv.rew), _stream()))
+        policy.counter += self.T
+        self.pos = self.T
+
     def compute_returns_and_advantage(self, last_values, dones):
         lv = last_values.to(torch.float32).contiguous()
         ld = dones.to(torch.uint8).contiguous()

@@ -403,10 +403,22 @@ class HipVecNormalize:
         lib.check(self._lib.dl_normalize_obs(_ptr(x), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), n, x.shape[1],
                                              self.epsilon, self.clip_obs, _stream()))
 
+    def _flags(self):
+        return (1 if (self.norm_obs and self.training) else 0) | (2 if self.norm_obs else 0) | \
+               (4 if (self.norm_reward and self.training) else 0) | (8 if self.norm_reward else 0)
+
+    def state_struct(self):
+        """dl_vecnorm_state for dl_rollout_policy: pointers to the device-resident moments of this object."""
+        st = abi.VecNormState()
+        st.obs_mean, st.obs_var, st.obs_count = self.obs_rms._mean.data_ptr(), self.obs_rms._var.data_ptr(), self.obs_rms._count.data_ptr()
+        st.ret, st.ret_mean, st.ret_var, st.ret_count = self.ret.data_ptr(), self.ret_rms._mean.data_ptr(), self.ret_rms._var.data_ptr(), self.ret_rms._count.data_ptr()
+        st.workspace = self._vn_work.data_ptr()
+        st.gamma, st.eps, st.clip_obs, st.clip_rew, st.flags = self.gamma, self.epsilon, self.clip_obs, self.clip_reward, self._flags()
+        return st
+
     def _vn_launch(self, obs, rew, done, obs_out, rew_out):
         n, d = obs.shape
-        flags = (1 if (self.norm_obs and self.training) else 0) | (2 if self.norm_obs else 0) | \
-                (4 if (self.norm_reward and self.training) else 0) | (8 if self.norm_reward else 0)
+        flags = self._flags()
         lib.check(self._lib.dl_vecnormalize_step(
             _ptr(obs), _ptr(rew), _ptr(done), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
             _ptr(self.ret), _ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, d,

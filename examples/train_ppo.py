@@ -50,7 +50,6 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
     obs = vn.norm_obs_t.clone()
     start = torch.ones(n_envs, dtype=torch.uint8, device=dev)
     last_done = torch.zeros(n_envs, dtype=torch.uint8, device=dev)
-    scratch_obs = torch.empty_like(obs)
     hist = []
     t0 = time.perf_counter()
     for upd in range(n_updates):
@@ -59,13 +58,8 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
             gp['lr'] = lr
         # ---- collect_rollouts
         with torch.no_grad():
-            buf.observations[0].copy_(obs); buf.episode_starts[0].copy_(start)
-            for t in range(T):
-                nxt = t + 1 < T
-                pol.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
-                vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else scratch_obs, rew_out=buf.rewards[t],
-                                done_out=buf.episode_starts[t + 1] if nxt else last_done)
-            obs.copy_(scratch_obs); start.copy_(last_done)
+            buf.collect_rollouts(vn, pol, obs, start)        # dl_rollout_policy: T x (policy -> step -> normalise) in one call
+            last_done.copy_(start)
             _, last_values, _ = pol.forward(obs, deterministic=True)
             buf.compute_returns_and_advantage(last_values, last_done)
         # ---- PPO.train

@@ -300,6 +300,34 @@ int dl_policy_forward(const dl_policy_params* params, const float* obs, int32_t 
                       uint64_t seed, uint64_t counter, int32_t index_base, int32_t deterministic,
                       float* actions, float* values, float* log_probs, void* stream);
 
+/* VecNormalize state as dl_vecnormalize_step takes it, bundled for dl_rollout_policy (all DEVICE pointers). */
+typedef struct dl_vecnorm_state {
+    double* obs_mean; double* obs_var; double* obs_count;     /* [D], [D], [1] */
+    double* ret; double* ret_mean; double* ret_var; double* ret_count;   /* [N], [1], [1], [1] */
+    void* workspace;                                          /* DL_VN_WORKSPACE_BYTES(D), zero-initialised once */
+    double gamma, eps, clip_obs, clip_rew;
+    int32_t flags;                                            /* as dl_vecnormalize_step */
+} dl_vecnorm_state;
+
+/* SB3 1.0 OnPolicyAlgorithm.collect_rollouts for T steps in ONE call (constructed at
+ * drloco/train.py:110-118, the loop SB3 runs between two PPO updates): for t = 0..T-1
+ *     actions[t], values[t], log_probs[t] = policy.forward(observations[t])        (dl_policy_forward, counter0 + t)
+ *     raw obs, raw reward, done           = env.step(actions[t])                   (dl_step incl. auto-reset)
+ *     observations[t+1], rewards[t]       = VecNormalize.step_wait(...)            (dl_vecnormalize_step)
+ *     episode_starts[t+1]                 = done
+ * with every producer writing straight into the rollout-buffer arrays (time-major, the layout dl_gae reads):
+ *   observations float[T, N, obs] (row 0 = the observation that opens the rollout, filled by the caller),
+ *   actions float[T, N, nu], values/log_probs/rewards float[T, N], episode_starts uint8[T, N] (row 0 by the caller).
+ * The observation and done flags after the last step go to next_obs float[N, obs] / next_done uint8[N] (they open
+ * the next rollout; SB3's _last_obs / _last_episode_starts).  raw_obs float[N, obs] / raw_rew float[N]: scratch that
+ * holds the un-normalised outputs of the last step (VecNormalize.get_original_obs / get_original_reward).
+ * 4 T launches are enqueued on `stream`; nothing returns to the host in between. */
+int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed, uint64_t counter0,
+                      int32_t index_base, const dl_vecnorm_state* vn, int32_t T, float* observations,
+                      float* actions, float* values, float* log_probs, float* rewards,
+                      uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
+                      float* raw_rew, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 
 def test_struct_sizes_and_version(L):
     assert L.dl_abi_version() == abi.DL_ABI_VERSION
-    for which, st in enumerate((abi.ModelDesc, abi.RefsDesc, abi.Config)):
+    for which, st in enumerate((abi.ModelDesc, abi.RefsDesc, abi.Config, abi.PolicyParams, abi.VecNormState)):
         assert L.dl_abi_sizeof(which) == C.sizeof(st)
 
 

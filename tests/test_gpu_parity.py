@@ -898,3 +898,37 @@ def test_overlapped_vecnormalize_is_identical(torch_cuda, model, refs):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
     assert a[2].sum() > 0          # episodes ended inside the window
+
+
+def test_rollout_policy_in_one_call(torch_cuda, model, refs):
+    """dl_rollout_policy (collect_rollouts as one C-ABI call: T x policy forward -> env step -> VecNormalize into the
+    rollout buffer) against the same loop driven step by step from Python: identical buffers, moments and counters."""
+    import torch
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    n, T = 256, 48
+    res = []
+    for one_call in (False, True):
+        vn = HipVecNormalize(HipVecEnv(num_envs=n, seed=21, model=model, refs=refs))
+        pol = HipPolicy(hidden=128, seed=4)
+        buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+        vn.reset()
+        last_obs = vn.norm_obs_t.clone(); last_done = torch.ones(n, dtype=torch.uint8, device='cuda')
+        for rollout in range(2):                                # the second rollout starts from the first one's last observation
+            if one_call:
+                buf.collect_rollouts(vn, pol, last_obs, last_done)
+            else:
+                buf.reset()
+                buf.observations[0].copy_(last_obs); buf.episode_starts[0].copy_(last_done)
+                for t in range(T):
+                    nxt = t + 1 < T
+                    pol.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
+                    vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t],
+                                    done_out=buf.episode_starts[t + 1] if nxt else last_done)
+        torch.cuda.synchronize()
+        res.append([x.cpu().clone() for x in (buf.observations, buf.actions, buf.values, buf.log_probs, buf.rewards, buf.episode_starts, last_obs, last_done)]
+                   + [torch.as_tensor(vn.obs_rms.mean), torch.as_tensor(vn.ret_rms.var), torch.as_tensor(vn.get_original_obs()), torch.tensor(pol.counter)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert res[0][5].sum() > 0 and res[0][11] == 2 * T
