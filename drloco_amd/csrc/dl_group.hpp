@@ -48,8 +48,8 @@ template <typename T> struct GModel {
 // per-walker LDS layout (in elements of T)
 struct GLds {
     static constexpr int Q = 0, V = Q + GL;                          // q, v staged for the observation writer
-    static constexpr int MS = GL + 1;                                // row stride of M (odd: row-wise and column-wise access are both conflict-free)
-    static constexpr int MM = V + GL;                                // M [16 rows][MS]: mirror of the lower triangle
+    static constexpr int MS = GL + 4;                                // row stride of M: rows are written as four 16-byte groups, columns read with consecutive lanes
+    static constexpr int MM = V + GL;                                // M [16 rows][MS]: every lane's chain part of its row (transposed read-back gives the rest)
     static constexpr int CON_W = 12;                                 // contact record: (px py pz body) (tx ty mu dist) (diagApprox - - -): three 16-byte groups
     static constexpr int C_P = 0, C_BODY = 3, C_TX = 4, C_TY = 5, C_MU = 6, C_DIST = 7, C_DIAG = 8;
     static constexpr int CON = MM + GL * MS;                         // contacts [G_MAXCON][CON_W]
@@ -64,7 +64,7 @@ struct GLds {
     static constexpr int TOTAL_RAW = JC + G_MAXCON * GL * 4;
     // walker regions are offset by 16 (mod 32) words so that the two rows of a half-wave use disjoint banks
     static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
-    static_assert(CON % 4 == 0 && ROW % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && G_MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
+    static_assert(MM % 4 == 0 && MS % 4 == 0 && CON % 4 == 0 && ROW % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && G_MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
 };
 
 // everything a lane needs about ITS OWN dof / body / collision candidates (incl. the inverse weight of the candidates'
@@ -474,7 +474,7 @@ __device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
 // The lower triangle of M is mirrored through LDS once so that every lane holds its full row (mrow).
 // Out: mrow, qfrc_smooth_j; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
 template <typename T, typename TP>
-__device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, GKin<T>& k, T (&mrow)[GL], T& mdiag) {
+__device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, GKin<T>& k, T (&mrow)[GL], T& mdiag, T& mcorr) {
     using Ld = GLds;
     constexpr int NV = TP::NV;
     const DL_CONST GModel<T>& m = *g.m;
@@ -531,21 +531,34 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     const SV<T> W = {mk<T>(cs16[10], cs16[11], cs16[12]), mk<T>(cs16[13], cs16[14], cs16[15])};
     const T bias = sdot(S, W);
     const SV<T> f = si_mul(Ic, S);
-    // M[j][a] for the dofs a on the chain of j; mirrored through LDS
+    // M[j][a] = S_a . (Ic_j S_j) for the dofs a on the chain of j (incl. j) -- zero elsewhere by the chain mask -- is what the
+    // lane can compute.  The lane writes this part of its row as four 16-byte groups, no per-entry predicates; after the
+    // exchange, own part + column j of the block (= the parts the descendants computed) is the full row.  The diagonal is
+    // then counted twice and lacks the armature: mrow[j] is only ever used in products M x, where mcorr * x_j repairs it
+    // (the factorisation takes the diagonal from mdiag).
     T Sr[6] = {S.w.x, S.w.y, S.w.z, S.v.x, S.v.y, S.v.z};
     g_dpp_ready_n<6>(Sr);
+    T ml[GL];
+#pragma unroll
+    for (int a = NV; a < GL; a++) ml[a] = T(0);
     static_for<NV>([&](auto ai) {
         constexpr int a = ai.value;
         T mij = T(0);
         if constexpr (TP::dof_type(a) == 1) { fmac_bcast<a, 1>(mij, Sr[0], f.w.x); fmac_bcast<a, 1>(mij, Sr[1], f.w.y); fmac_bcast<a, 1>(mij, Sr[2], f.w.z); }
         fmac_bcast<a, 1>(mij, Sr[3], f.v.x); fmac_bcast<a, 1>(mij, Sr[4], f.v.y); fmac_bcast<a, 1>(mij, Sr[5], f.v.z);
-        mij *= lt.ancf[a];
-        if (a == j) { mij += ln.armature; mdiag = mij; }
-        if (a <= j && isdof) { wb[Ld::MM + j * Ld::MS + a] = mij; wb[Ld::MM + a * Ld::MS + j] = mij; }
+        ml[a] = mij * lt.ancf[a];
     });
+    {
+        const T mjj = sdot(S, f);
+        mdiag = isdof ? mjj + ln.armature : T(1);
+        mcorr = isdof ? ln.armature - mjj : T(0);
+        DL_LDS T* row = wb + Ld::MM + j * Ld::MS;
+        st4(row, ml[0], ml[1], ml[2], ml[3]); st4(row + 4, ml[4], ml[5], ml[6], ml[7]);
+        st4(row + 8, ml[8], ml[9], ml[10], ml[11]); st4(row + 12, ml[12], ml[13], ml[14], ml[15]);
+    }
     g_sync<T>();
 #pragma unroll
-    for (int a = 0; a < GL; a++) mrow[a] = (a < NV && isdof) ? wb[Ld::MM + j * Ld::MS + a] : T(0);
+    for (int a = 0; a < GL; a++) mrow[a] = (a < NV) ? ml[a] + wb[Ld::MM + a * Ld::MS + j] : T(0);
     // [3P] xfrc_applied on the torso (body 1): J^T of a world-frame force at its centre of mass
     T push_q = T(0);
     if (g.wk->pushed) {
@@ -774,11 +787,11 @@ template <> struct GEps<double> { static constexpr double value = 2.220446049250
 // J x: the limit row of a dof is +-x_j; per contact the three contact-frame components are row sums of the lane's own
 // Jacobian column times x_j, expanded to the four pyramid rows by lanes 0..3.
 template <typename T, int N>
-__device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T lim_sign, T x, const T (&mrow)[GL]) {
+__device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T lim_sign, T x, const T (&mrow)[GL], T mcorr) {
     using Ld = GLds;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    T mx = T(0), xb = x;
+    T mx = mcorr * x, xb = x;
     g_dpp_ready(xb);
     static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(mx, xb, mrow[a]); });
     if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * G_MAXROW + my_lim] = lim_sign * x;
@@ -824,8 +837,8 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     GKin<T> kin;
-    T mrow[GL], mdiag;
-    const T smooth = g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, kin, mrow, mdiag);
+    T mrow[GL], mdiag, mcorr;
+    const T smooth = g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, kin, mrow, mdiag, mcorr);
     tick(0);
     int nlim, ncon, my_lim;
     T lim_sign;
@@ -837,7 +850,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
     DL_LDS T* rJA = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW;
     DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
     DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
-    T qacc = warm, Ma = T(0);
+    T qacc = warm, Ma = mcorr * warm;
     static_for<N>([&](auto ai) { constexpr int a = ai.value; Ma += mrow[a] * rbcast<a>(qacc); });
     T h[GL], hd = mdiag;       // row j of H = M + sum_active D row^T row (off-diagonal part) and its diagonal
 #pragma unroll
@@ -926,7 +939,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
             dir = -g_chol_solve<T, N>(lo, up, invd, grad, j);
         }
         tick(3);
-        const T Md = g_apply<T, N>(g, ncon, my_lim, lim_sign, dir, mrow);      // rows JV = J dir
+        const T Md = g_apply<T, N>(g, ncon, my_lim, lim_sign, dir, mrow, mcorr);      // rows JV = J dir
         g_sync<T>();
         tick(4);
         // ---- the common case: the full Newton step leaves the active set as it is.  The cost is quadratic on that
