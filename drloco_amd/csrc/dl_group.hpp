@@ -29,6 +29,20 @@ constexpr int G_MAXCAND = 32;   // collision candidate points
 constexpr int G_MAXCON = 20;    // >= 18
 constexpr int G_MAXROW = 80;
 
+// what a lane needs about ITS OWN dof / body / collision candidates; built once on the host (g_load_lane) for the 16
+// lanes and kept in the model block, so that a kernel fetches its lane's record with a handful of wide loads
+template <typename T> struct GLane {
+    int type, axis, body, limited, act;
+    T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
+    // inertial parameters of the body of this dof
+    T mass, ipos[3], inertia[3];
+    // the two collision candidates of this lane (capsule end points / box corners in contact order, c = j and j + 16)
+    // as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
+    // to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
+    int cinfo[2];                                      // bit0 valid, 1 box, 2-4 sub index, 5-7 body
+    T cpl[2][3], crad[2], cal[2][3], crl[2][3], cmu[2], cinvw[2];   // cinvw: body_invweight0 of the candidate's body (diagApprox of its contact rows)
+};
+
 // model as data (host-built from dl_model_desc), read through the constant address space
 template <typename T> struct GModel {
     int32_t nv, nb, nu, ngeom, nsite, frame_skip, iterations, ls_iterations, ncand, root_last_dof;
@@ -43,6 +57,7 @@ template <typename T> struct GModel {
     T geom_pos[G_MAXB][3], geom_mat[G_MAXB][9], geom_size[G_MAXB][3], geom_friction[G_MAXB], floor_friction;
     int32_t site_body[8];
     T site_pos[8][3];
+    GLane<T> lanes[GL];                        // per-lane records (g_load_lane of the fields above), filled by fill_group_model
 };
 
 // per-walker LDS layout (in elements of T)
@@ -70,20 +85,9 @@ struct GLds {
 // everything a lane needs about ITS OWN dof / body / collision candidates (incl. the inverse weight of the candidates'
 // bodies) is preloaded into registers (GLane), uniform scalars are pinned in VGPRs (GConst); nothing of the model is
 // indexed dynamically inside the loops, so there is no shared model block in LDS.
-template <typename T> struct GLane {
-    int type, axis, body, limited, act;
-    T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
-    // inertial parameters of the body of this dof
-    T mass, ipos[3], inertia[3];
-    // the two collision candidates of this lane (capsule end points / box corners in contact order, c = j and j + 16)
-    // as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
-    // to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
-    int cinfo[2];                                      // bit0 valid, 1 box, 2-4 sub index, 5-7 body
-    T cpl[2][3], crad[2], cal[2][3], crl[2][3], cmu[2], cinvw[2];   // cinvw: body_invweight0 of the candidate's body (diagApprox of its contact rows)
-};
 
-template <typename T>
-__device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, GLane<T>& ln) {
+template <typename T, typename MODEL>       // MODEL: GModel<T> in whatever address space the caller holds it
+__host__ __device__ __forceinline__ void g_load_lane(const MODEL& m, int j, GLane<T>& ln) {
     const int jj = j < m.nv ? j : 0;
     ln.type = m.dof_type[jj]; ln.axis = m.dof_axis[jj]; ln.body = m.dof_body[jj]; ln.limited = m.dof_limited[jj]; ln.act = m.dof_act[jj];
     ln.sign = m.dof_sign[jj]; ln.qpos0 = m.qpos0[jj]; ln.range_lo = m.range_lo[jj]; ln.range_hi = m.range_hi[jj];
@@ -98,7 +102,7 @@ __device__ __forceinline__ void g_load_lane(const DL_CONST GModel<T>& m, int j, 
         const int ge = ok ? m.cand_geom[c] : 0, sub = ok ? m.cand_sub[c] : 0;
         const bool box = m.geom_type[ge] != 0;
         ln.cinfo[pass] = (ok ? 1 : 0) | (box ? 2 : 0) | (sub << 2) | (m.geom_body[ge] << 5);
-        const DL_CONST T* mat = m.geom_mat[ge];
+        const auto* mat = m.geom_mat[ge];
         T rel[3];
         if (box) {
             const T sx = (sub & 1) ? m.geom_size[ge][0] : -m.geom_size[ge][0];

@@ -163,6 +163,7 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
     g.ncand = nc;
     g.floor_friction = (T)d.floor_friction;
     for (int s = 0; s < d.nsite; s++) { g.site_body[s] = d.site_body[s]; for (int k = 0; k < 3; k++) g.site_pos[s][k] = (T)d.site_pos[s][k]; }
+    for (int j = 0; j < GL; j++) g_load_lane<T>(g, j, g.lanes[j]);      // per-lane records, read by the kernels with wide loads
     return true;
 }
 }  // namespace dl

@@ -89,8 +89,7 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
     const bool valid = w < n;
     const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    GLane<T> ln;
-    g_load_lane<T>(*m, j, ln);
+    const GLane<T> ln = m->lanes[j];               // this lane's record of the model block (built on the host by g_load_lane)
     GConst<T> cst;
     g_load_const<T>(*m, cst);
     GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
@@ -139,8 +138,7 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     const bool valid = w0 < n;
     const int w = valid ? w0 : n - 1;
     const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    GLane<T> ln;
-    g_load_lane<T>(*m, j, ln);
+    const GLane<T> ln = m->lanes[j];               // this lane's record of the model block (built on the host by g_load_lane)
     GConst<T> cst;
     g_load_const<T>(*m, cst);
     GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
