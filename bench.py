@@ -64,7 +64,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
-    ap.add_argument('--profile-every', type=int, default=16, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
+    ap.add_argument('--profile-every', type=int, default=4, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -103,7 +103,8 @@ def main():
     if not args.policy and not args.no_overlap:
         vn.enable_overlap()      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
-    last_done = torch.ones(n, dtype=torch.uint8, device=dev)
+    last_done = buf.next_starts                                 # row T of the episode-start array: the flags after the last step
+    last_done.fill_(1)
     push_phase = push_force = None
     if args.randomize:
         import numpy as np
@@ -122,7 +123,18 @@ def main():
     def rollout():
         # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
         # (dl_step -> episode_starts[t+1]; dl_vecnormalize_step -> observations[t+1], rewards[t])
-        if policy is not None and push_force is None:
+        if policy is None and push_force is None and not args.no_overlap:
+            # pre-generated actions: dl_rollout_fixed in runs of 8 control steps (one launch of the 16-lane kernel each), their
+            # normalisations on the side stream
+            buf.reset()
+            buf.observations[0].copy_(last_obs)
+            buf.episode_starts[0].copy_(last_done)
+            for t0 in range(0, T, 8):
+                ts = range(t0, min(t0 + 8, T))
+                vn.steps_fixed(buf.actions[t0:ts[-1] + 1], [buf.observations[t + 1] if t + 1 < T else last_obs for t in ts], [buf.rewards[t] for t in ts],
+                               buf._starts[t0 + 1:ts[-1] + 2])
+            T_loop = 0
+        elif policy is not None and push_force is None:
             buf.collect_rollouts(vn, policy, last_obs, last_done)     # dl_rollout_policy: the whole loop in one C-ABI call
             T_loop = 0
         else:
@@ -172,7 +184,8 @@ def main():
         env_steps = n * T * args.steps * world
         value = env_steps / dt
         avg_launch_s = tot_ms.value / max(1, launches.value) / 1e3
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / avg_launch_s / 1e9
+        steps_per_launch = venv._lib.dl_profile_steps(venv._h) / max(1, launches.value)      # 8 with dl_rollout_fixed, 1 with dl_step
+        achieved = ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch / avg_launch_s / 1e9
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
         if os.path.exists(tfile):
@@ -191,7 +204,7 @@ def main():
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
-                         'launches': launches.value, 'sampled_every': args.profile_every, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n,
+                         'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch,
                          'note': 'the fused dynamics kernel is FP32-VALU/latency bound (SURVEY.md 8d); HBM fraction is reported as the contract asks'},
         }
         if world == 1 and not args.no_cpu_baseline:

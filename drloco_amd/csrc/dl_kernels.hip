@@ -125,9 +125,9 @@ __global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict_
 // g_forward, cursor / observation / reward / termination / Monitor, and the vec-env auto reset of finished
 // walkers (RSI draw, mocap lookup, foot-site kinematics, first observation) in the same launch.
 template <typename T, bool TIMED = false>
-__global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions,
-                                                     float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms,
-                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode, long long* tim = nullptr) {
+__global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions_all,
+                                                     float* obs_all, float* rew_all, uint8_t* done_all, float* term_obs_all, float* rew_terms_all,
+                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode, int nsteps, long long* tim = nullptr) {
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        // TIMED: 0-6 g_forward's sections, 7 whole kernel, 8 before the physics, 9 after it
     long long t_begin = 0;
     if constexpr (TIMED) t_begin = (long long)__builtin_readcyclecounter();
@@ -159,6 +159,22 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
     int32_t cur[DL_CUR_WORDS];
 #pragma unroll
     for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w];
+    // per-walker words of the environment logic live in registers across the control steps of this launch
+    double walked = st.walked[w];
+    T comz = st.comz_off[w];
+    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
+    long long t_phys_end = 0;
+    // ---- nsteps control steps (time-major arrays: step s uses actions[s], writes obs[s], rew[s], done[s]).  More than one
+    // step per launch is for callers whose actions do not depend on the observations (dl_rollout_fixed): the launch then
+    // lasts as long as the wave with the largest SUM over the steps, not the sum of the per-step maxima.
+#pragma unroll 1
+    for (int step = 0; step < nsteps; step++) {
+    const float* __restrict__ actions = actions_all + (size_t)step * n * nu;
+    float* obs = obs_all + (size_t)step * n * TPS::OBS;
+    float* rew = rew_all + (size_t)step * n;
+    uint8_t* done = done_all + (size_t)step * n;
+    float* term_obs = term_obs_all ? term_obs_all + (size_t)step * n * TPS::OBS : nullptr;
+    float* rew_terms = rew_terms_all ? rew_terms_all + (size_t)step * n * 3 : nullptr;
     // ---- _rescale_actions + mirror_action (cursor BEFORE refs.next()), per actuated dof
     const bool mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
     T ctrl = T(0), force = T(0);
@@ -219,13 +235,9 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
             if (simulate && !exc) { q = q0 + h * dq; v = v0 + h * dv; }
         }
     }
-    long long t_phys_end = 0;
     if constexpr (TIMED) t_phys_end = (long long)__builtin_readcyclecounter();
     // ---- environment logic
     const double tor_mean = (double)tor_sum / nu;
-    double walked = st.walked[w];
-    T comz = st.comz_off[w];
-    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
     float r;
     bool dn;
     // observation (mimic_env.py:403-437 + mirror_obs :440-480) from q, v staged in LDS: 29 outputs over 16 lanes
@@ -323,9 +335,10 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict
         }
         walked = 0;
         terms[0] = terms[1] = terms[2] = 1.0;       // reset_model's sanity check evaluates the reward terms at the init state (:562)
-        if (valid && j == 0) st.comz_off[w] = comz;
     }
+    }   // control steps of this launch
     if (valid && j == 0) {
+        st.comz_off[w] = comz;
         st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
         st.walked[w] = walked;
 #pragma unroll
@@ -610,6 +623,9 @@ struct dl_env_s {
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
     virtual int step(const float*, float*, float*, uint8_t*, float*, float*, hipStream_t) = 0;
+    // up to `nsteps` control steps of a time-major action tape in one launch; returns the number of steps taken (>= 1) or a negative error
+    virtual int steps_fixed(int nsteps, const float*, float*, float*, uint8_t*, hipStream_t) = 0;
+    int prof_steps = 0, prof_last_steps = 0;   // control steps covered by the bracketed launches (since / at the last dl_profile_read)
     virtual int get_state(void*, void*, void*, int32_t*, double*, hipStream_t) = 0;
     virtual int set_state(const void*, const void*, const void*, const int32_t*, const double*, hipStream_t) = 0;
     virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
@@ -756,13 +772,31 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         HIPCHK(hipGetLastError());
         return DL_OK;
     }
+    // dl_rollout_fixed: the 16-lane step kernel takes several control steps per launch (state in registers in between, and the
+    // launch lasts as long as the wave with the largest SUM over the steps instead of paying every step's slowest wave)
+    static constexpr int MULTI = 8;
+    int steps_fixed(int nsteps, const float* act, float* obs, float* rew, uint8_t* done, hipStream_t s) override {
+        if (!(variant == 1 && gmd) || inj_armed || nsteps <= 1) { const int rc = step(act, obs, rew, done, nullptr, nullptr, s); return rc == DL_OK ? 1 : rc; }
+        if constexpr (TP::ENV_KIND == 0) {
+            const int k = nsteps < MULTI ? nsteps : MULTI;
+            prof_begin(s);
+            hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
+                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, k);
+            if (prof_open) prof_steps += k;
+            prof_end(s);
+            HIPCHK(hipGetLastError());
+            return k;
+        }
+        return fail(DL_E_INVAL, "steps_fixed: unreachable");
+    }
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
         if (variant == 1 && gmd) {
             if constexpr (TP::ENV_KIND == 0) {
                 prof_begin(s);
                 hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
-                                   (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), eval_mode);
+                                   (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), eval_mode, 1);
+                if (prof_open) prof_steps += 1;
                 prof_end(s);
             }
             HIPCHK(hipGetLastError());
@@ -770,6 +804,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             return DL_OK;                 // finished walkers were re-initialised inside the launch
         } else {
         prof_begin(s);
+        if (prof_open) prof_steps += 1;
         hipLaunchKernelGGL((k_env_step<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, act, obs, rew, done, term, terms,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr));
         prof_end(s);
@@ -868,7 +903,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             static bool attr = false;
             if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T))))); attr = true; }
             hipLaunchKernelGGL((k_env_step_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
-                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, tim);
+                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, 1, tim);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
@@ -953,9 +988,10 @@ int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, f
     NEED(h);
     if (T <= 0 || !actions || !obs || !rew || !done) return fail(DL_E_INVAL, "dl_rollout_fixed: bad arguments");
     const size_t n = (size_t)h->n;
-    for (int32_t t = 0; t < T; t++) {
-        const int rc = h->step(actions + (size_t)t * n * h->act_dim, obs + (size_t)t * n * h->obs_dim, rew + (size_t)t * n, done + (size_t)t * n, nullptr, nullptr, (hipStream_t)stream);
-        if (rc != DL_OK) return rc;
+    for (int32_t t = 0; t < T;) {
+        const int k = h->steps_fixed(T - t, actions + (size_t)t * n * h->act_dim, obs + (size_t)t * n * h->obs_dim, rew + (size_t)t * n, done + (size_t)t * n, (hipStream_t)stream);
+        if (k <= 0) return k < 0 ? k : fail(DL_E_INVAL, "dl_rollout_fixed: no progress");
+        t += k;
     }
     return DL_OK;
 }
@@ -1032,6 +1068,7 @@ int dl_profile(dl_handle h, int32_t enable) {
     NEED(h);
     h->prof = enable > 0 ? enable : 0;
     h->prof_tick = 0;
+    h->prof_steps = 0;
     h->ev_used = 0;
     return DL_OK;
 }
@@ -1048,8 +1085,15 @@ int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches) {
     }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = cnt;
+    h->prof_last_steps = h->prof_steps;
+    h->prof_steps = 0;
     h->ev_used = 0;
     return DL_OK;
+}
+
+int dl_profile_steps(dl_handle h) {
+    NEED(h);
+    return h->prof_last_steps;
 }
 
 int dl_moments_update(double* mean, double* var, double* count, const float* x, int32_t B, int32_t D, void* stream) {

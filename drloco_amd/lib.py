@@ -59,6 +59,7 @@ _SIGNATURES = {
     'dl_stats_snapshot': (C.c_int, [_V, C.c_char_p, _P, _P]),
     'dl_profile': (C.c_int, [_V, _I]),
     'dl_profile_read': (C.c_int, [_V, C.POINTER(C.c_double), C.POINTER(_I)]),
+    'dl_profile_steps': (C.c_int, [_V]),
     'dl_moments_update': (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     'dl_normalize_obs': (C.c_int, [_P, _P, _P, _I, _I, C.c_double, C.c_double, _P]),
     'dl_normalize_reward': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, _P]),

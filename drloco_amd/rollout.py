@@ -17,7 +17,11 @@ class HipRolloutBuffer:
         f = lambda *s: torch.zeros(*s, device=device)
         self.observations, self.actions = f(n_steps, n_envs, obs_dim), f(n_steps, n_envs, act_dim)
         self.rewards, self.values, self.log_probs = f(n_steps, n_envs), f(n_steps, n_envs), f(n_steps, n_envs)
-        self.episode_starts = torch.zeros(n_steps, n_envs, dtype=torch.uint8, device=device)
+        # one row more than SB3's array: row T takes the done flags of the last step (SB3's _last_episode_starts), so that a
+        # run of steps can write its flags into consecutive rows t+1..
+        self._starts = torch.zeros(n_steps + 1, n_envs, dtype=torch.uint8, device=device)
+        self.episode_starts = self._starts[:n_steps]
+        self.next_starts = self._starts[n_steps]
         self.advantages, self.returns = f(n_steps, n_envs), f(n_steps, n_envs)
         self._sums = torch.zeros(3, dtype=torch.float64, device=device)
         self.pos = 0

@@ -480,10 +480,34 @@ class HipVecNormalize:
         ev = lambda: torch.cuda.Event()
         # high priority: its own hardware-queue pool (a default-priority stream may share the main stream's queue once other
         # libraries -- RCCL -- have created streams) and the tiny launches are dispatched while the step kernel runs
+        n, d = self.venv.obs.shape
+        raw_obs, raw_rew = torch.zeros(2 * chunk, n, d, device=dev), torch.zeros(2 * chunk, n, device=dev)     # contiguous: dl_rollout_fixed writes runs of slots
+        done = torch.zeros(2 * chunk, n, dtype=torch.uint8, device=dev)
         self._ov = dict(stream=torch.cuda.Stream(device=dev, priority=-1), chunk=int(chunk), k=0, last=None, pending=[], read=[None, None], readev=[ev(), ev()],
-                        stepped=[ev(), ev()],
-                        raw=[(torch.zeros_like(self.venv.obs), torch.zeros_like(self.venv.rew)) for _ in range(2 * chunk)],
-                        done=[torch.zeros_like(self.venv.done) for _ in range(2 * chunk)])
+                        stepped=[ev(), ev()], raw_obs=raw_obs, raw_rew=raw_rew,
+                        raw=[(raw_obs[i], raw_rew[i]) for i in range(2 * chunk)], done=[done[i] for i in range(2 * chunk)])
+
+    def steps_fixed(self, actions, obs_outs, rew_outs, done_out):
+        """K <= chunk control steps with a pre-generated action tape (float32 [K, N, nu], contiguous) in ONE dl_rollout_fixed
+        call -- the 16-lane kernel then takes all K steps in one launch -- followed by the K normalisations on the side
+        stream.  done_out: uint8 [K, N] contiguous (e.g. rows t+1.. of the episode-start array); obs_outs / rew_outs: K
+        destinations each (rollout-buffer slots).  Needs enable_overlap(); results are complete after flush()."""
+        ov = self._ov
+        assert ov is not None, 'enable_overlap() first'
+        C, K = ov['chunk'], actions.shape[0]
+        assert 1 <= K <= C and len(obs_outs) == K and len(rew_outs) == K and done_out.shape[0] == K and done_out.is_contiguous()
+        if ov['pending']:
+            self._submit_pending()
+        k0 = ((ov['k'] + C - 1) // C * C) % (2 * C)          # start of a ring half
+        half = k0 // C
+        main = torch.cuda.current_stream()
+        if ov['read'][half] is not None:
+            main.wait_event(ov['read'][half])
+        self.venv.rollout_fixed(actions, obs_out=ov['raw_obs'][k0:k0 + K], rew_out=ov['raw_rew'][k0:k0 + K], done_out=done_out)
+        ov['pending'] = [(k0 + i, done_out[i], obs_outs[i], rew_outs[i]) for i in range(K)]
+        ov['last'] = k0 + K - 1
+        ov['k'] = (k0 + C) % (2 * C)
+        self._submit_pending()
 
     def flush(self):
         """Issue what is still pending and make the main stream wait for the side stream."""

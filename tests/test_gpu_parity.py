@@ -932,3 +932,28 @@ def test_rollout_policy_in_one_call(torch_cuda, model, refs):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert res[0][5].sum() > 0 and res[0][11] == 2 * T
+
+
+def test_rollout_fixed_multi_step_launches_match_single_steps(torch_cuda, model, refs):
+    """dl_rollout_fixed takes up to 8 control steps per launch of the 16-lane kernel (walker state in registers in
+    between): outputs, final state and Monitor statistics are those of T single dl_step calls, bit for bit."""
+    import torch
+    from drloco_amd.vec_env import HipVecEnv
+    n, T = 700, 117                                            # ragged walker count; 14 launches of 8 + one of 5; episodes end inside
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    acts = torch.clamp(0.6 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
+    a = HipVecEnv(num_envs=n, seed=17, model=model, refs=refs)
+    b = HipVecEnv(num_envs=n, seed=17, model=model, refs=refs)
+    a.reset_tensors(); b.reset_tensors()
+    obs = torch.zeros(T, n, 29, device='cuda'); rew = torch.zeros(T, n, device='cuda'); done = torch.zeros(T, n, dtype=torch.uint8, device='cuda')
+    for t in range(T):
+        o, r, d, _ = a.step_tensors(acts[t])
+        obs[t].copy_(o); rew[t].copy_(r); done[t].copy_(d)
+    obs2, rew2, done2 = b.rollout_fixed(acts)
+    assert torch.equal(obs, obs2) and torch.equal(rew, rew2) and torch.equal(done, done2)
+    assert done.sum() > 0
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    for name in ('ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance', 'mean_ep_pos_rew_smoothed'):
+        assert a.get_attr(name) == b.get_attr(name), name

@@ -42,10 +42,12 @@ print('per wave max iters: mean %.2f' % w.mean())
 # ---- the same sections inside whole control steps of the rollout (20 evaluations each)
 acts2 = torch.clamp(0.5 * torch.randn(30, n, 8, device='cuda', generator=g), -1, 1)
 tot = np.zeros((10, nb))
+launch_max, launch_mean, per_launch = [], [], []
 for t in range(30):
     lib.check(env._lib.dl_debug_step_timed(env._h, _ptr(acts2[t]), _ptr(env.obs), _ptr(env.rew), _ptr(env.done), _ptr(tim), _stream()))
     torch.cuda.synchronize()
     tot += tim.cpu().numpy().astype(np.float64)
+    launch_max.append(float(tim[7].max())); launch_mean.append(float(tim[7].double().mean())); per_launch.append(tim[7].cpu().numpy().astype(np.float64))
 tot /= 30
 whole = tot[7]
 print(f'control step: per wave cycles mean {whole.mean():.0f} median {np.median(whole):.0f} max {whole.max():.0f} (the launch lasts as long as its slowest wave); wave iterations per step mean {tot[6].mean():.1f} max {tot[6].max():.0f}')
@@ -54,3 +56,10 @@ for k in range(6):
     print(f'  {names[k]:22s} mean {tot[k].mean():9.0f}  ({100 * tot[k].mean() / whole.mean():5.1f} %)  slowest wave {tot[k][whole.argmax()]:9.0f}')
 print(f'  {"outside the evaluations":22s} mean {(whole - tot[:6].sum(0)).mean():9.0f}  ({100 * (whole - tot[:6].sum(0)).mean() / whole.mean():5.1f} %)')
 print(f'    of which: before the physics (model/state/action loads) {tot[8].mean():9.0f}   after it (cursor, reward, observation, Monitor, reset, stores) {tot[9].mean():9.0f}   inside the RK4 loop {(whole - tot[:6].sum(0) - tot[8] - tot[9]).mean():9.0f}')
+print(f'per launch: slowest wave mean over launches {np.mean(launch_max):.0f} (min {np.min(launch_max):.0f}, max {np.max(launch_max):.0f}); mean wave {np.mean(launch_mean):.0f}; '
+      f'slowest / mean = {np.mean(launch_max) / np.mean(launch_mean):.3f}; slowest of the 30-step averages / mean = {whole.max() / whole.mean():.3f}')
+P = np.stack(per_launch)                                  # [launches, waves]
+for K in (2, 4, 8, 16):
+    # a launch of K control steps would last as long as the wave with the largest K-step sum
+    m = [P[i:i + K].sum(0).max() / K for i in range(0, P.shape[0] - K + 1, K)]
+    print(f'  {K:2d} control steps per launch: slowest wave per control step {np.mean(m):.0f}  ({np.mean(m) / np.mean(launch_mean):.3f} x the mean wave)')

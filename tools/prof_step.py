@@ -12,13 +12,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--steps', type=int, default=40)
 ap.add_argument('--warm', type=int, default=60)
+ap.add_argument('--single', action='store_true', help='one control step per launch (dl_step) instead of dl_rollout_fixed')
 ap.add_argument('--variant', type=int, default=0, help='lanes per walker: 0 auto, 1, 16')
 args = ap.parse_args()
 env = HipVecEnv(num_envs=args.envs, lanes_per_walker=args.variant)
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
 acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, 8, device='cuda', generator=g), -1, 1)
-for t in range(args.warm + args.steps):
-    env.step_tensors(acts[t])
+if args.single:
+    for t in range(args.warm + args.steps):
+        env.step_tensors(acts[t])
+else:       # the benchmark's form: dl_rollout_fixed, 8 control steps per launch of the 16-lane kernel (every launch of this run)
+    env.rollout_fixed(acts[:8 * ((args.warm + args.steps) // 8)])
 torch.cuda.synchronize()
 print('done')
