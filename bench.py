@@ -64,7 +64,8 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
-    ap.add_argument('--profile-every', type=int, default=4, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
+    ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
+    ap.add_argument('--steps-per-launch', type=int, default=64, help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (<= 64) in the policy-free configuration')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -101,7 +102,7 @@ def main():
     last_values = torch.randn(n, device=dev, generator=gen)
     vn.reset()
     if not args.policy and not args.no_overlap:
-        vn.enable_overlap()      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
+        vn.enable_overlap(chunk=args.steps_per_launch)      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = buf.next_starts                                 # row T of the episode-start array: the flags after the last step
     last_done.fill_(1)
@@ -124,13 +125,13 @@ def main():
         # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
         # (dl_step -> episode_starts[t+1]; dl_vecnormalize_step -> observations[t+1], rewards[t])
         if policy is None and push_force is None and not args.no_overlap:
-            # pre-generated actions: dl_rollout_fixed in runs of 8 control steps (one launch of the 16-lane kernel each), their
-            # normalisations on the side stream
+            # pre-generated actions: dl_rollout_fixed in runs of --steps-per-launch control steps (one launch of the 16-lane kernel
+            # each), their normalisations on the side stream
             buf.reset()
             buf.observations[0].copy_(last_obs)
             buf.episode_starts[0].copy_(last_done)
-            for t0 in range(0, T, 8):
-                ts = range(t0, min(t0 + 8, T))
+            for t0 in range(0, T, args.steps_per_launch):
+                ts = range(t0, min(t0 + args.steps_per_launch, T))
                 vn.steps_fixed(buf.actions[t0:ts[-1] + 1], [buf.observations[t + 1] if t + 1 < T else last_obs for t in ts], [buf.rewards[t] for t in ts],
                                buf._starts[t0 + 1:ts[-1] + 2])
             T_loop = 0
