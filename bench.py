@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
-    ap.add_argument('--steps-per-launch', type=int, default=64, help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (<= 64) in the policy-free configuration')
+    ap.add_argument('--steps-per-launch', type=int, default=0, help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (<= 512) in the policy-free configuration; 0 = rollout length - 64: one long launch, then a 64-step launch under which the normalisations of the long one run on the side stream')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -91,6 +91,9 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     n, T = args.envs_per_gpu, args.rollout_len
+    if args.steps_per_launch <= 0:
+        args.steps_per_launch = T - 64 if T >= 128 else T
+    args.steps_per_launch = min(args.steps_per_launch, 512)
     venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
     vn = HipVecNormalize(venv)
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)

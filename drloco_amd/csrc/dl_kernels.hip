@@ -774,7 +774,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     // dl_rollout_fixed: the 16-lane step kernel takes several control steps per launch (state in registers in between, and the
     // launch lasts as long as the wave with the largest SUM over the steps instead of paying every step's slowest wave)
-    static constexpr int MULTI = 64;
+    static constexpr int MULTI = 512;
     int steps_fixed(int nsteps, const float* act, float* obs, float* rew, uint8_t* done, hipStream_t s) override {
         if (!(variant == 1 && gmd) || inj_armed || nsteps <= 1) { const int rc = step(act, obs, rew, done, nullptr, nullptr, s); return rc == DL_OK ? 1 : rc; }
         if constexpr (TP::ENV_KIND == 0) {

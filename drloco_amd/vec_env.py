@@ -489,7 +489,7 @@ class HipVecNormalize:
 
     def steps_fixed(self, actions, obs_outs, rew_outs, done_out):
         """K <= chunk control steps with a pre-generated action tape (float32 [K, N, nu], contiguous) in ONE dl_rollout_fixed
-        call -- the 16-lane kernel then takes all K steps in one launch (K <= 64) -- followed by the K normalisations on the side
+        call -- the 16-lane kernel then takes all K steps in one launch (K <= 512) -- followed by the K normalisations on the side
         stream.  done_out: uint8 [K, N] contiguous (e.g. rows t+1.. of the episode-start array); obs_outs / rew_outs: K
         destinations each (rollout-buffer slots).  Needs enable_overlap(); results are complete after flush()."""
         ov = self._ov

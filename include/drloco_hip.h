@@ -199,7 +199,7 @@ int dl_step(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* 
 
 /* T control steps with pre-generated actions (synthetic fixed-length rollout; no policy):
  *   actions float[T, N, nu]; obs float[T, N, obs]; rew float[T, N]; done uint8[T, N].
- * Same results as T calls of dl_step.  Because no action depends on an observation, the 16-lane kernels take up to 64
+ * Same results as T calls of dl_step.  Because no action depends on an observation, the 16-lane kernels take up to 512
  * control steps per launch (walker state stays in registers in between; a launch lasts as long as the wave with the
  * largest sum over its steps rather than paying the slowest wave of every step). */
 int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, float* rew,
@@ -244,7 +244,7 @@ int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream);
  * the summed duration and the number of bracketed launches. */
 int dl_profile(dl_handle h, int32_t enable);
 int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches);
-/* control steps covered by the launches the last dl_profile_read reported (dl_rollout_fixed takes up to 64 control steps per
+/* control steps covered by the launches the last dl_profile_read reported (dl_rollout_fixed takes up to 512 control steps per
  * launch of the 16-lane kernel, dl_step one) */
 int dl_profile_steps(dl_handle h);
 

@@ -935,11 +935,11 @@ def test_rollout_policy_in_one_call(torch_cuda, model, refs):
 
 
 def test_rollout_fixed_multi_step_launches_match_single_steps(torch_cuda, model, refs):
-    """dl_rollout_fixed takes up to 64 control steps per launch of the 16-lane kernel (walker state in registers in
+    """dl_rollout_fixed takes up to 512 control steps per launch of the 16-lane kernel (walker state in registers in
     between): outputs, final state and Monitor statistics are those of T single dl_step calls, bit for bit."""
     import torch
     from drloco_amd.vec_env import HipVecEnv
-    n, T = 700, 117                                            # ragged walker count; launches of 64 + 53 steps; episodes end inside
+    n, T = 700, 117                                            # ragged walker count; ONE launch of 117 steps; episodes end inside
     g = torch.Generator(device='cuda'); g.manual_seed(3)
     acts = torch.clamp(0.6 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
     a = HipVecEnv(num_envs=n, seed=17, model=model, refs=refs)
