@@ -10,8 +10,8 @@ from drloco_amd.vec_env import HipVecEnv
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096)
-ap.add_argument('--steps', type=int, default=40)
-ap.add_argument('--warm', type=int, default=60)
+ap.add_argument('--steps', type=int, default=448)
+ap.add_argument('--warm', type=int, default=64)
 ap.add_argument('--single', action='store_true', help='one control step per launch (dl_step) instead of dl_rollout_fixed')
 ap.add_argument('--variant', type=int, default=0, help='lanes per walker: 0 auto, 1, 16')
 args = ap.parse_args()
@@ -22,7 +22,9 @@ acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, 8, devic
 if args.single:
     for t in range(args.warm + args.steps):
         env.step_tensors(acts[t])
-else:       # the benchmark's form: dl_rollout_fixed, 8 control steps per launch of the 16-lane kernel (every launch of this run)
-    env.rollout_fixed(acts[:8 * ((args.warm + args.steps) // 8)])
+else:       # the benchmark's form: dl_rollout_fixed in the benchmark's launch schedule (one launch of T - 64 control steps, one of 64)
+    T = args.warm + args.steps
+    env.rollout_fixed(acts[:T - 64])
+    env.rollout_fixed(acts[T - 64:T])
 torch.cuda.synchronize()
 print('done')
