@@ -957,3 +957,43 @@ def test_rollout_fixed_multi_step_launches_match_single_steps(torch_cuda, model,
         assert np.array_equal(sa[k], sb[k]), k
     for name in ('ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance', 'mean_ep_pos_rew_smoothed'):
         assert a.get_attr(name) == b.get_attr(name), name
+
+
+def test_steps_fixed_runs_match_the_step_by_step_path(torch_cuda, model, refs):
+    """HipVecNormalize.steps_fixed (the benchmark's path: runs of control steps in one dl_rollout_fixed launch each, their
+    normalisations on the side stream) against step_tensors one step at a time: identical rollout-buffer contents and moments."""
+    import torch
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    n, T = 384, 96
+    g = torch.Generator(device='cuda'); g.manual_seed(8)
+    acts = torch.clamp(0.6 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
+    res = []
+    for runs in (None, 64, 40):
+        vn = HipVecNormalize(HipVecEnv(num_envs=n, seed=2, model=model, refs=refs))
+        buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+        buf.actions.copy_(acts)
+        vn.reset()
+        last_obs = vn.norm_obs_t.clone(); last_done = buf.next_starts; last_done.fill_(1)
+        for rollout in range(2):
+            buf.observations[0].copy_(last_obs); buf.episode_starts[0].copy_(last_done)
+            if runs is None:
+                for t in range(T):
+                    nxt = t + 1 < T
+                    vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t], done_out=buf._starts[t + 1])
+            else:
+                if vn._ov is None:
+                    vn.enable_overlap(chunk=runs)
+                for t0 in range(0, T, runs):
+                    ts = range(t0, min(t0 + runs, T))
+                    vn.steps_fixed(buf.actions[t0:ts[-1] + 1], [buf.observations[t + 1] if t + 1 < T else last_obs for t in ts], [buf.rewards[t] for t in ts],
+                                   buf._starts[t0 + 1:ts[-1] + 2])
+                vn.flush()
+        torch.cuda.synchronize()
+        res.append([x.cpu().clone() for x in (buf.observations, buf.rewards, buf._starts, last_obs)] + [torch.as_tensor(vn.obs_rms.mean), torch.as_tensor(vn.ret_rms.var),
+                                                                                                       torch.as_tensor(vn.get_original_obs())])
+    names = ('observations', 'rewards', 'episode_starts', 'last_obs', 'obs mean', 'ret var', 'original obs')
+    for which, other in zip((64, 40), res[1:]):
+        for name, a, b in zip(names, res[0], other):
+            assert torch.equal(a, b), (which, name, float((a.double() - b.double()).abs().max()))
+    assert res[0][2].sum() > 100        # episodes ended inside the window
