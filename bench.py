@@ -7,16 +7,19 @@
 Workload (BASELINE.json configs[1], per GPU; configs[2] is the same per GPU at N = 8):
   straight_walking 3D walker, 4096 parallel walkers per GPU, fixed 512-step synthetic rollout.
 One "step" of this benchmark = ONE 512-step rollout of all walkers of a rank:
-  per control step   dl_step (5 RK4 mj_steps + mocap cursor + imitation reward + observation +
-                     termination + Monitor statistics + auto-reset/RSI) -> raw obs/reward, done flags
-                     into the next episode_starts slot of the rollout buffer,
-                     dl_vecnormalize_step (moments update + observation/reward normalisation) -> the
-                     rollout buffer's observations[t+1] / rewards[t] slots (3 launches per control step; with
-                     pre-generated actions nothing on the main stream waits for the normalised observation, so
-                     these two launches run on a side HIP stream while dl_step of t+1 executes -- ping-pong raw
-                     buffers, HIP events both ways; --no-overlap or --policy keeps everything on one stream);
+  per control step   MimicEnv.step (5 RK4 mj_steps + mocap cursor + imitation reward + observation + termination +
+                     Monitor statistics + auto-reset/RSI) -> raw obs/reward, done flags into the next episode_starts
+                     slot of the rollout buffer; VecNormalize.step_wait (moments update + observation/reward
+                     normalisation) -> the rollout buffer's observations[t+1] / rewards[t] slots;
   per rollout        GAE(lambda) return/advantage scan, advantage statistics + normalisation
-                     (RCCL all-reduce of 3 doubles when N > 1 -- the only collective).
+                     (RCCL all-reduce of 3 doubles when N > 1 -- the only collective), VecNormalize moment merge across ranks.
+The actions are pre-generated, so nothing waits for an observation: the env steps go through dl_rollout_fixed, whose
+16-lane kernel takes a whole run of control steps per launch (walker state in registers; a launch lasts as long as the
+wave with the largest SUM over its steps, not the sum of every step's slowest wave) -- one run of 448 steps, one of 64 --
+and the two dl_vecnormalize_step launches of every step run on a side HIP stream under the following run (raw
+outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
+the fused policy into the loop (dl_rollout_policy: 4 launches per control step).  Same results in all forms
+(tests/test_gpu_parity.py::test_steps_fixed_runs_match_the_step_by_step_path).
 Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) (seed 4321 + rank), values are synthetic,
 RSI comes from the counter-based stream keyed by the global walker index.  Inputs are resident in
 HBM before the timed region.  value = walkers * 512 * K * N / time  [env-steps/s, whole job].
