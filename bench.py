@@ -207,7 +207,9 @@ def main():
             'config': {'workload': f'straight_walking 3D walker, {n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated',
-                       'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, overlapped with the next env step',
+                       'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, under the following run of env steps',
+                       'env_launches': 'one per control step' if (args.policy or args.no_overlap or args.randomize) else
+                                       'dl_rollout_fixed, runs of ' + ' + '.join(str(min(args.steps_per_launch, T - t0)) for t0 in range(0, T, args.steps_per_launch)) + ' control steps per launch',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
