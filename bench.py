@@ -193,11 +193,12 @@ def main():
         avg_launch_s = tot_ms.value / max(1, launches.value) / 1e3
         steps_per_launch = venv._lib.dl_profile_steps(venv._h) / max(1, launches.value)      # 8 with dl_rollout_fixed, 1 with dl_step
         achieved = ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch / avg_launch_s / 1e9
-        traffic = None
+        traffic = valu_busy = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+                pj = json.load(open(tfile))
+                traffic, valu_busy = pj.get('hbm_bytes_per_launch'), pj.get('valu_busy_frac')
             except Exception:
                 traffic = None
         out = {
@@ -214,7 +215,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch,
-                         'note': 'the fused dynamics kernel is FP32-VALU/latency bound (SURVEY.md 8d); HBM fraction is reported as the contract asks'},
+                         'valu_busy_frac': valu_busy,
+                         'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(256, 512)       # ~12 s of CPU work on one host core
