@@ -57,6 +57,50 @@ def cpu_baseline(n_envs, n_steps, seed=4321):
                        f'({os.cpu_count()} cores present), {dt:.1f} s')
 
 
+def _subproc_worker(conn, seed):
+    import numpy as np
+    from drloco_amd import abi, mocap, models
+    from oracle import oracle as O
+    env = O.OracleEnv(models.make_model(), mocap.RefTable.load(), abi.default_config(seed=seed), 1)
+    conn.send(env.reset())
+    while True:
+        a = conn.recv()
+        if a is None:
+            break
+        conn.send(env.step(a)[:3])
+    conn.close()
+
+
+def cpu_baseline_subproc(n_envs=4, n_steps=2048, seed=4321):
+    """BASELINE configs[0] in the reference's own process structure (SB3 SubprocVecEnv, drloco/common/utils.py:97-134): one
+    worker process per env stepping the oracle, pipes to a learner process that only distributes actions."""
+    import multiprocessing as mp
+    import numpy as np
+    ctx = mp.get_context('fork')
+    pipes, procs = [], []
+    for i in range(n_envs):
+        a, b = ctx.Pipe()
+        p = ctx.Process(target=_subproc_worker, args=(b, 1234 + i), daemon=True)
+        p.start(); pipes.append(a); procs.append(p)
+    for c in pipes:
+        c.recv()
+    rng = np.random.default_rng(seed)
+    acts = np.clip(0.5 * rng.standard_normal((n_steps, n_envs, 1, 8)), -1, 1)
+    t0 = time.perf_counter()
+    for t in range(n_steps):
+        for i, c in enumerate(pipes):
+            c.send(acts[t, i])
+        for c in pipes:
+            c.recv()
+    dt = time.perf_counter() - t0
+    for c in pipes:
+        c.send(None)
+    for p in procs:
+        p.join(timeout=5)
+    return dict(value=n_envs * n_steps / dt, unit='env-steps/s', cores=n_envs + 1,
+                sample=f'{n_envs} worker processes x 1 env (oracle) + 1 learner process over pipes, {n_steps}-step rollout, {dt:.2f} s')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -85,6 +129,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    # the CPU baselines run BEFORE this process touches the GPU (the worker processes of the second one are forked)
+    cpu_base = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(256, 512)                  # ~12 s of CPU work on one host core
+        try:        # configs[0] in the reference's process structure (reported next to it, not the baseline value)
+            cpu_base['subproc_vec_env_4'] = cpu_baseline_subproc(4, 2048)
+        except Exception as e:      # a box that cannot fork workers still gets its benchmark line
+            cpu_base['subproc_vec_env_4'] = {'error': repr(e)}
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or 'RANK' in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
     if use_dist:
@@ -219,7 +271,7 @@ def main():
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(256, 512)       # ~12 s of CPU work on one host core
+            out['cpu_baseline'] = cpu_base
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
