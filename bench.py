@@ -112,7 +112,7 @@ def main():
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
-    ap.add_argument('--steps-per-launch', type=int, default=0, help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (<= 512) in the policy-free configuration; 0 = rollout length - 64: one long launch, then a 64-step launch under which the normalisations of the long one run on the side stream')
+    ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: rollout length - 64, 64 -- one long launch, then a 64-step launch under which the normalisations of the long one execute on the side stream (tools/prof_step.py issues the same schedule for the PMC passes)')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -146,9 +146,14 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     n, T = args.envs_per_gpu, args.rollout_len
-    if args.steps_per_launch <= 0:
-        args.steps_per_launch = T - 64 if T >= 128 else T
-    args.steps_per_launch = min(args.steps_per_launch, 512)
+    runs = [int(x) for x in args.runs.split(',')] if args.runs else ([T - 64, 64] if T >= 128 else [T])
+    if sum(runs) < T:
+        runs += [runs[-1]] * ((T - sum(runs) + runs[-1] - 1) // runs[-1])
+    run_starts, t0 = [], 0
+    for r in runs:
+        r = min(r, 512, T - t0)
+        if r > 0:
+            run_starts.append((t0, r)); t0 += r
     venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
     vn = HipVecNormalize(venv)
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
@@ -160,7 +165,7 @@ def main():
     last_values = torch.randn(n, device=dev, generator=gen)
     vn.reset()
     if not args.policy and not args.no_overlap:
-        vn.enable_overlap(chunk=args.steps_per_launch)      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
+        vn.enable_overlap(chunk=max(r for _, r in run_starts))      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = buf.next_starts                                 # row T of the episode-start array: the flags after the last step
     last_done.fill_(1)
@@ -188,8 +193,8 @@ def main():
             buf.reset()
             buf.observations[0].copy_(last_obs)
             buf.episode_starts[0].copy_(last_done)
-            for t0 in range(0, T, args.steps_per_launch):
-                ts = range(t0, min(t0 + args.steps_per_launch, T))
+            for t0, r in run_starts:
+                ts = range(t0, t0 + r)
                 vn.steps_fixed(buf.actions[t0:ts[-1] + 1], [buf.observations[t + 1] if t + 1 < T else last_obs for t in ts], [buf.rewards[t] for t in ts],
                                buf._starts[t0 + 1:ts[-1] + 2])
             T_loop = 0
@@ -262,7 +267,7 @@ def main():
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, under the following run of env steps',
                        'env_launches': 'one per control step' if (args.policy or args.no_overlap or args.randomize) else
-                                       'dl_rollout_fixed, runs of ' + ' + '.join(str(min(args.steps_per_launch, T - t0)) for t0 in range(0, T, args.steps_per_launch)) + ' control steps per launch',
+                                       'dl_rollout_fixed, runs of ' + ' + '.join(str(r) for _, r in run_starts) + ' control steps per launch',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
