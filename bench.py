@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
     ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: rollout length - 64, 64 -- one long launch, then a 64-step launch under which the normalisations of the long one execute on the side stream (tools/prof_step.py issues the same schedule for the PMC passes)')
+    ap.add_argument('--handles', type=int, default=1, help='with --policy: split the walkers of a rank over this many env handles, each driving its policy -> step -> normalise chain on its own stream (drloco_amd/group.py); balanced single-step launches need >= 8192 walkers per GPU')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -184,6 +185,18 @@ def main():
         from drloco_amd.policy import HipPolicy
         policy = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=512, seed=99, index_base=rank * n)
 
+    group = None
+    if args.policy and args.handles > 1:
+        from drloco_amd.group import HipEnvGroup
+        venv.close()
+        group = HipEnvGroup(T, num_envs=n, handles=args.handles, device=local_rank, seed=1234, index_base=rank * n)
+        venv = group.venvs[0]                      # the handle whose step-kernel launches are bracketed by events
+
+    def rollout_group():
+        group.collect_rollouts(policy)
+        group.compute_returns_and_advantage(policy)
+        group.sync_moments()
+
     def rollout():
         # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
         # (dl_step -> episode_starts[t+1]; dl_vecnormalize_step -> observations[t+1], rewards[t])
@@ -227,6 +240,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if group is not None:
+        rollout = rollout_group
     for _ in range(args.warmup):
         rollout()
     lib.check(venv._lib.dl_profile(venv._h, args.profile_every))    # HIP events around every k-th launch of the step kernel
@@ -249,7 +264,8 @@ def main():
         value = env_steps / dt
         avg_launch_s = tot_ms.value / max(1, launches.value) / 1e3
         steps_per_launch = venv._lib.dl_profile_steps(venv._h) / max(1, launches.value)      # 8 with dl_rollout_fixed, 1 with dl_step
-        achieved = ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch / avg_launch_s / 1e9
+        n_prof = venv.num_envs                       # walkers of the handle whose launches were bracketed (all of the rank's unless --handles)
+        achieved = ALGO_BYTES_PER_ENV_STEP * n_prof * steps_per_launch / avg_launch_s / 1e9
         traffic = valu_busy = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
         if os.path.exists(tfile):
@@ -264,14 +280,14 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'straight_walking 3D walker, {n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
-                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': 'device policy (dl_policy_forward)' if args.policy else 'pre-generated',
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, under the following run of env steps',
                        'env_launches': 'one per control step' if (args.policy or args.no_overlap or args.randomize) else
                                        'dl_rollout_fixed, runs of ' + ' + '.join(str(r) for _, r in run_starts) + ' control steps per launch',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'k_env_step<float,64>' if args.lanes == 1 else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
-                         'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch,
+                         'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n_prof * steps_per_launch,
                          'valu_busy_frac': valu_busy,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }

@@ -997,3 +997,56 @@ def test_steps_fixed_runs_match_the_step_by_step_path(torch_cuda, model, refs):
         for name, a, b in zip(names, res[0], other):
             assert torch.equal(a, b), (which, name, float((a.double() - b.double()).abs().max()))
     assert res[0][2].sum() > 100        # episodes ended inside the window
+
+
+def test_env_group_handles_are_shards(torch_cuda, model, refs):
+    """HipEnvGroup (several handles, each with its policy -> step -> normalise chain on its own stream): every handle's
+    rollout is exactly what that shard produces when run on its own, the moment merge is the exact Chan merge of the
+    handles' moments, and the advantage normalisation uses the statistics of all handles."""
+    import torch
+    from drloco_amd.group import HipEnvGroup
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    T, H, n = 40, 2, 192
+    pol = HipPolicy(hidden=128, seed=6)
+    grp = HipEnvGroup(T, num_envs=H * n, handles=H, seed=77, index_base=1000, model=model, refs=refs)
+    grp.collect_rollouts(pol, chunk=8)
+    grp.join()
+    torch.cuda.synchronize()
+    ref_moments = []
+    for h in range(H):
+        vn = HipVecNormalize(HipVecEnv(num_envs=n, seed=77, env_index_base=1000 + h * n, model=model, refs=refs))
+        p2 = HipPolicy(hidden=128, seed=6, index_base=1000 + h * n)
+        p2.load_state(pol.w1, pol.b1, pol.w2, pol.b2, pol.wa, pol.ba, pol.wv, pol.bv, pol.log_std)
+        buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+        vn.reset()
+        last_obs = vn.norm_obs_t.clone(); last_done = torch.ones(n, dtype=torch.uint8, device='cuda')
+        buf.collect_rollouts(vn, p2, last_obs, last_done)
+        torch.cuda.synchronize()
+        for name in ('observations', 'actions', 'values', 'log_probs', 'rewards', 'episode_starts'):
+            assert torch.equal(getattr(buf, name), getattr(grp.bufs[h], name)), (h, name)
+        assert torch.equal(last_obs, grp.last_obs[h]) and torch.equal(last_done, grp.last_done[h])
+        ref_moments.append((vn.obs_rms.mean.copy(), vn.obs_rms.var.copy(), vn.obs_rms.count))
+    assert pol.counter == T
+    # exact merge of the handles' moments (both started from mean 0, var 1, count 1e-4)
+    grp.sync_moments()
+    (m0, v0, c0), (m1, v1, c1) = ref_moments
+    eps = 1e-4
+    n0, n1 = c0 - eps, c1 - eps                                  # samples each handle added to the common initial state
+    s = eps * 0 + (c0 * m0 - eps * 0) + (c1 * m1 - eps * 0)
+    q = eps * 1 + (c0 * (v0 + m0 * m0) - eps * 1) + (c1 * (v1 + m1 * m1) - eps * 1)
+    ntot = eps + n0 + n1
+    mean = s / ntot
+    var = q / ntot - mean * mean
+    for vn in grp.vns:
+        np.testing.assert_allclose(vn.obs_rms.mean, mean, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(vn.obs_rms.var, var, rtol=1e-10, atol=1e-12)
+        assert vn.obs_rms.count == pytest.approx(ntot, rel=1e-14)
+    # advantage normalisation over the union
+    grp.compute_returns_and_advantage(pol)
+    torch.cuda.synchronize()
+    adv = grp.cat('advantages').double()
+    assert abs(float(adv.mean())) < 1e-5 and abs(float(adv.std(unbiased=True)) - 1) < 1e-4
+    assert grp.cat('observations').shape == (T, H * n, 29)
+    grp.close()
