@@ -15,6 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 _SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.h')))
 
 _lib = None
+EXTRA_FLAGS = []          # compiler flags of the product build beyond -O3 (experiments: DL_EXTRA_FLAGS in the environment)
 
 
 class DrlocoError(RuntimeError):
@@ -27,8 +28,8 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I' + INCLUDE, '-I' + CSRC,
-           os.path.join(CSRC, 'dl_kernels.hip'), '-o', LIB_PATH]
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I' + INCLUDE, '-I' + CSRC] + EXTRA_FLAGS + \
+          os.environ.get('DL_EXTRA_FLAGS', '').split() + [os.path.join(CSRC, 'dl_kernels.hip'), '-o', LIB_PATH]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
