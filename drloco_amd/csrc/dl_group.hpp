@@ -303,6 +303,31 @@ template <typename TP> struct GTopo {
     static constexpr bool dof_first(int j) { return j == 0 || TP::dof_body(j - 1) != TP::dof_body(j); }
     static constexpr bool run_start(int j) { return j == 0 || TP::dof_parent(j) != j - 1; }
     static constexpr int max_run() { int m = 1; for (int j = 0; j < TP::NV; j++) { const int l = tab.re[j] - tab.rs[j] + 1; if (l > m) m = l; } return m; }
+    // Twin branches (two legs): a run b.. that hangs off dof P and has the same shape (length, joint types / axes, body boundaries) as
+    // the dofs P + 1.. that continue P's own run.  Their hinges act on disjoint sets of lanes, so the kinematics applies hinge a + i and
+    // its twin b + i in ONE rotation step (the lane takes the sine / cosine of whichever of the two is on its chain).
+    static constexpr int run_len(int a) { return tab.re[a] - tab.rs[a] + 1; }
+    static constexpr int twin_of_run(int b) {    // b: start of a run (> 0) -> first dof of its twin segment, or -1
+        const int P = TP::dof_parent(b), L = run_len(b), a = P + 1;
+        if (P < 0 || a + L - 1 > tab.re[P] || a + L - 1 >= b) return -1;
+        for (int i = 0; i < L; i++) {
+            if (TP::dof_type(a + i) != 1 || TP::dof_type(b + i) != 1 || TP::dof_axis(a + i) != TP::dof_axis(b + i)) return -1;
+            if (dof_first(a + i) != dof_first(b + i)) return -1;
+        }
+        return a;
+    }
+    static constexpr bool is_follower(int d) {   // dof d is applied together with an earlier twin
+        const int b = tab.rs[d];
+        return b > 0 && run_start(b) && twin_of_run(b) >= 0;
+    }
+    static constexpr int partner(int d) {        // the dof applied in the same step as dof d, or -1
+        for (int b = d + 1; b < TP::NV; b++) {
+            if (!run_start(b)) continue;
+            const int a = twin_of_run(b);
+            if (a >= 0 && d >= a && d < a + run_len(b)) return b + (d - a);
+        }
+        return -1;
+    }
     static constexpr bool slides_first() {       // slide joints: root body only, world-aligned (before any hinge)
         bool hinge = false;
         for (int j = 0; j < TP::NV; j++) { if (TP::dof_type(j) == 1) hinge = true; else if (hinge || TP::dof_body(j) != 1) return false; }
@@ -424,14 +449,22 @@ __device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T
     T rootz = g.c->root_z0;
     static_for<TP::NV>([&](auto ai) {
         constexpr int a = ai.value;
+        if constexpr (GTopo<TP>::is_follower(a)) return;   // applied together with its twin (the other leg)
+        constexpr int p = GTopo<TP>::partner(a);
         const T f = lt.ancf[a];                           // 1 where hinge / body a is on this lane's chain, else the identity
         if constexpr (GTopo<TP>::dof_first(a) && TP::dof_body(a) != 1) {
             constexpr int b = TP::dof_body(a);
-            const T bx = f * g.c->body_pos[b][0], by = f * g.c->body_pos[b][1], bz = f * g.c->body_pos[b][2];
+            T bx = f * g.c->body_pos[b][0], by = f * g.c->body_pos[b][1], bz = f * g.c->body_pos[b][2];
+            if constexpr (p >= 0) {
+                constexpr int bp = TP::dof_body(p);
+                const T fp = lt.ancf[p];
+                bx += fp * g.c->body_pos[bp][0]; by += fp * g.c->body_pos[bp][1]; bz += fp * g.c->body_pos[bp][2];
+            }
             pos = pos + bx * X + by * Y + bz * Z;
         }
         if constexpr (TP::dof_type(a) == 1) {
-            const T sa = rbcast<a>(s) * f, ca = T(1) + rbcast<a>(cm1) * f;
+            T sa = rbcast<a>(s) * f, ca = T(1) + rbcast<a>(cm1) * f;
+            if constexpr (p >= 0) { const T fp = lt.ancf[p]; sa += rbcast<p>(s) * fp; ca += rbcast<p>(cm1) * fp; }
             rot_axis_c<TP::dof_axis(a)>(X, Y, Z, sa, ca);
         } else if constexpr (TP::dof_axis(a) == 2) {
             rootz += T(TP::dof_sign(a)) * rbcast<a>(dq);
