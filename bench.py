@@ -84,21 +84,37 @@ def cpu_baseline_subproc(n_envs=4, n_steps=2048, seed=4321):
         p.start(); pipes.append(a); procs.append(p)
     for c in pipes:
         c.recv()
+    from oracle import oracle as O
     rng = np.random.default_rng(seed)
     acts = np.clip(0.5 * rng.standard_normal((n_steps, n_envs, 1, 8)), -1, 1)
+    vals = rng.standard_normal((n_steps + 1, n_envs)).astype(np.float32)
+    # learner side as in the reference: VecNormalize (running moments + normalisation) every step, GAE at the end of the rollout
+    om, ov, oc = np.zeros(29), np.ones(29), 1e-4
+    rm, rv, rc = np.zeros(1), np.ones(1), 1e-4
+    ret = np.zeros(n_envs)
+    rews = np.zeros((n_steps, n_envs), np.float32); starts = np.zeros((n_steps + 1, n_envs), np.uint8); starts[0] = 1
     t0 = time.perf_counter()
     for t in range(n_steps):
         for i, c in enumerate(pipes):
             c.send(acts[t, i])
-        for c in pipes:
-            c.recv()
+        res = [c.recv() for c in pipes]
+        obs = np.concatenate([r[0] for r in res]); rew = np.concatenate([r[1] for r in res]); done = np.concatenate([r[2] for r in res])
+        oc = O.moments_update(om, ov, oc, obs)
+        obs_n = np.clip((obs - om) / np.sqrt(ov + 1e-8), -10, 10)
+        ret = ret * 0.99 + rew
+        rc = O.moments_update(rm, rv, rc, ret[:, None])
+        rews[t] = np.clip(rew / np.sqrt(rv[0] + 1e-8), -10, 10)
+        ret[done != 0] = 0
+        starts[t + 1] = done != 0
+    O.gae(rews, vals[:n_steps], starts[:n_steps], vals[n_steps], starts[n_steps], 0.995, 0.95)
     dt = time.perf_counter() - t0
+    del obs_n
     for c in pipes:
         c.send(None)
     for p in procs:
         p.join(timeout=5)
     return dict(value=n_envs * n_steps / dt, unit='env-steps/s', cores=n_envs + 1,
-                sample=f'{n_envs} worker processes x 1 env (oracle) + 1 learner process over pipes, {n_steps}-step rollout, {dt:.2f} s')
+                sample=f'{n_envs} worker processes x 1 env (oracle) + 1 learner process (VecNormalize every step, GAE at the end) over pipes, {n_steps}-step rollout, {dt:.2f} s')
 
 
 def main():
