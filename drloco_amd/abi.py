@@ -5,7 +5,7 @@ library's own view (dl_abi_sizeof) and that every declared symbol is exported.
 """
 import ctypes as C
 
-DL_ABI_VERSION = 1
+DL_ABI_VERSION = 2
 DL_MAX_BODY, DL_MAX_DOF, DL_MAX_GEOM, DL_MAX_SITE, DL_MAX_ACT = 12, 20, 12, 8, 16
 DL_JNT_SLIDE, DL_JNT_HINGE = 0, 1
 DL_ENV_STRAIGHT, DL_ENV_LOCO3D = 0, 1

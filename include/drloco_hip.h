@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 1
+#define DL_ABI_VERSION 2   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
