@@ -1142,19 +1142,20 @@ int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, co
     if (!p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->wa || !p->ba || !p->wv || !p->bv || !p->log_std) return fail(DL_E_INVAL, "dl_policy_forward: NULL parameter array");
     if (p->hidden <= 0 || p->hidden % 64 || p->hidden > 64 * POL_MAXT || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15)
         return fail(DL_E_INVAL, "dl_policy_forward: hidden must be a multiple of 64 and <= 512, obs_dim <= 48, act_dim <= 15");
-    const size_t lds = ((size_t)2 * POL_ROWS * (p->hidden + 4) + 4 * 16 * 16) * sizeof(float);
-    const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(256);
-#define DL_POL_LAUNCH(NTW)                                                                                                                              \
+    const int nw = p->hidden == 512 ? 8 : 4;                    // waves per workgroup
+    const size_t lds = ((size_t)2 * POL_ROWS * (p->hidden + 4) + (size_t)nw * 16 * 16) * sizeof(float);
+    const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(64 * nw);
+#define DL_POL_LAUNCH(NTW, NW)                                                                                                                          \
     {                                                                                                                                                   \
         static bool attr = false;                                                                                                                       \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_forward<NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-        hipLaunchKernelGGL((k_policy_forward<NTW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs); \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_forward<NTW, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+        hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs); \
     }
     switch (p->hidden / 64) {
-        case 1: DL_POL_LAUNCH(1) break;
-        case 2: DL_POL_LAUNCH(2) break;
-        case 4: DL_POL_LAUNCH(4) break;
-        case 8: DL_POL_LAUNCH(8) break;
+        case 1: DL_POL_LAUNCH(1, 4) break;
+        case 2: DL_POL_LAUNCH(2, 4) break;
+        case 4: DL_POL_LAUNCH(4, 4) break;
+        case 8: DL_POL_LAUNCH(4, 8) break;
         default: return fail(DL_E_INVAL, "dl_policy_forward: hidden must be 64, 128, 256 or 512");
     }
 #undef DL_POL_LAUNCH

@@ -8,15 +8,15 @@
 //     action  = mean + exp(log_std) * eps,  eps ~ N(0, 1)   (DiagGaussianDistribution.sample)
 //     log_prob = sum_a( -eps_a^2 / 2 - log_std_a - log(2 pi) / 2 )
 // This is the one genuinely GEMM-shaped piece of the path: [N,29]x[29,512], [N,512]x[512,512], [N,512]x[512,9].
-// One workgroup (4 waves) owns 16 walkers; the three layers run back to back on v_mfma_f32_16x16x4f32 (float32 in,
+// One workgroup (4 or 8 waves) owns 16 walkers; the three layers run back to back on v_mfma_f32_16x16x4f32 (float32 in,
 // float32 accumulate -- parity with the float32 torch module to ~1e-6), the activations never leave LDS.
 //   A operand (activations): lane l supplies row l % 16, the reduction index is permuted so that a lane's four k
 //     values of a 16-wide k block are contiguous: one ds_read_b128 feeds four MFMAs;
 //   B operand (weights, torch layout [out][in]): lane l supplies output column n0 + l % 16 with the same four k:
 //     one global_load_dwordx4 per tile and k block; two k blocks (one 128-byte line per weight row) per step, in two
 //     ping-pong register sets loaded by inline asm one step ahead of the 64 MFMAs that consume them;
-//   layer 2: each wave owns hidden/4 output columns (up to 8 accumulator tiles); heads: the reduction is split over
-//     the four waves and summed through LDS.
+//   layer 2: each wave owns hidden/NW output columns (NTW accumulator tiles); heads: the reduction is split over
+//     the waves and summed through LDS.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -52,21 +52,23 @@ __device__ __forceinline__ float pol_gauss(uint64_t seed, uint64_t counter, uint
 constexpr int POL_ROWS = 16;       // walkers per workgroup
 constexpr int POL_MAXT = 8;        // accumulator tiles per wave in the hidden layer (hidden <= 512)
 
-// NTW = accumulator tiles per wave in the hidden layer: hidden = 64 * NTW (compile time, so that the tile loops are
-// straight-line code)
-template <int NTW>
-__global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
+// NTW = accumulator tiles per wave in the hidden layer, NW = waves per workgroup: hidden = 16 * NTW * NW (compile time, so
+// that the tile loops are straight-line code).  hidden = 512 runs as 8 waves x 4 tiles: two waves per SIMD, so that the LDS /
+// weight-load latency of one overlaps the MFMAs of the other (4 waves x 8 tiles left the matrix pipe idle for ~ 45 % of the
+// hidden layer).
+template <int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                         uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                         float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int H = 64 * NTW, LDH = H + 4, ntw = NTW;
+    constexpr int H = 16 * NTW * NW, LDH = H + 4, ntw = NTW;
     const int D = p.obs_dim, A = p.act_dim;
     float* h1 = sm;
     float* h2 = sm + POL_ROWS * LDH;
-    float* part = h2 + POL_ROWS * LDH;            // [4][16][16] partial head tiles, then [16][16] log-prob terms
+    float* part = h2 + POL_ROWS * LDH;            // [NW][16][16] partial head tiles, then [16][16] log-prob terms
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
     const int row0 = blockIdx.x * POL_ROWS;
-    constexpr int ncw = H / 4;
+    constexpr int ncw = H / NW;
     const int n0w = wave * ncw;
     // ---- layer 1: [16, D] x [D, H].  D is small (29): all operand loads of the wave are issued before the first MFMA
     // (one memory latency for the layer instead of one per tile)
@@ -124,14 +126,14 @@ __global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p
                 asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(b[t][1]) : "v"(q) : "memory");
             }
         };
-        auto wait_set = [&](pf4 (&b)[NTW][2], bool newer_in_flight) {
-            // loads return in order: allow the 2 * NTW loads of the other set to stay in flight
-            if (newer_in_flight) {
-                if constexpr (NTW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if constexpr (NTW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if constexpr (NTW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // wait until the OLDEST set in flight has arrived while `newer` younger sets (2 * NTW loads each; loads return in order) stay
+        // in flight; vmcnt takes an immediate, hence the ladder
+        auto wait_set = [&](pf4 (&b)[NTW][2], int newer) {
+            constexpr int L = 2 * NTW;
+            if (newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L < 63 ? 3 * L : 63) : "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(b[t][0]), "+v"(b[t][1]));
         };
@@ -143,17 +145,24 @@ __global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p
             DL_POL_KSTEP(a4b.x, 1, x) DL_POL_KSTEP(a4b.y, 1, y) DL_POL_KSTEP(a4b.z, 1, z) DL_POL_KSTEP(a4b.w, 1, w)
 #undef DL_POL_KSTEP
         };
-        pf4 bs0[NTW][2], bs1[NTW][2];
+        // DEPTH register sets, DEPTH - 1 of them in flight while one is consumed.  Measured: 4 sets are no faster than 2 (37 us for one
+        // workgroup either way, 149 vs 141 us for 16 384 rows) -- the hidden layer is bound by the matrix pipe (1024 MFMAs of 32 cycles
+        // per SIMD = 14 us) plus the L2 -> CU stream of the whole weight matrix per workgroup, not by the latency of a single load.
+        constexpr int DEPTH = 2;
+        static_assert((H / 32) % DEPTH == 0, "steps come in groups of DEPTH");
+        pf4 bs[DEPTH][NTW][2];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the compiler's own loads may be counted against the sets
-        load_set(bs0, 0);
-        for (int kp = 0; kp < npair; kp += 2) {
-            load_set(bs1, kp + 1);
-            wait_set(bs0, true);
-            compute(bs0, kp);
-            const bool more = kp + 2 < npair;
-            if (more) load_set(bs0, kp + 2);
-            wait_set(bs1, more);
-            compute(bs1, kp + 1);
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; d++) load_set(bs[d], d);
+        for (int kp0 = 0; kp0 < npair; kp0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                const int kp = kp0 + d, ahead = kp + DEPTH - 1;
+                if (ahead < npair) load_set(bs[(d + DEPTH - 1) % DEPTH], ahead);
+                const int left = npair - 1 - kp;
+                wait_set(bs[d], left < DEPTH - 1 ? left : DEPTH - 1);
+                compute(bs[d], kp);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p
     // ---- heads: one 16 x 16 tile (columns 0..A-1 action means, column A the value); reduction split over the waves
     {
         pf4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int kper = H / 4;
+        const int kper = H / NW;
         const float* wrow = lm < A ? p.wa + (size_t)lm * H : (lm == A ? p.wv : nullptr);
         for (int kb = 0; kb < kper / 16; kb++) {
             const int k0 = wave * kper + kb * 16 + lk * 4;
@@ -189,7 +198,9 @@ __global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p
     float lp = 0.0f;
     const int row = tid >> 4, col = tid & 15, r = row0 + row;
     if (tid < 256) {
-        const float v = part[(0 * 16 + row) * 16 + col] + part[(1 * 16 + row) * 16 + col] + part[(2 * 16 + row) * 16 + col] + part[(3 * 16 + row) * 16 + col];
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) v += part[(w * 16 + row) * 16 + col];
         if (r < n) {
             if (col < A) {
                 const float mean = v + p.ba[col], ls = p.log_std[col];
@@ -200,9 +211,9 @@ __global__ __launch_bounds__(256) void k_policy_forward(const dl_policy_params p
         }
     }
     __syncthreads();
-    part[tid] = lp;
+    if (tid < 256) part[tid] = lp;
     __syncthreads();
-    if (col == 0 && r < n) {
+    if (tid < 256 && col == 0 && r < n) {
         float s = 0.0f;
         for (int a = 0; a < A; a++) s += part[row * 16 + a];
         logp[r] = s;
