@@ -149,7 +149,7 @@ def write_policy_zip(policy, path, data=None):
             sd[f'mlp_extractor.value_net.{layer}.{p}'] = sd[f'mlp_extractor.policy_net.{layer}.{p}']
     buf = io.BytesIO(); torch.save(sd, buf)
     empty = io.BytesIO(); torch.save({}, empty)
-    meta = dict(policy_class='CustomActorCriticPolicy', policy_kwargs=dict(log_std_init=float(getattr(policy, 'log_std')[0])))
+    meta = dict(policy_class='CustomActorCriticPolicy', policy_kwargs=dict(log_std_init=float(getattr(policy, 'log_std').detach()[0])))
     meta.update(data or {})
     with zipfile.ZipFile(path, 'w') as z:
         z.writestr('data', json.dumps(meta, indent=4))

@@ -27,7 +27,7 @@ from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 
-def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False):
+def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False, save_path=None):
     dev = torch.device('cuda', 0)
     torch.manual_seed(seed)
     venv = HipVecEnv(num_envs=n_envs, seed=seed)
@@ -107,6 +107,15 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
             print(f"evaluation (20 deterministic episodes): mean distance {res['mean_walked_distance']:.1f} m, min {res['min_walked_distance']:.1f} m, "
                   f"mean episode length {res['mean_episode_duration'] * 3000:.0f}, stable walks {res['count_stable_walks']}/20, "
                   f"mean step reward (normalised) {res['mean_reward_means']:.2f}")
+    if save_path:
+        # utils.save_model (drloco/common/utils.py:175-192): models/model_<ckpt>.zip + envs/env_<ckpt> in the SB3 1.0 layouts
+        from drloco_amd import checkpoint
+        os.makedirs(os.path.join(save_path, 'models'), exist_ok=True); os.makedirs(os.path.join(save_path, 'envs'), exist_ok=True)
+        ckpt = f'{int(total / 1e5)}'
+        checkpoint.write_policy_zip(pol, os.path.join(save_path, 'models', f'model_{ckpt}.zip'))
+        vn.save(os.path.join(save_path, 'envs', f'env_{ckpt}'), sb3_format=True)
+        if not quiet:
+            print('saved', os.path.join(save_path, 'models', f'model_{ckpt}.zip'), 'and', os.path.join(save_path, 'envs', f'env_{ckpt}'))
     return hist
 
 
@@ -117,6 +126,7 @@ if __name__ == '__main__':
     ap.add_argument('--batch', type=int, default=16384, help='samples per update = envs x rollout steps (the reference: 16 384)')
     ap.add_argument('--minibatch', type=int, default=2048)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--save', default=None, help='directory for models/model_<ckpt>.zip and envs/env_<ckpt> (SB3 1.0 layouts, drloco_amd/checkpoint.py)')
     ap.add_argument('--no-norm-reward', action='store_true', help='VecNormalize(norm_reward=False)')
     args = ap.parse_args()
-    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward, evaluate=True)
+    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward, evaluate=True, save_path=args.save)
