@@ -59,6 +59,21 @@ class HipRolloutBuffer:
                                    _ptr(self.advantages), _ptr(self.returns), _stream()))
         return self.advantages, self.returns
 
+    def get(self, batch_size=None, generator=None):
+        """SB3 1.0 RolloutBuffer.get: minibatches of the flattened rollout in a random order, as RolloutBufferSamples-like
+        named tuples (observations, actions, old_values, old_log_prob, advantages, returns) of device tensors.  The rollout is
+        flattened env-major as SB3's swap_and_flatten does ([T, N, ...] -> [N * T, ...]); batch_size None = one batch."""
+        import collections
+        Samples = collections.namedtuple('RolloutBufferSamples', 'observations actions old_values old_log_prob advantages returns')
+        flat = lambda x: x.transpose(0, 1).reshape(self.T * self.N, *x.shape[2:])
+        cols = [flat(x) for x in (self.observations, self.actions, self.values, self.log_probs, self.advantages, self.returns)]
+        total = self.T * self.N
+        perm = torch.randperm(total, device=self.observations.device, generator=generator)
+        bs = total if batch_size is None else int(batch_size)
+        for i in range(0, total, bs):
+            idx = perm[i:i + bs]
+            yield Samples(*(c[idx] for c in cols))
+
     def advantage_sums(self, adv=None):
         a = self.advantages if adv is None else adv
         lib.check(self._lib.dl_adv_stats(_ptr(a), a.numel(), _ptr(self._sums), _stream()))

@@ -932,6 +932,17 @@ def test_rollout_policy_in_one_call(torch_cuda, model, refs):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert res[0][5].sum() > 0 and res[0][11] == 2 * T
+    # RolloutBuffer.get: every sample exactly once, env-major flattening as SB3's swap_and_flatten
+    buf.compute_returns_and_advantage(torch.zeros(n, device='cuda'), last_done)
+    seen = torch.zeros(T * n, dtype=torch.int32, device='cuda')
+    flat_val = buf.values.transpose(0, 1).reshape(-1)
+    for mb in buf.get(batch_size=1000):
+        assert mb.observations.shape[1:] == (29,) and mb.actions.shape[1:] == (8,) and mb.advantages.shape == mb.returns.shape == mb.old_values.shape
+        # locate the samples through their (unique with probability 1) value predictions
+        pos = (flat_val[None, :] == mb.old_values[:8, None]).float().argmax(1)
+        assert torch.equal(buf.returns.transpose(0, 1).reshape(-1)[pos], mb.returns[:8])
+        seen[pos] += 1
+    assert sum(len(mb.returns) for mb in buf.get(batch_size=1000)) == T * n and seen.max() <= 1
 
 
 def test_rollout_fixed_multi_step_launches_match_single_steps(torch_cuda, model, refs):
