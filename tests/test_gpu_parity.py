@@ -1066,3 +1066,29 @@ def test_env_group_handles_are_shards(torch_cuda, model, refs):
     assert abs(float(adv.mean())) < 1e-5 and abs(float(adv.std(unbiased=True)) - 1) < 1e-4
     assert grp.cat('observations').shape == (T, H * n, 29)
     grp.close()
+
+
+@pytest.mark.parametrize('T,N', [(128, 128), (512, 4096), (129, 130), (4, 4096), (2048, 8)])
+def test_gae_and_adv_norm_at_training_shapes(torch_cuda, T, N):
+    """dl_gae (chunked parallel scan) + dl_adv_stats / dl_adv_normalize against a float64 torch restatement of SB3 1.0's loops at the
+    shapes learners use (the reference's 8 x 2048, the example's 128 x 128, the benchmark's 4096 x 512, ragged ones)."""
+    import torch
+    from drloco_amd.rollout import HipRolloutBuffer
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev); g.manual_seed(T * 100003 + N)
+    buf = HipRolloutBuffer(T, N, 29, 8, dev)
+    buf.rewards.copy_(torch.randn(T, N, device=dev, generator=g)); buf.values.copy_(torch.randn(T, N, device=dev, generator=g))
+    buf.episode_starts.copy_((torch.rand(T, N, device=dev, generator=g) < 0.02).to(torch.uint8))
+    lv = torch.randn(N, device=dev, generator=g); ld = (torch.rand(N, device=dev, generator=g) < 0.1).to(torch.uint8)
+    adv, ret = buf.compute_returns_and_advantage(lv, ld)
+    ra = torch.zeros(T, N, dtype=torch.float64, device=dev); last = torch.zeros(N, dtype=torch.float64, device=dev)
+    for t in reversed(range(T)):
+        nnt = 1.0 - (ld if t == T - 1 else buf.episode_starts[t + 1]).double()
+        nv = (lv if t == T - 1 else buf.values[t + 1]).double()
+        last = buf.rewards[t].double() + 0.995 * nv * nnt - buf.values[t].double() + 0.995 * 0.95 * nnt * last
+        ra[t] = last
+    assert float((adv.double() - ra).abs().max()) < 3e-5 and float((ret.double() - (ra + buf.values.double())).abs().max()) < 3e-5
+    a0 = adv.double().clone()
+    buf.normalize_advantages()
+    ref = (a0 - a0.mean()) / (a0.std(unbiased=True) + 1e-8)
+    assert float((buf.advantages.double() - ref).abs().max()) < 2e-6
