@@ -155,12 +155,18 @@ def main():
             cpu_base['subproc_vec_env_4'] = cpu_baseline_subproc(4, 2048)
         except Exception as e:      # a box that cannot fork workers still gets its benchmark line
             cpu_base['subproc_vec_env_4'] = {'error': repr(e)}
+    if local_rank >= torch.cuda.device_count():      # test rigs with fewer GPUs than ranks (DL_BENCH_BACKEND=gloo): share the last device
+        local_rank = torch.cuda.device_count() - 1
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or 'RANK' in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('DL_BENCH_BACKEND', 'nccl')          # nccl = RCCL; gloo only to exercise the multi-rank code path on a box with one GPU
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device('cuda', local_rank)
 
     n, T = args.envs_per_gpu, args.rollout_len
