@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 664          # 336 B read + 328 B written per walker and control step
+ALGO_BYTES_PER_ENV_STEP_LOCO3D = 916   # the same count for the 19-dof walker: 456 B read (3 x 19 state + 13 action + 6 cursor + 38 reference words) + 460 B written (57 state + 6 cursor + 47 obs + 5)
 HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -125,7 +126,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--rollout-len', type=int, default=512)
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
-    ap.add_argument('--walker', choices=['straight', 'loco3d'], default='straight', help='loco3d: BASELINE configs[3] (19-dof walker, lane-per-walker kernels, synthetic loco3d table); not the benchmark configuration')
+    ap.add_argument('--walker', choices=['straight', 'loco3d'], default='straight', help='loco3d: BASELINE configs[3] (19-dof walker, synthetic loco3d table); not the benchmark configuration')
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
@@ -179,11 +180,11 @@ def main():
         if r > 0:
             run_starts.append((t0, r)); t0 += r
     if args.walker == 'loco3d':
-        # BASELINE configs[3] (not the benchmark configuration): MimicWalker165cm65kg (19 dofs: one walker per lane -- the 16-lane row does not
-        # fit) on the synthetic stand-in for the missing loco3d_guoping.mat (8 clips), mixed-clip reference-state init
+        # BASELINE configs[3] (not the benchmark configuration): MimicWalker165cm65kg (19 dofs: 16 lane dofs + 3 replicated root translations)
+        # on the synthetic stand-in for the missing loco3d_guoping.mat (8 clips), mixed-clip reference-state init
         from drloco_amd import mocap, models
         ang, vel = mocap.synthetic_loco3d(L=60000, seed=0)
-        venv = HipVecEnv(models.WALKER_165CM, num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, refs=mocap.loco3d_table(ang, vel))
+        venv = HipVecEnv(models.WALKER_165CM, num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, refs=mocap.loco3d_table(ang, vel), lanes_per_walker=args.lanes)
     else:
         venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
     vn = HipVecNormalize(venv)
@@ -295,7 +296,8 @@ def main():
         avg_launch_s = tot_ms.value / max(1, launches.value) / 1e3
         steps_per_launch = venv._lib.dl_profile_steps(venv._h) / max(1, launches.value)      # 8 with dl_rollout_fixed, 1 with dl_step
         n_prof = venv.num_envs                       # walkers of the handle whose launches were bracketed (all of the rank's unless --handles)
-        achieved = ALGO_BYTES_PER_ENV_STEP * n_prof * steps_per_launch / avg_launch_s / 1e9
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP_LOCO3D if args.walker == 'loco3d' else ALGO_BYTES_PER_ENV_STEP
+        achieved = algo_bytes * n_prof * steps_per_launch / avg_launch_s / 1e9
         traffic = valu_busy = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
         if os.path.exists(tfile):
@@ -310,14 +312,15 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('loco3d 19-dof walker (synthetic mocap table), ' if args.walker == 'loco3d' else 'straight_walking 3D walker, ') + f'{n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
-                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, under the following run of env steps',
                        'env_launches': 'one per control step' if (args.policy or args.no_overlap or args.randomize) else
                                        'dl_rollout_fixed, runs of ' + ' + '.join(str(r) for _, r in run_starts) + ' control steps per launch',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_env_step<float,64>' if (args.lanes == 1 or args.walker == 'loco3d') else 'k_env_step_g16<float>', 'avg_launch_us': avg_launch_s * 1e6,
-                         'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_ENV_STEP * n_prof * steps_per_launch,
+                         'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
+                                   ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else 'k_env_step_g16<float,TopoStraight>'), 'avg_launch_us': avg_launch_s * 1e6,
+                         'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
                          'valu_busy_frac': valu_busy,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }

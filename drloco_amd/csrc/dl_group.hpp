@@ -2,21 +2,39 @@
 //
 // The lane-per-walker kernels (dl_core.hpp) leave 15/16 of the chip idle at the benchmark size
 // (4096 walkers = 64 waves on 1024 SIMDs) and their run time is the serial instruction stream of
-// one walker.  Here a walker is spread over a 16-lane DPP row: lane j owns degree of freedom j (and the
-// body whose last dof it is, the collision candidates j and j + 16, contact j, its own limit row), four
+// one walker.  Here a walker is spread over a 16-lane DPP row: a lane owns one degree of freedom (and the
+// body whose last dof it is, the collision candidates j, j + 16, ..., contact j, its own limit row), four
 // walkers share a wave, 4096 walkers are 1024 waves -- one per SIMD.  At one wave per SIMD nothing hides
 // latency, so the design goal is few instructions and few dependent round trips:
 //   * the dynamics run in registers; lanes exchange data through DPP (row_newbcast broadcasts, row_shr /
 //     row_shl segmented scans over the dof tree, row_ror sums), mostly folded into v_fmac_f32_dpp;
 //   * LDS holds only what is indexed dynamically (contacts, constraint rows, contact Jacobians, body frames
 //     for the collision stage), in 16-byte groups; a workgroup is one wave, so LDS needs no barrier;
-//   * the kinematic tree is a compile-time constant (GTopo<TopoStraight>), all numeric parameters are data.
+//   * the kinematic tree is a compile-time constant (GTopo<TP>), all numeric parameters are data.
+//
+// Models with more than 16 dofs (the 19-dof walker of BASELINE configs[3]) keep the 16-lane row: their NX = nv - 16
+// leading dofs -- the world-aligned root translations, ancestors of every other dof -- are carried REPLICATED in every
+// lane of the row (GX): their rows of the mass matrix / Hessian are uniform values or one coupling entry per lane,
+// their Jacobian columns are the contact frame itself, and they are eliminated first in the Cholesky factorisation.
+// NX = 0 (straight walker) compiles to exactly the lane-only code.
 //
 // Results follow dl_core.hpp / the CPU restatement (same model, same minimiser); the parity tests run both device
-// paths against the CPU oracle.
+// paths against the CPU oracle, and tests/host_emu runs THIS source on the host (DL_GROUP_EMU: a wave as 64 fibers).
 #pragma once
 
+#if defined(DL_GROUP_EMU)
+#include "dl_group_emu.hpp"       // tests/host_emu: host stand-ins for the wave-level builtins (test infrastructure)
+#define DL_VPIN(x) ((void)0)
+#define DL_SPIN(x) ((void)0)
+#define DL_CLOCK() 0ll
+#else
 #include <hip/hip_runtime.h>
+#define DL_VPIN(x) asm volatile("" : "+v"(x))
+#define DL_SPIN(x) asm volatile("" : "+s"(x))
+#define DL_CLOCK() ((long long)__builtin_readcyclecounter())
+#endif
+
+#include <type_traits>
 
 #include "dl_env.hpp"
 
@@ -24,71 +42,110 @@ namespace dl {
 
 constexpr int GL = 16;          // lanes per walker
 constexpr int GW = 4;           // walkers per wave
-constexpr int G_MAXB = 8;       // bodies incl. world
-constexpr int G_MAXCAND = 32;   // collision candidate points
-constexpr int G_MAXCON = 20;    // >= 18
-constexpr int G_MAXROW = 80;
+
+// sizes of the 16-lane formulation of model TP
+template <typename TP> struct GD {
+    static constexpr int NV = TP::NV;
+    static constexpr int NX = NV > GL ? NV - GL : 0;      // leading root-translation dofs carried replicated
+    static constexpr int NXA = NX > 0 ? NX : 1;           // array extent (no zero-length arrays)
+    static constexpr int NL = NV - NX;                    // dofs that own a lane: lane l <-> dof l + NX
+    static constexpr int MAXB = TP::NB;                   // bodies incl. world
+    static constexpr int MAXCON = TP::MAXCON <= 20 ? 20 : ((TP::MAXCON + 1) & ~1);     // even: contacts are processed in pairs
+    static constexpr int MAXROW = ((TP::NLIM + 4 * TP::MAXCON + 3) / 4) * 4;
+    static constexpr int ncand_() { int n = 0; for (int g = 0; g < TP::NG; g++) n += TP::geom_type(g) ? 8 : 2; return n; }
+    static constexpr int NCAND = ncand_();                // capsule end points / box corners in contact order
+    static constexpr int NPASS = (NCAND + GL - 1) / GL;   // candidate c = lane + 16 * pass
+    static constexpr bool slides_ok_() {                  // the replicated dofs: world-aligned slides of the root body, unlimited, not actuated
+        for (int t = 0; t < NX; t++) if (TP::dof_type(t) != 0 || TP::dof_body(t) != 1 || TP::dof_limited(t) || TP::dof_parent(t) != t - 1) return false;
+        for (int a = 0; a < TP::NU; a++) if (TP::act_dof(a) < NX) return false;
+        return true;
+    }
+    // Register budget: the straight walker pins every model constant a lane touches in VGPRs (nothing of the model is loaded
+    // inside an evaluation).  The 19-dof walker does not have the registers for that (three candidate passes, nine bodies, the
+    // replicated dofs' state): what is used ONCE per evaluation -- collision candidates, body offsets, solimp -- is fetched at
+    // its point of use from the L1-resident model block instead (a few hundred cycles per evaluation against scratch spills).
+    static constexpr bool PIN_ALL = NX == 0;
+    static_assert(slides_ok_(), "the dofs beyond 16 must be leading root translations");
+    static_assert(NL <= GL && MAXB <= 16 && NCAND <= 64 && TP::NS <= GL, "model too large for a 16-lane row");
+};
+// a value per replicated dof (uniform over the lanes of a walker's row)
+template <typename T, int NX> struct GX { T x[NX > 0 ? NX : 1]; };
+template <int AX, typename T> __device__ __forceinline__ T& vcomp(V3<T>& a) { if constexpr (AX == 0) return a.x; else if constexpr (AX == 1) return a.y; else return a.z; }
+template <int AX, typename T> __device__ __forceinline__ T vcomp(const V3<T>& a) { if constexpr (AX == 0) return a.x; else if constexpr (AX == 1) return a.y; else return a.z; }
 
 // what a lane needs about ITS OWN dof / body / collision candidates; built once on the host (g_load_lane) for the 16
 // lanes and kept in the model block, so that a kernel fetches its lane's record with a handful of wide loads
-template <typename T> struct GLane {
+// the collision candidates of a lane (capsule end points / box corners in contact order, c = j + 16 * pass)
+// as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
+// to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
+template <typename T, int NP> struct GLaneCand {
+    int cinfo[NP];                                     // bit0 valid, 1 box, 2-4 sub index, 5-8 body
+    T cpl[NP][3], crad[NP], cal[NP][3], crl[NP][3], cmu[NP], cinvw[NP];   // cinvw: body_invweight0 of the candidate's body (diagApprox of its contact rows)
+};
+template <typename T, int NP> struct GLane {
     int type, axis, body, limited, act;
     T sign, qpos0, range_lo, range_hi, damping, armature, invw, ctrl_lo, ctrl_hi, force_lo, force_hi, gear;
     // inertial parameters of the body of this dof
     T mass, ipos[3], inertia[3];
-    // the two collision candidates of this lane (capsule end points / box corners in contact order, c = j and j + 16)
-    // as body-local constants: point, radius (0 for a box corner), capsule axis (tangent direction), corner relative
-    // to the box centre (mjc_PlaneBox keeps only corners below the centre), friction
-    int cinfo[2];                                      // bit0 valid, 1 box, 2-4 sub index, 5-7 body
-    T cpl[2][3], crad[2], cal[2][3], crl[2][3], cmu[2], cinvw[2];   // cinvw: body_invweight0 of the candidate's body (diagApprox of its contact rows)
+    GLaneCand<T, NP> cand;
 };
 
-// model as data (host-built from dl_model_desc), read through the constant address space
-template <typename T> struct GModel {
+// model as data (host-built from dl_model_desc), read through the constant address space.  Per-dof arrays are indexed
+// by LANE (dof - NX); the replicated dofs have their own small arrays (xs_*).
+template <typename T, typename TP> struct GModel {
+    using D = GD<TP>;
     int32_t nv, nb, nu, ngeom, nsite, frame_skip, iterations, ls_iterations, ncand, root_last_dof;
     T timestep, gravity_z, solK, solB, solimp[5], solimp_inv[3], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, root_z0;
     int32_t dof_body[GL], dof_type[GL], dof_axis[GL], dof_limited[GL];
     T dof_sign[GL], qpos0[GL], range_lo[GL], range_hi[GL], damping[GL], armature[GL], dof_invw[GL];
     int32_t dof_act[GL];                       // actuator index driving this dof, or -1
-    T ctrl_lo[GL], ctrl_hi[GL], force_lo[GL], force_hi[GL], gear[GL];   // indexed by dof
-    T body_pos[G_MAXB][3], body_mass[G_MAXB], body_ipos[G_MAXB][3], body_inertia[G_MAXB][3], body_invw[G_MAXB];
-    int32_t cand_geom[G_MAXCAND], cand_sub[G_MAXCAND];
-    int32_t geom_body[G_MAXB], geom_type[G_MAXB];
-    T geom_pos[G_MAXB][3], geom_mat[G_MAXB][9], geom_size[G_MAXB][3], geom_friction[G_MAXB], floor_friction;
-    int32_t site_body[8];
-    T site_pos[8][3];
-    GLane<T> lanes[GL];                        // per-lane records (g_load_lane of the fields above), filled by fill_group_model
+    T ctrl_lo[GL], ctrl_hi[GL], force_lo[GL], force_hi[GL], gear[GL];   // indexed by lane
+    T xs_qpos0[D::NXA], xs_damping[D::NXA], xs_armature[D::NXA];        // replicated root translations
+    T body_pos[D::MAXB][3], body_mass[D::MAXB], body_ipos[D::MAXB][3], body_inertia[D::MAXB][3], body_invw[D::MAXB];
+    int32_t cand_geom[GL * D::NPASS], cand_sub[GL * D::NPASS];
+    int32_t geom_body[D::MAXB], geom_type[D::MAXB];
+    T geom_pos[D::MAXB][3], geom_mat[D::MAXB][9], geom_size[D::MAXB][3], geom_friction[D::MAXB], floor_friction;
+    int32_t site_body[GL];
+    T site_pos[GL][3];
+    GLane<T, D::NPASS> lanes[GL];              // per-lane records (g_load_lane of the fields above), filled by fill_group_model
 };
 
-// per-walker LDS layout (in elements of T)
-struct GLds {
-    static constexpr int Q = 0, V = Q + GL;                          // q, v staged for the observation writer
-    static constexpr int MS = GL + 4;                                // row stride of M: rows are written as four 16-byte groups, columns read with consecutive lanes
-    static constexpr int MM = V + GL;                                // M [16 rows][MS]: every lane's chain part of its row (transposed read-back gives the rest)
-    static constexpr int CON_W = 12;                                 // contact record: (px py pz body) (tx ty mu dist) (diagApprox - - -): three 16-byte groups
-    static constexpr int C_P = 0, C_BODY = 3, C_TX = 4, C_TY = 5, C_MU = 6, C_DIST = 7, C_DIAG = 8;
-    static constexpr int CON = MM + GL * MS;                         // contacts [G_MAXCON][CON_W]
-    static constexpr int ROW = CON + CON_W * G_MAXCON;               // rows [4][G_MAXROW]: D, JAREF, JV, TMP; contact c owns rows 4c..4c+3 (16-byte groups), limits follow
+// per-walker LDS layout (in elements of T).  Regions that are never live at the same time share their space: the mirror
+// block of the mass matrix (MM, smooth dynamics) sits in the constraint rows (first written by the constraint stage), the
+// body frames (BFR, dead once the contacts exist) in the contact Jacobians, the q / v staging of the observation writer
+// (outside the forward evaluation) in the contact forces.  10 KB per walker for the 19-dof walker: four waves per CU.
+template <typename TP> struct GLds {
+    using D = GD<TP>;
+    static constexpr int MAXCON = D::MAXCON, MAXROW = D::MAXROW;
+    static constexpr int ROW = 0;                                    // rows [4][MAXROW]: D, JAREF, JV, TMP; contact c owns rows 4c..4c+3 (16-byte groups), limits follow
     static constexpr int R_D = 0, R_JAREF = 1, R_JV = 2, R_TMP = 3;
-    static constexpr int FC_W = 12;                                  // per contact: Fn F1 F2 flip | w00 w01 w02 w11 | w22 - - -
-    static constexpr int FC = ROW + 4 * G_MAXROW;                    // contact-frame force and Hessian weights [G_MAXCON][FC_W]
-    static constexpr int MISC = FC + FC_W * G_MAXCON;                // rootz ... [8]
-    static constexpr int JC = MISC + 8;                              // contact Jacobians, dof-lane major [G_MAXCON][16 lanes][4]: normal, tangent 1, tangent 2, -
+    static constexpr int MS = GL + 4;                                // row stride of M: rows are written as four 16-byte groups, columns read with consecutive lanes
+    static constexpr int MM = ROW;                                   // M [16 rows][MS]: every lane's chain part of its row (transposed read-back gives the rest)
+    static constexpr int CON_W = 8;                                  // contact record: (px py pz body) (tx ty mu dist): two 16-byte groups
+    static constexpr int C_P = 0, C_BODY = 3, C_TX = 4, C_TY = 5, C_MU = 6, C_DIST = 7;
+    static constexpr int CON = ROW + 4 * MAXROW;                     // contacts [MAXCON][CON_W]
+    static constexpr int FC_W = 12;                                  // per contact: Fn F1 F2 flip | w00 w01 w02 w11 | w22 Fx Fy Fz (world-frame force: the replicated dofs' J^T f)
+    static constexpr int FC = CON + CON_W * MAXCON;                  // contact-frame force and Hessian weights [MAXCON][FC_W]
+    static constexpr int Q = FC, V = Q + D::NV;                      // q, v staged for the observation writer
+    static constexpr int MISC = FC + FC_W * MAXCON;                  // rootz ... [8]
+    static constexpr int JC = MISC + 8;                              // contact Jacobians, dof-lane major [MAXCON][16 lanes][4]: normal, tangent 1, tangent 2, -
     static constexpr int BFR_W = 12;                                 // body frame record: X (3) Y (3) Z (3) pos (3) = three 16-byte groups
-    static constexpr int BFR = JC;                                   // body frames [8][BFR_W] (dead once the contacts exist) share the space of JC
-    static constexpr int TOTAL_RAW = JC + G_MAXCON * GL * 4;
+    static constexpr int BFR = JC;                                   // body frames [MAXB][BFR_W]
+    static constexpr int TOTAL_RAW = JC + MAXCON * GL * 4;
     // walker regions are offset by 16 (mod 32) words so that the two rows of a half-wave use disjoint banks
     static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
-    static_assert(MM % 4 == 0 && MS % 4 == 0 && CON % 4 == 0 && ROW % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && G_MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
+    static_assert(GL * MS <= 4 * MAXROW && 2 * D::NV <= FC_W * MAXCON && D::MAXB * BFR_W <= MAXCON * GL * 4, "aliased regions must fit");
+    static_assert(MS % 4 == 0 && CON % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
 };
 
 // everything a lane needs about ITS OWN dof / body / collision candidates (incl. the inverse weight of the candidates'
 // bodies) is preloaded into registers (GLane), uniform scalars are pinned in VGPRs (GConst); nothing of the model is
 // indexed dynamically inside the loops, so there is no shared model block in LDS.
 
-template <typename T, typename MODEL>       // MODEL: GModel<T> in whatever address space the caller holds it
-__host__ __device__ __forceinline__ void g_load_lane(const MODEL& m, int j, GLane<T>& ln) {
-    const int jj = j < m.nv ? j : 0;
+template <typename T, typename TP, typename MODEL>       // MODEL: GModel<T, TP> in whatever address space the caller holds it
+__host__ __device__ __forceinline__ void g_load_lane(const MODEL& m, int j, GLane<T, GD<TP>::NPASS>& ln) {
+    constexpr int NL = GD<TP>::NL;
+    const int jj = j < NL ? j : 0;
     ln.type = m.dof_type[jj]; ln.axis = m.dof_axis[jj]; ln.body = m.dof_body[jj]; ln.limited = m.dof_limited[jj]; ln.act = m.dof_act[jj];
     ln.sign = m.dof_sign[jj]; ln.qpos0 = m.qpos0[jj]; ln.range_lo = m.range_lo[jj]; ln.range_hi = m.range_hi[jj];
     ln.damping = m.damping[jj]; ln.armature = m.armature[jj]; ln.invw = m.dof_invw[jj];
@@ -96,28 +153,28 @@ __host__ __device__ __forceinline__ void g_load_lane(const MODEL& m, int j, GLan
     const int b = ln.body;                            // inertial parameters of the body this dof belongs to
     ln.mass = m.body_mass[b];
     for (int k = 0; k < 3; k++) { ln.ipos[k] = m.body_ipos[b][k]; ln.inertia[k] = m.body_inertia[b][k]; }
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < GD<TP>::NPASS; pass++) {
         const int c = j + GL * pass;
         const bool ok = c < m.ncand;
         const int ge = ok ? m.cand_geom[c] : 0, sub = ok ? m.cand_sub[c] : 0;
         const bool box = m.geom_type[ge] != 0;
-        ln.cinfo[pass] = (ok ? 1 : 0) | (box ? 2 : 0) | (sub << 2) | (m.geom_body[ge] << 5);
+        ln.cand.cinfo[pass] = (ok ? 1 : 0) | (box ? 2 : 0) | (sub << 2) | (m.geom_body[ge] << 5);
         const auto* mat = m.geom_mat[ge];
         T rel[3];
         if (box) {
             const T sx = (sub & 1) ? m.geom_size[ge][0] : -m.geom_size[ge][0];
             const T sy = (sub & 2) ? m.geom_size[ge][1] : -m.geom_size[ge][1];
             const T sz = (sub & 4) ? m.geom_size[ge][2] : -m.geom_size[ge][2];
-            for (int k = 0; k < 3; k++) { rel[k] = mat[3 * k] * sx + mat[3 * k + 1] * sy + mat[3 * k + 2] * sz; ln.cal[pass][k] = T(0); ln.crl[pass][k] = rel[k]; }
-            ln.crad[pass] = T(0);
+            for (int k = 0; k < 3; k++) { rel[k] = mat[3 * k] * sx + mat[3 * k + 1] * sy + mat[3 * k + 2] * sz; ln.cand.cal[pass][k] = T(0); ln.cand.crl[pass][k] = rel[k]; }
+            ln.cand.crad[pass] = T(0);
         } else {
             const T hs = sub == 0 ? m.geom_size[ge][1] : -m.geom_size[ge][1];
-            for (int k = 0; k < 3; k++) { ln.cal[pass][k] = mat[3 * k + 2]; rel[k] = hs * mat[3 * k + 2]; ln.crl[pass][k] = T(0); }
-            ln.crad[pass] = m.geom_size[ge][0];
+            for (int k = 0; k < 3; k++) { ln.cand.cal[pass][k] = mat[3 * k + 2]; rel[k] = hs * mat[3 * k + 2]; ln.cand.crl[pass][k] = T(0); }
+            ln.cand.crad[pass] = m.geom_size[ge][0];
         }
-        for (int k = 0; k < 3; k++) ln.cpl[pass][k] = m.geom_pos[ge][k] + rel[k];
-        ln.cmu[pass] = m.geom_friction[ge];          // the contact uses max(geom, floor) with the walker's floor friction
-        ln.cinvw[pass] = m.body_invw[m.geom_body[ge]];
+        for (int k = 0; k < 3; k++) ln.cand.cpl[pass][k] = m.geom_pos[ge][k] + rel[k];
+        ln.cand.cmu[pass] = m.geom_friction[ge];          // the contact uses max(geom, floor) with the walker's floor friction
+        ln.cand.cinvw[pass] = m.body_invw[m.geom_body[ge]];
     }
 }
 
@@ -141,7 +198,7 @@ template <int CTRL> __device__ __forceinline__ double dpp_f(double x) {
 // asm hides the producer of x; the pragma keeps the adds themselves un-contracted.
 template <typename T> __device__ __forceinline__ T gsum(T x) {
 #pragma clang fp contract(off)
-    asm volatile("" : "+v"(x));
+    DL_VPIN(x);
     x += dpp_f<0x128>(x);
     x += dpp_f<0x124>(x);
     x += dpp_f<0x122>(x);
@@ -153,7 +210,7 @@ template <typename T> __device__ __forceinline__ T gsum(T x) {
 template <int NV, typename T> __device__ __forceinline__ void gsum_n(T (&x)[NV]) {
 #pragma clang fp contract(off)
 #pragma unroll
-    for (int i = 0; i < NV; i++) asm volatile("" : "+v"(x[i]));
+    for (int i = 0; i < NV; i++) DL_VPIN(x[i]);
 #pragma unroll
     for (int i = 0; i < NV; i++) x[i] += dpp_f<0x128>(x[i]);
 #pragma unroll
@@ -173,44 +230,12 @@ template <typename T> __device__ __forceinline__ void g_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ------------------------------------------------------------------------------------------
-// Uniform model scalars of the hot path, read ONCE per kernel and pinned in VGPRs (the empty asm makes the values
-// opaque: the compiler would otherwise re-issue the scalar loads inside the solver loops and wait for each --
-// s_waitcnt lgkmcnt(0) also drains the LDS queue).  VGPRs are plentiful at one wave per SIMD.
-template <typename T> struct GConst {
-    T body_pos[G_MAXB][3], root_z0, gravity_z, solK, solB, solimp[5], solimp_inv[3], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, scale, nvf;
-    int iterations, ls_iterations;
-};
-template <typename T> __device__ __forceinline__ void g_pin(T& x) { asm volatile("" : "+v"(x)); }
-template <typename T>
-__device__ __forceinline__ void g_load_const(const DL_CONST GModel<T>& m, GConst<T>& c) {
-    for (int b = 0; b < G_MAXB; b++) for (int k = 0; k < 3; k++) { c.body_pos[b][k] = b < m.nb ? m.body_pos[b][k] : T(0); g_pin(c.body_pos[b][k]); }
-    c.root_z0 = m.root_z0; c.gravity_z = m.gravity_z; c.solK = m.solK; c.solB = m.solB; c.meaninertia = m.meaninertia;
-    c.tolerance = m.tolerance; c.ls_tolerance = m.ls_tolerance; c.ls_reltol = m.ls_reltol; c.tol_rel = m.tol_rel;
-    c.nvf = T(m.nv); c.scale = T(1) / (m.meaninertia * c.nvf);
-    for (int k = 0; k < 5; k++) { c.solimp[k] = m.solimp[k]; g_pin(c.solimp[k]); }
-    for (int k = 0; k < 3; k++) { c.solimp_inv[k] = m.solimp_inv[k]; g_pin(c.solimp_inv[k]); }
-    c.iterations = m.iterations; c.ls_iterations = m.ls_iterations;
-    g_pin(c.root_z0); g_pin(c.gravity_z); g_pin(c.solK); g_pin(c.solB); g_pin(c.meaninertia); g_pin(c.tolerance); g_pin(c.ls_tolerance);
-    g_pin(c.ls_reltol); g_pin(c.tol_rel); g_pin(c.nvf); g_pin(c.scale); g_pin(c.iterations); g_pin(c.ls_iterations);
-}
+template <typename T> __device__ __forceinline__ void g_pin(T& x) { DL_VPIN(x); }
 
-// build-defined dynamics randomisation of one walker (the reference's dynamics_randomization is a stub,
-// drloco/mujoco/mimic_env.py:492-524; BASELINE config 5): scale of all body masses / inertias, sliding friction of
-// the floor, world-frame push force at the torso's centre of mass ([3P] xfrc_applied)
-template <typename T> struct GWalk { T mscale, floor_mu; V3<T> push; bool pushed; };
-
-template <typename T> struct GCtx {
-    DL_LDS T* wb;                        // walker's LDS region
-    const DL_CONST GModel<T>* m;         // uniform scalars only on the hot path
-    int j;                               // lane in the row
-    const GLane<T>* ln;                  // this lane's preloaded model data
-    const GConst<T>* c;                  // pinned uniform scalars
-    const GWalk<T>* wk;                  // this walker's randomisation
-};
 template <typename T> __device__ __forceinline__ V3<T> ld3(DL_LDS T* p, int stride) { return {p[0], p[stride], p[2 * stride]}; }
 // four consecutive, 16-byte aligned LDS words as one ds_read_b128 / ds_write_b128 (float); plain accesses for double
 template <typename T> struct Q4 { T a, b, c, d; };
+#if !defined(DL_GROUP_EMU)
 __device__ __forceinline__ Q4<float> ld4(const DL_LDS float* p) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 v = *(const DL_LDS f4*)p;
@@ -221,6 +246,10 @@ __device__ __forceinline__ void st4(DL_LDS float* p, float a, float b, float c, 
     f4 v; v.x = a; v.y = b; v.z = c; v.w = d;
     *(DL_LDS f4*)p = v;
 }
+#else
+__device__ __forceinline__ Q4<float> ld4(const DL_LDS float* p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void st4(DL_LDS float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+#endif
 __device__ __forceinline__ Q4<double> ld4(const DL_LDS double* p) { return {p[0], p[1], p[2], p[3]}; }
 __device__ __forceinline__ void st4(DL_LDS double* p, double a, double b, double c, double d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
@@ -229,15 +258,13 @@ __device__ __forceinline__ void st4(DL_LDS double* p, double a, double b, double
 template <int K> __device__ __forceinline__ float rbcast(float x) { return dpp_f<0x150 + K>(x); }
 template <int K> __device__ __forceinline__ double rbcast(double x) { return dpp_f<0x150 + K>(x); }
 
+#if !defined(DL_GROUP_EMU)
 // d += bcast_K(a) * b  (SIGN = +1)  or  d -= bcast_K(a) * b  (SIGN = -1).  float: ONE instruction, v_fmac_f32_dpp with the
 // row broadcast folded into src0 (the compiler only folds DPP into add/mul).  The DPP read of `a` needs two wait states
 // after the VALU write of `a`; inline asm is opaque to the hazard recogniser, so callers fence with g_dpp_ready(a).
 template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(float& d, float a, float b) {
     if constexpr (SIGN > 0) asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
     else asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
-}
-template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
-    if constexpr (SIGN > 0) d += rbcast<K>(a) * b; else d -= rbcast<K>(a) * b;
 }
 // d += dpp<CTRL>(a) * b for the row shifts of the segmented scans (lanes without a source lane read 0)
 #define DL_FMAC_DPP_CASE(code, text) \
@@ -247,7 +274,6 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp(float& d, float a, 
     DL_FMAC_DPP_CASE(0x101, "row_shl:1") DL_FMAC_DPP_CASE(0x102, "row_shl:2") DL_FMAC_DPP_CASE(0x104, "row_shl:4") DL_FMAC_DPP_CASE(0x108, "row_shl:8")
 }
 #undef DL_FMAC_DPP_CASE
-template <int CTRL> __device__ __forceinline__ void fmac_dpp(double& d, double a, double b) { d += dpp_f<CTRL>(a) * b; }
 // x += dpp<CTRL>(x) * b with x as destination AND DPP source of the same instruction (no register copy)
 #define DL_FMAC_SELF_CASE(code, text) \
     if constexpr (CTRL == code) asm("v_fmac_f32_dpp %0, %0, %1 " text " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x) : "v"(b));
@@ -256,11 +282,9 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, floa
     DL_FMAC_SELF_CASE(0x101, "row_shl:1") DL_FMAC_SELF_CASE(0x102, "row_shl:2") DL_FMAC_SELF_CASE(0x104, "row_shl:4") DL_FMAC_SELF_CASE(0x108, "row_shl:8")
 }
 #undef DL_FMAC_SELF_CASE
-template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(double& x, double b) { x += dpp_f<CTRL>(x) * b; }
 template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) {
     asm("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
-template <int K> __device__ __forceinline__ void fmac_bcast_self(double& x, double b) { x += rbcast<K>(x) * b; }
 __device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
 // one wait for a whole group of values that are about to be read through DPP
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) {
@@ -268,60 +292,133 @@ template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) 
     else if constexpr (NV == 16) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
     else { for (int i = 0; i < NV; i++) asm volatile("s_nop 1" : "+v"(x[i])); }
 }
+#else
+// host emulation: the generic forms (a DPP read followed by a multiply-add)
+template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(float& d, float a, float b) { if constexpr (SIGN > 0) d += rbcast<K>(a) * b; else d -= rbcast<K>(a) * b; }
+template <int CTRL> __device__ __forceinline__ void fmac_dpp(float& d, float a, float b) { d += dpp_f<CTRL>(a) * b; }
+template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, float b) { x += dpp_f<CTRL>(x) * b; }
+template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) { x += rbcast<K>(x) * b; }
+__device__ __forceinline__ void g_dpp_ready(float&) {}
+template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&)[NV]) {}
+#endif
+template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
+    if constexpr (SIGN > 0) d += rbcast<K>(a) * b; else d -= rbcast<K>(a) * b;
+}
+template <int CTRL> __device__ __forceinline__ void fmac_dpp(double& d, double a, double b) { d += dpp_f<CTRL>(a) * b; }
+template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(double& x, double b) { x += dpp_f<CTRL>(x) * b; }
+template <int K> __device__ __forceinline__ void fmac_bcast_self(double& x, double b) { x += rbcast<K>(x) * b; }
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(double (&)[NV]) {}
 __device__ __forceinline__ void g_dpp_ready(double&) {}
 
+// ------------------------------------------------------------------------------------------
+// Uniform model scalars of the hot path, read ONCE per kernel and pinned in VGPRs (the empty asm makes the values
+// opaque: the compiler would otherwise re-issue the scalar loads inside the solver loops and wait for each --
+// s_waitcnt lgkmcnt(0) also drains the LDS queue).  VGPRs are plentiful at one wave per SIMD.
+template <typename T, typename TP> struct GConst {
+    using D = GD<TP>;
+    T body_pos[D::MAXB][3], root_z0, gravity_z, solK, solB, solimp[5], solimp_inv[3], meaninertia, tolerance, ls_tolerance, ls_reltol, tol_rel, scale, nvf;
+    T xs_qpos0[D::NXA], xs_damping[D::NXA], xs_armature[D::NXA];
+    int iterations, ls_iterations;
+};
+template <typename T, typename TP>
+__device__ __forceinline__ void g_load_const(const DL_CONST GModel<T, TP>& m, GConst<T, TP>& c) {
+    if constexpr (GD<TP>::PIN_ALL) for (int b = 0; b < GD<TP>::MAXB; b++) for (int k = 0; k < 3; k++) { c.body_pos[b][k] = b < m.nb ? m.body_pos[b][k] : T(0); g_pin(c.body_pos[b][k]); }
+    c.root_z0 = m.root_z0; c.gravity_z = m.gravity_z; c.solK = m.solK; c.solB = m.solB; c.meaninertia = m.meaninertia;
+    c.tolerance = m.tolerance; c.ls_tolerance = m.ls_tolerance; c.ls_reltol = m.ls_reltol; c.tol_rel = m.tol_rel;
+    c.nvf = T(m.nv); c.scale = T(1) / (m.meaninertia * c.nvf);
+    if constexpr (GD<TP>::PIN_ALL) {
+        for (int k = 0; k < 5; k++) { c.solimp[k] = m.solimp[k]; g_pin(c.solimp[k]); }
+        for (int k = 0; k < 3; k++) { c.solimp_inv[k] = m.solimp_inv[k]; g_pin(c.solimp_inv[k]); }
+    }
+    for (int t = 0; t < GD<TP>::NXA; t++) {
+        c.xs_qpos0[t] = m.xs_qpos0[t]; c.xs_damping[t] = m.xs_damping[t]; c.xs_armature[t] = m.xs_armature[t];
+        g_pin(c.xs_qpos0[t]); g_pin(c.xs_damping[t]); g_pin(c.xs_armature[t]);
+    }
+    c.iterations = m.iterations; c.ls_iterations = m.ls_iterations;
+    g_pin(c.root_z0); g_pin(c.gravity_z); g_pin(c.solK); g_pin(c.solB); g_pin(c.meaninertia); g_pin(c.tolerance); g_pin(c.ls_tolerance);
+    g_pin(c.ls_reltol); g_pin(c.tol_rel); g_pin(c.nvf); g_pin(c.scale); g_pin(c.iterations); g_pin(c.ls_iterations);
+}
 
+// build-defined dynamics randomisation of one walker (the reference's dynamics_randomization is a stub,
+// drloco/mujoco/mimic_env.py:492-524; BASELINE config 5): scale of all body masses / inertias, sliding friction of
+// the floor, world-frame push force at the torso's centre of mass ([3P] xfrc_applied)
+template <typename T> struct GWalk { T mscale, floor_mu; V3<T> push; bool pushed; };
+
+template <typename T, typename TP> struct GCtx {
+    DL_LDS T* wb;                                // walker's LDS region
+    const DL_CONST GModel<T, TP>* m;             // uniform scalars only on the hot path
+    int j;                                       // lane in the row
+    const GLane<T, GD<TP>::NPASS>* ln;           // this lane's preloaded model data
+    const GConst<T, TP>* c;                      // pinned uniform scalars
+    const GWalk<T>* wk;                          // this walker's randomisation
+};
 
 // ------------------------------------------------------------------------------------------
-// Compile-time topology for the lane-per-dof layout.  The dof order of a model is topological and mostly
-// contiguous: a "run" is a maximal sequence ..., j-1, j with dof_parent(j) == j-1 (straight walker: root + right
-// leg = dofs 0..9, left leg = 10..13 hanging off dof 5).  Sums over a dof's ancestor chain / over its subtree
-// are then segmented scans inside the runs (row_shr / row_shl DPP steps) plus one broadcast per run boundary.
+// Compile-time topology for the lane-per-dof layout (lane l <-> dof l + NX).  The dof order of a model is topological
+// and mostly contiguous: a "run" is a maximal sequence ..., l-1, l with parent(l) == l-1 (straight walker: root + right
+// leg = lanes 0..9, left leg = 10..13 hanging off lane 5; 19-dof walker: root rotations + lumbar = lanes 0..5, the legs
+// = 6..10 and 11..15 hanging off lane 2).  Sums over a dof's ancestor chain / over its subtree are then segmented
+// scans inside the runs (row_shr / row_shl DPP steps) plus one broadcast per run boundary.
 template <typename TP> struct GTopoTab {
-    uint32_t anc[GL];        // bit a: dof a is on the root -> j chain (incl. j)
-    uint32_t bodies[GL];     // bit b: dof j moves body b
-    int32_t rs[GL], re[GL];  // first / last dof of the run of j
-    int32_t last[GL];        // j is the last dof of its body
+    uint32_t anc[GL];        // bit a: lane a is on the root -> l chain (incl. l)
+    uint32_t bodies[GL];     // bit b: the dof of lane l moves body b
+    int32_t rs[GL], re[GL];  // first / last lane of the run of l
+    int32_t last[GL];        // l is the last dof of its body
 };
 template <typename TP> constexpr GTopoTab<TP> g_make_topo() {
+    constexpr int NX = GD<TP>::NX, NL = GD<TP>::NL;
     GTopoTab<TP> t{};
     for (int j = 0; j < GL; j++) { t.anc[j] = 0; t.bodies[j] = 0; t.rs[j] = j; t.re[j] = j; t.last[j] = 0; }
-    for (int j = 0; j < TP::NV; j++) {
-        for (int a = 0; a < TP::NV; a++) if (TP::dof_anc(j, a)) t.anc[j] |= 1u << a;
-        for (int b = 1; b < TP::NB; b++) if (TP::body_anc(b, j)) t.bodies[j] |= 1u << b;
-        int r = j; while (r > 0 && TP::dof_parent(r) == r - 1) r--;
+    for (int j = 0; j < NL; j++) {
+        for (int a = 0; a < NL; a++) if (TP::dof_anc(j + NX, a + NX)) t.anc[j] |= 1u << a;
+        for (int b = 1; b < TP::NB; b++) if (TP::body_anc(b, j + NX)) t.bodies[j] |= 1u << b;
+        int r = j; while (r > 0 && TP::dof_parent(r + NX) == r + NX - 1) r--;
         t.rs[j] = r;
-        int e = j; while (e + 1 < TP::NV && TP::dof_parent(e + 1) == e) e++;
+        int e = j; while (e + 1 < NL && TP::dof_parent(e + 1 + NX) == e + NX) e++;
         t.re[j] = e;
-        t.last[j] = (j == TP::NV - 1 || TP::dof_body(j + 1) != TP::dof_body(j)) ? 1 : 0;
+        t.last[j] = (j == NL - 1 || TP::dof_body(j + 1 + NX) != TP::dof_body(j + NX)) ? 1 : 0;
     }
     return t;
 }
 template <typename TP> struct GTopo {
+    static constexpr int NX = GD<TP>::NX, NL = GD<TP>::NL;
     static constexpr GTopoTab<TP> tab = g_make_topo<TP>();
-    static constexpr bool dof_first(int j) { return j == 0 || TP::dof_body(j - 1) != TP::dof_body(j); }
-    static constexpr bool run_start(int j) { return j == 0 || TP::dof_parent(j) != j - 1; }
-    static constexpr int max_run() { int m = 1; for (int j = 0; j < TP::NV; j++) { const int l = tab.re[j] - tab.rs[j] + 1; if (l > m) m = l; } return m; }
-    // Twin branches (two legs): a run b.. that hangs off dof P and has the same shape (length, joint types / axes, body boundaries) as
-    // the dofs P + 1.. that continue P's own run.  Their hinges act on disjoint sets of lanes, so the kinematics applies hinge a + i and
-    // its twin b + i in ONE rotation step (the lane takes the sine / cosine of whichever of the two is on its chain).
+    // per-lane views of the dof tables
+    static constexpr int l_type(int l) { return TP::dof_type(l + NX); }
+    static constexpr int l_axis(int l) { return TP::dof_axis(l + NX); }
+    static constexpr int l_body(int l) { return TP::dof_body(l + NX); }
+    static constexpr int l_parent(int l) { const int p = TP::dof_parent(l + NX) - NX; return p < 0 ? -1 : p; }
+    static constexpr bool dof_first(int l) { return l + NX == 0 || TP::dof_body(l + NX - 1) != TP::dof_body(l + NX); }
+    static constexpr bool run_start(int l) { return l == 0 || l_parent(l) != l - 1; }
+    static constexpr int max_run() { int m = 1; for (int j = 0; j < NL; j++) { const int l = tab.re[j] - tab.rs[j] + 1; if (l > m) m = l; } return m; }
+    // Twin branches (two legs): a run b.. that hangs off lane P and has the same shape (length, joint types / axes, body
+    // boundaries) as an earlier sequence a.. of the same length below the same parent -- either the lanes P + 1.. that continue
+    // P's own run (straight walker) or an earlier run that also hangs off P (19-dof walker).  Their hinges act on disjoint sets
+    // of lanes, so the kinematics applies hinge a + i and its twin b + i in ONE rotation step (a lane takes the sine / cosine
+    // of whichever of the two is on its chain).
     static constexpr int run_len(int a) { return tab.re[a] - tab.rs[a] + 1; }
-    static constexpr int twin_of_run(int b) {    // b: start of a run (> 0) -> first dof of its twin segment, or -1
-        const int P = TP::dof_parent(b), L = run_len(b), a = P + 1;
-        if (P < 0 || a + L - 1 > tab.re[P] || a + L - 1 >= b) return -1;
+    static constexpr bool same_shape(int a, int b, int L) {
         for (int i = 0; i < L; i++) {
-            if (TP::dof_type(a + i) != 1 || TP::dof_type(b + i) != 1 || TP::dof_axis(a + i) != TP::dof_axis(b + i)) return -1;
-            if (dof_first(a + i) != dof_first(b + i)) return -1;
+            if (l_type(a + i) != 1 || l_type(b + i) != 1 || l_axis(a + i) != l_axis(b + i)) return false;
+            if (dof_first(a + i) != dof_first(b + i)) return false;
         }
-        return a;
+        return true;
     }
-    static constexpr bool is_follower(int d) {   // dof d is applied together with an earlier twin
+    static constexpr int twin_of_run(int b) {    // b: start of a run (> 0) -> first lane of its twin segment, or -1
+        const int P = l_parent(b), L = run_len(b);
+        if (P < 0) return -1;
+        const int a = P + 1;                     // continuation of the parent's run
+        if (a + L - 1 <= tab.re[P] && a + L - 1 < b && same_shape(a, b, L)) return a;
+        for (int r = P + 1; r < b; r++)          // an earlier run below the same parent
+            if (run_start(r) && l_parent(r) == P && run_len(r) == L && twin_of_run(r) < 0 && same_shape(r, b, L)) return r;
+        return -1;
+    }
+    static constexpr bool is_follower(int d) {   // lane d is applied together with an earlier twin
         const int b = tab.rs[d];
         return b > 0 && run_start(b) && twin_of_run(b) >= 0;
     }
-    static constexpr int partner(int d) {        // the dof applied in the same step as dof d, or -1
-        for (int b = d + 1; b < TP::NV; b++) {
+    static constexpr int partner(int d) {        // the lane applied in the same step as lane d, or -1
+        for (int b = d + 1; b < NL; b++) {
             if (!run_start(b)) continue;
             const int a = twin_of_run(b);
             if (a >= 0 && d >= a && d < a + run_len(b)) return b + (d - a);
@@ -333,6 +430,10 @@ template <typename TP> struct GTopo {
         for (int j = 0; j < TP::NV; j++) { if (TP::dof_type(j) == 1) hinge = true; else if (hinge || TP::dof_body(j) != 1) return false; }
         return true;
     }
+    static constexpr bool rooted() {             // lane 0 is an ancestor of every lane (its subtree is the whole walker)
+        for (int j = 0; j < NL; j++) if (!(tab.anc[j] & 1u)) return false;
+        return true;
+    }
 };
 // this lane's topology words (registers)
 template <typename T> struct GLaneTopo {
@@ -340,7 +441,7 @@ template <typename T> struct GLaneTopo {
     int rs;
     bool last;
     T ms[4], ns[4];          // 1/0: lane j - 2^k (j + 2^k) belongs to the same run
-    T ancf[GL];              // 1/0: dof a is on the root -> j chain.  Float masks in VGPRs: the boolean form lives in SGPR pairs,
+    T ancf[GL];              // 1/0: lane a is on the root -> j chain.  Float masks in VGPRs: the boolean form lives in SGPR pairs,
                              // which the step kernel has to spill (two v_readlane per use inside the evaluation)
 };
 template <typename T, typename TP> __device__ __forceinline__ void g_lane_topo(int j, GLaneTopo<T>& lt) {
@@ -352,7 +453,7 @@ template <typename T, typename TP> __device__ __forceinline__ void g_lane_topo(i
 #pragma unroll
     for (int a = 0; a < GL; a++) { lt.ancf[a] = ((lt.anc >> a) & 1u) ? T(1) : T(0); g_pin(lt.ancf[a]); }
 }
-// x_j <- sum over the dofs a on the root -> j chain of x_a, for NVAL values at once (one v_fmac_f32_dpp per value
+// x_j <- sum over the lanes a on the root -> j chain of x_a, for NVAL values at once (one v_fmac_f32_dpp per value
 // and scan step)
 template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_chain_sum_n(T (&x)[NVAL], int j, const GLaneTopo<T>& lt) {
     constexpr int MR = GTopo<TP>::max_run();
@@ -374,10 +475,10 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_c
 #pragma unroll
         for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x118>(x[i], lt.ms[3]);
     }
-    static_for<TP::NV>([&](auto ri) {
+    static_for<GD<TP>::NL>([&](auto ri) {
         constexpr int r = ri.value;
         if constexpr (r > 0 && GTopo<TP>::run_start(r)) {
-            constexpr int P = TP::dof_parent(r);
+            constexpr int P = GTopo<TP>::l_parent(r);
             const T f = lt.rs == r ? T(1) : T(0);
             g_dpp_ready_n<NVAL>(x);
 #pragma unroll
@@ -385,9 +486,9 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_c
         }
     });
 }
-// x_j <- sum over the dofs d of the subtree of j (j on the root -> d chain) of x_d
+// x_j <- sum over the lanes d of the subtree of j (j on the root -> d chain) of x_d
 template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_subtree_sum_n(T (&x)[NVAL], int j, const GLaneTopo<T>& lt) {
-    constexpr int MR = GTopo<TP>::max_run();
+    constexpr int MR = GTopo<TP>::max_run(), NL = GD<TP>::NL;
     g_dpp_ready_n<NVAL>(x);
 #pragma unroll
     for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x101>(x[i], lt.ns[0]);
@@ -406,10 +507,10 @@ template <typename T, typename TP, int NVAL> __device__ __forceinline__ void g_s
 #pragma unroll
         for (int i = 0; i < NVAL; i++) fmac_dpp_self<0x108>(x[i], lt.ns[3]);
     }
-    static_for<TP::NV>([&](auto ri) {
-        constexpr int r = TP::NV - 1 - ri.value;           // deepest runs first
+    static_for<NL>([&](auto ri) {
+        constexpr int r = NL - 1 - ri.value;               // deepest runs first
         if constexpr (r > 0 && GTopo<TP>::run_start(r)) {
-            constexpr int P = TP::dof_parent(r);
+            constexpr int P = GTopo<TP>::l_parent(r);
             constexpr uint32_t ancP = GTopo<TP>::tab.anc[P];
             const T f = ((ancP >> j) & 1u) ? T(1) : T(0);
             g_dpp_ready_n<NVAL>(x);
@@ -428,52 +529,63 @@ template <int IDX, typename T> __device__ __forceinline__ void rot_axis_c(V3<T>&
 // what a dof lane keeps in registers after the kinematics
 template <typename T> struct GKin { V3<T> X, Y, Z, pos, axis; T rootz; };
 
-// [3P] mj_kinematics.  Lane j ends with the frame after dof j (= the frame of its body if j is the body's last
+// [3P] mj_kinematics.  Lane j ends with the frame after its dof (= the frame of its body if that is the body's last
 // dof), the origin of its body relative to the root origin, and its joint axis.  Every lane runs the SAME
 // straight-line code over all hinges in dof order; hinges that are not on the lane's chain enter as the identity
 // (s, c) = (0, 1), so no lane waits for another one and nothing goes through LDS except the body frames that the
-// collision stage reads (BFR) and rootz (MISC[0]).
+// collision stage reads (BFR) and rootz (MISC[0]).  qx: the replicated root translations (only the vertical one
+// matters: positions are relative to the root origin).
 template <typename T, typename TP>
-__device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T q, GKin<T>& k) {
+__device__ __forceinline__ void g_fk(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, const GX<T, GD<TP>::NX>& qx, GKin<T>& k) {
     static_assert(GTopo<TP>::slides_first(), "slide joints must be world-aligned root joints");
-    using Ld = GLds;
-    const DL_CONST GModel<T>& m = *g.m;
+    using Ld = GLds<TP>;
+    using TPL = GTopo<TP>;
+    constexpr int NL = GD<TP>::NL, NX = GD<TP>::NX;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    const GLane<T>& ln = *g.ln;
-    const T dq = (j < TP::NV) ? q - ln.qpos0 : T(0);
+    const auto& ln = *g.ln;
+    const T dq = (j < NL) ? q - ln.qpos0 : T(0);
     T s = T(0), c = T(1);
-    if (j < TP::NV && ln.type == 1) dl_sincos(ln.sign * dq, s, c);
+    if (j < NL && ln.type == 1) dl_sincos(ln.sign * dq, s, c);
     const T cm1 = c - T(1);
     V3<T> X = mk<T>(1, 0, 0), Y = mk<T>(0, 1, 0), Z = mk<T>(0, 0, 1), pos = mk<T>(0, 0, 0);
     T rootz = g.c->root_z0;
-    static_for<TP::NV>([&](auto ai) {
+    // body offsets: pinned registers, or (19-dof walker) scalar loads of this evaluation -- the opaque pointer keeps them from
+    // being hoisted out of the RK4 loops into registers the kernel does not have
+    const DL_CONST GModel<T, TP>* mc = g.m;
+    if constexpr (!GD<TP>::PIN_ALL) DL_SPIN(mc);
+    auto body_pos = [&](int b, int kk) -> T { if constexpr (GD<TP>::PIN_ALL) return g.c->body_pos[b][kk]; else return mc->body_pos[b][kk]; };
+    static_for<NX>([&](auto ti) {
+        constexpr int t = ti.value;
+        if constexpr (TP::dof_axis(t) == 2) rootz += T(TP::dof_sign(t)) * (qx.x[t] - g.c->xs_qpos0[t]);
+    });
+    static_for<NL>([&](auto ai) {
         constexpr int a = ai.value;
-        if constexpr (GTopo<TP>::is_follower(a)) return;   // applied together with its twin (the other leg)
-        constexpr int p = GTopo<TP>::partner(a);
+        if constexpr (TPL::is_follower(a)) return;   // applied together with its twin (the other leg)
+        constexpr int p = TPL::partner(a);
         const T f = lt.ancf[a];                           // 1 where hinge / body a is on this lane's chain, else the identity
-        if constexpr (GTopo<TP>::dof_first(a) && TP::dof_body(a) != 1) {
-            constexpr int b = TP::dof_body(a);
-            T bx = f * g.c->body_pos[b][0], by = f * g.c->body_pos[b][1], bz = f * g.c->body_pos[b][2];
+        if constexpr (TPL::dof_first(a) && TPL::l_body(a) != 1) {
+            constexpr int b = TPL::l_body(a);
+            T bx = f * body_pos(b, 0), by = f * body_pos(b, 1), bz = f * body_pos(b, 2);
             if constexpr (p >= 0) {
-                constexpr int bp = TP::dof_body(p);
+                constexpr int bp = TPL::l_body(p);
                 const T fp = lt.ancf[p];
-                bx += fp * g.c->body_pos[bp][0]; by += fp * g.c->body_pos[bp][1]; bz += fp * g.c->body_pos[bp][2];
+                bx += fp * body_pos(bp, 0); by += fp * body_pos(bp, 1); bz += fp * body_pos(bp, 2);
             }
             pos = pos + bx * X + by * Y + bz * Z;
         }
-        if constexpr (TP::dof_type(a) == 1) {
+        if constexpr (TPL::l_type(a) == 1) {
             T sa = rbcast<a>(s) * f, ca = T(1) + rbcast<a>(cm1) * f;
             if constexpr (p >= 0) { const T fp = lt.ancf[p]; sa += rbcast<p>(s) * fp; ca += rbcast<p>(cm1) * fp; }
-            rot_axis_c<TP::dof_axis(a)>(X, Y, Z, sa, ca);
-        } else if constexpr (TP::dof_axis(a) == 2) {
-            rootz += T(TP::dof_sign(a)) * rbcast<a>(dq);
+            rot_axis_c<TPL::l_axis(a)>(X, Y, Z, sa, ca);
+        } else if constexpr (TPL::l_axis(a) == 2) {
+            rootz += T(TP::dof_sign(a + NX)) * rbcast<a>(dq);
         }
     });
     const int idx = ln.axis;
     const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
     k.X = X; k.Y = Y; k.Z = Z; k.pos = pos; k.axis = ln.sign * col; k.rootz = rootz;
-    if (j < TP::NV && lt.last) {
+    if (j < NL && lt.last) {
         DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
         st4(f, X.x, X.y, X.z, Y.x); st4(f + 4, Y.y, Y.z, Z.x, Z.y); st4(f + 8, Z.z, pos.x, pos.y, pos.z);
     }
@@ -483,10 +595,10 @@ __device__ __forceinline__ void g_fk(const GCtx<T>& g, const GLaneTopo<T>& lt, T
 
 // height of the lowest foot-sole site above the floor at the configuration last passed to g_fk
 // (reset_model's COM-z adjustment, drloco/mujoco/mimic_env.py:547-559); identical in the 16 lanes of the row
-template <typename T>
-__device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
-    using Ld = GLds;
-    const DL_CONST GModel<T>& m = *g.m;
+template <typename T, typename TP>
+__device__ __forceinline__ T g_lowest_site(const GCtx<T, TP>& g) {
+    using Ld = GLds<TP>;
+    const DL_CONST GModel<T, TP>& m = *g.m;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     T low = T(1e30);
@@ -503,24 +615,35 @@ __device__ __forceinline__ T g_lowest_site(const GCtx<T>& g) {
     return low;
 }
 
+// the smooth dynamics of a walker as its lanes hold them
+template <typename T, typename TP> struct GSmooth {
+    static constexpr int NXA = GD<TP>::NXA;
+    T mrow[GL];              // row j of M over the lane dofs (diagonal entry: see mcorr)
+    T mdiag, mcorr;
+    T smooth;                // qfrc_smooth of the lane's dof
+    // replicated root translations (NX > 0): M[j][t] of this lane, M[t][t] (the translations are mutually orthogonal: M[t][t'] = 0), qfrc_smooth[t]
+    T mxl[NXA], mxx[NXA], smoothx[NXA];
+};
+
 // [3P] mj_kinematics + mj_crb + mj_rne + passive/actuator forces, one dof per lane, everything in registers:
 //   spatial quantities in world orientation about the root origin (parent <-> child transforms are the identity),
 //   body twist / velocity-product acceleration = chain sums of the joint contributions (segmented scans),
 //   spatial inertia + inertial wrench of a body on the lane of its last dof,
 //   composite inertia / wrench = subtree sums, bias_j = S_j . W_j, M[j][a] = S_a . (Ic_j S_j) for a on the chain of j.
 // The lower triangle of M is mirrored through LDS once so that every lane holds its full row (mrow).
-// Out: mrow, qfrc_smooth_j; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
+// The replicated root translations are ancestors of every lane: their velocity enters every twist, their composite
+// inertia / wrench is the whole walker's (the subtree of lane 0), M[j][t] = S_t . (Ic_j S_j) is one entry per lane.
+// Out: sm; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
 template <typename T, typename TP>
-__device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, GKin<T>& k, T (&mrow)[GL], T& mdiag, T& mcorr) {
-    using Ld = GLds;
-    constexpr int NV = TP::NV;
-    const DL_CONST GModel<T>& m = *g.m;
+__device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx,
+                                                  GKin<T>& k, GSmooth<T, TP>& sm) {
+    using Ld = GLds<TP>;
+    constexpr int NL = GD<TP>::NL, NX = GD<TP>::NX;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    const GLane<T>& ln = *g.ln;
-    g_fk<T, TP>(g, lt, q, k);
-    const bool isdof = j < NV;
-    mdiag = T(1);
+    const auto& ln = *g.ln;
+    g_fk<T, TP>(g, lt, q, qx, k);
+    const bool isdof = j < NL;
     // motion subspace of dof j and its joint velocity contribution
     SV<T> S;
     if (ln.type == 0) { S.w = mk<T>(0, 0, 0); S.v = k.axis; } else { S.w = k.axis; S.v = cross(k.pos, k.axis); }
@@ -529,9 +652,10 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     const SV<T> vJ = {qd * S.w, qd * S.v};
     T sv[6] = {vJ.w.x, vJ.w.y, vJ.w.z, vJ.v.x, vJ.v.y, vJ.v.z};
     g_chain_sum_n<T, TP, 6>(sv, j, lt);
-    const SV<T> vel = {mk<T>(sv[0], sv[1], sv[2]), mk<T>(sv[3], sv[4], sv[5])};
+    SV<T> vel = {mk<T>(sv[0], sv[1], sv[2]), mk<T>(sv[3], sv[4], sv[5])};
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; vcomp<TP::dof_axis(t)>(vel.v) += T(TP::dof_sign(t)) * vx.x[t]; });
     // velocity-product acceleration: sum over the chain of (twist of the parent) x (joint velocity); the twist of
-    // the parent is vel - vJ and vJ x vJ = 0
+    // the parent is vel - vJ and vJ x vJ = 0 (a translation of the root contributes nothing: its parent does not rotate)
     const SV<T> cJ = {cross(vel.w, vJ.w), cross(vel.w, vJ.v) + cross(vel.v, vJ.w)};
     T sa[6] = {cJ.w.x, cJ.w.y, cJ.w.z, cJ.v.x, cJ.v.y, cJ.v.z};
     g_chain_sum_n<T, TP, 6>(sa, j, lt);
@@ -577,33 +701,48 @@ __device__ __forceinline__ T g_smooth_dynamics(const GCtx<T>& g, const GLaneTopo
     g_dpp_ready_n<6>(Sr);
     T ml[GL];
 #pragma unroll
-    for (int a = NV; a < GL; a++) ml[a] = T(0);
-    static_for<NV>([&](auto ai) {
+    for (int a = NL; a < GL; a++) ml[a] = T(0);
+    static_for<NL>([&](auto ai) {
         constexpr int a = ai.value;
         T mij = T(0);
-        if constexpr (TP::dof_type(a) == 1) { fmac_bcast<a, 1>(mij, Sr[0], f.w.x); fmac_bcast<a, 1>(mij, Sr[1], f.w.y); fmac_bcast<a, 1>(mij, Sr[2], f.w.z); }
+        if constexpr (GTopo<TP>::l_type(a) == 1) { fmac_bcast<a, 1>(mij, Sr[0], f.w.x); fmac_bcast<a, 1>(mij, Sr[1], f.w.y); fmac_bcast<a, 1>(mij, Sr[2], f.w.z); }
         fmac_bcast<a, 1>(mij, Sr[3], f.v.x); fmac_bcast<a, 1>(mij, Sr[4], f.v.y); fmac_bcast<a, 1>(mij, Sr[5], f.v.z);
         ml[a] = mij * lt.ancf[a];
     });
     {
         const T mjj = sdot(S, f);
-        mdiag = isdof ? mjj + ln.armature : T(1);
-        mcorr = isdof ? ln.armature - mjj : T(0);
+        sm.mdiag = isdof ? mjj + ln.armature : T(1);
+        sm.mcorr = isdof ? ln.armature - mjj : T(0);
         DL_LDS T* row = wb + Ld::MM + j * Ld::MS;
         st4(row, ml[0], ml[1], ml[2], ml[3]); st4(row + 4, ml[4], ml[5], ml[6], ml[7]);
         st4(row + 8, ml[8], ml[9], ml[10], ml[11]); st4(row + 12, ml[12], ml[13], ml[14], ml[15]);
     }
     g_sync<T>();
 #pragma unroll
-    for (int a = 0; a < GL; a++) mrow[a] = (a < NV) ? ml[a] + wb[Ld::MM + a * Ld::MS + j] : T(0);
+    for (int a = 0; a < GL; a++) sm.mrow[a] = (a < NL) ? ml[a] + wb[Ld::MM + a * Ld::MS + j] : T(0);
     // [3P] xfrc_applied on the torso (body 1): J^T of a world-frame force at its centre of mass
     T push_q = T(0);
     if (g.wk->pushed) {
-        constexpr int RL = TP::body_last_dof(1);
+        constexpr int RL = TP::body_last_dof(1) - NX;
         const V3<T> pc = mk<T>(rbcast<RL>(com.x), rbcast<RL>(com.y), rbcast<RL>(com.z));
         if ((lt.bodies >> 1) & 1u) push_q = dot(S.w, cross(pc, g.wk->push)) + dot(S.v, g.wk->push);
     }
-    return isdof ? -ln.damping * v - bias + ctrl_force + push_q : T(0);
+    sm.smooth = isdof ? -ln.damping * v - bias + ctrl_force + push_q : T(0);
+    if constexpr (NX > 0) {
+        static_assert(GTopo<TP>::rooted(), "lane 0 must be the root of the lane tree");
+        // total mass and wrench of the walker = composite quantities of lane 0
+        const T mtot = rbcast<0>(Ic.m);
+        const V3<T> Wv = mk<T>(rbcast<0>(W.v.x), rbcast<0>(W.v.y), rbcast<0>(W.v.z));
+        static_for<NX>([&](auto ti) {
+            constexpr int t = ti.value, ax = TP::dof_axis(t);
+            const T sg = T(TP::dof_sign(t));
+            sm.mxl[t] = isdof ? sg * vcomp<ax>(f.v) : T(0);
+            sm.mxx[t] = mtot + g.c->xs_armature[t];
+            T fs = -g.c->xs_damping[t] * vx.x[t] - sg * vcomp<ax>(Wv);
+            if (g.wk->pushed) fs += sg * vcomp<ax>(g.wk->push);
+            sm.smoothx[t] = fs;
+        });
+    }
 }
 
 // 1/x: float = v_rcp_f32 + one Newton step; double = exact division
@@ -613,7 +752,7 @@ __device__ __forceinline__ float dl_rcp(float x) {
 }
 __device__ __forceinline__ double dl_rcp(double x) { return 1.0 / x; }
 // [3P] solimp sigmoid (getimpedance) with the three reciprocals of the constants taken once (GModel::solimp_inv)
-template <typename T> __device__ __forceinline__ T g_impedance(const GConst<T>& m, T pos) {
+template <typename C, typename T> __device__ __forceinline__ T g_impedance(const C& m, T pos) {
     const T x = dl_abs(pos) * m.solimp_inv[0];
     T y;
     if (m.solimp[4] == T(1)) y = x;
@@ -686,22 +825,108 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
     return x;
 }
 
+// The replicated dofs are eliminated FIRST: with the Hessian ordered [replicated | lanes], L = [[Lxx, 0], [Lxl, Lll]].
+// Lxx (NX x NX, uniform) and the pivots live in every lane, row j of Lxl in lane j; the trailing update leaves the lane block
+// for g_chol.  hxx: lower triangle of the uniform block, hxl: this lane's coupling entries H[j][t].
+template <typename T, int NXA> struct GCholX { T lxx[NXA][NXA], lxl[NXA], invd[NXA]; };
+template <typename T, int NX, int NL> __device__ __forceinline__ void g_chol_x(T (&hxx)[NX > 0 ? NX : 1][NX > 0 ? NX : 1], T (&hxl)[NX > 0 ? NX : 1], T (&h)[GL], T& hd,
+                                                                                  GCholX<T, (NX > 0 ? NX : 1)>& cx, T floor_) {
+    static_for<NX>([&](auto kk) {
+        constexpr int k = kk.value;
+        const T inv = dl_rsqrt_pivot(dl_max(hxx[k][k], floor_));
+        cx.invd[k] = inv;
+        T lik = hxl[k] * inv;                                 // L[lane j][k]
+        cx.lxl[k] = lik;
+        static_for<NX - 1 - k>([&](auto tt) { constexpr int t = k + 1 + tt.value; cx.lxx[t][k] = hxx[t][k] * inv; });
+        static_for<NX - 1 - k>([&](auto tt) {
+            constexpr int t = k + 1 + tt.value;
+            static_for<t - k>([&](auto uu) { constexpr int u = k + 1 + uu.value; hxx[t][u] -= cx.lxx[t][k] * cx.lxx[u][k]; });
+            hxl[t] -= cx.lxx[t][k] * lik;
+        });
+        hd -= lik * lik;
+        g_dpp_ready(lik);
+        static_for<NL>([&](auto aa) { constexpr int a = aa.value; fmac_bcast<a, -1>(h[a], lik, lik); });   // h[a] -= L[a][k] L[j][k]
+    });
+}
+// (L L^T) x = b for the full system: bx / xx are the replicated components (uniform), b / return value the lane's
+template <typename T, int NX, int NL> __device__ __forceinline__ T g_chol_solve_x(const GCholX<T, (NX > 0 ? NX : 1)>& cx, const T (&lo)[GL], const T (&up)[GL], T invd, T b,
+                                                                                   const T (&bx)[NX > 0 ? NX : 1], T (&xx)[NX > 0 ? NX : 1], int j) {
+    if constexpr (NX == 0) return g_chol_solve<T, NL>(lo, up, invd, b, j);
+    else {
+        T yx[NX];
+        static_for<NX>([&](auto kk) {
+            constexpr int k = kk.value;
+            T acc = bx[k];
+            static_for<k>([&](auto tt) { acc -= cx.lxx[k][tt.value] * yx[tt.value]; });
+            yx[k] = acc * cx.invd[k];
+        });
+        T bl = b;
+        static_for<NX>([&](auto kk) { bl -= cx.lxl[kk.value] * yx[kk.value]; });
+        const T x = g_chol_solve<T, NL>(lo, up, invd, bl, j);
+        T s[NX];
+        static_for<NX>([&](auto kk) { s[kk.value] = cx.lxl[kk.value] * x; });
+        gsum_n<NX>(s);
+        static_for<NX>([&](auto kk) {
+            constexpr int k = NX - 1 - kk.value;
+            T acc = yx[k] - s[k];
+            static_for<NX - 1 - k>([&](auto tt) { constexpr int t = k + 1 + tt.value; acc -= cx.lxx[t][k] * xx[t]; });
+            xx[k] = acc * cx.invd[k];
+        });
+        return x;
+    }
+}
+
+// contact-frame Jacobian of the replicated root translations: the columns are the contact frame itself (normal = floor
+// normal z, tangent 1 = (tx, ty, 0), tangent 2 = (-ty, tx, 0)), whatever body the contact is on.
+// (dn, d1, d2) += J_x xs
+template <typename T, typename TP> __device__ __forceinline__ void g_slide_jx(T tx, T ty, const T (&xs)[GD<TP>::NXA], T& dn, T& d1, T& d2) {
+    static_for<GD<TP>::NX>([&](auto ti) {
+        constexpr int t = ti.value, ax = TP::dof_axis(t);
+        const T s = T(TP::dof_sign(t)) * xs[t];
+        if constexpr (ax == 0) { d1 += tx * s; d2 -= ty * s; }
+        else if constexpr (ax == 1) { d1 += ty * s; d2 += tx * s; }
+        else dn += s;
+    });
+}
+// column t of J_x: (jn, j1, j2)
+template <typename T, typename TP, int t> __device__ __forceinline__ void g_slide_col(T tx, T ty, T& jn, T& j1, T& j2) {
+    constexpr int ax = TP::dof_axis(t);
+    const T s = T(TP::dof_sign(t));
+    if constexpr (ax == 0) { jn = T(0); j1 = s * tx; j2 = -s * ty; }
+    else if constexpr (ax == 1) { jn = T(0); j1 = s * ty; j2 = s * tx; }
+    else { jn = s; j1 = T(0); j2 = T(0); }
+}
+
+template <typename TP> using GCandMask = std::conditional_t<(GD<TP>::NPASS > 2), uint64_t, uint32_t>;
+__device__ __forceinline__ int g_popc(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int g_popc(uint64_t x) { return __popcll(x); }
 
 // ------------------------------------------------------------------------------------------
 // [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
 // Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
-template <typename T>
-__device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, T x0, int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
-    using Ld = GLds;
-    const DL_CONST GModel<T>& m = *g.m;
+// x0 / x0x = B v + a (lane / replicated dofs): the start point of the solver, folded into the rows' J a - aref.
+template <typename T, typename TP>
+__device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, T x0, const T (&x0x)[GD<TP>::NXA],
+                                                   int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
+    using Ld = GLds<TP>;
+    using CM = GCandMask<TP>;
+    constexpr int NL = GD<TP>::NL, NX = GD<TP>::NX, NPASS = GD<TP>::NPASS, MAXROW = Ld::MAXROW, MAXCON = Ld::MAXCON;
     DL_LDS T* wb = g.wb;
-    const int j = g.j, nv = m.nv;
-    const GLane<T>& ln = *g.ln;
+    const int j = g.j;
+    const auto& ln = *g.ln;
+    // collision candidates and solimp: pinned registers, or (19-dof walker) loads of this evaluation from the model block
+    GLaneCand<T, NPASS> cfetch;
+    const DL_CONST GModel<T, TP>* mc = g.m;
+    if constexpr (!GD<TP>::PIN_ALL) { int jj = j; DL_VPIN(jj); DL_SPIN(mc); cfetch = mc->lanes[jj].cand; }
+    const GLaneCand<T, NPASS>& cd = GD<TP>::PIN_ALL ? ln.cand : cfetch;
+    struct { T solimp[5], solimp_inv[3]; } simp;
+    for (int k = 0; k < 5; k++) simp.solimp[k] = GD<TP>::PIN_ALL ? g.c->solimp[k] : mc->solimp[k];
+    for (int k = 0; k < 3; k++) simp.solimp_inv[k] = GD<TP>::PIN_ALL ? g.c->solimp_inv[k] : mc->solimp_inv[k];
     const T rootz = wb[Ld::MISC + 0];
     // ---- joint limits (dof lanes), ranked by dof order through a ballot
     bool lim = false, lim_lo = false;
     T lim_dist = T(0);
-    if (j < nv && ln.limited) {
+    if (j < NL && ln.limited) {
         const T dlo = q - ln.range_lo, dhi = ln.range_hi - q;
         lim_lo = dlo < T(0);
         lim = lim_lo || dhi < T(0);
@@ -710,80 +935,90 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
     const uint32_t lmask = (uint32_t)((__ballot(lim) >> (GL * grp)) & 0xFFFFull);
     const int nlim = __popc(lmask);
     my_lim = -1; lim_sign = lim_lo ? T(1) : T(-1);
-    // ---- contact candidates: two passes of 16 (capsule ends and box corners in geom order); a candidate is a
+    // ---- contact candidates: NPASS passes of 16 (capsule ends and box corners in geom order); a candidate is a
     // constant body-local point (GLane), so the test is one frame transform + the floor distance
-    bool act[2];
-    V3<T> cp[2];
-    T cdist[2], ctx[2], cty[2];
-    int cinf[2];
+    bool act[NPASS];
+    V3<T> cp[NPASS];
+    T cdist[NPASS], ctx[NPASS], cty[NPASS];
+    int cinf[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int cinfo = ln.cinfo[pass];
+    for (int pass = 0; pass < NPASS; pass++) {
+        const int cinfo = cd.cinfo[pass];
         cinf[pass] = cinfo;
-        const int b = (cinfo >> 5) & 7;
+        const int b = (cinfo >> 5) & 15;
         DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * b;
         const Q4<T> f0 = ld4(f), f1 = ld4(f + 4), f2 = ld4(f + 8);
         const V3<T> X = mk<T>(f0.a, f0.b, f0.c), Y = mk<T>(f0.d, f1.a, f1.b), Z = mk<T>(f1.c, f1.d, f2.a), pos = mk<T>(f2.b, f2.c, f2.d);
-        const V3<T> pt = pos + ln.cpl[pass][0] * X + ln.cpl[pass][1] * Y + ln.cpl[pass][2] * Z;
-        const T relz = ln.crl[pass][0] * X.z + ln.crl[pass][1] * Y.z + ln.crl[pass][2] * Z.z;
-        T tx = ln.cal[pass][0] * X.x + ln.cal[pass][1] * Y.x + ln.cal[pass][2] * Z.x;
-        T ty = ln.cal[pass][0] * X.y + ln.cal[pass][1] * Y.y + ln.cal[pass][2] * Z.y;
+        const V3<T> pt = pos + cd.cpl[pass][0] * X + cd.cpl[pass][1] * Y + cd.cpl[pass][2] * Z;
+        const T relz = cd.crl[pass][0] * X.z + cd.crl[pass][1] * Y.z + cd.crl[pass][2] * Z.z;
+        T tx = cd.cal[pass][0] * X.x + cd.cal[pass][1] * Y.x + cd.cal[pass][2] * Z.x;
+        T ty = cd.cal[pass][0] * X.y + cd.cal[pass][1] * Y.y + cd.cal[pass][2] * Z.y;
         const T n2 = tx * tx + ty * ty;
         const bool box = (cinfo >> 1) & 1;
         if (n2 < T(1e-30)) { tx = box ? T(0) : T(1); ty = box ? T(1) : T(0); } else { const T inv = dl_rsqrt(n2); tx *= inv; ty *= inv; }
-        const T rad = ln.crad[pass];
+        const T rad = cd.crad[pass];
         const T dist = rootz + pt.z - rad;
         act[pass] = (cinfo & 1) && dist < T(0) && !(relz > T(0));
         cp[pass] = mk<T>(pt.x, pt.y, pt.z - (rad + T(0.5) * dist));
         cdist[pass] = dist; ctx[pass] = tx; cty[pass] = ty;
     }
     // box rule: only the first four qualifying corners of a box make contacts (mjc_PlaneBox)
-    uint32_t cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
-    for (int pass = 0; pass < 2; pass++) {
+    auto cand_mask = [&]() {
+        CM m = 0;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) m |= (CM)((__ballot(act[pass]) >> (GL * grp)) & 0xFFFFull) << (GL * pass);
+        return m;
+    };
+    CM cm = cand_mask();
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
         const int c = j + GL * pass;
         if (act[pass] && ((cinf[pass] >> 1) & 1)) {
             const int first = c - ((cinf[pass] >> 2) & 7);                             // first corner of this box in the candidate list
-            const uint32_t before = cm & ((1u << c) - 1u) & ~((1u << first) - 1u);
-            if (__popc(before) >= 4) act[pass] = false;
+            const CM before = cm & (((CM)1 << c) - (CM)1) & ~(((CM)1 << first) - (CM)1);
+            if (g_popc(before) >= 4) act[pass] = false;
         }
     }
-    cm = (uint32_t)((__ballot(act[0]) >> (GL * grp)) & 0xFFFFull) | ((uint32_t)((__ballot(act[1]) >> (GL * grp)) & 0xFFFFull) << 16);
-    const int ncon = __popc(cm);
-    // (BFR is aliased with JC, which is first written after the next g_sync: the frame reads above are complete by then)
+    cm = cand_mask();
+    const int ncon = g_popc(cm);
+    // (BFR is aliased with JC, which is first written after the next g_sync: the frame reads above are complete by then;
+    //  the rows written below overwrite the mirror block of the mass matrix, whose reads precede them in program order)
     // ---- the lane of a candidate writes the contact record AND the contact's rows (rows 4c..4c+3: D, K imp r, cleared
     // active flags): nothing about a contact waits for another lane
-    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
         const int c = j + GL * pass;
         if (act[pass]) {
-            const int slot = __popc(cm & ((1u << c) - 1u));
-            const T mu = dl_max(ln.cmu[pass], g.wk->floor_mu), dist = cdist[pass];
+            const int slot = g_popc((CM)(cm & (((CM)1 << c) - (CM)1)));
+            const T mu = dl_max(cd.cmu[pass], g.wk->floor_mu), dist = cdist[pass];
             DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * slot;
-            st4(cn, cp[pass].x, cp[pass].y, cp[pass].z, T((cinf[pass] >> 5) & 7));
+            st4(cn, cp[pass].x, cp[pass].y, cp[pass].z, T((cinf[pass] >> 5) & 15));
             st4(cn + 4, ctx[pass], cty[pass], mu, dist);
-            const T imp = g_impedance(*g.c, dist);
-            const T diag = ln.cinvw[pass] * (T(1) + mu * mu);
+            const T imp = g_impedance(simp, dist);
+            const T diag = cd.cinvw[pass] * (T(1) + mu * mu);
             const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
             const T D = dl_rcp(R), kd = g.c->solK * imp * dist;
-            st4(wb + Ld::ROW + Ld::R_D * G_MAXROW + 4 * slot, D, D, D, D);
-            st4(wb + Ld::ROW + Ld::R_JAREF * G_MAXROW + 4 * slot, kd, kd, kd, kd);
-            st4(wb + Ld::ROW + Ld::R_TMP * G_MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
+            st4(wb + Ld::ROW + Ld::R_D * MAXROW + 4 * slot, D, D, D, D);
+            st4(wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * slot, kd, kd, kd, kd);
+            st4(wb + Ld::ROW + Ld::R_TMP * MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
         }
     }
     // contacts are processed in pairs: a neutral record (world body: no dof moves it; mu = 0) closes an odd count
-    if (j == 0 && ncon < G_MAXCON) {
+    if (j == 0 && ncon < MAXCON) {
         DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * ncon;
         st4(cn, T(0), T(0), T(0), T(0)); st4(cn + 4, T(1), T(0), T(0), T(0));
         st4(wb + Ld::FC + Ld::FC_W * ncon, T(0), T(0), T(0), T(0));
+        if constexpr (NX > 0) st4(wb + Ld::FC + Ld::FC_W * ncon + 8, T(0), T(0), T(0), T(0));
     }
     // limit rows follow in dof order; jar = J a - aref at the start point x0 = B v + a:  K imp r + (+-x0_j)
     if (lim) {
         const int r = 4 * ncon + __popc(lmask & ((1u << j) - 1u));
         my_lim = r;
-        const T imp = g_impedance(*g.c, lim_dist);
+        const T imp = g_impedance(simp, lim_dist);
         const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
-        wb[Ld::ROW + Ld::R_D * G_MAXROW + r] = dl_rcp(R);
-        wb[Ld::ROW + Ld::R_JAREF * G_MAXROW + r] = g.c->solK * imp * lim_dist + lim_sign * x0;
-        wb[Ld::ROW + Ld::R_TMP * G_MAXROW + r] = T(0);
+        wb[Ld::ROW + Ld::R_D * MAXROW + r] = dl_rcp(R);
+        wb[Ld::ROW + Ld::R_JAREF * MAXROW + r] = g.c->solK * imp * lim_dist + lim_sign * x0;
+        wb[Ld::ROW + Ld::R_TMP * MAXROW + r] = T(0);
     }
     g_sync<T>();
     // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
@@ -793,7 +1028,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
     for (int c = 0; c < ncon; c += 2) {
         const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * c;
         const Q4<T> A0 = ld4(cn), B0 = ld4(cn + 4), A1 = ld4(cn + Ld::CON_W), B1 = ld4(cn + Ld::CON_W + 4);
-        DL_LDS T* rja = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW + 4 * c + j;
+        DL_LDS T* rja = wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * c + j;
         const bool writer = j < 4 || (j < 8 && c + 1 < ncon);
         const T base = writer ? *rja : T(0);
         V3<T> w0 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A0.a, A0.b, A0.c) - kin.pos);
@@ -806,6 +1041,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T>& g, const GLane
         st4(wb + Ld::JC + ((c + 1) * GL + j) * 4, j1n, j1a, j1b, T(0));
         T r[6] = {j0n * x0, j0a * x0, j0b * x0, j1n * x0, j1a * x0, j1b * x0};
         gsum_n<6>(r);
+        if constexpr (NX > 0) { g_slide_jx<T, TP>(B0.a, B0.b, x0x, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1.a, B1.b, x0x, r[3], r[4], r[5]); }
         if (writer) {
             const bool second = j >= 4;
             const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? B1.c : B0.c;
@@ -820,35 +1056,50 @@ template <typename T> struct GEps;
 template <> struct GEps<float> { static constexpr float value = 1.1920929e-7f; };
 template <> struct GEps<double> { static constexpr double value = 2.220446049250313e-16; };
 
-// rows JV = J x for the walker and (M x)_j; x_j lives in lane j.  M x: row broadcasts of x against the lane's row of M.
-// J x: the limit row of a dof is +-x_j; per contact the three contact-frame components are row sums of the lane's own
-// Jacobian column times x_j, expanded to the four pyramid rows by lanes 0..3.
-template <typename T, int N>
-__device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T lim_sign, T x, const T (&mrow)[GL], T mcorr) {
-    using Ld = GLds;
+// rows JV = J x for the walker and (M x)_j; x_j lives in lane j (xx: the replicated dofs).  M x: row broadcasts of x against
+// the lane's row of M.  J x: the limit row of a dof is +-x_j; per contact the three contact-frame components are row sums of the
+// lane's own Jacobian column times x_j, expanded to the four pyramid rows by lanes 0..3.
+template <typename T, typename TP>
+__device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim, T lim_sign, T x, const T (&xx)[GD<TP>::NXA], const GSmooth<T, TP>& sm, T (&mxx_out)[GD<TP>::NXA]) {
+    using Ld = GLds<TP>;
+    constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, MAXROW = Ld::MAXROW;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    T mx = mcorr * x, xb = x;
+    T mx = sm.mcorr * x, xb = x;
     g_dpp_ready(xb);
-    static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(mx, xb, mrow[a]); });
-    if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * G_MAXROW + my_lim] = lim_sign * x;
+    static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(mx, xb, sm.mrow[a]); });
+    if constexpr (NX > 0) {
+        T s[NX];
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; mx += sm.mxl[t] * xx[t]; s[t] = sm.mxl[t] * x; });
+        gsum_n<NX>(s);
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; mxx_out[t] = sm.mxx[t] * xx[t] + s[t]; });
+    }
+    if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * MAXROW + my_lim] = lim_sign * x;
     // two contacts per trip (the Jacobian record after the last contact is zero): six interleaved row sums
     for (int c = 0; c < ncon; c += 2) {
         const Q4<T> ja = ld4(wb + Ld::JC + (c * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c + 1) * GL + j) * 4);
-        const T mua = wb[Ld::CON + Ld::CON_W * c + Ld::C_MU], mub = wb[Ld::CON + Ld::CON_W * (c + 1) + Ld::C_MU];
+        T mua, mub;
         T r[6] = {ja.a * x, ja.b * x, ja.c * x, jb.a * x, jb.b * x, jb.c * x};
-        gsum_n<6>(r);
+        if constexpr (NX > 0) {
+            const Q4<T> B0 = ld4(wb + Ld::CON + Ld::CON_W * c + 4), B1 = ld4(wb + Ld::CON + Ld::CON_W * (c + 1) + 4);
+            mua = B0.c; mub = B1.c;
+            gsum_n<6>(r);
+            g_slide_jx<T, TP>(B0.a, B0.b, xx, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1.a, B1.b, xx, r[3], r[4], r[5]);
+        } else {
+            mua = wb[Ld::CON + Ld::CON_W * c + Ld::C_MU]; mub = wb[Ld::CON + Ld::CON_W * (c + 1) + Ld::C_MU];
+            gsum_n<6>(r);
+        }
         if (j < 8) {
             const bool second = j >= 4;
             const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? mub : mua;
-            if (!second || c + 1 < ncon) wb[Ld::ROW + Ld::R_JV * G_MAXROW + 4 * c + j] = vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
+            if (!second || c + 1 < ncon) wb[Ld::ROW + Ld::R_JV * MAXROW + 4 * c + j] = vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
         }
     }
     return mx;
 }
 
-// [3P] mj_forward for one walker spread over 16 lanes.  In: q_j, v_j, force of the motor on dof j,
-// warmstart_j.  Out: qacc_j.  nefc/niter for diagnostics.
+// [3P] mj_forward for one walker spread over 16 lanes.  In: q_j, v_j, force of the motor on dof j, warmstart_j (and the
+// replicated root translations qx, vx, warmx).  Out: qacc_j (qaccx).  nefc/niter for diagnostics.
 //
 // Constraint solver: primal Newton on MuJoCo's convex cost  1/2 (a - a_s)^T M (a - a_s) + sum_i 1/2 D_i min(0, (J a - aref)_i)^2
 // (mj_solNewton), started at the warm start.  The minimiser is unique, so the path may differ from MuJoCo's
@@ -859,40 +1110,58 @@ __device__ __forceinline__ T g_apply(const GCtx<T>& g, int ncon, int my_lim, T l
 // Line search: the 1-D cost is convex piecewise quadratic; safeguarded Newton on its derivative (bracket [lo, hi],
 // Newton candidate, bisection when the candidate leaves the bracket), first trial alpha = 1 (exact when no row
 // changes state).  It is written with selects so that the 4 walkers of a wave do not serialise on it.
-// TIMED: accumulate shader-clock cycles per section into tacc[8] (diagnostics build of k_forward_g16 only):
+// TIMED: accumulate shader-clock cycles per section into tacc[8] (diagnostics build only):
 // 0 smooth dynamics, 1 constraints, 2 rows/J^T f/Hessian, 3 factor + solve, 4 J dir / M dir, 5 line search + step, 6 #iterations of the wave
 template <typename T, typename TP, bool TIMED = false>
-__device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm, int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr) {
-    constexpr int N = TP::NV;
-    using Ld = GLds;
+__device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm,
+                                       const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx, const GX<T, GD<TP>::NX>& warmx, GX<T, GD<TP>::NX>& qaccx,
+                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr) {
+    constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, NXA = GD<TP>::NXA;
+    using Ld = GLds<TP>;
+    constexpr int MAXROW = Ld::MAXROW;
     long long t_last = 0;
-    if constexpr (TIMED) t_last = (long long)__builtin_readcyclecounter();
+    if constexpr (TIMED) t_last = DL_CLOCK();
     auto tick = [&](int k) {
-        if constexpr (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[k] += t - t_last; t_last = t; }
+        if constexpr (TIMED) { const long long t = DL_CLOCK(); tacc[k] += t - t_last; t_last = t; }
     };
-    const DL_CONST GModel<T>& m = *g.m;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     GKin<T> kin;
-    T mrow[GL], mdiag, mcorr;
-    const T smooth = g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, kin, mrow, mdiag, mcorr);
+    GSmooth<T, TP> sm;
+    g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
+    const T smooth = sm.smooth;
     tick(0);
     int nlim, ncon, my_lim;
     T lim_sign;
+    const GConst<T, TP>& cs = *g.c;
     // rows: D, jar = J a - aref at a = warm start (K imp r + J (B v + a)), cleared "active" flags (TMP) of the Hessian
-    g_make_constraints<T>(g, lt, kin, grp, q, (j < N) ? g.c->solB * v + warm : T(0), nlim, ncon, my_lim, lim_sign);
+    T x0x[NXA];
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; x0x[t] = cs.solB * vx.x[t] + warmx.x[t]; });
+    g_make_constraints<T, TP>(g, lt, kin, grp, q, (j < N) ? cs.solB * v + warm : T(0), x0x, nlim, ncon, my_lim, lim_sign);
     const int nefc = nlim + 4 * ncon;
     ncon_o = ncon; nefc_o = nefc;
-    DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * G_MAXROW;
-    DL_LDS T* rJA = wb + Ld::ROW + Ld::R_JAREF * G_MAXROW;
-    DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * G_MAXROW;
-    DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * G_MAXROW;
-    T qacc = warm, Ma = mcorr * warm;
-    static_for<N>([&](auto ai) { constexpr int a = ai.value; Ma += mrow[a] * rbcast<a>(qacc); });
-    T h[GL], hd = mdiag;       // row j of H = M + sum_active D row^T row (off-diagonal part) and its diagonal
+    DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * MAXROW;
+    DL_LDS T* rJA = wb + Ld::ROW + Ld::R_JAREF * MAXROW;
+    DL_LDS T* rJV = wb + Ld::ROW + Ld::R_JV * MAXROW;
+    DL_LDS T* rTM = wb + Ld::ROW + Ld::R_TMP * MAXROW;
+    T qacc = warm, Ma = sm.mcorr * warm;
+    static_for<N>([&](auto ai) { constexpr int a = ai.value; Ma += sm.mrow[a] * rbcast<a>(qacc); });
+    // replicated dofs: acceleration, M a, and their part of the Hessian (uniform block hxx, this lane's coupling hxl)
+    T qax[NXA], Max[NXA], hxx[NXA][NXA], hxl[NXA];
+    if constexpr (NX > 0) {
+        T s[NX];
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; qax[t] = warmx.x[t]; Ma += sm.mxl[t] * qax[t]; s[t] = sm.mxl[t] * qacc; });
+        gsum_n<NX>(s);
+        static_for<NX>([&](auto ti) {
+            constexpr int t = ti.value;
+            Max[t] = sm.mxx[t] * qax[t] + s[t];
+            hxl[t] = sm.mxl[t];
+            static_for<NX>([&](auto ui) { hxx[t][ui.value] = (ui.value == t) ? sm.mxx[t] : T(0); });
+        });
+    }
+    T h[GL], hd = sm.mdiag;       // row j of H = M + sum_active D row^T row (off-diagonal part) and its diagonal
 #pragma unroll
-    for (int a = 0; a < GL; a++) h[a] = mrow[a];
-    const GConst<T>& cs = *g.c;
+    for (int a = 0; a < GL; a++) h[a] = sm.mrow[a];
     const T nvf = cs.nvf, scale = cs.scale;
     bool alive = true;         // this walker still iterates (identical in the 16 lanes of the row)
     int iter = 0;
@@ -912,7 +1181,10 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         }
         for (int cc = j; cc < ncon; cc += GL) {
             const Q4<T> ja = ld4(rJA + 4 * cc), tm = ld4(rTM + 4 * cc);
-            const T D = rD[4 * cc], mu = wb[Ld::CON + Ld::CON_W * cc + Ld::C_MU];
+            const T D = rD[4 * cc];
+            T mu, ctx = T(0), cty = T(0);
+            if constexpr (NX > 0) { const Q4<T> B = ld4(wb + Ld::CON + Ld::CON_W * cc + 4); ctx = B.a; cty = B.b; mu = B.c; }
+            else mu = wb[Ld::CON + Ld::CON_W * cc + Ld::C_MU];
             const T jar[4] = {ja.a, ja.b, ja.c, ja.d}, was[4] = {tm.a, tm.b, tm.c, tm.d};
             T f4[4], dD[4], onf[4];
             bool anyflip = false;
@@ -927,17 +1199,27 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
             }
             // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
             DL_LDS T* fc = wb + Ld::FC + Ld::FC_W * cc;
-            st4(fc, f4[0] + f4[1] + f4[2] + f4[3], mu * (f4[0] - f4[1]), mu * (f4[2] - f4[3]), anyflip ? T(1) : T(0));
+            const T Fn = f4[0] + f4[1] + f4[2] + f4[3], F1 = mu * (f4[0] - f4[1]), F2 = mu * (f4[2] - f4[3]);
+            st4(fc, Fn, F1, F2, anyflip ? T(1) : T(0));
             st4(fc + 4, dD[0] + dD[1] + dD[2] + dD[3], mu * (dD[0] - dD[1]), mu * (dD[2] - dD[3]), mu * mu * (dD[0] + dD[1]));
-            fc[8] = mu * mu * (dD[2] + dD[3]);
+            // world-frame force of the contact: what the replicated root translations see of it
+            if constexpr (NX > 0) st4(fc + 8, mu * mu * (dD[2] + dD[3]), ctx * F1 - cty * F2, cty * F1 + ctx * F2, Fn);
+            else fc[8] = mu * mu * (dD[2] + dD[3]);
             st4(rTM + 4 * cc, onf[0], onf[1], onf[2], onf[3]);
         }
         g_sync<T>();
         // ---- J^T f and the Hessian rows (dof lanes; the lane's Jacobian column of contact cc is one 16-byte read)
+        T fcx[NXA];
+        static_for<NX>([&](auto ti) { fcx[ti.value] = T(0); });
         for (int c2 = 0; c2 < ncon; c2 += 2) {
             const DL_LDS T* fca = wb + Ld::FC + Ld::FC_W * c2;
             const Q4<T> Fa = ld4(fca), Fb = ld4(fca + Ld::FC_W), ja = ld4(wb + Ld::JC + (c2 * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c2 + 1) * GL + j) * 4);
             fcon += ja.a * Fa.a + ja.b * Fa.b + ja.c * Fa.c + jb.a * Fb.a + jb.b * Fb.b + jb.c * Fb.c;
+            if constexpr (NX > 0) {
+                const Q4<T> Ga = ld4(fca + 8), Gb = ld4(fca + Ld::FC_W + 8);      // (w22, Fx, Fy, Fz)
+                const V3<T> Fw = mk<T>(Ga.b + Gb.b, Ga.c + Gb.c, Ga.d + Gb.d);
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; fcx[t] += T(TP::dof_sign(t)) * vcomp<TP::dof_axis(t)>(Fw); });
+            }
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const Q4<T>& F = half ? Fb : Fa;
@@ -951,12 +1233,34 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
                     T bn = jt.a, b1 = jt.b, b2 = jt.c;
                     g_dpp_ready(bn); g_dpp_ready(b1); g_dpp_ready(b2);
                     static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(h[a], bn, t0); fmac_bcast<a, 1>(h[a], b1, t1); fmac_bcast<a, 1>(h[a], b2, t2); });
+                    if constexpr (NX > 0) {
+                        // replicated dofs: H[j][t] += J_x[t] . (W J_j), H[t][u] += J_x[t] . (W J_x[u])
+                        const Q4<T> B = ld4(wb + Ld::CON + Ld::CON_W * (c2 + half) + 4);
+                        T jn[NX], j1[NX], j2[NX], u0[NX], u1[NX], u2[NX];
+                        static_for<NX>([&](auto ti) {
+                            constexpr int t = ti.value;
+                            g_slide_col<T, TP, t>(B.a, B.b, jn[t], j1[t], j2[t]);
+                            hxl[t] += jn[t] * t0 + j1[t] * t1 + j2[t] * t2;
+                            u0[t] = W.a * jn[t] + W.b * j1[t] + W.c * j2[t]; u1[t] = W.b * jn[t] + W.d * j1[t]; u2[t] = W.c * jn[t] + w22 * j2[t];
+                        });
+                        static_for<NX>([&](auto ti) {
+                            constexpr int t = ti.value;
+                            static_for<t + 1>([&](auto ui) { constexpr int u = ui.value; hxx[t][u] += jn[t] * u0[u] + j1[t] * u1[u] + j2[t] * u2[u]; });
+                        });
+                    }
                 }
             }
         }
         const T grad = Ma - smooth - fcon;
+        T gradx[NXA];
         T r3[3] = {c, grad * grad, dl_abs(Ma) + dl_abs(smooth) + dl_abs(fcon)};
         gsum_n<3>(r3);
+        static_for<NX>([&](auto ti) {
+            constexpr int t = ti.value;
+            gradx[t] = Max[t] - sm.smoothx[t] - fcx[t];
+            r3[1] += gradx[t] * gradx[t];
+            r3[2] += dl_abs(Max[t]) + dl_abs(sm.smoothx[t]) + dl_abs(fcx[t]);
+        });
         const T pc0 = r3[0];
         {
             const T gn = r3[1], gmag = r3[2];
@@ -967,16 +1271,25 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         if (!__any(alive)) break;
         if constexpr (TIMED) tacc[6] += 1;
         // ---- Newton direction
-        T dir;
+        T dir, dirx[NXA];
         {
-            T up[GL], lo[GL], invd = T(1);
+            T up[GL], lo[GL], invd = T(1), hdk = hd;
 #pragma unroll
             for (int a = 0; a < GL; a++) { up[a] = h[a]; lo[a] = T(0); }
-            g_chol<T, N>(up, lo, hd, invd, j, T(1e-10));
-            dir = -g_chol_solve<T, N>(lo, up, invd, grad, j);
+            GCholX<T, NXA> cx;
+            if constexpr (NX > 0) {
+                T wxx[NXA][NXA], wxl[NXA];
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; wxl[t] = hxl[t]; static_for<NX>([&](auto ui) { wxx[t][ui.value] = hxx[t][ui.value]; }); });
+                g_chol_x<T, NX, N>(wxx, wxl, up, hdk, cx, T(1e-10));
+            }
+            g_chol<T, N>(up, lo, hdk, invd, j, T(1e-10));
+            T sx[NXA];
+            dir = -g_chol_solve_x<T, NX, N>(cx, lo, up, invd, grad, gradx, sx, j);
+            static_for<NX>([&](auto ti) { dirx[ti.value] = -sx[ti.value]; });
         }
         tick(3);
-        const T Md = g_apply<T, N>(g, ncon, my_lim, lim_sign, dir, mrow, mcorr);      // rows JV = J dir
+        T Mdx[NXA];
+        const T Md = g_apply<T, TP>(g, ncon, my_lim, lim_sign, dir, dirx, sm, Mdx);      // rows JV = J dir
         g_sync<T>();
         tick(4);
         // ---- the common case: the full Newton step leaves the active set as it is.  The cost is quadratic on that
@@ -998,12 +1311,19 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
                 flips = flips || (ok && ((a_ + v_ < T(0)) != (t_ != T(0))));
             }
             for (int r = j + GL * NS; r < nefc; r += GL) flips = flips || ((rJA[r] + rJV[r] < T(0)) != (rTM[r] != T(0)));
-            if (alive && !gany(flips)) { qacc += dir; iter++; alive = false; }
+            if (alive && !gany(flips)) {
+                qacc += dir; iter++; alive = false;
+                static_for<NX>([&](auto ti) { qax[ti.value] += dirx[ti.value]; });
+            }
         }
         if (!__any(alive)) { tick(5); break; }
         // ---- exact line search along dir
         T r4[4] = {dir * (Ma - smooth), T(0.5) * dir * Md, dir * grad, dir * dir};
         gsum_n<4>(r4);
+        static_for<NX>([&](auto ti) {
+            constexpr int t = ti.value;
+            r4[0] += dirx[t] * (Max[t] - sm.smoothx[t]); r4[1] += T(0.5) * dirx[t] * Mdx[t]; r4[2] += dirx[t] * gradx[t]; r4[3] += dirx[t] * dirx[t];
+        });
         const T g1s = r4[0], g2 = r4[1], d0 = r4[2], snorm = dl_sqrt(r4[3]);
         const T gtol = cs.tolerance * cs.ls_tolerance * snorm * cs.meaninertia * nvf + cs.ls_reltol * dl_abs(d0);
         T alpha = T(1), lo = T(0), hi = T(1e30), best_a = T(0), best_dc = T(0), best_mag = T(0), res_a = T(0), res_dc = T(0), res_mag = T(0);
@@ -1022,7 +1342,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
                 const T jvr = rJV[r], xx = rJA[r] + alpha * jvr;
                 if (xx < T(0)) { const T D = rD[r]; pc += T(0.5) * D * xx * xx; pd1 += D * xx * jvr; pd2 += D * jvr * jvr; }
             }
-            { T r3[3] = {pc, pd1, pd2}; gsum_n<3>(r3); pc = r3[0]; pd1 = r3[1]; pd2 = r3[2]; }
+            { T r3b[3] = {pc, pd1, pd2}; gsum_n<3>(r3b); pc = r3b[0]; pd1 = r3b[1]; pd2 = r3b[2]; }
             const T d1 = g1s + T(2) * alpha * g2 + pd1, d2 = T(2) * g2 + pd2;
             const T dc = alpha * g1s + alpha * alpha * g2 + (pc - pc0);
             const T mag = dl_abs(alpha * g1s) + alpha * alpha * g2 + pc + pc0;
@@ -1045,6 +1365,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
             if (res_a == T(0)) alive = false;                      // no improvement along a descent direction: converged to working precision
             else {
                 qacc += res_a * dir; Ma += res_a * Md;
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; qax[t] += res_a * dirx[t]; Max[t] += res_a * Mdx[t]; });
 #pragma unroll
                 for (int s = 0; s < NS; s++) { const int r = j + GL * s; if (r < nefc) rJA[r] = ja[s] + res_a * jv[s]; }
                 for (int r = j + GL * NS; r < nefc; r += GL) rJA[r] += res_a * rJV[r];
@@ -1057,6 +1378,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T>& g, const GLaneTopo<T>& lt,
         tick(5);
     }
     niter_o = iter;
+    static_for<NX>([&](auto ti) { qaccx.x[ti.value] = qax[ti.value]; });
     return qacc;
 }
 

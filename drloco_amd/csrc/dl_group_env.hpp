@@ -1,0 +1,374 @@
+// dl_group_env.hpp -- the bodies of the 16-lanes-per-walker kernels (one wave = four walkers): a forward evaluation
+// and one or more control steps of the environment (action map, frame_skip x RK4 mj_step through g_forward, cursor /
+// observation / reward / termination / Monitor, and the vec-env auto reset of finished walkers in the same launch).
+// Written as device functions of (lane, walker block) so that dl_kernels.hip wraps them into __global__ kernels and
+// tests/host_emu runs the very same source on the host (a wave as 64 fibers).
+// Restates, per walker (citations relative to /root/reference): MimicEnv.step drloco/mujoco/mimic_env.py:60-126,
+// _rescale_actions / mirror_action :170-192 / :483-489, _get_obs / mirror_obs :403-437 / :440-480 (165 cm walker:
+// joint phase features :330-401, desired velocities drloco/ref_trajecs/loco3d_trajecs.py:51-97), get_imitation_reward
+// :592-649, reset_model :526-572, refs.next drloco/ref_trajecs/straight_walk_trajecs.py:141-159,322-348 /
+// base_ref_trajecs.py:95-103, Monitor.step drloco/mujoco/monitor_wrapper.py:88-133.
+#pragma once
+
+#include "dl_group.hpp"
+
+namespace dl {
+
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.  The SoA
+// state rows put 16 consecutive walkers into one 64-byte line, i.e. 4 consecutive walker groups share their lines:
+// map workgroup i to walker group (i % 8) * (G / 8) + i / 8 so that neighbouring groups run on the SAME XCD and a
+// line is fetched into one L2 only.  (G not a multiple of 8: identity.)
+__device__ __forceinline__ int g_block_of_workgroup(int wg, int nwg) {
+    constexpr int XCDS = 8;
+    if (nwg % XCDS) return wg;
+    return (wg % XCDS) * (nwg / XCDS) + wg / XCDS;
+}
+
+// value of dof d (compile time) of the walker, identical in the 16 lanes of its row: a replicated root translation or the
+// row broadcast of the owning lane
+template <typename TP, int d, typename T> __device__ __forceinline__ T g_dof_value(T lane_val, const GX<T, GD<TP>::NX>& xs) {
+    if constexpr (d < GD<TP>::NX) return xs.x[d]; else return rbcast<d - GD<TP>::NX>(lane_val);
+}
+
+template <typename T, typename TP> __device__ __forceinline__ void g_load_walk(const DL_CONST GModel<T, TP>* m, const DevState<T>& st, int w, GWalk<T>& wk) {
+    wk = GWalk<T>{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
+    if (st.rnd) {
+        const size_t ws = (size_t)w, n = (size_t)st.n;
+        wk.mscale = st.rnd[ws]; wk.floor_mu = st.rnd[n + ws];
+        wk.push = mk<T>(st.rnd[2 * n + ws], st.rnd[3 * n + ws], st.rnd[4 * n + ws]);
+        wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
+    }
+}
+
+// forward dynamics of the walkers' current state (dl_forward): `wblock` = walker block of this wave, `tim` (TIMED) = [8][nwg]
+template <typename T, typename TP, bool TIMED = false>
+__device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int nwg, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevState<T>& st, const T* ctrl,
+                                               T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, long long* tim) {
+    using D = GD<TP>;
+    constexpr int NL = D::NL, NX = D::NX;
+    const int grp = lane >> 4, j = lane & 15, n = st.n;
+    const int w = wblock * GW + grp;
+    const bool valid = w < n;
+    const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
+    const DL_CONST GModel<T, TP>* m = (const DL_CONST GModel<T, TP>*)gm;
+    const GLane<T, D::NPASS> ln = m->lanes[j];     // this lane's record of the model block (built on the host by g_load_lane)
+    GConst<T, TP> cst;
+    g_load_const<T, TP>(*m, cst);
+    GWalk<T> wk;
+    g_load_walk<T, TP>(m, st, wi, wk);
+    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk};
+    T q = T(0), v = T(0), wm = T(0), force = T(0);
+    if (j < NL) {
+        const size_t o = (size_t)(j + NX) * n + wi;
+        q = st.qpos[o]; v = st.qvel[o]; wm = st.warm[o];
+        const int a = ln.act;
+        if (a >= 0) {
+            const T u = dl_clamp(ctrl ? ctrl[(size_t)a * n + wi] : T(0), ln.ctrl_lo, ln.ctrl_hi);
+            force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
+        }
+    }
+    GX<T, NX> qx, vx, wx, ax;
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + wi; qx.x[t] = st.qpos[o]; vx.x[t] = st.qvel[o]; wx.x[t] = st.warm[o]; });
+    int nc, ne, ni;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    GLaneTopo<T> lt;
+    g_lane_topo<T, TP>(j, lt);
+    const T a = g_forward<T, TP, TIMED>(g, lt, grp, q, v, force, wm, qx, vx, wx, ax, nc, ne, ni, tacc);
+    if constexpr (TIMED) { if (lane == 0) for (int k = 0; k < 8; k++) tim[(size_t)k * nwg + wg] = tacc[k]; }
+    if (valid && j < NL) qacc[(size_t)(j + NX) * n + w] = a;
+    if (valid && j == 0) {
+        static_for<NX>([&](auto ti) { qacc[(size_t)ti.value * n + w] = ax.x[ti.value]; });
+        if (ncon) ncon[w] = nc; if (nefc) nefc[w] = ne; if (niter) niter[w] = ni;
+    }
+}
+
+// `nsteps` control steps (time-major arrays: step s uses actions[s], writes obs[s], rew[s], done[s]).  More than one
+// step per launch is for callers whose actions do not depend on the observations (dl_rollout_fixed): the launch then
+// lasts as long as the wave with the largest SUM over the steps, not the sum of the per-step maxima.
+// TIMED: tim = [10][nwg]: 0-6 g_forward's sections, 7 whole kernel, 8 before the physics, 9 after it.
+template <typename T, typename TP, bool TIMED = false>
+__device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, int nwg, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevCfg<T>& c, const DevState<T>& st,
+                                                const float* __restrict__ actions_all, float* obs_all, float* rew_all, uint8_t* done_all, float* term_obs_all, float* rew_terms_all,
+                                                const T* inj_q, const T* inj_v, const int32_t* inj_flags, float* ctrl_out, int eval_mode, int nsteps, long long* tim) {
+    using D = GD<TP>;
+    using Ld = GLds<TP>;
+    constexpr int NL = D::NL, NX = D::NX, NV = D::NV, NU = TP::NU, OBS = TP::OBS;
+    static_assert(NX == 0 || NX == 3, "the replicated dofs are the three root translations");
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_begin = 0;
+    if constexpr (TIMED) t_begin = DL_CLOCK();
+    const int grp = lane >> 4, j = lane & 15, n = st.n;
+    const int w0 = wblock * GW + grp;
+    const bool valid = w0 < n;
+    const int w = valid ? w0 : n - 1;
+    const DL_CONST GModel<T, TP>* m = (const DL_CONST GModel<T, TP>*)gm;
+    const GLane<T, D::NPASS> ln = m->lanes[j];     // this lane's record of the model block (built on the host by g_load_lane)
+    GConst<T, TP> cst;
+    g_load_const<T, TP>(*m, cst);
+    GWalk<T> wk;
+    g_load_walk<T, TP>(m, st, w, wk);
+    GCtx<T, TP> g{smem + (size_t)grp * Ld::TOTAL, m, j, &ln, &cst, &wk};
+    DL_LDS T* wb = g.wb;
+    const bool isdof = j < NL;
+    const int jd = j + NX;                         // dof of this lane
+    GLaneTopo<T> lt;
+    g_lane_topo<T, TP>(j, lt);
+    T q = T(0), v = T(0), warm = T(0);
+    if (isdof) { const size_t o = (size_t)jd * n + w; q = st.qpos[o]; v = st.qvel[o]; warm = st.warm[o]; }
+    GX<T, NX> qx, vx, warmx;
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w; qx.x[t] = st.qpos[o]; vx.x[t] = st.qvel[o]; warmx.x[t] = st.warm[o]; });
+    int32_t cur[DL_CUR_WORDS];
+#pragma unroll
+    for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w];
+    // per-walker words of the environment logic live in registers across the control steps of this launch
+    double walked = st.walked[w];
+    T comz = st.comz_off[w];
+    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
+    long long t_phys_end = 0;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; step++) {
+    const float* __restrict__ actions = actions_all + (size_t)step * n * NU;
+    float* obs = obs_all + (size_t)step * n * OBS;
+    float* rew = rew_all + (size_t)step * n;
+    uint8_t* done = done_all + (size_t)step * n;
+    float* term_obs = term_obs_all ? term_obs_all + (size_t)step * n * OBS : nullptr;
+    float* rew_terms = rew_terms_all ? rew_terms_all + (size_t)step * n * 3 : nullptr;
+    // ---- _rescale_actions + mirror_action (cursor BEFORE refs.next()), per actuated dof
+    bool mirr_a = false;
+    if constexpr (TP::ENV_KIND == 0) mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+    T ctrl = T(0), force = T(0);
+    const int a = isdof ? ln.act : -1;
+    if (a >= 0) {
+        const int src = mirr_a ? TP::act_perm(a) : a;
+        const int jsrc = TP::act_dof(src) - NX;
+        const T x = dl_clamp((T)actions[(size_t)w * NU + src], T(-1), T(1));
+        const T raw = x > T(0) ? x * m->ctrl_hi[jsrc] : dl_abs(x) * m->ctrl_lo[jsrc];
+        ctrl = (mirr_a && TP::act_neg(a)) ? -raw : raw;
+        const T u = dl_clamp(ctrl, ln.ctrl_lo, ln.ctrl_hi);
+        force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
+        if (ctrl_out && valid) ctrl_out[(size_t)step * n * NU + (size_t)w * NU + a] = (float)ctrl;      // test hook: sim.data.ctrl as the reference sets it
+    }
+    const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
+    if constexpr (TIMED) tacc[8] = DL_CLOCK() - t_begin;
+    // ---- physics
+    bool exc = false;
+    const int flag = inj_flags ? inj_flags[w] : 0;
+    if (flag == 2) exc = true;
+    else if (flag == 1) {
+        if (isdof) { q = inj_q[(size_t)jd * n + w]; v = inj_v[(size_t)jd * n + w]; }
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = inj_q[(size_t)t * n + w]; vx.x[t] = inj_v[(size_t)t * n + w]; });
+    }
+    const bool simulate = flag == 0;
+    int dbg_it = 0, dbg_max = 0, dbg_rows = 0;
+    if (__any(simulate)) {
+        const T h = m->timestep;
+        const int fs = m->frame_skip;
+        T acc_s2_prev = T(0);
+        GX<T, NX> accx_s2_prev;
+        static_for<NX>([&](auto ti) { accx_s2_prev.x[ti.value] = T(0); });
+#pragma unroll 1
+        for (int kf = 0; kf < fs; kf++) {
+            // mj_checkPos / mj_checkVel
+            {
+                bool bad = isdof && (dl_bad(q) || dl_bad(v));
+                static_for<NX>([&](auto ti) { bad = bad || dl_bad(qx.x[ti.value]) || dl_bad(vx.x[ti.value]); });
+                if (simulate && !exc && gany(bad)) exc = true;
+            }
+            const T q0 = q, v0 = v;
+            T dq = T(0), dv = T(0), qs = q, vs = v;
+            T acc_s0 = warm;
+            GX<T, NX> qx0 = qx, vx0 = vx, dqx, dvx, qsx = qx, vsx = vx, accx_s0 = warmx;
+            static_for<NX>([&](auto ti) { dqx.x[ti.value] = T(0); dvx.x[ti.value] = T(0); });
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                int nc, ne, ni;
+                // starting point of the Newton iteration (the minimiser does not depend on it): the last solution (MuJoCo's
+                // qacc_warmstart), linearly extrapolated where the next stage lies half a time step further: stage 1 from
+                // (stage 2 of the previous mj_step, stage 0), stage 3 from (stage 0, stage 2)
+                T start = warm;
+                GX<T, NX> startx = warmx, accx;
+                if (stage == 1 && kf > 0) { start = warm + (warm - acc_s2_prev); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s2_prev.x[t]); }); }
+                else if (stage == 3) { start = warm + (warm - acc_s0); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s0.x[t]); }); }
+                const T acc = g_forward<T, TP, TIMED>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc);
+                if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
+                if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
+                dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
+                if (st.dbgf && valid && ni >= st.dbg_cap) {
+                    st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)start;
+                }
+                if (simulate && !exc) { warm = acc; warmx = accx; }
+                if (stage == 0 && simulate && !exc) {     // mj_checkAcc
+                    bool bad = isdof && dl_bad(acc);
+                    static_for<NX>([&](auto ti) { bad = bad || dl_bad(accx.x[ti.value]); });
+                    if (gany(bad)) exc = true;
+                }
+                const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
+                const T al = stage == 2 ? T(1) : T(0.5);
+                dq += wgt * vs; dv += wgt * acc;
+                const T vstage = vs;
+                qs = q0 + h * al * vstage; vs = v0 + h * al * acc;
+                static_for<NX>([&](auto ti) {
+                    constexpr int t = ti.value;
+                    dqx.x[t] += wgt * vsx.x[t]; dvx.x[t] += wgt * accx.x[t];
+                    const T vst = vsx.x[t];
+                    qsx.x[t] = qx0.x[t] + h * al * vst; vsx.x[t] = vx0.x[t] + h * al * accx.x[t];
+                });
+            }
+            if (simulate && !exc) {
+                q = q0 + h * dq; v = v0 + h * dv;
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = qx0.x[t] + h * dqx.x[t]; vx.x[t] = vx0.x[t] + h * dvx.x[t]; });
+            }
+        }
+    }
+    if constexpr (TIMED) t_phys_end = DL_CLOCK();
+    // ---- environment logic
+    const double tor_mean = (double)tor_sum / NU;
+    float r;
+    bool dn;
+    // stage q, v in LDS for the observation writer (all NV dofs in dof order)
+    auto stage_qv = [&]() {
+        if (isdof) { wb[Ld::Q + jd] = q; wb[Ld::V + jd] = v; }
+        if (j == 0) static_for<NX>([&](auto ti) { constexpr int t = ti.value; wb[Ld::Q + t] = qx.x[t]; wb[Ld::V + t] = vx.x[t]; });
+    };
+    // observation from q, v staged in LDS: OBS outputs over 16 lanes
+    auto write_obs = [&](float* dst_base) {
+        if (!(valid && dst_base)) return;
+        if constexpr (TP::ENV_KIND == 0) {
+            // mimic_env.py:403-437 + mirror_obs :440-480
+            const int rs = cur[DL_CUR_READ_STEP];
+            const T phase_var = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
+            const int iv = cur[DL_CUR_I_STEP] - cur[DL_CUR_COUNT] + 1;
+            const T desvel = c.step_vel[iv > 0 ? iv : 0];
+            const bool mirr_o = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+            auto raw_obs = [&](int k) -> T { return k == 0 ? phase_var : (k == 1 ? desvel : (k < 1 + NV ? wb[Ld::Q + (k - 1)] : wb[Ld::V + (k - 1 - NV)])); };
+            for (int k = j; k < OBS; k += GL) {
+                const T plain = raw_obs(k);
+                const T mir = TP::obs_neg(k) ? -raw_obs(TP::obs_perm(k)) : raw_obs(TP::obs_perm(k));
+                dst_base[(size_t)w * OBS + k] = (float)(mirr_o ? mir : plain);
+            }
+        } else {
+            // MimicWalker165cm65kg: 4 x (phase angle, phase radius) from joint phase plots (mimic_env.py:330-401), 2 desired
+            // velocities = mean reference pelvis x / z velocity over the next 0.5 s (loco3d_trajecs.py:51-97, through float64
+            // prefix sums), qpos[1:], qvel
+            const int L = c.step_off[1] - c.step_off[0], pos = cur[DL_CUR_POS];
+            const int end = pos + 250 < L - 1 ? pos + 250 : L - 1;
+            const double cnt = (double)(end - pos);
+            for (int k = j; k < OBS; k += GL) {
+                float o;
+                if (k < 8) {
+                    const int d = TP::phase_joint(k >> 1);
+                    const T qj = wb[Ld::Q + d], vj = wb[Ld::V + d];
+                    o = (k & 1) ? (float)(dl_sqrt(qj * qj + vj * vj) / T(5)) : (float)(dl_atan2(vj, -qj) * T(0.31830988618379067154));
+                }
+                else if (k == 8) o = (float)((c.pref[end] - c.pref[pos]) / cnt);
+                else if (k == 9) o = (float)((c.pref[(size_t)c.total_len + 1 + end] - c.pref[(size_t)c.total_len + 1 + pos]) / cnt);
+                else if (k < 9 + NV) o = (float)wb[Ld::Q + (k - 9)];
+                else o = (float)wb[Ld::V + (k - 9 - NV)];
+                dst_base[(size_t)w * OBS + k] = o;
+            }
+        }
+    };
+    if (exc) {
+        r = 0.0f; dn = true; walked = 0;
+        terms[0] = terms[1] = terms[2] = 1.0;
+    } else {
+        cursor_next<T, TP>(c, cur);
+        g_sync<T>();
+        stage_qv();
+        g_sync<T>();
+        cur[DL_CUR_EP_DUR] += 1;
+        const T vx0 = dl_clamp(g_dof_value<TP, 0>(v, vx), T(-5.5), T(5.5)), vy0 = dl_clamp(g_dof_value<TP, 1>(v, vx), T(-5.5), T(5.5));
+        walked += (double)dl_sqrt(vx0 * vx0 + vy0 * vy0) * (double)c.inv_ctrl_freq;
+        const bool timeout = cur[DL_CUR_EP_DUR] >= c.ep_dur_max;
+        const T qz = g_dof_value<TP, 2>(q, qx);
+        dn = (qz < c.com_z_min) || timeout;
+        if (dn) r = timeout ? 0.0f : -0.0f;
+        else {
+            // imitation reward: every dof lane contributes its squared differences (dofs 0..2 = COM term)
+            const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
+            auto ref_q = [&](int d) -> T {
+                T qr = ref_at(c, d, base);
+                if (cur[DL_CUR_HAS_DIST]) { if (d == 0) qr += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1); }
+                else if (d == 2) qr -= comz;
+                return qr;
+            };
+            T dp = T(0), dvv = T(0), dc = T(0);
+            if (isdof) {
+                const T d1 = q - ref_q(jd), d2 = v - ref_at(c, NV + jd, base);
+                if (jd < 3) dc = d1 * d1; else { dp = d1 * d1; dvv = d2 * d2; }
+            }
+            T s3[3] = {dp, dvv, dc};
+            gsum_n<3>(s3);
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; const T d1 = qx.x[t] - ref_q(t); s3[2] += d1 * d1; });
+            const T tp = dl_exp(T(-3) * s3[0]), tv = dl_exp(T(-0.05) * s3[1]), tc = dl_exp(T(-16) * s3[2]);
+            terms[0] = (double)tp; terms[1] = (double)tv; terms[2] = (double)tc;
+            r = (float)((c.rew_w[0] * tp + c.rew_w[1] * tv + c.rew_w[2] * tc) * c.rew_scale + c.alive_bonus);
+        }
+        write_obs(dn ? term_obs : obs);
+    }
+    if (valid && j == 0 && st.dbg) {
+        st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
+    }
+    if (valid && j == 0) {
+        monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked);
+        if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
+        rew[w] = r;
+        done[w] = dn ? 1 : 0;
+    }
+    // ---- vec-env auto reset inside the same launch (SubprocVecEnv worker: obs = env.reset() after done; a
+    // diverged step resets twice, the first reset's observation being the terminal observation):
+    // MujocoEnv.reset -> reset_model (mimic_env.py:526-572).  The warm start of the new episode is zero: the
+    // solver's minimiser does not depend on it.
+    const int nrep = exc ? 2 : (dn ? 1 : 0);
+    if (nrep > 0) {
+#pragma unroll 1
+        for (int rep = 0; rep < nrep; rep++) {
+            int s0, p0, read = -1;
+            if (eval_mode && TP::ENV_KIND == 1) { s0 = 0; p0 = 0; }       // base get_deterministic_init_state(0 %)
+            else if (eval_mode) {
+                s0 = cur[DL_CUR_EVAL_K];
+                p0 = (int)(0.75 * (double)(c.step_off[s0 + 1] - c.step_off[s0]));
+                read = 0;
+                cur[DL_CUR_EVAL_K] = (s0 + 1 >= 20) ? 0 : s0 + 1;
+            }
+            else if (st.inj_rsi && st.inj_rsi[w] >= 0) { s0 = st.inj_rsi[w]; p0 = st.inj_rsi[(size_t)n + w]; }
+            else rsi_draw(c, (uint32_t)(c.env_index_base + w), (uint32_t)cur[DL_CUR_EPISODE], s0, p0);
+            cur[DL_CUR_EPISODE] += 1;
+            cur[DL_CUR_EP_DUR] = 0;
+            cur[DL_CUR_I_STEP] = s0; cur[DL_CUR_RSI_STEP] = s0; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s0; cur[DL_CUR_POS] = p0; cur[DL_CUR_HAS_DIST] = 0;
+            const int base = c.step_off[cur[DL_CUR_READ_STEP]] + p0;
+            if (isdof) { q = ref_at(c, jd, base); v = ref_at(c, NV + jd, base); }
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = ref_at(c, t, base); vx.x[t] = ref_at(c, NV + t, base); });
+            { GKin<T> kin; g_fk<T, TP>(g, lt, q, qx, kin); }
+            comz = g_lowest_site<T, TP>(g);
+            if constexpr (NX > 0) qx.x[2] -= comz; else { if (j == 2) q -= comz; }
+            g_sync<T>();
+            stage_qv();
+            warm = T(0);
+            static_for<NX>([&](auto ti) { warmx.x[ti.value] = T(0); });
+            cursor_next<T, TP>(c, cur);
+            g_sync<T>();
+            write_obs((nrep == 2 && rep == 0) ? term_obs : obs);
+            g_sync<T>();
+        }
+        walked = 0;
+        terms[0] = terms[1] = terms[2] = 1.0;       // reset_model's sanity check evaluates the reward terms at the init state (:562)
+    }
+    }   // control steps of this launch
+    if (valid && j == 0) {
+        st.comz_off[w] = comz;
+        st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
+        st.walked[w] = walked;
+#pragma unroll
+        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w; st.qpos[o] = qx.x[t]; st.qvel[o] = vx.x[t]; st.warm[o] = warmx.x[t]; });
+    }
+    if (valid && isdof) { const size_t o = (size_t)jd * n + w; st.qpos[o] = q; st.qvel[o] = v; st.warm[o] = warm; }
+    if constexpr (TIMED) {
+        const long long t_end = DL_CLOCK();
+        tacc[7] = t_end - t_begin; tacc[9] = t_end - t_phys_end;
+        if (lane == 0) for (int k = 0; k < 10; k++) tim[(size_t)k * nwg + wg] = tacc[k];
+    }
+}
+
+}  // namespace dl

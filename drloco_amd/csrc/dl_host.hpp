@@ -110,12 +110,14 @@ inline void loco3d_prefix_sums(const dl_refs_desc& r, int nv, std::vector<double
 
 // ---- table-driven model for the 16-lanes-per-walker kernels (dl_group.hpp)
 }  // namespace dl
-#if defined(__HIPCC__)
-#include "dl_group.hpp"
+#if defined(__HIPCC__) || defined(DL_GROUP_EMU)
+#include "dl_group_env.hpp"
 namespace dl {
-template <typename T> inline bool fill_group_model(const dl_model_desc& d, GModel<T>& g, std::string& why) {
+template <typename T, typename TP> inline bool fill_group_model(const dl_model_desc& d, GModel<T, TP>& g, std::string& why) {
+    using D = GD<TP>;
+    constexpr int NX = D::NX;
     std::memset(&g, 0, sizeof g);
-    if (d.nv > GL - 0 || d.nbody > G_MAXB || d.ngeom > G_MAXB || d.nsite > 8) { why = "model too large for the 16-lane kernels"; return false; }
+    if (d.nv != TP::NV || d.nbody > D::MAXB || d.ngeom > D::MAXB || d.nsite > GL) { why = "model does not fit the 16-lane kernels"; return false; }
     g.nv = d.nv; g.nb = d.nbody; g.nu = d.nu; g.ngeom = d.ngeom; g.nsite = d.nsite; g.frame_skip = d.frame_skip;
     g.iterations = d.iterations; g.ls_iterations = d.ls_iterations;
     g.timestep = (T)d.timestep; g.gravity_z = (T)d.gravity[2];
@@ -133,22 +135,26 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
         for (int k = 0; k < 3; k++) { g.body_pos[b][k] = (T)d.body_pos[b][k]; g.body_ipos[b][k] = (T)d.body_ipos[b][k]; g.body_inertia[b][k] = (T)d.body_inertia[b][k]; }
         g.body_mass[b] = (T)d.body_mass[b]; g.body_invw[b] = (T)d.body_invweight0[b][0];
     }
-    for (int j = 0; j < d.nv; j++) {
-        g.dof_body[j] = d.jnt_body[j]; g.dof_type[j] = d.jnt_type[j]; g.dof_limited[j] = d.jnt_limited[j];
+    // the leading NX dofs (root translations) are carried replicated, the others own lane dof - NX
+    for (int t = 0; t < NX; t++) { g.xs_qpos0[t] = (T)d.jnt_qpos0[t]; g.xs_damping[t] = (T)d.jnt_damping[t]; g.xs_armature[t] = (T)d.jnt_armature[t]; }
+    for (int l = 0; l < D::NL; l++) {
+        const int j = l + NX;
+        g.dof_body[l] = d.jnt_body[j]; g.dof_type[l] = d.jnt_type[j]; g.dof_limited[l] = d.jnt_limited[j];
         int ax = -1; double sg = 0;
         for (int k = 0; k < 3; k++) if (std::fabs(d.jnt_axis[j][k]) > 0.5) { ax = k; sg = d.jnt_axis[j][k] > 0 ? 1 : -1; }
-        g.dof_axis[j] = ax; g.dof_sign[j] = (T)sg;
-        g.qpos0[j] = (T)d.jnt_qpos0[j]; g.range_lo[j] = (T)d.jnt_range[j][0]; g.range_hi[j] = (T)d.jnt_range[j][1];
-        g.damping[j] = (T)d.jnt_damping[j]; g.armature[j] = (T)d.jnt_armature[j]; g.dof_invw[j] = (T)d.dof_invweight0[j];
-        g.dof_act[j] = -1;
+        g.dof_axis[l] = ax; g.dof_sign[l] = (T)sg;
+        g.qpos0[l] = (T)d.jnt_qpos0[j]; g.range_lo[l] = (T)d.jnt_range[j][0]; g.range_hi[l] = (T)d.jnt_range[j][1];
+        g.damping[l] = (T)d.jnt_damping[j]; g.armature[l] = (T)d.jnt_armature[j]; g.dof_invw[l] = (T)d.dof_invweight0[j];
+        g.dof_act[l] = -1;
     }
     g.root_last_dof = -1;
     for (int j = 0; j < d.nv; j++) if (d.jnt_body[j] == 1) g.root_last_dof = j;
     for (int a = 0; a < d.nu; a++) {
-        const int j = d.act_dof[a];
-        g.dof_act[j] = a;
-        g.ctrl_lo[j] = (T)d.act_ctrlrange[a][0]; g.ctrl_hi[j] = (T)d.act_ctrlrange[a][1];
-        g.force_lo[j] = (T)d.act_forcerange[a][0]; g.force_hi[j] = (T)d.act_forcerange[a][1]; g.gear[j] = (T)d.act_gear[a];
+        const int l = d.act_dof[a] - NX;
+        if (l < 0) { why = "a replicated root translation is actuated"; return false; }
+        g.dof_act[l] = a;
+        g.ctrl_lo[l] = (T)d.act_ctrlrange[a][0]; g.ctrl_hi[l] = (T)d.act_ctrlrange[a][1];
+        g.force_lo[l] = (T)d.act_forcerange[a][0]; g.force_hi[l] = (T)d.act_forcerange[a][1]; g.gear[l] = (T)d.act_gear[a];
     }
     // geoms and collision candidates in contact order
     int nc = 0;
@@ -158,12 +164,12 @@ template <typename T> inline bool fill_group_model(const dl_model_desc& d, GMode
         for (int k = 0; k < 9; k++) g.geom_mat[ge][k] = (T)d.geom_mat[ge][k];
         g.geom_friction[ge] = (T)d.geom_friction[ge];
         const int cnt = d.geom_type[ge] == DL_GEOM_CAPSULE ? 2 : 8;
-        for (int k = 0; k < cnt; k++) { if (nc >= G_MAXCAND) { why = "too many collision candidates"; return false; } g.cand_geom[nc] = ge; g.cand_sub[nc] = k; nc++; }
+        for (int k = 0; k < cnt; k++) { if (nc >= GL * D::NPASS) { why = "too many collision candidates"; return false; } g.cand_geom[nc] = ge; g.cand_sub[nc] = k; nc++; }
     }
     g.ncand = nc;
     g.floor_friction = (T)d.floor_friction;
     for (int s = 0; s < d.nsite; s++) { g.site_body[s] = d.site_body[s]; for (int k = 0; k < 3; k++) g.site_pos[s][k] = (T)d.site_pos[s][k]; }
-    for (int j = 0; j < GL; j++) g_load_lane<T>(g, j, g.lanes[j]);      // per-lane records, read by the kernels with wide loads
+    for (int j = 0; j < GL; j++) g_load_lane<T, TP>(g, j, g.lanes[j]);      // per-lane records, read by the kernels with wide loads
     return true;
 }
 }  // namespace dl

@@ -70,286 +70,23 @@ __global__ __launch_bounds__(BLOCK) void k_forward(const DevModel<T, TP>* __rest
     if (niter) niter[i] = info >> 16;
 }
 
-// Workgroups are dealt round-robin to the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.  The SoA
-// state rows put 16 consecutive walkers into one 64-byte line, i.e. 4 consecutive walker groups share their lines:
-// map workgroup i to walker group (i % 8) * (G / 8) + i / 8 so that neighbouring groups run on the SAME XCD and a
-// line is fetched into one L2 only.  (G not a multiple of 8: identity.)
-__device__ __forceinline__ int g_block_of_workgroup(int wg, int nwg) {
-    constexpr int XCDS = 8;
-    if (nwg % XCDS) return wg;
-    return (wg % XCDS) * (nwg / XCDS) + wg / XCDS;
-}
-
-// forward dynamics with 16 lanes per walker (dl_group.hpp): 4 walkers per 64-lane workgroup
-template <typename T, bool TIMED = false>
-__global__ __launch_bounds__(64) void k_forward_g16(const GModel<T>* __restrict__ gm, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, long long* tim = nullptr) {
+// forward dynamics with 16 lanes per walker (dl_group.hpp, dl_group_env.hpp): 4 walkers per 64-lane workgroup
+template <typename T, typename TP, bool TIMED = false>
+__global__ __launch_bounds__(64) void k_forward_g16(const GModel<T, TP>* __restrict__ gm, const DevState<T> st, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, long long* tim = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
-    const int w = g_block_of_workgroup(blockIdx.x, gridDim.x) * GW + grp;
-    const bool valid = w < n;
-    const int wi = valid ? w : n - 1;          // out-of-range rows redo the last walker (keeps the wave uniform)
-    const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    const GLane<T> ln = m->lanes[j];               // this lane's record of the model block (built on the host by g_load_lane)
-    GConst<T> cst;
-    g_load_const<T>(*m, cst);
-    GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
-    if (st.rnd) {
-        const size_t ws = (size_t)(wi);
-        wk.mscale = st.rnd[ws]; wk.floor_mu = st.rnd[(size_t)n + ws];
-        wk.push = mk<T>(st.rnd[(size_t)2 * n + ws], st.rnd[(size_t)3 * n + ws], st.rnd[(size_t)4 * n + ws]);
-        wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
-    }
-    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j, &ln, &cst, &wk};
-    const int nv = m->nv;
-    T q = T(0), v = T(0), wm = T(0), force = T(0);
-    if (j < nv) {
-        q = st.qpos[(size_t)j * n + wi]; v = st.qvel[(size_t)j * n + wi]; wm = st.warm[(size_t)j * n + wi];
-        const int a = ln.act;
-        if (a >= 0) {
-            const T u = dl_clamp(ctrl ? ctrl[(size_t)a * n + wi] : T(0), ln.ctrl_lo, ln.ctrl_hi);
-            force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
-        }
-    }
-    int nc, ne, ni;
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    GLaneTopo<T> lt;
-    g_lane_topo<T, TopoStraight>(j, lt);
-    const T a = g_forward<T, TopoStraight, TIMED>(g, lt, grp, q, v, force, wm, nc, ne, ni, tacc);
-    if constexpr (TIMED) { if (lane == 0) for (int k = 0; k < 8; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k]; }
-    if (valid && j < nv) qacc[(size_t)j * n + w] = a;
-    if (valid && j == 0) { if (ncon) ncon[w] = nc; if (nefc) nefc[w] = ne; if (niter) niter[w] = ni; }
+    g_wave_forward<T, TP, TIMED>(threadIdx.x, g_block_of_workgroup(blockIdx.x, gridDim.x), blockIdx.x, gridDim.x, (DL_LDS T*)smem, gm, st, ctrl, qacc, ncon, nefc, niter, tim);
 }
 
-
-// one control step with 16 lanes per walker (straight walker): action map, 5 x RK4 mj_step through
-// g_forward, cursor / observation / reward / termination / Monitor, and the vec-env auto reset of finished
-// walkers (RSI draw, mocap lookup, foot-site kinematics, first observation) in the same launch.
-template <typename T, bool TIMED = false>
-__global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions_all,
+// control steps with 16 lanes per walker: action map, frame_skip x RK4 mj_step through g_forward, cursor / observation /
+// reward / termination / Monitor, and the vec-env auto reset of finished walkers (RSI draw, mocap lookup, foot-site
+// kinematics, first observation) in the same launch (dl_group_env.hpp).
+template <typename T, typename TP, bool TIMED = false>
+__global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T, TP>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions_all,
                                                      float* obs_all, float* rew_all, uint8_t* done_all, float* term_obs_all, float* rew_terms_all,
-                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, int eval_mode, int nsteps, long long* tim = nullptr) {
-    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        // TIMED: 0-6 g_forward's sections, 7 whole kernel, 8 before the physics, 9 after it
-    long long t_begin = 0;
-    if constexpr (TIMED) t_begin = (long long)__builtin_readcyclecounter();
-    using TPS = TopoStraight;
+                                                     const T* inj_q, const T* inj_v, const int32_t* inj_flags, float* ctrl_out, int eval_mode, int nsteps, long long* tim = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15, n = st.n;
-    const int w0 = g_block_of_workgroup(blockIdx.x, gridDim.x) * GW + grp;
-    const bool valid = w0 < n;
-    const int w = valid ? w0 : n - 1;
-    const DL_CONST GModel<T>* m = (const DL_CONST GModel<T>*)gm;
-    const GLane<T> ln = m->lanes[j];               // this lane's record of the model block (built on the host by g_load_lane)
-    GConst<T> cst;
-    g_load_const<T>(*m, cst);
-    GWalk<T> wk{T(1), m->floor_friction, mk<T>(0, 0, 0), false};
-    if (st.rnd) {
-        const size_t ws = (size_t)(w);
-        wk.mscale = st.rnd[ws]; wk.floor_mu = st.rnd[(size_t)n + ws];
-        wk.push = mk<T>(st.rnd[(size_t)2 * n + ws], st.rnd[(size_t)3 * n + ws], st.rnd[(size_t)4 * n + ws]);
-        wk.pushed = wk.push.x != T(0) || wk.push.y != T(0) || wk.push.z != T(0);
-    }
-    GCtx<T> g{(DL_LDS T*)smem + (size_t)grp * GLds::TOTAL, m, j, &ln, &cst, &wk};
-    DL_LDS T* wb = g.wb;
-    const int nv = m->nv, nu = m->nu;
-    const bool isdof = j < nv;
-    GLaneTopo<T> lt;
-    g_lane_topo<T, TPS>(j, lt);
-    T q = T(0), v = T(0), warm = T(0);
-    if (isdof) { q = st.qpos[(size_t)j * n + w]; v = st.qvel[(size_t)j * n + w]; warm = st.warm[(size_t)j * n + w]; }
-    int32_t cur[DL_CUR_WORDS];
-#pragma unroll
-    for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w];
-    // per-walker words of the environment logic live in registers across the control steps of this launch
-    double walked = st.walked[w];
-    T comz = st.comz_off[w];
-    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
-    long long t_phys_end = 0;
-    // ---- nsteps control steps (time-major arrays: step s uses actions[s], writes obs[s], rew[s], done[s]).  More than one
-    // step per launch is for callers whose actions do not depend on the observations (dl_rollout_fixed): the launch then
-    // lasts as long as the wave with the largest SUM over the steps, not the sum of the per-step maxima.
-#pragma unroll 1
-    for (int step = 0; step < nsteps; step++) {
-    const float* __restrict__ actions = actions_all + (size_t)step * n * nu;
-    float* obs = obs_all + (size_t)step * n * TPS::OBS;
-    float* rew = rew_all + (size_t)step * n;
-    uint8_t* done = done_all + (size_t)step * n;
-    float* term_obs = term_obs_all ? term_obs_all + (size_t)step * n * TPS::OBS : nullptr;
-    float* rew_terms = rew_terms_all ? rew_terms_all + (size_t)step * n * 3 : nullptr;
-    // ---- _rescale_actions + mirror_action (cursor BEFORE refs.next()), per actuated dof
-    const bool mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
-    T ctrl = T(0), force = T(0);
-    const int a = isdof ? ln.act : -1;
-    if (a >= 0) {
-        const int src = mirr_a ? TPS::act_perm_[a] : a;
-        const int jsrc = TPS::act_dof_[src];
-        const T x = dl_clamp((T)actions[(size_t)w * nu + src], T(-1), T(1));
-        const T raw = x > T(0) ? x * m->ctrl_hi[jsrc] : dl_abs(x) * m->ctrl_lo[jsrc];
-        ctrl = (mirr_a && TPS::act_neg_[a]) ? -raw : raw;
-        const T u = dl_clamp(ctrl, ln.ctrl_lo, ln.ctrl_hi);
-        force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
-    }
-    const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
-    if constexpr (TIMED) tacc[8] = (long long)__builtin_readcyclecounter() - t_begin;
-    // ---- physics
-    bool exc = false;
-    const int flag = inj_flags ? inj_flags[w] : 0;
-    if (flag == 2) exc = true;
-    else if (flag == 1) { if (isdof) { q = inj_q[(size_t)j * n + w]; v = inj_v[(size_t)j * n + w]; } }
-    const bool simulate = flag == 0;
-    int dbg_it = 0, dbg_max = 0, dbg_rows = 0;
-    if (__any(simulate)) {
-        const T h = m->timestep;
-        const int fs = m->frame_skip;
-        T acc_s2_prev = T(0);
-#pragma unroll 1
-        for (int kf = 0; kf < fs; kf++) {
-            // mj_checkPos / mj_checkVel
-            if (simulate && !exc && gany(isdof && (dl_bad(q) || dl_bad(v)))) exc = true;
-            const T q0 = q, v0 = v;
-            T dq = T(0), dv = T(0), qs = q, vs = v;
-            T acc_s0 = warm;
-#pragma unroll 1
-            for (int stage = 0; stage < 4; stage++) {
-                int nc, ne, ni;
-                // starting point of the Newton iteration (the minimiser does not depend on it): the last solution (MuJoCo's
-                // qacc_warmstart), linearly extrapolated where the next stage lies half a time step further: stage 1 from
-                // (stage 2 of the previous mj_step, stage 0), stage 3 from (stage 0, stage 2)
-                T start = warm;
-                if (stage == 1 && kf > 0) start = warm + (warm - acc_s2_prev);
-                else if (stage == 3) start = warm + (warm - acc_s0);
-                const T acc = g_forward<T, TPS, TIMED>(g, lt, grp, qs, vs, force, start, nc, ne, ni, tacc);
-                if (stage == 0) acc_s0 = acc;
-                if (stage == 2) acc_s2_prev = acc;
-                dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
-                if (st.dbgf && valid && ni >= st.dbg_cap) {
-                    st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)start;
-                }
-                if (simulate && !exc) warm = acc;
-                if (stage == 0 && simulate && !exc && gany(isdof && dl_bad(acc))) exc = true;     // mj_checkAcc
-                const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
-                const T al = stage == 2 ? T(1) : T(0.5);
-                dq += wgt * vs; dv += wgt * acc;
-                const T vstage = vs;
-                qs = q0 + h * al * vstage; vs = v0 + h * al * acc;
-            }
-            if (simulate && !exc) { q = q0 + h * dq; v = v0 + h * dv; }
-        }
-    }
-    if constexpr (TIMED) t_phys_end = (long long)__builtin_readcyclecounter();
-    // ---- environment logic
-    const double tor_mean = (double)tor_sum / nu;
-    float r;
-    bool dn;
-    // observation (mimic_env.py:403-437 + mirror_obs :440-480) from q, v staged in LDS: 29 outputs over 16 lanes
-    auto write_obs = [&](float* dst_base) {
-        const int rs = cur[DL_CUR_READ_STEP];
-        const T phase_var = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
-        const int iv = cur[DL_CUR_I_STEP] - cur[DL_CUR_COUNT] + 1;
-        const T desvel = c.step_vel[iv > 0 ? iv : 0];
-        const bool mirr_o = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
-        auto raw_obs = [&](int k) -> T { return k == 0 ? phase_var : (k == 1 ? desvel : (k < 1 + nv ? wb[GLds::Q + (k - 1)] : wb[GLds::V + (k - 1 - nv)])); };
-        if (valid && dst_base) {
-            for (int k = j; k < TPS::OBS; k += GL) {
-                const T plain = raw_obs(k);
-                const T mir = TPS::obs_neg_[k] ? -raw_obs(TPS::obs_perm_[k]) : raw_obs(TPS::obs_perm_[k]);
-                dst_base[(size_t)w * TPS::OBS + k] = (float)(mirr_o ? mir : plain);
-            }
-        }
-    };
-    if (exc) {
-        r = 0.0f; dn = true; walked = 0;
-        terms[0] = terms[1] = terms[2] = 1.0;
-    } else {
-        cursor_next<T, TPS>(c, cur);
-        g_sync<T>();
-        if (isdof) { wb[GLds::Q + j] = q; wb[GLds::V + j] = v; }
-        g_sync<T>();
-        cur[DL_CUR_EP_DUR] += 1;
-        const T vx = dl_clamp(rbcast<0>(v), T(-5.5), T(5.5)), vy = dl_clamp(rbcast<1>(v), T(-5.5), T(5.5));
-        walked += (double)dl_sqrt(vx * vx + vy * vy) * (double)c.inv_ctrl_freq;
-        const bool timeout = cur[DL_CUR_EP_DUR] >= c.ep_dur_max;
-        const T qz = rbcast<2>(q);
-        dn = (qz < c.com_z_min) || timeout;
-        if (dn) r = timeout ? 0.0f : -0.0f;
-        else {
-            // imitation reward: every dof lane contributes its squared differences
-            T dp = T(0), dvv = T(0), dc = T(0);
-            if (isdof) {
-                const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
-                T qr = ref_at(c, j, base);
-                const T vr = ref_at(c, nv + j, base);
-                if (cur[DL_CUR_HAS_DIST]) { if (j == 0) qr += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1); }
-                else if (j == 2) qr -= comz;
-                const T d1 = q - qr, d2 = v - vr;
-                if (j < 3) dc = d1 * d1; else { dp = d1 * d1; dvv = d2 * d2; }
-            }
-            const T tp = dl_exp(T(-3) * gsum(dp)), tv = dl_exp(T(-0.05) * gsum(dvv)), tc = dl_exp(T(-16) * gsum(dc));
-            terms[0] = (double)tp; terms[1] = (double)tv; terms[2] = (double)tc;
-            r = (float)((c.rew_w[0] * tp + c.rew_w[1] * tv + c.rew_w[2] * tc) * c.rew_scale + c.alive_bonus);
-        }
-        write_obs(dn ? term_obs : obs);
-    }
-    if (valid && j == 0 && st.dbg) {
-        st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
-    }
-    if (valid && j == 0) {
-        monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked);
-        if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
-        rew[w] = r;
-        done[w] = dn ? 1 : 0;
-    }
-    // ---- vec-env auto reset inside the same launch (SubprocVecEnv worker: obs = env.reset() after done; a
-    // diverged step resets twice, the first reset's observation being the terminal observation):
-    // MujocoEnv.reset -> reset_model (mimic_env.py:526-572).  The warm start of the new episode is zero: the
-    // solver's minimiser does not depend on it.
-    const int nrep = exc ? 2 : (dn ? 1 : 0);
-    if (nrep > 0) {
-#pragma unroll 1
-        for (int rep = 0; rep < nrep; rep++) {
-            int s0, p0, read = -1;
-            if (eval_mode) {
-                s0 = cur[DL_CUR_EVAL_K];
-                p0 = (int)(0.75 * (double)(c.step_off[s0 + 1] - c.step_off[s0]));
-                read = 0;
-                cur[DL_CUR_EVAL_K] = (s0 + 1 >= 20) ? 0 : s0 + 1;
-            }
-            else if (st.inj_rsi && st.inj_rsi[w] >= 0) { s0 = st.inj_rsi[w]; p0 = st.inj_rsi[(size_t)n + w]; }
-            else rsi_draw(c, (uint32_t)(c.env_index_base + w), (uint32_t)cur[DL_CUR_EPISODE], s0, p0);
-            cur[DL_CUR_EPISODE] += 1;
-            cur[DL_CUR_EP_DUR] = 0;
-            cur[DL_CUR_I_STEP] = s0; cur[DL_CUR_RSI_STEP] = s0; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s0; cur[DL_CUR_POS] = p0; cur[DL_CUR_HAS_DIST] = 0;
-            if (isdof) {
-                const int base = c.step_off[cur[DL_CUR_READ_STEP]] + p0;
-                q = ref_at(c, j, base);
-                v = ref_at(c, nv + j, base);
-            }
-            { GKin<T> kin; g_fk<T, TPS>(g, lt, q, kin); }
-            comz = g_lowest_site<T>(g);
-            if (j == 2) q -= comz;
-            if (isdof) { wb[GLds::Q + j] = q; wb[GLds::V + j] = v; }
-            warm = T(0);
-            cursor_next<T, TPS>(c, cur);
-            g_sync<T>();
-            write_obs((nrep == 2 && rep == 0) ? term_obs : obs);
-            g_sync<T>();
-        }
-        walked = 0;
-        terms[0] = terms[1] = terms[2] = 1.0;       // reset_model's sanity check evaluates the reward terms at the init state (:562)
-    }
-    }   // control steps of this launch
-    if (valid && j == 0) {
-        st.comz_off[w] = comz;
-        st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
-        st.walked[w] = walked;
-#pragma unroll
-        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
-    }
-    if (valid && isdof) { st.qpos[(size_t)j * n + w] = q; st.qvel[(size_t)j * n + w] = v; st.warm[(size_t)j * n + w] = warm; }
-    if constexpr (TIMED) {
-        const long long t_end = (long long)__builtin_readcyclecounter();
-        tacc[7] = t_end - t_begin; tacc[9] = t_end - t_phys_end;
-        if (lane == 0) for (int k = 0; k < 10; k++) tim[(size_t)k * gridDim.x + blockIdx.x] = tacc[k];
-    }
+    g_wave_env_step<T, TP, TIMED>(threadIdx.x, g_block_of_workgroup(blockIdx.x, gridDim.x), blockIdx.x, gridDim.x, (DL_LDS T*)smem, gm, c, st, actions_all, obs_all, rew_all, done_all,
+                                  term_obs_all, rew_terms_all, inj_q, inj_v, inj_flags, ctrl_out, eval_mode, nsteps, tim);
 }
 
 // row primitives of dl_group.hpp on known data (tests/test_gpu_parity.py::test_row_primitives)
@@ -635,6 +372,7 @@ struct dl_env_s {
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
+    virtual int last_ctrl(float* out, hipStream_t) = 0;
     virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
     virtual int step_timed(const float*, float*, float*, uint8_t*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
@@ -665,7 +403,9 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     DevCfg<T> c;
     DevState<T> st{};
     std::vector<void*> allocs;
-    GModel<T>* gmd = nullptr;        // table-driven model of the 16-lane kernels (straight walker only)
+    GModel<T, TP>* gmd = nullptr;    // table-driven model of the 16-lane kernels
+    static constexpr size_t GLDS = (size_t)GW * GLds<TP>::TOTAL * sizeof(T);      // LDS of one wave (four walkers) of the 16-lane kernels
+    float* ctrl_dbg = nullptr;       // test hook (dl_debug_last_ctrl): sim.data.ctrl of the last single-step launch, float[N, nu]
     T *inj_q = nullptr, *inj_v = nullptr;
     int32_t* inj_flags = nullptr;
     bool inj_armed = false;
@@ -742,18 +482,17 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&scratch_obs, (size_t)TP::OBS * n))) return rc;
         if (cfg.lanes_per_walker != 0 && cfg.lanes_per_walker != 1 && cfg.lanes_per_walker != GL) return fail(DL_E_INVAL, "lanes_per_walker must be 0 (auto), 1 or 16");
         variant = cfg.lanes_per_walker == 1 ? 0 : 1;      // auto prefers the 16-lane kernels
-        if (TP::ENV_KIND == 0 && TP::NV <= GL && TP::NB <= G_MAXB) {
-            GModel<T> gmh;
+        {
+            GModel<T, TP> gmh;
             std::string why;
-            if (!fill_group_model<T>(d, gmh, why)) { if (cfg.lanes_per_walker == GL) return fail(DL_E_INVAL, why); variant = 0; }
+            if (!fill_group_model<T, TP>(d, gmh, why)) { if (cfg.lanes_per_walker == GL) return fail(DL_E_INVAL, why); variant = 0; }
             else {
                 if ((rc = dalloc(&gmd, 1))) return rc;
                 HIPCHK(hipMemcpy(gmd, &gmh, sizeof gmh, hipMemcpyHostToDevice));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T)))));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T)))));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLDS));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLDS));
             }
-        } else if (cfg.lanes_per_walker == GL) return fail(DL_E_INVAL, "the 16-lane kernels support the straight walker (<= 16 dofs, <= 8 bodies)");
-        else variant = 0;
+        }
         const unsigned g256 = (unsigned)((n + 255) / 256);
         for (int j = 0; j < TP::NV; j++) k_fill<T><<<g256, 256>>>(st.qpos + (size_t)j * n, (T)d.jnt_qpos0[j], (size_t)n);
         k_fill<int32_t><<<g256, 256>>>(st.cur + (size_t)DL_CUR_COUNT * n, 1, (size_t)n);   // count_steps_same_vel = 1
@@ -777,28 +516,23 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     static constexpr int MULTI = 512;
     int steps_fixed(int nsteps, const float* act, float* obs, float* rew, uint8_t* done, hipStream_t s) override {
         if (!(variant == 1 && gmd) || inj_armed || nsteps <= 1) { const int rc = step(act, obs, rew, done, nullptr, nullptr, s); return rc == DL_OK ? 1 : rc; }
-        if constexpr (TP::ENV_KIND == 0) {
-            const int k = nsteps < MULTI ? nsteps : MULTI;
-            prof_begin(s);
-            hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
-                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, k);
-            if (prof_open) prof_steps += k;
-            prof_end(s);
-            HIPCHK(hipGetLastError());
-            return k;
-        }
-        return fail(DL_E_INVAL, "steps_fixed: unreachable");
+        const int k = nsteps < MULTI ? nsteps : MULTI;
+        prof_begin(s);
+        hipLaunchKernelGGL((k_env_step_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
+                           (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, (float*)nullptr, eval_mode, k);
+        if (prof_open) prof_steps += k;
+        prof_end(s);
+        HIPCHK(hipGetLastError());
+        return k;
     }
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
         if (variant == 1 && gmd) {
-            if constexpr (TP::ENV_KIND == 0) {
-                prof_begin(s);
-                hipLaunchKernelGGL((k_env_step_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, term, terms,
-                                   (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), eval_mode, 1);
-                if (prof_open) prof_steps += 1;
-                prof_end(s);
-            }
+            prof_begin(s);
+            hipLaunchKernelGGL((k_env_step_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, term, terms,
+                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), ctrl_dbg, eval_mode, 1);
+            if (prof_open) prof_steps += 1;
+            prof_end(s);
             HIPCHK(hipGetLastError());
             if (inj_armed) { HIPCHK(hipMemsetAsync(inj_flags, 0, (size_t)n * sizeof(int32_t), s)); inj_armed = false; }
             return DL_OK;                 // finished walkers were re-initialised inside the launch
@@ -836,7 +570,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
         if (!qacc) return fail(DL_E_INVAL, "qacc must not be NULL");
         if (variant == 1 && gmd) {
-            hipLaunchKernelGGL((k_forward_g16<T>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
+            hipLaunchKernelGGL((k_forward_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, st, (const T*)ctrl, (T*)qacc, ncon, nefc, niter);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
@@ -888,26 +622,30 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int forward_timed(const void* ctrl, void* qacc, long long* tim, hipStream_t s) override {
         if (!gmd || !qacc || !tim) return fail(DL_E_INVAL, "dl_debug_forward_timed: needs the 16-lane kernels, qacc and tim");
-        if constexpr (TP::ENV_KIND == 0 && sizeof(T) == 4) {
-            static bool attr = false;
-            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T))))); attr = true; }
-            hipLaunchKernelGGL((k_forward_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, st, (const T*)ctrl, (T*)qacc, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, tim);
+        if constexpr (sizeof(T) == 4) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLDS));
+            hipLaunchKernelGGL((k_forward_g16<T, TP, true>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, st, (const T*)ctrl, (T*)qacc, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, tim);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
-        return fail(DL_E_INVAL, "dl_debug_forward_timed: float32 straight walker only");
+        return fail(DL_E_INVAL, "dl_debug_forward_timed: float32 only");
     }
     int step_timed(const float* act, float* obs, float* rew, uint8_t* done, long long* tim, hipStream_t s) override {
         if (!gmd || !act || !obs || !rew || !done || !tim) return fail(DL_E_INVAL, "dl_debug_step_timed: needs the 16-lane kernels and all arrays");
-        if constexpr (TP::ENV_KIND == 0 && sizeof(T) == 4) {
-            static bool attr = false;
-            if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GW * GLds::TOTAL * sizeof(T))))); attr = true; }
-            hipLaunchKernelGGL((k_env_step_g16<T, true>), dim3((n + GW - 1) / GW), dim3(64), (GW * GLds::TOTAL * sizeof(T)), s, (const GModel<T>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
-                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, eval_mode, 1, tim);
+        if constexpr (sizeof(T) == 4) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLDS));
+            hipLaunchKernelGGL((k_env_step_g16<T, TP, true>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
+                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, (float*)nullptr, eval_mode, 1, tim);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
-        return fail(DL_E_INVAL, "dl_debug_step_timed: float32 straight walker only");
+        return fail(DL_E_INVAL, "dl_debug_step_timed: float32 only");
+    }
+    int last_ctrl(float* out, hipStream_t s) override {
+        if (!(variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_debug_last_ctrl: implemented by the 16-lane kernels");
+        if (!ctrl_dbg) { const int rc = dalloc(&ctrl_dbg, (size_t)n * TP::NU); if (rc) return rc; }      // the first call enables the record
+        if (out) HIPCHK(hipMemcpyAsync(out, ctrl_dbg, (size_t)n * TP::NU * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
     }
     int capstate(float* out, hipStream_t s) override {
         if (!st.dbgf || !out) return fail(DL_E_INVAL, "dl_debug_capstate: enable the counters first");
@@ -1040,6 +778,12 @@ int dl_debug_selftest(const float* in, float* out, void* stream) {
 int dl_debug_capstate(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->capstate(out, (hipStream_t)stream);
+}
+/* sim.data.ctrl as the last dl_step set it (after _rescale_actions and mirror_action): float[N, nu] device; the first call
+ * (out may be NULL) enables the record */
+int dl_debug_last_ctrl(dl_handle h, float* out, void* stream) {
+    NEED(h);
+    return h->last_ctrl(out, (hipStream_t)stream);
 }
 int dl_set_randomization(dl_handle h, const float* mass_scale, const float* floor_friction, void* stream) {
     NEED(h);

@@ -273,6 +273,13 @@ class HipVecEnv:
         lib.check(self._lib.dl_debug_capstate(self._h, _ptr(out), _stream()))
         return out.cpu().numpy()
 
+    def debug_last_ctrl(self):
+        """sim.data.ctrl of the last step() (after _rescale_actions / mirror_action), float32 [N, nu]; the first call enables
+        the record (and returns zeros)."""
+        out = torch.zeros(self.num_envs, self.nu, device=self.device)
+        lib.check(self._lib.dl_debug_last_ctrl(self._h, _ptr(out), _stream()))
+        return out.cpu().numpy()
+
     def debug_inject(self, qpos=None, qvel=None, flags=None, rsi=None):
         dev = self.device
         f = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev).contiguous()

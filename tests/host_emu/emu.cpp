@@ -1,6 +1,9 @@
 // emu.cpp -- TEST INFRASTRUCTURE: compiles the kernels' per-lane source (drloco_amd/csrc/dl_core.hpp,
 // dl_env.hpp) for the host and drives it one lane at a time, so that the device code's logic can be
 // checked against the independent oracle on a machine without a GPU.  Never linked into the product.
+// The 16-lanes-per-walker kernels (dl_group.hpp, dl_group_env.hpp) run here too: DL_GROUP_EMU swaps the wave-level
+// builtins for dl_group_emu.hpp's fibers (one wave = four walkers = 64 cooperative lanes).
+#define DL_GROUP_EMU 1
 #include <cstdlib>
 #include <vector>
 
@@ -19,6 +22,9 @@ template <typename T, typename TP> struct Emu {
     int n;
     int eval_mode = 0;
     std::vector<double> pref;
+    GModel<T, TP> gm;                 // table-driven model of the 16-lane kernels
+    bool gm_ok = false;
+    std::vector<T> rnd, smem;
 };
 
 template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
@@ -50,6 +56,9 @@ template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_
     e->lane.assign(MemLayout<TP>::TOTAL, 0);
     e->work.assign((size_t)4 * TP::NV * n, 0);
     e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), e->work.data(), n};
+    e->st.rnd = nullptr; e->st.dbgf = nullptr; e->st.dbg = nullptr; e->st.dbg_cap = 1 << 30;
+    e->gm_ok = fill_group_model<T, TP>(*d, e->gm, why);
+    e->smem.assign((size_t)GW * GLds<TP>::TOTAL, 0);
     return e;
 }
 
@@ -84,7 +93,42 @@ template <typename T, typename TP> static void emu_forward(Emu<T, TP>* e, const 
     }
 }
 
-#define EMU_API(SUF, T, TP)                                                                                                   \
+// ---- the 16-lane kernels: every wave (four walkers) is run as 64 fibers, waves one after the other
+template <typename T, typename TP> static int emu_gforward(Emu<T, TP>* e, const T* ctrl, T* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
+    if (!e->gm_ok) return -1;
+    const int nwg = (e->n + GW - 1) / GW;
+    for (int wg = 0; wg < nwg; wg++)
+        dlemu::run_wave(64, [&](int lane) { g_wave_forward<T, TP, false>(lane, g_block_of_workgroup(wg, nwg), wg, nwg, e->smem.data(), &e->gm, e->st, ctrl, qacc, ncon, nefc, niter, nullptr); });
+    return 0;
+}
+template <typename T, typename TP> static int emu_gstep(Emu<T, TP>* e, int nsteps, const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, float* ctrl_out) {
+    if (!e->gm_ok) return -1;
+    const int nwg = (e->n + GW - 1) / GW;
+    bool armed = false;
+    for (int i = 0; i < e->n; i++) armed = armed || e->inj_flags[i] != 0;
+    for (int wg = 0; wg < nwg; wg++)
+        dlemu::run_wave(64, [&](int lane) {
+            g_wave_env_step<T, TP, false>(lane, g_block_of_workgroup(wg, nwg), wg, nwg, e->smem.data(), &e->gm, e->c, e->st, act, obs, rew, done, term, terms,
+                                          e->inj_q.data(), e->inj_v.data(), armed ? e->inj_flags.data() : nullptr, ctrl_out, e->eval_mode, nsteps, nullptr);
+        });
+    for (int i = 0; i < e->n; i++) e->inj_flags[i] = 0;
+    return 0;
+}
+template <typename T, typename TP> static void emu_set_rnd(Emu<T, TP>* e, const float* mass_scale, const float* floor_mu, const float* push) {
+    const int n = e->n;
+    if (e->rnd.empty()) { e->rnd.assign((size_t)5 * n, 0); for (int i = 0; i < n; i++) { e->rnd[i] = 1; e->rnd[(size_t)n + i] = e->gm.floor_friction; } e->st.rnd = e->rnd.data(); }
+    for (int i = 0; i < n; i++) {
+        if (mass_scale) e->rnd[i] = (T)mass_scale[i];
+        if (floor_mu) e->rnd[(size_t)n + i] = (T)floor_mu[i];
+        if (push) for (int k = 0; k < 3; k++) e->rnd[(size_t)(2 + k) * n + i] = (T)push[3 * i + k];
+    }
+}
+
+#define EMU_API(SUF, T, TP) \
+    extern "C" int dle_gforward_##SUF(void* h, const T* u, T* qa, int32_t* nc, int32_t* ne, int32_t* ni) { return emu_gforward<T, TP>((Emu<T, TP>*)h, u, qa, nc, ne, ni); } \
+    extern "C" int dle_gstep_##SUF(void* h, int k, const float* a, float* o, float* r, uint8_t* d, float* t, float* tt, float* cu) { return emu_gstep<T, TP>((Emu<T, TP>*)h, k, a, o, r, d, t, tt, cu); } \
+    extern "C" void dle_set_rnd_##SUF(void* h, const float* ms, const float* mu, const float* push) { emu_set_rnd<T, TP>((Emu<T, TP>*)h, ms, mu, push); } \
+    extern "C" int dle_glds_bytes_##SUF(void) { return (int)(GW * GLds<TP>::TOTAL * sizeof(T)); }                                                                                                   \
     extern "C" void* dle_create_##SUF(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* c, int n) { return emu_create<T, TP>(d, r, c, n); } \
     extern "C" void dle_destroy_##SUF(void* h) { delete (Emu<T, TP>*)h; }                                                     \
     extern "C" void dle_reset_##SUF(void* h, const uint8_t* m, const int32_t* is, const int32_t* ip, float* obs) { emu_reset<T, TP>((Emu<T, TP>*)h, m, is, ip, obs); } \

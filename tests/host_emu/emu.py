@@ -14,11 +14,12 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, 'emu.cpp')] + [os.path.join(_ROOT, 'drloco_amd', 'csrc', f) for f in ('dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp')] \
+    srcs = [os.path.join(_HERE, 'emu.cpp'), os.path.join(_HERE, 'dl_group_emu.hpp')] \
+        + [os.path.join(_ROOT, 'drloco_amd', 'csrc', f) for f in ('dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp', 'dl_group.hpp', 'dl_group_env.hpp')] \
         + [os.path.join(_ROOT, 'include', 'drloco_hip.h')]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-                               '-I' + os.path.join(_ROOT, 'include'), '-I' + os.path.join(_ROOT, 'drloco_amd', 'csrc'),
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+                               '-I' + os.path.join(_ROOT, 'include'), '-I' + os.path.join(_ROOT, 'drloco_amd', 'csrc'), '-I' + _HERE,
                                '-o', _LIB, srcs[0]])
     return _LIB
 
@@ -92,6 +93,36 @@ class EmuEnv:
         ncon = np.zeros(self.n, np.int32); nefc = np.zeros(self.n, np.int32); nit = np.zeros(self.n, np.int32)
         self._f('forward')(self.h, _p(u, self.ct), _p(qacc, self.ct), _p(ncon, C.c_int32), _p(nefc, C.c_int32), _p(nit, C.c_int32))
         return qacc, ncon, nefc, nit
+
+    # ---- the 16-lanes-per-walker kernels (dl_group.hpp / dl_group_env.hpp), a wave as 64 fibers
+    def gforward(self, ctrl=None):
+        u = np.zeros((self.nu, self.n), self.rt) if ctrl is None else np.ascontiguousarray(ctrl, self.rt)
+        qacc = np.zeros((self.nv, self.n), self.rt)
+        ncon = np.zeros(self.n, np.int32); nefc = np.zeros(self.n, np.int32); nit = np.zeros(self.n, np.int32)
+        rc = self._f('gforward')(self.h, _p(u, self.ct), _p(qacc, self.ct), _p(ncon, C.c_int32), _p(nefc, C.c_int32), _p(nit, C.c_int32))
+        assert rc == 0
+        return qacc, ncon, nefc, nit
+
+    def gstep(self, actions, return_ctrl=False):
+        """actions [N, nu] (one control step, term_obs / reward terms returned) or [T, N, nu] (T steps in one 'launch')."""
+        a = np.ascontiguousarray(actions, np.float32)
+        multi = a.ndim == 3
+        T = a.shape[0] if multi else 1
+        obs = np.zeros((T, self.n, self.obs_dim), np.float32); term = np.zeros((T, self.n, self.obs_dim), np.float32)
+        rew = np.zeros((T, self.n), np.float32); done = np.zeros((T, self.n), np.uint8); terms = np.zeros((T, self.n, 3), np.float32)
+        ctrl = np.zeros((T, self.n, self.nu), np.float32)
+        rc = self._f('gstep')(self.h, C.c_int(T), _p(a, C.c_float), _p(obs, C.c_float), _p(rew, C.c_float), _p(done, C.c_uint8), _p(term, C.c_float), _p(terms, C.c_float), _p(ctrl, C.c_float))
+        assert rc == 0
+        out = (obs, rew, done, term, terms) if multi else (obs[0], rew[0], done[0], term[0], terms[0])
+        return out + ((ctrl if multi else ctrl[0]),) if return_ctrl else out
+
+    def set_randomization(self, mass_scale=None, floor_friction=None, push=None):
+        f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)
+        ms, mu, pu = f(mass_scale), f(floor_friction), f(push)
+        self._f('set_rnd')(self.h, _p(ms, C.c_float), _p(mu, C.c_float), _p(pu, C.c_float))
+
+    def glds_bytes(self):
+        return self._f('glds_bytes')()
 
     def inject_state(self, i, qpos, qvel):
         q = np.ascontiguousarray(qpos, self.rt); v = np.ascontiguousarray(qvel, self.rt)

@@ -661,10 +661,11 @@ def _loco3d_pair(oracle, n, precision, L=6000, seed=0, **cfg):
     return dev, orc
 
 
+@LANES
 @pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 1e-2)])
-def test_loco3d_forward_dynamics(torch_cuda, oracle, precision, tol):
+def test_loco3d_forward_dynamics(torch_cuda, oracle, precision, tol, lanes):
     n = 512
-    dev, orc = _loco3d_pair(oracle, n, precision)
+    dev, orc = _loco3d_pair(oracle, n, precision, lanes_per_walker=lanes)
     assert dev.obs_dim == 47 and dev.nu == 13 and dev.nv == 19
     rng = np.random.default_rng(0)
     q = np.array(dev.model.jnt_qpos0[:19])[:, None] + 0.2 * rng.standard_normal((19, n)); q[2] = rng.uniform(0.75, 1.2, n)
@@ -678,9 +679,10 @@ def test_loco3d_forward_dynamics(torch_cuda, oracle, precision, tol):
         assert np.median(err.max(axis=0)) < 2e-4
 
 
-def test_loco3d_rollout_f64_matches_oracle(torch_cuda, oracle):
+@LANES
+def test_loco3d_rollout_f64_matches_oracle(torch_cuda, oracle, lanes):
     n, T = 128, 120
-    dev, orc = _loco3d_pair(oracle, n, 64)
+    dev, orc = _loco3d_pair(oracle, n, 64, lanes_per_walker=lanes)
     np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
     rng = np.random.default_rng(1)
     nd = 0
@@ -697,9 +699,10 @@ def test_loco3d_rollout_f64_matches_oracle(torch_cuda, oracle):
     np.testing.assert_allclose(s2['walked'], s1['walked'], rtol=1e-6, atol=1e-9)
 
 
-def test_loco3d_single_step_f32(torch_cuda, oracle):
+@LANES
+def test_loco3d_single_step_f32(torch_cuda, oracle, lanes):
     n = 1024
-    dev, orc = _loco3d_pair(oracle, n, 32)
+    dev, orc = _loco3d_pair(oracle, n, 32, lanes_per_walker=lanes)
     rng = np.random.default_rng(2)
     orc.reset(); dev.reset()
     for t in range(8):
@@ -711,18 +714,20 @@ def test_loco3d_single_step_f32(torch_cuda, oracle):
     assert np.array_equal(d1.astype(bool), d2)
     live = ~d2
     rel = np.abs(r1 - r2)[live] / np.abs(r1[live])
-    assert np.quantile(rel, 0.99) < 1e-4 and rel.max() < 5e-3, (np.quantile(rel, 0.99), rel.max())
+    print('loco3d f32 one-step reward error: q50 %.2e q99 %.2e max %.2e (lanes %d)' % (np.median(rel), np.quantile(rel, 0.99), rel.max(), lanes))
+    assert rel.max() < 1e-4, (np.quantile(rel, 0.99), rel.max())
     assert np.array_equal(orc.get_state()['cursor'], dev.get_state()['cursor'])
 
 
-def test_G9_loco3d_trace_on_device(torch_cuda):
+@LANES
+def test_G9_loco3d_trace_on_device(torch_cuda, lanes):
     """The reference's own MimicWalker165cm65kgEnv.step() trace through the device kernels."""
     from drloco_amd import mocap, models
     from drloco_amd.vec_env import HipVecEnv
     with np.load(os.path.join(GOLDEN, 'G9_loco3d.npz')) as z:
         g = {k: z[k] for k in z.files}
     ang, vel = mocap.synthetic_loco3d(L=int(g['L']), seed=int(g['seed']))
-    env = HipVecEnv(models.WALKER_165CM, num_envs=1, precision=64, refs=mocap.loco3d_table(ang, vel), ep_dur_max=10 ** 9)
+    env = HipVecEnv(models.WALKER_165CM, num_envs=1, precision=64, refs=mocap.loco3d_table(ang, vel), ep_dur_max=10 ** 9, lanes_per_walker=lanes)
     cur = np.zeros((abi.DL_CUR_WORDS, 1), np.int32); cur[abi.DL_CUR_POS] = int(g['s_start']); cur[abi.DL_CUR_COUNT] = 1
     env.set_state(cursor=cur)
     for t in range(len(g['s_rew'])):

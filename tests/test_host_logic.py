@@ -175,3 +175,119 @@ def test_checkpoint_formats_round_trip(tmp_path):
         zz.writestr('policy.pth', buf.getvalue())
     with pytest.raises(ValueError):
         ck.read_policy_zip(z2)
+
+
+# ---------------------------------------------------------------------------------------------
+# The 16-lanes-per-walker kernels (drloco_amd/csrc/dl_group.hpp, dl_group_env.hpp: the product's step kernel) compiled for
+# the host with a wave emulated as 64 fibers (tests/host_emu/dl_group_emu.hpp) against the oracle.  Both walkers: the
+# straight walker (14 lane dofs) and the 19-dof walker (16 lane dofs + 3 replicated root translations).
+def _walker(which):
+    if which == 'straight':
+        return models.make_model(), mocap.RefTable.load(), abi.default_config()
+    ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
+    return models.make_model(models.WALKER_165CM), mocap.loco3d_table(ang, vel), abi.loco3d_config()
+
+
+def _states(m, n, seed, zlo):
+    rng = np.random.default_rng(seed)
+    nv, nu = m.nv, m.nu
+    q = np.array(m.jnt_qpos0[:nv])[:, None] + 0.22 * rng.standard_normal((nv, n)); q[2] = rng.uniform(zlo, zlo + 0.45, n)
+    return q, 1.5 * rng.standard_normal((nv, n)), rng.standard_normal((nv, n)), rng.uniform(-300, 300, (nu, n))
+
+
+@pytest.mark.parametrize('which,zlo', [('straight', 0.85), ('loco3d', 0.75)])
+@pytest.mark.parametrize('precision,tol', [(64, 1e-10), (32, 5e-3)])
+def test_group_kernel_source_on_host_forward(emu, oracle, which, zlo, precision, tol):
+    m, table, cfg = _walker(which)
+    n = 48
+    q, v, w, u = _states(m, n, 3, zlo)
+    o = oracle.OracleEnv(m, table, cfg, n); e = emu.EmuEnv(m, table, cfg, n, precision)
+    o.set_state(qpos=q, qvel=v, warm=w); e.set_state(qpos=q, qvel=v, warm=w)
+    qa, nc, ne, _ = o.forward(u); qb, nc2, ne2, _ = e.gforward(u)
+    assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2) and nc.max() >= 6
+    err = np.abs(qa - qb) / (1 + np.abs(qa))
+    assert err.max() < tol, err.max()
+    # four waves per CU: the float32 build's LDS per wave (four walkers) times 4 fits the 160 KiB of a CU
+    if precision == 32:
+        assert 4 * ((e.glds_bytes() + 1279) // 1280 * 1280) <= 160 * 1024
+
+
+@pytest.mark.parametrize('which,zlo', [('straight', 0.85), ('loco3d', 0.75)])
+def test_group_kernel_source_on_host_randomization_and_push(emu, oracle, which, zlo):
+    """dl_set_randomization / dl_set_push (BASELINE config 5, build-defined) for BOTH walkers: mass scale, floor friction and a
+    push on the torso, float64 against the oracle."""
+    m, table, cfg = _walker(which)
+    n = 32
+    rng = np.random.default_rng(9)
+    ms = rng.uniform(0.8, 1.2, n).astype(np.float32); fr = rng.uniform(0.5, 1.1, n).astype(np.float32)
+    push = np.zeros((n, 3), np.float32); k = rng.random(n) < 0.6
+    ang = rng.uniform(0, 2 * np.pi, n); push[k, 0] = 50 * np.cos(ang[k]); push[k, 1] = 50 * np.sin(ang[k]); push[k, 2] = rng.uniform(-20, 20, k.sum())
+    q, v, w, u = _states(m, n, 5, zlo)
+    o = oracle.OracleEnv(m, table, cfg, n); e = emu.EmuEnv(m, table, cfg, n, 64)
+    o.set_state(qpos=q, qvel=v, warm=w); e.set_state(qpos=q, qvel=v, warm=w)
+    qa0, _, _, _ = o.forward(u)
+    o.set_randomization(ms.astype(np.float64), fr.astype(np.float64), push.astype(np.float64)); e.set_randomization(ms, fr, push)
+    qa, nc, ne, _ = o.forward(u); qb, nc2, ne2, _ = e.gforward(u)
+    assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2)
+    assert (np.abs(qa - qb) / (1 + np.abs(qa))).max() < 1e-10
+    assert np.abs(qa0 - qa).max() > 1.0          # the randomisation really changes the dynamics
+
+
+@pytest.mark.parametrize('which,n,T', [('straight', 8, 14), ('loco3d', 8, 10)])
+def test_group_kernel_source_on_host_rollout(emu, oracle, which, n, T):
+    """Whole control steps of the product's step kernel (action map, RK4 x frame_skip, cursor, observation, reward, done,
+    auto reset) on the host, float64, against the oracle; then the same steps again as ONE multi-step launch."""
+    m, table, cfg = _walker(which)
+    cfg.ep_dur_max = 9           # every walker times out inside the test: the in-kernel auto reset runs
+    o = oracle.OracleEnv(m, table, cfg, n); e = emu.EmuEnv(m, table, cfg, n, 64); e2 = emu.EmuEnv(m, table, cfg, n, 64)
+    np.testing.assert_allclose(e.reset(), o.reset(), atol=2e-6)
+    st = o.get_state()
+    e2.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=e.get_state()['warm'], cursor=st['cursor'], walked=st['walked'])
+    rng = np.random.default_rng(1)
+    acts = np.clip(0.5 * rng.standard_normal((T, n, m.nu)), -1, 1).astype(np.float32)
+    nd = 0
+    single = []
+    for t in range(T):
+        o1, r1, d1, t1, _ = o.step(acts[t].astype(np.float64)); o2, r2, d2, t2, _ = e.gstep(acts[t])
+        assert np.array_equal(d1, d2), t
+        np.testing.assert_allclose(o2, o1, atol=5e-5, rtol=2e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(r2, r1, atol=1e-6)
+        dm = d1.astype(bool)
+        if dm.any():
+            np.testing.assert_allclose(t2[dm], t1[dm], atol=5e-5, rtol=2e-6)
+        nd += int(d1.sum())
+        single.append((o2, r2, d2))
+    assert nd >= n
+    s1, s2 = o.get_state(), e.get_state()
+    assert np.array_equal(s1['cursor'], s2['cursor'])
+    np.testing.assert_allclose(s2['walked'], s1['walked'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(s2['qpos'], s1['qpos'], rtol=1e-7, atol=1e-8)
+    # dl_rollout_fixed's long launches: bit-identical to single steps
+    om, rm, dm_, _, _ = e2.gstep(acts)
+    for t in range(T):
+        assert np.array_equal(om[t], single[t][0]) and np.array_equal(rm[t], single[t][1]) and np.array_equal(dm_[t], single[t][2])
+
+
+def test_group_kernel_source_on_host_ctrl_matches_G5(emu):
+    """_rescale_actions + mirror_action of the step kernel itself against the reference's golden vector G5.  The C-ABI takes
+    float32 actions and records float32 torques, so the comparison is exact up to those two roundings (2 ulp of float32);
+    signs (incl. the -0.0 of a zero action), saturation and the left-step permutation must match exactly."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'G5_actions.npz'))
+    m, table, cfg = _walker('straight')
+    cfg.ep_dur_max = 10 ** 9
+    n = len(g['actions'])
+    e = emu.EmuEnv(m, table, cfg, 2 * n, 64)
+    cur = np.zeros((abi.DL_CUR_WORDS, 2 * n), np.int32)
+    cur[abi.DL_CUR_I_STEP] = np.concatenate([np.full(n, 4), np.full(n, 5)]); cur[abi.DL_CUR_READ_STEP] = cur[abi.DL_CUR_I_STEP]
+    cur[abi.DL_CUR_POS] = 10; cur[abi.DL_CUR_COUNT] = 1
+    e.set_state(cursor=cur)
+    q_up = np.array(m.jnt_qpos0[:14])
+    for k in range(2 * n):
+        e.inject_state(k, q_up, np.zeros(14))
+    out = e.gstep(np.concatenate([g['actions'], g['actions']]).astype(np.float32), return_ctrl=True)
+    ctrl = out[-1].astype(np.float64)
+    want = np.concatenate([g['rescaled'], g['mirrored']])
+    np.testing.assert_allclose(ctrl, want, rtol=2.5e-7, atol=0)
+    assert np.array_equal(np.signbit(ctrl), np.signbit(want)) and np.array_equal(np.abs(ctrl) == 300, np.abs(want) == 300)
+    z = np.where((g['actions'] == 0).all(axis=1))[0][0]
+    assert np.signbit(ctrl[z]).all()
