@@ -196,7 +196,7 @@ __global__ void k_reward_finish(float* rew, double* ret, const uint8_t* done, co
 // partial sums of (x - K) and (x - K)^2, K = the running mean (shift against cancellation); the returns are column D.
 // The last block to arrive merges them into (mean, var) with RunningMeanStd's Chan update.  The counts are read here
 // and advanced by k_vn_apply (stream order), so every merge sees the old count.
-constexpr int VN_BLOCKS = 32;
+constexpr int VN_BLOCKS = DL_VN_BLOCKS;        // 128: four rows per thread at 4096 walkers -- the loads of a thread are issued together, one memory round trip
 __global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
                                                    double* ret, double* ret_mean, double* ret_var, const double* ret_count,
                                                    int B, int D, double gamma, int flags, double* work, unsigned* arrive) {
@@ -211,7 +211,14 @@ __global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, 
         const int col = t % D, rsub = t / D;
         if (t < nthr) {
             const double K = mean[col];
-            for (int row = blockIdx.x * rpb + rsub; row < B; row += VN_BLOCKS * rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
+            const int stride = VN_BLOCKS * rpb;
+            int row = blockIdx.x * rpb + rsub;
+            for (; row + 3 * stride < B; row += 4 * stride) {          // four independent loads in flight
+                const float a0 = x[(size_t)row * D + col], a1 = x[(size_t)(row + stride) * D + col], a2 = x[(size_t)(row + 2 * stride) * D + col], a3 = x[(size_t)(row + 3 * stride) * D + col];
+                const double d0 = (double)a0 - K, d1 = (double)a1 - K, d2 = (double)a2 - K, d3 = (double)a3 - K;
+                s += d0; ss += d0 * d0; s += d1; ss += d1 * d1; s += d2; ss += d2 * d2; s += d3; ss += d3 * d3;
+            }
+            for (; row < B; row += stride) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
         }
         sh[0][t] = s; sh[1][t] = ss;
         __syncthreads();
@@ -235,17 +242,30 @@ __global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, 
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    const bool do_obs = t < D && (flags & 1), do_ret = t == D && (flags & 4);
-    if (do_obs || do_ret) {
+    // the last block to arrive merges the partial sums in block order (the result does not depend on the arrival order):
+    // 8 threads per column, each over a fixed subset of the blocks, combined in a fixed order
+    constexpr int SPLIT = 8, CPP = 256 / SPLIT;          // columns per pass
+    const int part = t % SPLIT;
+    for (int c0 = 0; c0 < W; c0 += CPP) {
+        const int colm = c0 + t / SPLIT;
         double S = 0, SS = 0;
-        for (int b = 0; b < VN_BLOCKS; b++) { S += __builtin_nontemporal_load(&work[((size_t)b * W + t) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * W + t) * 2 + 1]); }
-        double* m = do_obs ? mean + t : ret_mean;
-        double* v = do_obs ? var + t : ret_var;
-        const double K = *m, bm = K + S / B, bv = SS / B - (S / B) * (S / B);
-        const double cnt = do_obs ? *count : *ret_count, tot = cnt + B, delta = bm - K;
-        const double M2 = *v * cnt + bv * B + delta * delta * cnt * B / tot;
-        *m = K + delta * B / tot;
-        *v = M2 / tot;
+        const bool active = colm < W && ((colm < D && (flags & 1)) || (colm == D && (flags & 4)));
+        if (active)
+            for (int b = part; b < VN_BLOCKS; b += SPLIT) { S += __builtin_nontemporal_load(&work[((size_t)b * W + colm) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * W + colm) * 2 + 1]); }
+        __syncthreads();
+        sh[0][t] = S; sh[1][t] = SS;
+        __syncthreads();
+        if (active && part == 0) {
+            for (int k = 1; k < SPLIT; k++) { S += sh[0][t + k]; SS += sh[1][t + k]; }
+            const bool do_obs = colm < D;
+            double* m = do_obs ? mean + colm : ret_mean;
+            double* v = do_obs ? var + colm : ret_var;
+            const double K = *m, bm = K + S / B, bv = SS / B - (S / B) * (S / B);
+            const double cnt = do_obs ? *count : *ret_count, tot = cnt + B, delta = bm - K;
+            const double M2 = *v * cnt + bv * B + delta * delta * cnt * B / tot;
+            *m = K + delta * B / tot;
+            *v = M2 / tot;
+        }
     }
     if (t == 0) *arrive = 0;
 }
@@ -271,61 +291,84 @@ __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, c
 }
 
 // RolloutBuffer.compute_returns_and_advantage.  The recurrence A_t = delta_t + c_t A_{t+1} (c_t = gamma lambda (1 - start_{t+1}))
-// is affine in A_{t+1}, so the T axis is cut into GAE_CHUNKS pieces that run in parallel (N x GAE_CHUNKS lanes instead of N:
-// a [512, 4096] buffer is 512 waves instead of 64):
-//   k_gae_local   per (walker, chunk): scan the chunk with A_in = 0, which yields its offset a; its slope b = prod c_t;
-//   k_gae_apply   per (walker, chunk): A_in of the chunk by composing the (a, b) of the later chunks (<= GAE_CHUNKS - 1 steps), then
-//                 A_t = A_t(local) + B_t A_in with the running product B_t, returns = A + V.
-// Inputs are read twice (40 B per sample instead of 20) in exchange for 8x the parallelism.  Float32; the grouping of the
-// operations differs from SB3's single loop by rounding only (<= 1e-6 relative, tests/test_gpu_parity.py::test_sb3_reductions).
-constexpr int GAE_CHUNKS = 8;
-__global__ void k_gae_local(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const float* __restrict__ last_val,
-                            const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N, int clen, float* adv, float* ab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (i >= N) return;
-    const int t1 = T - 1 - k * clen, t0 = t1 - clen + 1 > 0 ? t1 - clen + 1 : 0;      // chunk k covers t1 down to t0 (chunk 0 is the latest)
-    if (t1 < 0) { ab[((size_t)k * N + i) * 2] = 0.f; ab[((size_t)k * N + i) * 2 + 1] = 1.f; return; }
-    // value / non-terminal flag of step t1 + 1
-    float nv, nnt;
-    if (t1 == T - 1) { nv = last_val[i]; nnt = 1.0f - (float)last_done[i]; }
-    else { const size_t o1 = (size_t)(t1 + 1) * N + i; nv = val[o1]; nnt = 1.0f - (float)ep_start[o1]; }
-    float last = 0.f, b = 1.f;
-    for (int t = t1; t >= t0; t--) {
-        const size_t o = (size_t)t * N + i;
-        const float vt = val[o];
-        const float delta = rew[o] + gamma * nv * nnt - vt;
-        const float c = gamma * lam * nnt;
-        last = delta + c * last;
-        b *= c;
-        adv[o] = last;
-        nnt = 1.0f - (float)ep_start[o];
-        nv = vt;
-    }
-    ab[((size_t)k * N + i) * 2] = last; ab[((size_t)k * N + i) * 2 + 1] = b;
-}
-__global__ void k_gae_apply(const float* __restrict__ val, const uint8_t* __restrict__ ep_start, const uint8_t* __restrict__ last_done, float gamma, float lam,
-                            int T, int N, int clen, const float* __restrict__ ab, float* adv, float* ret) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (i >= N) return;
-    const int t1 = T - 1 - k * clen, t0 = t1 - clen + 1 > 0 ? t1 - clen + 1 : 0;
-    if (t1 < 0) return;
-    // advantage entering this chunk = A at the first step of chunk k - 1, ...: compose the later chunks from the latest on
-    float ain = 0.f;
-    for (int kk = 0; kk < k; kk++) ain = ab[((size_t)kk * N + i) * 2] + ab[((size_t)kk * N + i) * 2 + 1] * ain;
-    float nnt = (t1 == T - 1) ? 1.0f - (float)last_done[i] : 1.0f - (float)ep_start[(size_t)(t1 + 1) * N + i];
-    float B = 1.f;
-    for (int t = t1; t >= t0; t--) {
-        const size_t o = (size_t)t * N + i;
-        B *= gamma * lam * nnt;
-        const float a = adv[o] + B * ain;
-        adv[o] = a;
-        ret[o] = a + val[o];
-        nnt = 1.0f - (float)ep_start[o];
+// is affine in A_{t+1}, so the T axis is cut into chunks of GAE_CL steps that run in parallel.  ONE kernel, every input read once:
+// a workgroup owns GAE_W = 32 neighbouring walkers (128-byte row segments) and GAE_CH = 32 chunks -- 512 steps per pass, longer
+// rollouts take further passes from the end of the rollout towards its start, the advantage carried in LDS.  A thread
+//   loads the GAE_CL steps of its (walker, chunk) into registers (all loads in flight at once) and scans them with A_in = 0,
+//   publishes the chunk's affine map (offset a = its first advantage, slope b = prod c_t) in LDS,
+//   composes the maps of the later chunks (<= 31 steps) into its A_in,
+//   writes A_t = A_t(local) + B_t A_in with the running product B_t, returns = A + V.
+// 17 bytes per sample of memory traffic (9 read, 8 written), no scratch buffer.  Float32; the grouping of the operations differs
+// from SB3's single loop by rounding only (<= 1e-6 relative, tests/test_gpu_parity.py::test_sb3_reductions).
+constexpr int GAE_CL = 16, GAE_CH = 32, GAE_W = 32;
+__global__ __launch_bounds__(GAE_CH * GAE_W) void k_gae_fused(const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ ep_start,
+                                                              const float* __restrict__ last_val, const uint8_t* __restrict__ last_done, float gamma, float lam, int T, int N,
+                                                              float* __restrict__ adv, float* __restrict__ ret) {
+    __shared__ float2 ab[GAE_CH][GAE_W];
+    __shared__ float carry[GAE_W];
+    const int wi = threadIdx.x % GAE_W, k = threadIdx.x / GAE_W;       // k: chunk inside the pass, 0 = the latest
+    const int i = blockIdx.x * GAE_W + wi;
+    const bool valid = i < N;
+    const size_t ii = valid ? i : N - 1;
+    if (k == 0) carry[wi] = 0.f;
+    const float gl = gamma * lam;
+    for (int top = T - 1; top >= 0; top -= GAE_CL * GAE_CH) {
+        const int t1 = top - k * GAE_CL;                               // this thread's chunk: steps t1 down to max(t1 - GAE_CL + 1, 0)
+        float r[GAE_CL], v[GAE_CL], nt[GAE_CL];
+        // value / non-terminal flag of step t1 + 1
+        float nv = 0.f, nnt = 0.f;
+        if (t1 >= 0) {
+            if (t1 == T - 1) { nv = last_val[ii]; nnt = 1.0f - (float)last_done[ii]; }
+            else { const size_t o1 = (size_t)(t1 + 1) * N + ii; nv = val[o1]; nnt = 1.0f - (float)ep_start[o1]; }
+        }
+#pragma unroll
+        for (int s = 0; s < GAE_CL; s++) {
+            const int t = t1 - s;
+            const bool ok = t >= 0;
+            const size_t o = (size_t)(ok ? t : 0) * N + ii;
+            r[s] = ok ? rew[o] : 0.f; v[s] = ok ? val[o] : 0.f; nt[s] = ok ? 1.0f - (float)ep_start[o] : 0.f;
+        }
+        float last = 0.f, b = 1.f, loc[GAE_CL], Bc[GAE_CL];
+#pragma unroll
+        for (int s = 0; s < GAE_CL; s++) {
+            if (t1 - s >= 0) {
+                const float delta = r[s] + gamma * nv * nnt - v[s];
+                const float c = gl * nnt;
+                last = delta + c * last;
+                b *= c;
+                nnt = nt[s]; nv = v[s];
+            }
+            loc[s] = last; Bc[s] = b;
+        }
+        ab[k][wi] = make_float2(last, b);                               // a chunk without steps is the identity map (0, 1)
+        __syncthreads();
+        // advantage entering this chunk: compose the later chunks from the latest on, starting from the previous pass
+        float ain = carry[wi];
+        for (int kk = 0; kk < k; kk++) { const float2 m = ab[kk][wi]; ain = m.x + m.y * ain; }
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < GAE_CL; s++) {
+                const int t = t1 - s;
+                if (t >= 0) {
+                    const size_t o = (size_t)t * N + i;
+                    const float a = loc[s] + Bc[s] * ain;
+                    adv[o] = a;
+                    ret[o] = a + v[s];
+                }
+            }
+        }
+        __syncthreads();
+        if (k == GAE_CH - 1) carry[wi] = last + b * ain;               // advantage of the earliest step of this pass
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_adv_stats(const float* __restrict__ a, long long n, double* out3) {
+// sums for the advantage normalisation, deterministic: every block leaves its partial sums in the workspace, the last
+// block to arrive adds them up in block order (no floating-point atomics: the same bits on every run)
+constexpr int ADV_MAXBLOCKS = 512;
+__global__ __launch_bounds__(256) void k_adv_stats(const float* __restrict__ a, long long n, double* out3, double* work, unsigned* arrive) {
     __shared__ double sh[4];
+    __shared__ bool is_last;
     double s = 0, s2 = 0;
     const long long n4 = n / 4, stride = (long long)gridDim.x * blockDim.x;
     const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -337,7 +380,18 @@ __global__ __launch_bounds__(256) void k_adv_stats(const float* __restrict__ a, 
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) { const double x = a[4 * n4 + threadIdx.x]; s += x; s2 += x * x; }
     s = block_sum(s, sh);
     s2 = block_sum(s2, sh);
-    if (threadIdx.x == 0) { atomicAdd(&out3[0], s); atomicAdd(&out3[1], s2); if (blockIdx.x == 0) atomicAdd(&out3[2], (double)n); }
+    if (threadIdx.x == 0) { work[2 * blockIdx.x] = s; work[2 * blockIdx.x + 1] = s2; }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(arrive, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    double S = 0, S2 = 0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) { S += __builtin_nontemporal_load(&work[2 * b]); S2 += __builtin_nontemporal_load(&work[2 * b + 1]); }
+    S = block_sum(S, sh);
+    S2 = block_sum(S2, sh);
+    if (threadIdx.x == 0) { out3[0] = S; out3[1] = S2; out3[2] = (double)n; *arrive = 0; }
 }
 __global__ void k_adv_normalize(float* a, long long n, const double* s3) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -929,33 +983,17 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
 }
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val, const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv, float* ret, void* stream) {
     if (!rew || !val || !ep_start || !last_val || !last_done || !adv || !ret || T <= 0 || N <= 0) return fail(DL_E_INVAL, "dl_gae: bad arguments");
-    const int clen = (T + GAE_CHUNKS - 1) / GAE_CHUNKS;
-    // (offset, slope) of every chunk and walker: a per-device scratch buffer owned by the library, grown on demand
-    // (calls are stream-ordered and a device is driven by one host thread, see the header)
-    static float* ws[64] = {nullptr};
-    static size_t ws_n[64] = {0};
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return fail(DL_E_INVAL, "dl_gae: device ordinal out of range");
-    const size_t need = (size_t)2 * GAE_CHUNKS * N;
-    if (ws_n[dev] < need) {
-        if (ws[dev]) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(ws[dev])); ws[dev] = nullptr; ws_n[dev] = 0; }
-        HIPCHK(hipMalloc((void**)&ws[dev], need * sizeof(float)));
-        ws_n[dev] = need;
-    }
-    float* ab = ws[dev];
-    hipLaunchKernelGGL(k_gae_local, dim3((N + 63) / 64, GAE_CHUNKS), dim3(64), 0, (hipStream_t)stream, rew, val, ep_start, last_val, last_done, gamma, lam, T, N, clen, adv, ab);
-    hipLaunchKernelGGL(k_gae_apply, dim3((N + 63) / 64, GAE_CHUNKS), dim3(64), 0, (hipStream_t)stream, val, ep_start, last_done, gamma, lam, T, N, clen, (const float*)ab, adv, ret);
+    hipLaunchKernelGGL(k_gae_fused, dim3((N + GAE_W - 1) / GAE_W), dim3(GAE_CH * GAE_W), 0, (hipStream_t)stream, rew, val, ep_start, last_val, last_done, gamma, lam, T, N, adv, ret);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
-int dl_adv_stats(const float* adv, int64_t n, double* out3, void* stream) {
-    if (!adv || !out3 || n <= 0) return fail(DL_E_INVAL, "dl_adv_stats: bad arguments");
-    HIPCHK(hipMemsetAsync(out3, 0, 3 * sizeof(double), (hipStream_t)stream));
+int dl_adv_stats(const float* adv, int64_t n, double* out3, void* workspace, void* stream) {
+    if (!adv || !out3 || !workspace || n <= 0) return fail(DL_E_INVAL, "dl_adv_stats: bad arguments");
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 512) blocks = 512;
+    if (blocks > ADV_MAXBLOCKS) blocks = ADV_MAXBLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_adv_stats, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, adv, (long long)n, out3);
+    double* work = (double*)workspace;
+    hipLaunchKernelGGL(k_adv_stats, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, adv, (long long)n, out3, work, (unsigned*)(work + 2 * ADV_MAXBLOCKS));
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

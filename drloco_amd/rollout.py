@@ -6,7 +6,7 @@ import ctypes as C
 
 import torch
 
-from . import lib
+from . import abi, lib
 from .vec_env import _ptr, _stream
 
 
@@ -24,6 +24,7 @@ class HipRolloutBuffer:
         self.next_starts = self._starts[n_steps]
         self.advantages, self.returns = f(n_steps, n_envs), f(n_steps, n_envs)
         self._sums = torch.zeros(3, dtype=torch.float64, device=device)
+        self._adv_work = torch.zeros(abi.DL_ADV_WORKSPACE_BYTES // 8, dtype=torch.float64, device=device)     # caller-owned scratch of dl_adv_stats
         self.pos = 0
 
     def reset(self):
@@ -76,7 +77,7 @@ class HipRolloutBuffer:
 
     def advantage_sums(self, adv=None):
         a = self.advantages if adv is None else adv
-        lib.check(self._lib.dl_adv_stats(_ptr(a), a.numel(), _ptr(self._sums), _stream()))
+        lib.check(self._lib.dl_adv_stats(_ptr(a), a.numel(), _ptr(self._sums), _ptr(self._adv_work), _stream()))
         return self._sums
 
     def normalize_advantages(self, adv=None, process_group=None):

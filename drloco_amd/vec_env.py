@@ -15,28 +15,15 @@ import pickle
 import numpy as np
 import torch
 
-from . import abi, lib, mocap, models
+from . import abi, compat, lib, mocap, models
 
 MONITOR_ATTRS = ('ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance',
                  'mean_ep_pos_rew_smoothed', 'mean_ep_vel_rew_smoothed', 'mean_ep_com_rew_smoothed',
                  'mean_abs_ep_torque_smoothed')
 
 
-class Box:
-    """Minimal stand-in for gym.spaces.Box (shape/low/high/dtype/sample)."""
-
-    def __init__(self, low, high, shape, dtype=np.float32):
-        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
-        self.low = np.full(shape, low, dtype=dtype)
-        self.high = np.full(shape, high, dtype=dtype)
-
-    def sample(self):
-        lo = np.where(np.isfinite(self.low), self.low, -1.0)
-        hi = np.where(np.isfinite(self.high), self.high, 1.0)
-        return np.random.uniform(lo, hi).astype(self.dtype)
-
-    def __repr__(self):
-        return f'Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})'
+Box = compat.MiniBox          # kept under its old name for callers that built spaces by hand
+_VecEnvBase, _VecEnvWrapperBase = compat.VecEnvBase, compat.VecEnvWrapperBase
 
 
 def _ptr(t):
@@ -47,8 +34,9 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class HipVecEnv:
-    """N MimicWalker3dEnv walkers stepped by the HIP kernels (one process per GPU)."""
+class HipVecEnv(_VecEnvBase):
+    """N MimicWalker3dEnv walkers stepped by the HIP kernels (one process per GPU).  An SB3 `VecEnv` when stable-baselines3
+    imports (drloco_amd/compat.py), so that `PPO(policy, env)` takes it as it is (train.py:110)."""
 
     def __init__(self, env_id=models.STRAIGHT_WALKER, num_envs=4096, device=None, seed=33, precision=32,
                  model=None, refs=None, env_index_base=0, **config):
@@ -78,11 +66,10 @@ class HipVecEnv:
         self._h = h
         self.nv, self.nu = self.model.nv, self.model.nu
         self.obs_dim = self._lib.dl_obs_dim(h)
-        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
-        lo = np.array([self.model.act_ctrlrange[a][0] for a in range(self.nu)], np.float32)
-        self.action_space = Box(0, 0, (self.nu,), np.float32)
-        self.action_space.low[:] = lo
-        self.action_space.high[:] = [self.model.act_ctrlrange[a][1] for a in range(self.nu)]
+        # MujocoEnv's spaces (gym 0.18 mujoco_env.py: observation Box(-inf, inf), action Box = the actuators' ctrlrange)
+        obs_space = compat.make_box(np.full(self.obs_dim, -np.inf), np.full(self.obs_dim, np.inf))
+        act_space = compat.make_box([self.model.act_ctrlrange[a][0] for a in range(self.nu)], [self.model.act_ctrlrange[a][1] for a in range(self.nu)])
+        _VecEnvBase.__init__(self, self.num_envs, obs_space, act_space)
         n, dev = self.num_envs, self.device
         self.obs = torch.zeros(n, self.obs_dim, device=dev)
         self.rew = torch.zeros(n, device=dev)
@@ -156,8 +143,10 @@ class HipVecEnv:
         if name in MONITOR_ATTRS:
             out = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
             lib.check(self._lib.dl_stats_snapshot(self._h, name.encode(), _ptr(out), _stream()))
-            vals = out.cpu().numpy()
-            return [float(vals[i]) for i in idx]
+            if indices is None:
+                return out.cpu().numpy().tolist()
+            sel = out[torch.as_tensor(list(idx), dtype=torch.long, device=self.device)]      # only the requested walkers cross PCIe
+            return sel.cpu().numpy().tolist()
         if name == 'ep_lens':
             return [list(self.ep_lens[i]) for i in idx]
         raise AttributeError(name)
@@ -169,6 +158,17 @@ class HipVecEnv:
                 self.ep_lens[i] = list(value)
             return
         raise AttributeError(f'cannot set {name!r} on HipVecEnv')
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        """SB3 VecEnv protocol: the walkers are not gym.Wrapper chains; Monitor's statistics are kept by the step kernel."""
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [getattr(wrapper_class, '__name__', '') == 'Monitor' for _ in idx]
+
+    def get_images(self):
+        raise NotImplementedError('rendering is outside the device path (SURVEY.md 8: out of scope)')
+
+    def render(self, mode='human'):
+        raise NotImplementedError('rendering is outside the device path (SURVEY.md 8: out of scope)')
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
         if method_name == 'activate_evaluation':
@@ -371,14 +371,23 @@ class RunningMeanStd:
         self._sync = (self._mean.clone(), self._var.clone(), self._count.clone())
 
 
-class HipVecNormalize:
-    """VecNormalize(venv, norm_obs=True, norm_reward=True, clip 10, gamma 0.99, eps 1e-8) on device."""
+class HipVecNormalize(_VecEnvWrapperBase):
+    """VecNormalize(venv, norm_obs=True, norm_reward=True, clip 10, gamma 0.99, eps 1e-8) on device.
+
+    Two points where SB3 releases differ are switches (SB3 1.0's source is not available here, so the
+    defaults follow what is known of 1.0 and the alternatives can be selected when a checkpoint says otherwise):
+      reset_moments          what reset() feeds into the running moments while training: 'none' (default), 'ret' (the zeroed
+                             returns into ret_rms, as the baselines-derived releases up to 1.0 may do) or 'obs' (the first
+                             observations into obs_rms, as later releases do);
+      norm_terminal_obs      whether infos['terminal_observation'] is normalised (later releases) or raw (1.0, default)."""
 
     def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
-                 gamma=0.99, epsilon=1e-8):
-        self.venv = venv
+                 gamma=0.99, epsilon=1e-8, reset_moments='none', norm_terminal_obs=False):
+        if reset_moments not in ('none', 'ret', 'obs'):
+            raise ValueError("reset_moments must be 'none', 'ret' or 'obs'")
+        _VecEnvWrapperBase.__init__(self, venv)          # venv, num_envs, observation_space, action_space
+        self.reset_moments, self.norm_terminal_obs = reset_moments, norm_terminal_obs
         self._lib = venv._lib
-        self.num_envs, self.observation_space, self.action_space = venv.num_envs, venv.observation_space, venv.action_space
         self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
         self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
         dev = venv.device
@@ -387,7 +396,7 @@ class HipVecNormalize:
         self.ret = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)
         self.norm_obs_t = torch.zeros_like(venv.obs)
         self.norm_rew_t = torch.zeros_like(venv.rew)
-        self._vn_work = torch.zeros(2 * 32 * (venv.obs_dim + 1) + 2, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
+        self._vn_work = torch.zeros(abi.vn_workspace_bytes(venv.obs_dim) // 8, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
         self._ov = None                                   # overlap state (enable_overlap)
 
     # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
@@ -411,8 +420,9 @@ class HipVecNormalize:
                                              self.epsilon, self.clip_obs, _stream()))
 
     def _flags(self):
-        return (1 if (self.norm_obs and self.training) else 0) | (2 if self.norm_obs else 0) | \
-               (4 if (self.norm_reward and self.training) else 0) | (8 if self.norm_reward else 0)
+        # SB3 1.0 step_wait: obs_rms / ret_rms (and ret) advance whenever training is on, whatever norm_obs / norm_reward say
+        # (the reference's load_env builds an evaluation env with norm_reward=False); the norm_* switches only gate the scaling
+        return (1 if self.training else 0) | (2 if self.norm_obs else 0) | (4 if self.training else 0) | (8 if self.norm_reward else 0)
 
     def state_struct(self):
         """dl_vecnorm_state for dl_rollout_policy: pointers to the device-resident moments of this object."""
@@ -546,7 +556,7 @@ class HipVecNormalize:
         self.venv._ep_len += 1
         if done_h.any():
             t = term.clone()
-            if self.norm_obs:
+            if self.norm_obs and self.norm_terminal_obs:
                 self._normalize_obs_inplace(t)
             term_h = t.cpu().numpy()
             for i in np.nonzero(done_h)[0]:
@@ -560,9 +570,15 @@ class HipVecNormalize:
         return self.step_wait()
 
     def reset(self):
-        """SB3 1.0: ret = 0; first observation is normalised (moments are not updated by reset)."""
+        """ret = 0; the first observation is normalised; what enters the moments is the reset_moments switch (see the class)."""
         self.venv.reset_tensors()
         self.ret.zero_()
+        if self.training and self.reset_moments == 'ret':
+            z = torch.zeros(self.num_envs, 1, device=self.venv.device)
+            lib.check(self._lib.dl_moments_update(_ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), _ptr(z), self.num_envs, 1, _stream()))
+        elif self.training and self.reset_moments == 'obs':
+            lib.check(self._lib.dl_moments_update(_ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count), _ptr(self.venv.obs), self.num_envs,
+                                                  self.venv.obs_dim, _stream()))
         self.norm_obs_t.copy_(self.venv.obs)
         if self.norm_obs:
             self._normalize_obs_inplace(self.norm_obs_t)
@@ -586,6 +602,12 @@ class HipVecNormalize:
     def set_attr(self, name, value, indices=None):
         return self.venv.set_attr(name, value, indices)
 
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return self.venv.env_method(method_name, *args, indices=indices, **kwargs)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return self.venv.env_is_wrapped(wrapper_class, indices)
+
     def seed(self, seed=None):
         return self.venv.seed(seed)
 
@@ -601,14 +623,14 @@ class HipVecNormalize:
         with open(path, 'wb') as f:
             pickle.dump(dict(obs_rms=self.obs_rms.state(), ret_rms=self.ret_rms.state(), clip_obs=self.clip_obs,
                              clip_reward=self.clip_reward, gamma=self.gamma, epsilon=self.epsilon,
-                             norm_obs=self.norm_obs, norm_reward=self.norm_reward), f)
+                             norm_obs=self.norm_obs, norm_reward=self.norm_reward, training=self.training), f)
 
     @staticmethod
     def load(path, venv):
         """Reads this package's dict pickle or an SB3 1.0 `VecNormalize.save` file (e.g. one written by the reference)."""
         from .checkpoint import read_vecnormalize
         s = read_vecnormalize(path)
-        vn = HipVecNormalize(venv, norm_obs=s['norm_obs'], norm_reward=s['norm_reward'], clip_obs=s['clip_obs'],
+        vn = HipVecNormalize(venv, training=bool(s.get('training', True)), norm_obs=s['norm_obs'], norm_reward=s['norm_reward'], clip_obs=s['clip_obs'],
                              clip_reward=s['clip_reward'], gamma=s['gamma'], epsilon=s['epsilon'])
         vn.obs_rms.load_state(s['obs_rms'])
         vn.ret_rms.load_state(s['ret_rms'])

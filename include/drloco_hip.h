@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 2   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride */
+#define DL_ABI_VERSION 3   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace, DL_VN_WORKSPACE_BYTES grew (128 blocks) */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -269,7 +269,8 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
  * moments (training), 8 normalise rewards.  obs/rew are not modified (get_original_obs / get_original_reward);
  * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
  * zero-initialised once by the caller and owned by this call sequence. */
-#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * ((D) + 1) + 2))
+#define DL_VN_BLOCKS 128
+#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * DL_VN_BLOCKS * ((D) + 1) + 2))
 int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean,
                          double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                          double* ret_count, int32_t B, int32_t D, double gamma, double eps, double clip_obs,
@@ -281,8 +282,11 @@ int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const fl
            const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv,
            float* ret, void* stream);
 /* sums for PPO advantage normalisation: out[0] = sum(a), out[1] = sum(a^2), out[2] = n
- * (double[3] device; all-reduced over ranks by the caller before dl_adv_normalize). */
-int dl_adv_stats(const float* adv, int64_t n, double* out3, void* stream);
+ * (double[3] device; all-reduced over ranks by the caller before dl_adv_normalize).  Deterministic (fixed summation
+ * order, no floating-point atomics).  workspace: device memory, DL_ADV_WORKSPACE_BYTES, zero-initialised once by
+ * the caller and owned by it (one per stream that may run this call concurrently). */
+#define DL_ADV_WORKSPACE_BYTES ((2 * 512 + 2) * 8)
+int dl_adv_stats(const float* adv, int64_t n, double* out3, void* workspace, void* stream);
 /* a = (a - mean)/(std_unbiased + 1e-8) from the (all-reduced) sums. */
 int dl_adv_normalize(float* adv, int64_t n, const double* sums3, void* stream);
 

@@ -1,0 +1,22 @@
+"""Interface stub (see tests/stubs/README.md): gym 0.18 spaces.Box's constructor and attributes."""
+import numpy as np
+
+
+class Space:
+    pass
+
+
+class Box(Space):
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        if shape is None:
+            shape = np.shape(low)
+        self.shape = tuple(shape)
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self.shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self.shape).copy()
+        self.bounded_below = -np.inf < self.low
+        self.bounded_above = np.inf > self.high
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))

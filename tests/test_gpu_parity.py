@@ -290,7 +290,7 @@ def test_sb3_reductions(torch_cuda, oracle):
         tc2 = torch.full((1,), 1e-4, dtype=torch.float64, device='cuda')
         trm = torch.zeros(1, dtype=torch.float64, device='cuda'); trv = torch.ones(1, dtype=torch.float64, device='cuda')
         trc = torch.full((1,), 1e-4, dtype=torch.float64, device='cuda'); tret = torch.zeros(B2, dtype=torch.float64, device='cuda')
-        work = torch.zeros(2 * 32 * (D2 + 1) + 2, dtype=torch.float64, device='cuda')
+        work = torch.zeros(abi.vn_workspace_bytes(D2) // 8, dtype=torch.float64, device="cuda")
         for it in range(4):
             x = (rng.standard_normal((B2, D2)) * rng.uniform(0.1, 5, D2) + rng.uniform(-20, 20, D2)).astype(np.float32)
             r = rng.uniform(0, 1.2, B2).astype(np.float32); dn = (rng.random(B2) < 0.1).astype(np.uint8)
@@ -1069,14 +1069,33 @@ def test_env_group_handles_are_shards(torch_cuda, model, refs):
     torch.cuda.synchronize()
     adv = grp.cat('advantages').double()
     assert abs(float(adv.mean())) < 1e-5 and abs(float(adv.std(unbiased=True)) - 1) < 1e-4
+    # every handle's returns are those of a single-handle scan of its own buffer (the scans of the handles run concurrently on
+    # their own streams and share nothing), the advantages are those scans normalised with the union's statistics
+    from drloco_amd.group import policy_forward_values
+    raw = []
+    for h in range(H):
+        b = grp.bufs[h]
+        _, lv, _ = policy_forward_values(pol, grp.last_obs[h], grp.index_bases[h])
+        ra = torch.zeros(T, n, dtype=torch.float64, device='cuda'); last = torch.zeros(n, dtype=torch.float64, device='cuda')
+        for t in reversed(range(T)):
+            nnt = 1.0 - (grp.last_done[h] if t == T - 1 else b.episode_starts[t + 1]).double()
+            nv = (lv if t == T - 1 else b.values[t + 1]).double()
+            last = b.rewards[t].double() + b.gamma * nv * nnt - b.values[t].double() + b.gamma * b.gae_lambda * nnt * last
+            ra[t] = last
+        assert float((b.returns.double() - (ra + b.values.double())).abs().max()) < 3e-5, h
+        raw.append(ra)
+    allraw = torch.cat(raw, dim=1)
+    want = (allraw - allraw.mean()) / (allraw.std(unbiased=True) + 1e-8)
+    assert float((adv - want).abs().max()) < 2e-5
     assert grp.cat('observations').shape == (T, H * n, 29)
     grp.close()
 
 
-@pytest.mark.parametrize('T,N', [(128, 128), (512, 4096), (129, 130), (4, 4096), (2048, 8)])
+@pytest.mark.parametrize('T,N', [(128, 128), (512, 4096), (129, 130), (4, 4096), (2048, 8), (1100, 70), (513, 33)])
 def test_gae_and_adv_norm_at_training_shapes(torch_cuda, T, N):
-    """dl_gae (chunked parallel scan) + dl_adv_stats / dl_adv_normalize against a float64 torch restatement of SB3 1.0's loops at the
-    shapes learners use (the reference's 8 x 2048, the example's 128 x 128, the benchmark's 4096 x 512, ragged ones)."""
+    """dl_gae (one fused kernel: chunked parallel scan, passes of 512 steps) + dl_adv_stats / dl_adv_normalize against a float64 torch
+    restatement of SB3 1.0's loops at the shapes learners use (the reference's 8 x 2048, the example's 128 x 128, the benchmark's
+    4096 x 512, ragged ones, rollouts longer than one pass); the advantage sums are deterministic (same bits on every call)."""
     import torch
     from drloco_amd.rollout import HipRolloutBuffer
     dev = torch.device('cuda')
@@ -1094,6 +1113,9 @@ def test_gae_and_adv_norm_at_training_shapes(torch_cuda, T, N):
         ra[t] = last
     assert float((adv.double() - ra).abs().max()) < 3e-5 and float((ret.double() - (ra + buf.values.double())).abs().max()) < 3e-5
     a0 = adv.double().clone()
+    s1 = buf.advantage_sums().clone(); s2 = buf.advantage_sums().clone(); s3 = buf.advantage_sums().clone()
+    assert torch.equal(s1, s2) and torch.equal(s1, s3)
+    assert float(s1[2]) == T * N and abs(float(s1[0]) - float(a0.sum())) <= 1e-9 * float(a0.abs().sum())
     buf.normalize_advantages()
     ref = (a0 - a0.mean()) / (a0.std(unbiased=True) + 1e-8)
     assert float((buf.advantages.double() - ref).abs().max()) < 2e-6

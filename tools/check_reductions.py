@@ -40,7 +40,7 @@ for N in (128, 96, 8, 4096, 1000):
     mean = torch.zeros(D, dtype=torch.float64, device=dev); var = torch.ones(D, dtype=torch.float64, device=dev); cnt = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
     rmean = torch.zeros(1, dtype=torch.float64, device=dev); rvar = torch.ones(1, dtype=torch.float64, device=dev); rcnt = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
     ret = torch.zeros(N, dtype=torch.float64, device=dev)
-    work = torch.zeros(2 * 32 * (D + 1) + 2, dtype=torch.float64, device=dev)
+    work = torch.zeros(abi.vn_workspace_bytes(D) // 8, dtype=torch.float64, device=dev)
     m, v, c = np.zeros(D), np.ones(D), 1e-4
     rm, rv, rc, rret = 0.0, 1.0, 1e-4, np.zeros(N)
     worst = 0.0
