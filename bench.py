@@ -20,8 +20,8 @@ and the two dl_vecnormalize_step launches of every step run on a side HIP stream
 outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
 the fused policy into the loop (dl_rollout_policy: 4 launches per control step).  Same results in all forms
 (tests/test_gpu_parity.py::test_steps_fixed_runs_match_the_step_by_step_path).
-Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) (seed 4321 + rank), values are synthetic,
-RSI comes from the counter-based stream keyed by the global walker index.  Inputs are resident in
+Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) and values synthetic, both keyed by the global walker index
+(one stream, every rank keeps its columns), RSI comes from the counter-based stream keyed by the global walker index.  Inputs are resident in
 HBM before the timed region.  value = walkers * 512 * K * N / time  [env-steps/s, whole job].
 """
 import argparse
@@ -37,6 +37,18 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_ENV_STEP = 664          # 336 B read + 328 B written per walker and control step
 ALGO_BYTES_PER_ENV_STEP_LOCO3D = 916   # the same count for the 19-dof walker: 456 B read (3 x 19 state + 13 action + 6 cursor + 38 reference words) + 460 B written (57 state + 6 cursor + 47 obs + 5)
 HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def kernel_sources_sha16():
+    """Identity of the kernel sources a profile was taken with: sha256 over drloco_amd/csrc/*.{hip,hpp} and the C-ABI header."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'drloco_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.hpp')):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'drloco_hip.h'), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(n_envs, n_steps, seed=4321):
@@ -189,12 +201,15 @@ def main():
         venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
     vn = HipVecNormalize(venv)
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
+    # what the policy would have produced lives where it would have written it: in the rollout buffer.  The tapes are keyed by the GLOBAL
+    # walker index (every rank draws the same stream and keeps its walkers' columns), so a walker sees the same actions / values
+    # whatever the number of GPUs -- as it does for its RSI draws
     gen = torch.Generator(device=dev)
-    gen.manual_seed(4321 + rank)
-    # what the policy would have produced lives where it would have written it: in the rollout buffer
-    buf.actions.copy_(torch.clamp(0.5 * torch.randn(T, n, venv.nu, device=dev, generator=gen), -1, 1))
-    buf.values.copy_(torch.randn(T, n, device=dev, generator=gen))
-    last_values = torch.randn(n, device=dev, generator=gen)
+    gen.manual_seed(4321)
+    sl = slice(rank * n, (rank + 1) * n)
+    buf.actions.copy_(torch.clamp(0.5 * torch.randn(T, n * world, venv.nu, device=dev, generator=gen)[:, sl], -1, 1))
+    buf.values.copy_(torch.randn(T, n * world, device=dev, generator=gen)[:, sl])
+    last_values = torch.randn(n * world, device=dev, generator=gen)[sl].contiguous()
     vn.reset()
     if not args.policy and not args.no_overlap:
         vn.enable_overlap(chunk=max(r for _, r in run_starts))      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
@@ -298,12 +313,19 @@ def main():
         n_prof = venv.num_envs                       # walkers of the handle whose launches were bracketed (all of the rank's unless --handles)
         algo_bytes = ALGO_BYTES_PER_ENV_STEP_LOCO3D if args.walker == 'loco3d' else ALGO_BYTES_PER_ENV_STEP
         achieved = algo_bytes * n_prof * steps_per_launch / avg_launch_s / 1e9
-        traffic = valu_busy = None
+        # counter-derived figures come from a committed rocprofv3 PMC pass (profiles/traffic_env_step.json, tools/gpu_traffic.sh): they are
+        # reported only for the configuration that pass measured AND only while the kernel sources are the ones it measured
+        traffic = valu_busy = prof_origin = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
-        if os.path.exists(tfile):
+        default_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.policy and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs
+        if os.path.exists(tfile) and default_cfg:
             try:
                 pj = json.load(open(tfile))
-                traffic, valu_busy = pj.get('hbm_bytes_per_launch'), pj.get('valu_busy_frac')
+                if pj.get('kernel_sources_sha16') == kernel_sources_sha16():
+                    traffic, valu_busy = pj.get('hbm_bytes_per_launch'), pj.get('valu_busy_frac')
+                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'tag': pj.get('tag'), 'kernel_sources_sha16': pj.get('kernel_sources_sha16')}
+                else:
+                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'stale': True, 'measured_sha16': pj.get('kernel_sources_sha16'), 'built_sha16': kernel_sources_sha16()}
             except Exception:
                 traffic = None
         out = {
@@ -321,9 +343,11 @@ def main():
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
                                    ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else 'k_env_step_g16<float,TopoStraight>'), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
-                         'valu_busy_frac': valu_busy,
+                         'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
+        out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'backend': dist.get_backend() if use_dist else None,
+                              'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_base
         print(json.dumps(out))

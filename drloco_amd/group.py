@@ -26,7 +26,7 @@ import ctypes as C
 
 import torch
 
-from . import lib, models
+from . import collectives, lib, models
 from .rollout import HipRolloutBuffer
 from .vec_env import HipVecEnv, HipVecNormalize, _ptr
 
@@ -94,8 +94,7 @@ class HipEnvGroup:
                 self.bufs[h].advantage_sums()
         self.join()
         sums = torch.stack([b._sums for b in self.bufs]).sum(0)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(process_group) > 1:
-            torch.distributed.all_reduce(sums, group=process_group)
+        collectives.all_reduce_sum_(sums, process_group)
         for b in self.bufs:
             lib.check(b._lib.dl_adv_normalize(_ptr(b.advantages), b.advantages.numel(), _ptr(sums), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 

@@ -6,7 +6,7 @@ import ctypes as C
 
 import torch
 
-from . import abi, lib
+from . import abi, collectives, lib
 from .vec_env import _ptr, _stream
 
 
@@ -83,8 +83,5 @@ class HipRolloutBuffer:
     def normalize_advantages(self, adv=None, process_group=None):
         """(A - mean)/(std + 1e-8) over all ranks: one all-reduce of [sum, sum^2, n]."""
         a = self.advantages if adv is None else adv
-        sums = self.advantage_sums(a)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(process_group) > 1:
-            torch.distributed.all_reduce(sums, group=process_group)
-        lib.check(self._lib.dl_adv_normalize(_ptr(a), a.numel(), _ptr(sums), _stream()))
-        return a
+        apply = lambda x, sums: lib.check(self._lib.dl_adv_normalize(_ptr(x), x.numel(), _ptr(sums), _stream()))
+        return collectives.normalize_advantages(a, self.advantage_sums, apply, process_group)

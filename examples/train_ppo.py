@@ -12,6 +12,11 @@ with thousands of walkers.  Everything of the rollout runs through the C-ABI:
 dl_policy_forward -> dl_step -> dl_vecnormalize_step -> dl_gae; torch autograd only evaluates the PPO loss.
 
   python examples/train_ppo.py --mio 8          # the reference's budget: 8 M env-steps, ~30 s on one MI355X, walks 23 m per episode (3 of 4 seeds)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ppo.py --envs 1024
+                                                # data parallel: walkers shard by global index (--envs is the GLOBAL count), one rank per GPU over RCCL;
+                                                # exchanges per update: VecNormalize moment merge (C3), per minibatch [sum a, sum a^2, n] (C1) and ONE
+                                                # all-reduce of the flat 1.13 MB gradient bucket (C2) -- drloco_amd/collectives.py; every rank takes the
+                                                # optimiser steps one process holding all walkers would take (tests/test_distributed_cpu.py)
 """
 import argparse
 import math
@@ -22,19 +27,31 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from drloco_amd import collectives
 from drloco_amd.policy import HipPolicy
 from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 
 def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False, save_path=None):
-    dev = torch.device('cuda', 0)
-    torch.manual_seed(seed)
-    venv = HipVecEnv(num_envs=n_envs, seed=seed)
+    # one process per GPU under torch.distributed.run (backend nccl = RCCL); a single process otherwise
+    import torch.distributed as dist
+    world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local_rank if local_rank < torch.cuda.device_count() else 0)
+    torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+        backend = os.environ.get('DL_BENCH_BACKEND', 'nccl')
+        dist.init_process_group(backend, rank=rank, world_size=world, **({'device_id': dev} if backend == 'nccl' else {}))
+    quiet = quiet or rank != 0
+    assert n_envs % world == 0 and batch % n_envs == 0
+    n_global, n_envs = n_envs, n_envs // world          # --envs is the global walker count; this rank owns [rank * n_envs, (rank + 1) * n_envs)
+    torch.manual_seed(seed)                             # the same initial policy on every rank
+    venv = HipVecEnv(num_envs=n_envs, seed=seed, device=dev.index, env_index_base=rank * n_envs)
     vn = HipVecNormalize(venv, norm_reward=norm_reward)
-    T = batch // n_envs
+    T = batch // n_global
     buf = HipRolloutBuffer(T, n_envs, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
-    pol = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=512, log_std_init=-0.75, seed=seed)
+    pol = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=512, log_std_init=-0.75, seed=seed, index_base=rank * n_envs, device=dev)
     names = ('w1', 'b1', 'w2', 'b2', 'wa', 'ba', 'wv', 'bv', 'log_std')
     # SB3's orthogonal initialisation (gain sqrt(2) trunk, 0.01 action head, 1 value head)
     for n_, g in (('w1', math.sqrt(2)), ('w2', math.sqrt(2)), ('wa', 0.01), ('wv', 1.0)):
@@ -42,6 +59,9 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
     for n_ in ('b1', 'b2', 'ba', 'bv'):
         getattr(pol, n_).zero_()
     params = [getattr(pol, n_).requires_grad_(True) for n_ in names]
+    wd = dict(zip(names, params))
+    bucket = collectives.FlatGradAllReducer(params)      # C2: one all-reduce of the flat gradient per optimiser step
+    perm_gen = torch.Generator().manual_seed(seed + 1000)    # minibatch permutations: the same on every rank
     opt = torch.optim.Adam(params, lr=5e-4, eps=1e-5)
     clip, ent_coef, vf_coef = 0.15, -0.0075, 0.5
     total = int(mio * 1e6)
@@ -62,30 +82,20 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
             last_done.copy_(start)
             _, last_values, _ = pol.forward(obs, deterministic=True)
             buf.compute_returns_and_advantage(last_values, last_done)
+            if world > 1:
+                vn.sync_moments()                            # C3: every rank normalises with the moments of all walkers
         # ---- PPO.train
         b_obs = buf.observations.reshape(-1, venv.obs_dim); b_act = buf.actions.reshape(-1, venv.nu)
         b_adv = buf.advantages.reshape(-1); b_ret = buf.returns.reshape(-1); b_val = buf.values.reshape(-1); b_lp = buf.log_probs.reshape(-1)
         for ep in range(epochs):
-            perm = torch.randperm(batch, device=dev)
+            perm = torch.randperm(batch, generator=perm_gen).to(dev)          # indices t * n_global + i into the rollout of ALL walkers
             for i in range(0, batch, minibatch):
-                idx = perm[i:i + minibatch]
-                o, a = b_obs[idx], b_act[idx]
-                h = torch.tanh(torch.nn.functional.linear(o, pol.w1, pol.b1))
-                h = torch.tanh(torch.nn.functional.linear(h, pol.w2, pol.b2))
-                mean = torch.nn.functional.linear(h, pol.wa, pol.ba)
-                value = torch.nn.functional.linear(h, pol.wv, pol.bv)[:, 0]
-                std = torch.exp(pol.log_std)
-                logp = (-0.5 * ((a - mean) / std) ** 2 - pol.log_std - 0.5 * math.log(2 * math.pi)).sum(1)
-                entropy = (0.5 + 0.5 * math.log(2 * math.pi) + pol.log_std).sum()
-                adv = b_adv[idx]
-                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-                ratio = torch.exp(logp - b_lp[idx])
-                pg_loss = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
-                v_pred = b_val[idx] + torch.clamp(value - b_val[idx], -clip, clip)
-                v_loss = torch.nn.functional.mse_loss(b_ret[idx], v_pred)
-                loss = pg_loss + ent_coef * (-entropy) + vf_coef * v_loss
+                idx = collectives.shard_minibatch(perm[i:i + minibatch], n_global, rank, world)      # this rank's samples of the global minibatch
+                adv, n_mb = collectives.minibatch_adv_normalize(b_adv[idx])                          # C1: statistics of the global minibatch
+                loss = collectives.ppo_minibatch_loss(wd, b_obs[idx], b_act[idx], adv, b_ret[idx], b_val[idx], b_lp[idx], n_mb, clip, ent_coef, vf_coef)
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
+                bucket.reduce()
                 torch.nn.utils.clip_grad_norm_(params, 0.5)
                 opt.step()
         if upd % log_every == 0 or upd == n_updates - 1:

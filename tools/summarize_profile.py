@@ -59,7 +59,9 @@ if 'hbm_bytes_per_launch' in out:
     if 'SQ_ACTIVE_INST_VALU' in pmc and 'SQ_WAVE_CYCLES' in pmc:
         extra = {'valu_busy_frac': pmc['SQ_ACTIVE_INST_VALU'] / pmc['SQ_WAVE_CYCLES'], 'wait_frac': pmc.get('SQ_WAIT_ANY', 0.0) / pmc['SQ_WAVE_CYCLES'],
                  'valu_insts_per_launch': pmc.get('SQ_INSTS_VALU')}
-    json.dump({**extra, 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_sha16          # the kernel sources these counters belong to: bench.py reports them only while they match
+    json.dump({**extra, 'tag': tag, 'kernel_sources_sha16': kernel_sources_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
                'source': f'profiles/{tag}_summary.txt', 'correction': 'FETCH_SIZE doubled (gfx950: 128 B requests tallied at 64 B), WRITE_SIZE as reported'},
               open(os.path.join(dst, 'traffic_env_step.json'), 'w'))
 print('\n'.join(lines))
