@@ -637,17 +637,30 @@ static int bad(const double* x, int n) {
     return 0;
 }
 
-/* [3P] mj_step with integrator RK4 (mj_RungeKutta, N = 4).  warm is qacc_warmstart: every
- * forward evaluation starts from and then overwrites it.  Returns 1 on divergence
- * (mj_checkPos/Vel/Acc -> MujocoException in mujoco-py). */
+/* Warm-start schedule of the RK4 stages.
+ * 0 (default, what the device kernels do): every forward evaluation starts from and then overwrites qacc_warmstart, so
+ *   stage k starts from the solution of stage k - 1.
+ * 1 (MuJoCo 2.x as published: mj_forward never writes qacc_warmstart, mj_advance saves d->qacc once per mj_step): all four
+ *   stages of a step start from the SAME vector, the one saved by the previous step -- which is the acceleration of that
+ *   step's LAST stage, the last forward evaluation before mj_advance.
+ * The minimiser of the convex solver cost is unique, so the two schedules differ in the iterate path only: results agree to
+ * the solver tolerance (tests/test_oracle_physics.py::test_warmstart_schedules_agree).  Schedule 1 is what vectors dumped
+ * from a real MuJoCo (tools/dump_mujoco_vectors.py -> tests/golden/G12_mujoco_step.npz) are compared under. */
+static int g_warm_schedule = 0;
+void dlo_set_warmstart_schedule(int schedule) { g_warm_schedule = schedule ? 1 : 0; }
+
+/* [3P] mj_step with integrator RK4 (mj_RungeKutta, N = 4).  warm is qacc_warmstart (see the schedules above).
+ * Returns 1 on divergence (mj_checkPos/Vel/Acc -> MujocoException in mujoco-py). */
 static int mj_step_rk4(const model_t* mm, double* q, double* v, const double* ctrl, double* warm, double h, int flags, data_t* d) {
     int nv = mm->m.nv;
     static const double A[3][3] = {{0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 1}};
     static const double Bw[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
-    double X[4][2 * NV], F[4][NV];
+    double X[4][2 * NV], F[4][NV], warm_in[NV];
+    const int per_step = g_warm_schedule == 1;
     if (bad(q, nv) || bad(v, nv)) return 1;
+    memcpy(warm_in, warm, nv * sizeof(double));
     forward(mm, q, v, ctrl, warm, flags, d);
-    memcpy(warm, d->qacc, nv * sizeof(double));
+    if (!per_step) memcpy(warm, d->qacc, nv * sizeof(double));
     if (bad(d->qacc, nv)) return 1;
     memcpy(X[0], q, nv * sizeof(double));
     memcpy(X[0] + NV, v, nv * sizeof(double));
@@ -659,10 +672,11 @@ static int mj_step_rk4(const model_t* mm, double* q, double* v, const double* ct
             X[i][j] = X[0][j] + h * dx;
             X[i][NV + j] = X[0][NV + j] + h * df;
         }
-        forward(mm, X[i], X[i] + NV, ctrl, warm, flags, d);
-        memcpy(warm, d->qacc, nv * sizeof(double));
+        forward(mm, X[i], X[i] + NV, ctrl, per_step ? warm_in : warm, flags, d);
+        if (!per_step) memcpy(warm, d->qacc, nv * sizeof(double));
         memcpy(F[i], d->qacc, nv * sizeof(double));
     }
+    if (per_step) memcpy(warm, d->qacc, nv * sizeof(double));       /* mj_advance: d->qacc is the last stage's */
     for (int j = 0; j < nv; j++) {
         double dx = 0, df = 0;
         for (int k = 0; k < 4; k++) { dx += Bw[k] * X[k][NV + j]; df += Bw[k] * F[k][j]; }

@@ -105,6 +105,10 @@ void dlo_probe_forward(const dl_model_desc* m, const double* qpos, const double*
 int dlo_probe_steps(const dl_model_desc* m, double* qpos, double* qvel, const double* ctrl,
                     double* warm, double dt, int n, int flags);
 
+/* warm-start schedule of the RK4 stages: 0 = per evaluation (the device kernels), 1 = per mj_step as in MuJoCo 2.x
+ * (qacc_warmstart saved once per step by mj_advance); process-global, see dl_oracle.c */
+void dlo_set_warmstart_schedule(int schedule);
+
 /* SB3 reductions (host, double / float as in SB3) */
 void dlo_moments_update(double* mean, double* var, double* count, const double* x, int32_t B,
                         int32_t D);

@@ -58,6 +58,11 @@ def _p(a, t=C.c_double):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
+def set_warmstart_schedule(schedule):
+    """0: every forward evaluation overwrites qacc_warmstart (device kernels); 1: once per mj_step (MuJoCo 2.x)."""
+    lib().dlo_set_warmstart_schedule(C.c_int(int(schedule)))
+
+
 def set_const(model):
     lib().dlo_set_const(C.byref(model))
     return model

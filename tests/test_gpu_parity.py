@@ -1119,3 +1119,35 @@ def test_gae_and_adv_norm_at_training_shapes(torch_cuda, T, N):
     buf.normalize_advantages()
     ref = (a0 - a0.mean()) / (a0.std(unbiased=True) + 1e-8)
     assert float((buf.advantages.double() - ref).abs().max()) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# G12: the REAL MuJoCo's vectors through the device kernels (see tests/test_oracle_golden.py::test_G12_*); skipped, loudly, until
+# tools/dump_mujoco_vectors.py has been run on a machine with MuJoCo and its output committed.
+G12 = os.path.join(GOLDEN, 'G12_mujoco_step.npz')
+
+
+@pytest.mark.skipif(not os.path.exists(G12), reason='tests/golden/G12_mujoco_step.npz is absent: device dynamics are checked against the oracle only, and the oracle '
+                                                    'is NOT pinned to a real MuJoCo build (PARITY UNPINNED) -- run tools/dump_mujoco_vectors.py where MuJoCo imports')
+@pytest.mark.parametrize('key', ['straight', 'walker165'])
+@pytest.mark.parametrize('precision,tol', [(64, 1e-6), (32, 1e-2)])
+def test_G12_device_forward_matches_real_mujoco(torch_cuda, key, precision, tol):
+    from drloco_amd import mocap, models
+    from drloco_amd.vec_env import HipVecEnv
+    with np.load(G12) as z:
+        g = {k: z[k] for k in z.files}
+    q, v, w, u = (g[f'{key}__fwd_{k}'] for k in ('qpos', 'qvel', 'warm', 'ctrl'))
+    n = q.shape[1]
+    if key == 'straight':
+        env = HipVecEnv(num_envs=n, precision=precision)
+    else:
+        ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
+        env = HipVecEnv(models.WALKER_165CM, num_envs=n, precision=precision, refs=mocap.loco3d_table(ang, vel))
+    env.set_state(qpos=q, qvel=v, warm=w)
+    qa, nc, ne, _ = env.forward(u)
+    want = g[f'{key}__fwd_qacc']
+    if precision == 64:
+        assert np.array_equal(nc, g[f'{key}__fwd_ncon']) and np.array_equal(ne, g[f'{key}__fwd_nefc'])
+    err = np.abs(qa - want) / (1 + np.abs(want))
+    assert err.max() < tol, err.max()
+    env.close()

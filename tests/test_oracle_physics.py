@@ -284,3 +284,127 @@ def test_randomization_and_push_known_answers(model, oracle, refs):
     qa2, nc2, _, _ = env2.forward(np.zeros((8, 2)))
     assert nc2[0] == nc2[1] and nc2[0] >= 1
     assert np.abs(qa2[:, 0] - qa2[:, 1]).max() > 1e-3         # 0.9 vs 1.1 changes the friction pyramid
+
+
+# ---------------------------------------------------------------------------------------------
+# Known-answer tests of the contact model on one-body probes: closed forms from solref / solimp.
+def _puck(geom='capsule'):
+    """One free body (3 slides + 3 hinges) with one geom: a vertical capsule (one sphere-like contact at its lower end) or a
+    flat box (four corner contacts)."""
+    from drloco_amd.mjcf import ModelBuilder
+    S, H = abi.DL_JNT_SLIDE, abi.DL_JNT_HINGE
+    mb = ModelBuilder(timestep=0.001, frame_skip=1)
+    mb.floor_friction = 0.7
+    b = mb.body('puck', 0, (0, 0, 0.5), 5.0, (0, 0, 0), (0.2, 0.2, 0.3))
+    for name, ax in (('x', (1, 0, 0)), ('y', (0, 1, 0))):
+        mb.joint(name, b, S, ax)
+    mb.joint('z', b, S, (0, 0, 1), ref=0.5)
+    for name, ax in (('rx', (1, 0, 0)), ('ry', (0, 1, 0)), ('rz', (0, 0, 1))):
+        mb.joint(name, b, H, ax)
+    if geom == 'capsule':
+        mb.capsule(b, (0, 0, -0.2, 0, 0, 0.2), 0.1, 0.9)          # lower end sphere: centre z = -0.2, radius 0.1
+    else:
+        mb.box(b, (0, 0, 0), (0.3, 0.3, 0.05), 0.9)
+    return mb.build()
+
+
+def _impedance(solimp, r):
+    d0, dw, width, mid, power = solimp
+    x = min(abs(r) / width, 1.0)
+    y = x ** power / mid ** (power - 1) if x <= mid else 1 - (1 - x) ** power / (1 - mid) ** (power - 1)
+    return d0 + y * (dw - d0)
+
+
+def test_steady_state_penetration_from_solref_solimp(oracle):
+    """A body resting on ONE sphere-like contact sinks in until the contact's four pyramid rows carry its weight:
+    at rest J a - aref = K d(r) r on every row, so  m g = 4 D(r) K d(r) |r|  with  K = 1/(dmax^2 tc^2 zeta^2),
+    D = 1/R,  R = 2 mu^2 (1 - d)/d * invweight (1 + mu^2)  (solref (0.02, 1), solimp (0.9, 0.95, 0.001, 0.5, 2), mu = 0.9)."""
+    m = _puck('capsule')
+    mass, mu = 5.0, 0.9
+    q = np.array([0, 0, 0.3005, 0, 0, 0.0]); v = np.zeros(6)       # lower end 0.5 mm above the floor
+    q, v, w, rc = oracle.probe_steps(m, q, v, n=2000)               # 2 s
+    assert rc == 0 and np.abs(v).max() < 1e-6
+    r = oracle.probe_forward(m, q, v, warm=w)
+    assert r['ncon'] == 1 and r['nefc'] == 4
+    pen = r['con_dist'][0]
+    assert pen < 0
+    tc, zeta, dmax = max(m.solref[0], 2 * m.timestep), m.solref[1], m.solimp[1]
+    K = 1.0 / (dmax ** 2 * tc ** 2 * zeta ** 2)
+    invw = m.body_invweight0[1][0]
+
+    def normal_force(rr):
+        d = _impedance(list(m.solimp), rr)
+        R = 2 * mu * mu * max(1e-15, (1 - d) / d * invw * (1 + mu * mu))
+        return 4 * K * d * abs(rr) / R
+
+    lo, hi = -0.01, 0.0                                              # bisection on the closed form
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if normal_force(mid) > mass * G else (lo, mid)
+    want = 0.5 * (lo + hi)
+    assert abs(normal_force(want) - mass * G) < 1e-6
+    np.testing.assert_allclose(pen, want, rtol=1e-5)
+    np.testing.assert_allclose(r['qfrc_constraint'][2], mass * G, rtol=1e-7)
+    assert abs(q[2] - (0.3 + want)) < 1e-9 and np.abs(q[3:]).max() < 1e-12    # still upright, no drift
+
+
+@pytest.mark.parametrize('tan_ratio,slides', [(0.8, False), (1.25, True)])
+def test_friction_cone_slip_threshold(oracle, tan_ratio, slides):
+    """A flat box on the floor under a tilted gravity vector g (sin t, 0, -cos t): it stays put for tan t < mu and slides for
+    tan t > mu with acceleration g (sin t - mu cos t) (pyramidal cone, push along a pyramid axis; mu = max(0.7, 0.9))."""
+    m = _puck('box')
+    mu = 0.9
+    th = np.arctan(tan_ratio * mu)
+    m.gravity[:] = [G * np.sin(th), 0.0, -G * np.cos(th)]
+    q = np.array([0, 0, 0.0495, 0, 0, 0.0]); v = np.zeros(6)
+    t_settle, t_run = (0.1, 1.4) if slides else (0.4, 0.4)
+    q, v, w, rc = oracle.probe_steps(m, q, v, n=int(round(t_settle / m.timestep)))       # vertical settling
+    assert rc == 0
+    q1, v1, w1, rc = oracle.probe_steps(m, q.copy(), v.copy(), warm=w, n=int(round(t_run / m.timestep)))
+    assert rc == 0
+    r = oracle.probe_forward(m, q1, v1, warm=w1)
+    acc = (v1[0] - v[0]) / t_run
+    if slides:
+        # a fast-sliding soft contact hovers at zero penetration (the row opposing the motion alone carries the weight, its
+        # normal part lifts the box until the contact is about to open), so the corners chatter; the TIME-AVERAGED friction is
+        # mu times the weight's normal component
+        np.testing.assert_allclose(acc, G * (np.sin(th) - mu * np.cos(th)), rtol=2e-2)
+        assert q1[0] - q[0] > 1.0 and abs(q1[2] - 0.05) < 1e-3
+    else:
+        # inside the cone the soft constraint only creeps at a constant velocity, which has a closed form too.  Per corner the rows
+        # are n +- mu t; with f0 = -D K d(r) r the force of a row without tangential velocity, the row opposing the motion carries
+        # f0 + D B mu v, the one along it f0 - D B mu v -- negative here, i.e. inactive.  Balance of the four corners:
+        #   tangential  4 mu (f0 + D B mu v) = m g sin t,    normal  4 (3 f0 + D B mu v) = m g cos t
+        assert abs(acc) < 1e-6 and r['ncon'] == 4
+        mass = 5.0
+        d = _impedance(list(m.solimp), r['con_dist'].mean())
+        R = 2 * mu * mu * (1 - d) / d * m.body_invweight0[1][0] * (1 + mu * mu)
+        B = 2.0 / (m.solimp[1] * max(m.solref[0], 2 * m.timestep))
+        f_opp = mass * G * np.sin(th) / (4 * mu)
+        f0 = (mass * G * np.cos(th) / 4 - f_opp) / 2
+        assert f0 - (f_opp - f0) < 0                                  # the row along the motion is indeed inactive
+        np.testing.assert_allclose(v1[0], (f_opp - f0) * R / (B * mu), rtol=5e-3)
+        assert v1[0] < 0.01
+    assert abs(v1[1]) < 1e-9 and abs(v1[5]) < 1e-9                  # nothing sideways, no yaw
+
+
+def test_warmstart_schedules_agree(model, oracle):
+    """MuJoCo saves qacc_warmstart once per mj_step (mj_advance), the device kernels after every RK4 stage: the solver's
+    minimiser is unique, so trajectories under the two schedules agree to the solver tolerance."""
+    rng = np.random.default_rng(3)
+    q = np.array(model.jnt_qpos0[:14]); q[2] = 1.02; q[4] = 0.15; q[8] = 0.3; q[12] = 0.2
+    v = 0.3 * rng.standard_normal(14)
+    ctrl = rng.uniform(-60, 60, 8)
+    out = []
+    for sched in (0, 1):
+        oracle.set_warmstart_schedule(sched)
+        try:
+            out.append(oracle.probe_steps(model, q.copy(), v.copy(), ctrl=ctrl, n=300))
+        finally:
+            oracle.set_warmstart_schedule(0)
+    (q0, v0, w0, rc0), (q1, v1, w1, rc1) = out
+    assert rc0 == 0 and rc1 == 0
+    assert oracle.probe_forward(model, q0, v0, warm=w0)['ncon'] >= 2            # the comparison ran through contact
+    np.testing.assert_allclose(q1, q0, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(v1, v0, rtol=0, atol=2e-5)
+    assert np.abs(w1 - w0).max() > 0                                            # the schedules are not the same code path
