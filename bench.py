@@ -216,16 +216,15 @@ def main():
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = buf.next_starts                                 # row T of the episode-start array: the flags after the last step
     last_done.fill_(1)
-    push_phase = push_force = None
     if args.randomize:
         import numpy as np
         gidx = np.arange(rank * n, (rank + 1) * n)
         u = lambda salt: np.array([np.random.default_rng((int(i), salt)).random() for i in gidx])     # seed = global walker index
         venv.set_randomization(0.8 + 0.4 * u(1), 0.5 + 0.6 * u(2))
         ang = 2 * np.pi * u(3)
-        push_force = torch.as_tensor(np.stack([50 * np.cos(ang), 50 * np.sin(ang), 0 * ang], 1), dtype=torch.float32, device=dev)
-        push_phase = torch.as_tensor((400 * u(4)).astype(np.int64), device=dev)
-        step_counter = [0]
+        # 0.1 s = 20 control steps of push every 2 s = 400 control steps, as a schedule kept on the device (dl_set_push_schedule): the long
+        # launches of dl_rollout_fixed need no host round trip per control step
+        venv.set_push_schedule(np.stack([50 * np.cos(ang), 50 * np.sin(ang), 0 * ang], 1), (400 * u(4)).astype(np.int32), period=400, duration=20)
     policy = None
     if args.policy:
         from drloco_amd.policy import HipPolicy
@@ -246,7 +245,7 @@ def main():
     def rollout():
         # RolloutBuffer.add without copies: every producer writes straight into the buffer slot of its result
         # (dl_step -> episode_starts[t+1]; dl_vecnormalize_step -> observations[t+1], rewards[t])
-        if policy is None and push_force is None and not args.no_overlap:
+        if policy is None and not args.no_overlap:
             # pre-generated actions: dl_rollout_fixed in runs of --steps-per-launch control steps (one launch of the 16-lane kernel
             # each), their normalisations on the side stream
             buf.reset()
@@ -257,7 +256,7 @@ def main():
                 vn.steps_fixed(buf.actions[t0:ts[-1] + 1], [buf.observations[t + 1] if t + 1 < T else last_obs for t in ts], [buf.rewards[t] for t in ts],
                                buf._starts[t0 + 1:ts[-1] + 2])
             T_loop = 0
-        elif policy is not None and push_force is None:
+        elif policy is not None:
             buf.collect_rollouts(vn, policy, last_obs, last_done)     # dl_rollout_policy: the whole loop in one C-ABI call
             T_loop = 0
         else:
@@ -267,10 +266,6 @@ def main():
             T_loop = T
         for t in range(T_loop):
             nxt = t + 1 < T
-            if push_force is not None:  # 0.1 s = 20 control steps of push every 2 s = 400 control steps
-                on = ((step_counter[0] + push_phase) % 400 < 20).to(torch.float32).unsqueeze(1)
-                lib.check(venv._lib.dl_set_push(venv._h, C.c_void_p((push_force * on).contiguous().data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-                step_counter[0] += 1
             if policy is not None:      # collect_rollouts: actions, values, log_probs = policy.forward(obs) -> straight into the buffer
                 policy.forward(buf.observations[t], actions_out=buf.actions[t], values_out=buf.values[t], log_probs_out=buf.log_probs[t])
             vn.step_tensors(buf.actions[t], obs_out=buf.observations[t + 1] if nxt else last_obs, rew_out=buf.rewards[t],
@@ -336,9 +331,9 @@ def main():
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, under the following run of env steps',
-                       'env_launches': 'one per control step' if (args.policy or args.no_overlap or args.randomize) else
+                       'env_launches': 'one per control step' if (args.policy or args.no_overlap) else
                                        'dl_rollout_fixed, runs of ' + ' + '.join(str(r) for _, r in run_starts) + ' control steps per launch',
-                       'dynamics': 'per-walker mass/friction randomisation + 50 N pushes (config 5 stress test)' if args.randomize else 'nominal'},
+                       'dynamics': 'per-walker mass/friction randomisation + 50 N pushes on a device-resident schedule (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
                                    ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else 'k_env_step_g16<float,TopoStraight>'), 'avg_launch_us': avg_launch_s * 1e6,

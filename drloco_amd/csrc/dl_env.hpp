@@ -34,6 +34,10 @@ template <typename T> struct DevState {
     T* work;                 // [4*NV][N] staging of the RK4 bookkeeping
     int32_t n;
     T* rnd;                  // [5][N] or NULL: per-walker mass scale, floor friction, push force on the torso (x, y, z)
+    // push schedule (dl_set_push_schedule) or NULL: the push force of rnd acts on walker w during control step k iff
+    // (k + push_phase[w]) % push_period < push_dur, k = push_step0 + step inside the launch (counted by the handle)
+    const int32_t* push_phase;
+    int32_t push_period, push_dur, push_step0;
     float* dbgf;             // [3*16][N] or NULL: stage input (q, v, solver start) of the last evaluation with >= dbg_cap iterations
     int dbg_cap;             // default: the iteration cap of the model (env DL_DEBUG_CAP_ITERS overrides; diagnostics)
     int32_t* dbg;            // [4][N] or NULL: solver diagnostics of the 16-lane step kernel (sum iters, max iters, sum rows, diverged)

@@ -38,6 +38,10 @@
 
 #include "dl_env.hpp"
 
+#ifndef DL_PIN_STRAIGHT
+#define DL_PIN_STRAIGHT 1       // experiment switch: 0 builds the straight walker with the fetch-at-use policy of the 19-dof walker
+#endif
+
 namespace dl {
 
 constexpr int GL = 16;          // lanes per walker
@@ -64,7 +68,7 @@ template <typename TP> struct GD {
     // inside an evaluation).  The 19-dof walker does not have the registers for that (three candidate passes, nine bodies, the
     // replicated dofs' state): what is used ONCE per evaluation -- collision candidates, body offsets, solimp -- is fetched at
     // its point of use from the L1-resident model block instead (a few hundred cycles per evaluation against scratch spills).
-    static constexpr bool PIN_ALL = NX == 0;
+    static constexpr bool PIN_ALL = (NX == 0) && DL_PIN_STRAIGHT;
     static_assert(slides_ok_(), "the dofs beyond 16 must be leading root translations");
     static_assert(NL <= GL && MAXB <= 16 && NCAND <= 64 && TP::NS <= GL, "model too large for a 16-lane row");
 };

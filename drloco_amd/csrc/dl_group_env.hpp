@@ -125,8 +125,16 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     T comz = st.comz_off[w];
     double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
     long long t_phys_end = 0;
+    // push schedule on the device (BASELINE config 5 without a host round trip per control step)
+    const V3<T> push_force = wk.push;
+    const int push_phase = (st.push_phase && st.rnd) ? st.push_phase[w] : -1;
 #pragma unroll 1
     for (int step = 0; step < nsteps; step++) {
+    if (push_phase >= 0) {
+        const bool on = ((st.push_step0 + step + push_phase) % st.push_period) < st.push_dur;
+        wk.push = on ? push_force : mk<T>(0, 0, 0);
+        wk.pushed = on && (push_force.x != T(0) || push_force.y != T(0) || push_force.z != T(0));
+    }
     const float* __restrict__ actions = actions_all + (size_t)step * n * NU;
     float* obs = obs_all + (size_t)step * n * OBS;
     float* rew = rew_all + (size_t)step * n;

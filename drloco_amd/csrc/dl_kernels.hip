@@ -191,83 +191,65 @@ __global__ void k_reward_finish(float* rew, double* ret, const uint8_t* done, co
 }
 
 // ---- VecNormalize.step_wait fused into two launches -------------------------------------------------------
-// k_vn_reduce: grid = VN_BLOCKS.  Every block reads a slab of x[B, D] with coalesced loads (thread t always meets
-// column t % D) and a slice of the discounted returns (ret = ret*gamma + r is advanced here) and leaves per-column
-// partial sums of (x - K) and (x - K)^2, K = the running mean (shift against cancellation); the returns are column D.
-// The last block to arrive merges them into (mean, var) with RunningMeanStd's Chan update.  The counts are read here
-// and advanced by k_vn_apply (stream order), so every merge sees the old count.
-constexpr int VN_BLOCKS = DL_VN_BLOCKS;        // 128: four rows per thread at 4096 walkers -- the loads of a thread are issued together, one memory round trip
-__global__ __launch_bounds__(256) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
-                                                   double* ret, double* ret_mean, double* ret_var, const double* ret_count,
-                                                   int B, int D, double gamma, int flags, double* work, unsigned* arrive) {
-    __shared__ double sh[2][256];
-    __shared__ double sh2[4];
-    __shared__ bool is_last;
-    const int t = threadIdx.x, W = D + 1;
-    // ---- observations: per-column partial sums of this block's rows
+// k_vn_reduce: ONE workgroup of 1024 lanes.  The batch is small (4096 x 29 floats = 0.5 MB, L2 / MALL resident: the step kernel
+// has just written it), so what a launch costs is latency, not bandwidth: a multi-block reduction pays two device-scope
+// fences and contended atomics across the 8 XCDs' L2s (measured: 20 us with 32 or 128 blocks), one CU streams 0.5 MB in ~4 us
+// and needs neither -- and the summation order is fixed, so the moments are the same bits on every run.
+// Thread t always meets column t % D (the slab of a pass is rpb = 1024 / D whole rows, read with coalesced 256-byte wave
+// loads); sums are of (x - K), K = the running mean (shift against cancellation), in float64.  The discounted returns
+// (ret = ret * gamma + r is advanced here) are column D.  RunningMeanStd's Chan update follows; the counts are read here and
+// advanced by k_vn_apply (stream order), so every merge sees the old count.
+constexpr int VN_THREADS = 1024;
+__global__ __launch_bounds__(VN_THREADS) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
+                                                          double* ret, double* ret_mean, double* ret_var, const double* ret_count,
+                                                          int B, int D, double gamma, int flags) {
+    __shared__ double sh[2][VN_THREADS];
+    __shared__ double sh2[VN_THREADS / 64];
+    const int t = threadIdx.x;
+    double rs = 0, rss = 0;
+    // ---- discounted returns first (their loads overlap the observation loads below)
+    if (flags & 4) {
+        const double K = *ret_mean;
+        for (int i = t; i < B; i += VN_THREADS) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; const double d = r - K; rs += d; rss += d * d; }
+    }
+    // ---- observations: per-column partial sums over this thread's rows
     if (flags & 1) {
-        const int rpb = blockDim.x / D, nthr = rpb * D;       // rows per pass of this block
+        const int rpb = VN_THREADS / D, nthr = rpb * D;       // rows per pass
         double s = 0, ss = 0;
         const int col = t % D, rsub = t / D;
         if (t < nthr) {
             const double K = mean[col];
-            const int stride = VN_BLOCKS * rpb;
-            int row = blockIdx.x * rpb + rsub;
-            for (; row + 3 * stride < B; row += 4 * stride) {          // four independent loads in flight
-                const float a0 = x[(size_t)row * D + col], a1 = x[(size_t)(row + stride) * D + col], a2 = x[(size_t)(row + 2 * stride) * D + col], a3 = x[(size_t)(row + 3 * stride) * D + col];
-                const double d0 = (double)a0 - K, d1 = (double)a1 - K, d2 = (double)a2 - K, d3 = (double)a3 - K;
-                s += d0; ss += d0 * d0; s += d1; ss += d1 * d1; s += d2; ss += d2 * d2; s += d3; ss += d3 * d3;
+            int row = rsub;
+            for (; row + 7 * rpb < B; row += 8 * rpb) {          // eight independent loads in flight
+                float a[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) a[k] = x[(size_t)(row + k * rpb) * D + col];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const double d = (double)a[k] - K; s += d; ss += d * d; }
             }
-            for (; row < B; row += stride) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
+            for (; row < B; row += rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
         }
         sh[0][t] = s; sh[1][t] = ss;
         __syncthreads();
         if (t < D) {
             for (int r = 1; r < rpb; r++) { s += sh[0][r * D + t]; ss += sh[1][r * D + t]; }
-            work[((size_t)blockIdx.x * W + t) * 2] = s; work[((size_t)blockIdx.x * W + t) * 2 + 1] = ss;
+            const double K = mean[t], bm = K + s / B, bv = ss / B - (s / B) * (s / B);
+            const double cnt = *count, tot = cnt + B, delta = bm - K;
+            const double M2 = var[t] * cnt + bv * B + delta * delta * cnt * B / tot;
+            mean[t] = K + delta * B / tot;
+            var[t] = M2 / tot;
         }
     }
-    // ---- discounted returns: advance this block's slice, partial sums as column D
     if (flags & 4) {
-        const int chunk = (B + VN_BLOCKS - 1) / VN_BLOCKS, lo = blockIdx.x * chunk, hi = lo + chunk < B ? lo + chunk : B;
-        const double K = *ret_mean;
-        double s = 0, ss = 0;
-        for (int i = lo + t; i < hi; i += blockDim.x) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; const double d = r - K; s += d; ss += d * d; }
-        s = block_sum(s, sh2); ss = block_sum(ss, sh2);
-        if (t == 0) { work[((size_t)blockIdx.x * W + D) * 2] = s; work[((size_t)blockIdx.x * W + D) * 2 + 1] = ss; }
-    }
-    __threadfence();
-    __syncthreads();
-    if (t == 0) is_last = atomicAdd(arrive, 1u) == (unsigned)(VN_BLOCKS - 1);
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    // the last block to arrive merges the partial sums in block order (the result does not depend on the arrival order):
-    // 8 threads per column, each over a fixed subset of the blocks, combined in a fixed order
-    constexpr int SPLIT = 8, CPP = 256 / SPLIT;          // columns per pass
-    const int part = t % SPLIT;
-    for (int c0 = 0; c0 < W; c0 += CPP) {
-        const int colm = c0 + t / SPLIT;
-        double S = 0, SS = 0;
-        const bool active = colm < W && ((colm < D && (flags & 1)) || (colm == D && (flags & 4)));
-        if (active)
-            for (int b = part; b < VN_BLOCKS; b += SPLIT) { S += __builtin_nontemporal_load(&work[((size_t)b * W + colm) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * W + colm) * 2 + 1]); }
-        __syncthreads();
-        sh[0][t] = S; sh[1][t] = SS;
-        __syncthreads();
-        if (active && part == 0) {
-            for (int k = 1; k < SPLIT; k++) { S += sh[0][t + k]; SS += sh[1][t + k]; }
-            const bool do_obs = colm < D;
-            double* m = do_obs ? mean + colm : ret_mean;
-            double* v = do_obs ? var + colm : ret_var;
-            const double K = *m, bm = K + S / B, bv = SS / B - (S / B) * (S / B);
-            const double cnt = do_obs ? *count : *ret_count, tot = cnt + B, delta = bm - K;
-            const double M2 = *v * cnt + bv * B + delta * delta * cnt * B / tot;
-            *m = K + delta * B / tot;
-            *v = M2 / tot;
+        rs = block_sum(rs, sh2); rss = block_sum(rss, sh2);
+        if (t == 0) {
+            const double K = *ret_mean, bm = K + rs / B, bv = rss / B - (rs / B) * (rs / B);
+            const double cnt = *ret_count, tot = cnt + B, delta = bm - K;
+            const double M2 = *ret_var * cnt + bv * B + delta * delta * cnt * B / tot;
+            *ret_mean = K + delta * B / tot;
+            *ret_var = M2 / tot;
         }
     }
-    if (t == 0) *arrive = 0;
 }
 // k_vn_apply: obs_out = clip((obs - mean)/sqrt(var + eps)); rew_out = clip(r/sqrt(ret_var + eps)); ret[done] = 0; counts += B
 __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, const float* __restrict__ rew, const uint8_t* __restrict__ done,
@@ -423,6 +405,7 @@ struct dl_env_s {
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
     virtual int terminate_early(int32_t* flags, hipStream_t) = 0;
     virtual int randomize(const float* mass_scale, const float* floor_friction, const float* push, bool set_push, hipStream_t) = 0;
+    virtual int push_schedule(const float* force, const int32_t* phase, int period, int duration, hipStream_t) = 0;
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
@@ -571,6 +554,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int steps_fixed(int nsteps, const float* act, float* obs, float* rew, uint8_t* done, hipStream_t s) override {
         if (!(variant == 1 && gmd) || inj_armed || nsteps <= 1) { const int rc = step(act, obs, rew, done, nullptr, nullptr, s); return rc == DL_OK ? 1 : rc; }
         const int k = nsteps < MULTI ? nsteps : MULTI;
+        st.push_step0 = push_step; push_step += k;
         prof_begin(s);
         hipLaunchKernelGGL((k_env_step_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, (float*)nullptr, eval_mode, k);
@@ -582,6 +566,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int step(const float* act, float* obs, float* rew, uint8_t* done, float* term, float* terms, hipStream_t s) override {
         if (!act || !obs || !rew || !done) return fail(DL_E_INVAL, "actions/obs/rew/done must not be NULL");
         if (variant == 1 && gmd) {
+            st.push_step0 = push_step; push_step += 1;
             prof_begin(s);
             hipLaunchKernelGGL((k_env_step_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, term, terms,
                                (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), ctrl_dbg, eval_mode, 1);
@@ -634,6 +619,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int randomize(const float* mass_scale, const float* floor_friction, const float* push, bool set_push, hipStream_t s) override {
         if (!(variant == 1 && gmd)) return fail(DL_E_INVAL, "dynamics randomisation / pushes are implemented by the 16-lane kernels (lanes_per_walker = 16)");
+        if (set_push) st.push_phase = nullptr;           // a plain dl_set_push ends a push schedule (push_schedule re-arms it afterwards)
         const unsigned g256 = (unsigned)((n + 255) / 256);
         if (!st.rnd) {
             int rc;
@@ -650,6 +636,20 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             }
         }
         HIPCHK(hipGetLastError());
+        return DL_OK;
+    }
+    // dl_set_push_schedule: force float[N, 3] (NULL switches the schedule off and clears the push), phase int32[N]
+    int32_t* push_phase = nullptr;
+    int push_step = 0;               // control steps taken since the schedule was set
+    int push_schedule(const float* force, const int32_t* phase, int period, int duration, hipStream_t s) override {
+        if (!force) { st.push_phase = nullptr; return randomize(nullptr, nullptr, nullptr, true, s); }
+        if (!phase || period <= 0 || duration < 0 || duration > period) return fail(DL_E_INVAL, "dl_set_push_schedule: needs phase, period > 0 and 0 <= duration <= period");
+        int rc = randomize(nullptr, nullptr, force, true, s);
+        if (rc) return rc;
+        if (!push_phase && (rc = dalloc(&push_phase, (size_t)n))) return rc;
+        HIPCHK(hipMemcpyAsync(push_phase, phase, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        st.push_phase = push_phase; st.push_period = period; st.push_dur = duration;
+        push_step = 0;
         return DL_OK;
     }
     int terminate_early(int32_t* flags, hipStream_t s) override {
@@ -847,6 +847,10 @@ int dl_set_push(dl_handle h, const float* force, void* stream) {
     NEED(h);
     return h->randomize(nullptr, nullptr, force, true, (hipStream_t)stream);
 }
+int dl_set_push_schedule(dl_handle h, const float* force, const int32_t* phase, int32_t period, int32_t duration, void* stream) {
+    NEED(h);
+    return h->push_schedule(force, phase, period, duration, (hipStream_t)stream);
+}
 int dl_terminate_early(dl_handle h, int32_t* flags, void* stream) {
     NEED(h);
     return h->terminate_early(flags, (hipStream_t)stream);
@@ -918,37 +922,41 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
+static int vn_reduce_launch(const float* obs, const float* rew, double* obs_mean, double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
+                            double* ret_count, int32_t B, int32_t D, double gamma, int32_t flags, void* stream) {
+    if (flags & 5)
+        hipLaunchKernelGGL(k_vn_reduce, dim3(1), dim3(VN_THREADS), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
+                           (const double*)ret_count, B, D, gamma, flags);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
 int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean, double* obs_var, double* obs_count,
                          double* ret, double* ret_mean, double* ret_var, double* ret_count, int32_t B, int32_t D, double gamma, double eps,
                          double clip_obs, double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace, void* stream) {
-    if (!obs || !rew || !done || !obs_mean || !obs_var || !obs_count || !ret || !ret_mean || !ret_var || !ret_count || !obs_out || !rew_out || !workspace || B <= 0 || D <= 0 || D > 128)
+    if (!obs || !rew || !done || !obs_mean || !obs_var || !obs_count || !ret || !ret_mean || !ret_var || !ret_count || !obs_out || !rew_out || B <= 0 || D <= 0 || D > 128)
         return fail(DL_E_INVAL, "dl_vecnormalize_step: bad arguments");
-    double* work = (double*)workspace;
-    unsigned* arrive = (unsigned*)(work + (size_t)2 * VN_BLOCKS * (D + 1));
-    if (flags & 5)
-        hipLaunchKernelGGL(k_vn_reduce, dim3(VN_BLOCKS), dim3(256), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
-                           (const double*)ret_count, B, D, gamma, flags, work, arrive);
+    (void)workspace;              // reserved (ABI 2 used it for cross-block partial sums; the reduction is one workgroup now)
+    {
+        const int rc = vn_reduce_launch(obs, rew, obs_mean, obs_var, obs_count, ret, ret_mean, ret_var, ret_count, B, D, gamma, flags, stream);
+        if (rc) return rc;
+    }
     const size_t ne = (size_t)B * D;
     hipLaunchKernelGGL(k_vn_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, rew, done, (const double*)obs_mean, (const double*)obs_var, obs_count,
                        ret, (const double*)ret_var, ret_count, B, D, eps, clip_obs, clip_rew, flags, obs_out, rew_out);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
-int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
-                      int32_t deterministic, float* actions, float* values, float* log_probs, void* stream) {
-    if (!p || !obs || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward: bad arguments");
+static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                         int32_t deterministic, float* actions, float* values, float* log_probs, const PolVnFuse& vf, void* stream) {
+    if (!p || !(obs || vf.raw_obs) || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward: bad arguments");
     if (!p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->wa || !p->ba || !p->wv || !p->bv || !p->log_std) return fail(DL_E_INVAL, "dl_policy_forward: NULL parameter array");
     if (p->hidden <= 0 || p->hidden % 64 || p->hidden > 64 * POL_MAXT || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15)
         return fail(DL_E_INVAL, "dl_policy_forward: hidden must be a multiple of 64 and <= 512, obs_dim <= 48, act_dim <= 15");
     const int nw = p->hidden == 512 ? 8 : 4;                    // waves per workgroup
-    const size_t lds = ((size_t)2 * POL_ROWS * (p->hidden + 4) + (size_t)nw * 16 * 16) * sizeof(float);
+    const size_t lds = pol_lds_bytes(nw);                       // 23 KB (8 waves): below the default limit, no attribute needed on any device
     const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(64 * nw);
-#define DL_POL_LAUNCH(NTW, NW)                                                                                                                          \
-    {                                                                                                                                                   \
-        static bool attr = false;                                                                                                                       \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_forward<NTW, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-        hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs); \
-    }
+#define DL_POL_LAUNCH(NTW, NW) \
+    hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf);
     switch (p->hidden / 64) {
         case 1: DL_POL_LAUNCH(1, 4) break;
         case 2: DL_POL_LAUNCH(2, 4) break;
@@ -960,6 +968,12 @@ int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, co
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
+int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                      int32_t deterministic, float* actions, float* values, float* log_probs, void* stream) {
+    if (!obs) return fail(DL_E_INVAL, "dl_policy_forward: bad arguments");
+    PolVnFuse none{};
+    return policy_launch(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, none, stream);
+}
 int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
                       float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
                       float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, void* stream) {
@@ -968,15 +982,30 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
         return fail(DL_E_INVAL, "dl_rollout_policy: bad arguments");
     const size_t n = (size_t)h->n, od = (size_t)h->obs_dim, ad = (size_t)h->act_dim;
     if (pol->obs_dim != h->obs_dim || pol->act_dim != h->act_dim) return fail(DL_E_INVAL, "dl_rollout_policy: the policy's observation / action sizes are not the environment's");
+    // Three launches per control step: env step, moment reduction, and the policy forward of the NEXT step with the normalisation
+    // of this step's outputs folded into its input stage (PolVnFuse).  Step 0 reads observations[0] as given; the outputs of the
+    // last step are normalised by the stand-alone k_vn_apply.
+    const uint8_t* prev_done = nullptr;
     for (int t = 0; t < T; t++) {
         const bool last = t + 1 == T;
-        int rc = dl_policy_forward(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, 0,
-                                   actions + t * n * ad, values + t * n, log_probs + t * n, stream);
+        PolVnFuse vf{};
+        if (t > 0) {
+            vf.raw_obs = raw_obs; vf.raw_rew = raw_rew; vf.done = prev_done;
+            vf.mean = vn->obs_mean; vf.var = vn->obs_var; vf.count = vn->obs_count; vf.ret = vn->ret; vf.ret_var = vn->ret_var; vf.ret_count = vn->ret_count;
+            vf.obs_out = observations + t * n * od; vf.rew_out = rewards + (t - 1) * n;
+            vf.eps = vn->eps; vf.clip_obs = vn->clip_obs; vf.clip_rew = vn->clip_rew; vf.flags = vn->flags;
+        }
+        int rc = policy_launch(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, 0,
+                               actions + t * n * ad, values + t * n, log_probs + t * n, vf, stream);
         if (rc) return rc;
         uint8_t* done = last ? next_done : episode_starts + (t + 1) * n;
         if ((rc = h->step(actions + t * n * ad, raw_obs, raw_rew, done, nullptr, nullptr, (hipStream_t)stream))) return rc;
-        rc = dl_vecnormalize_step(raw_obs, raw_rew, done, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od,
-                                  vn->gamma, vn->eps, vn->clip_obs, vn->clip_rew, vn->flags, last ? next_obs : observations + (t + 1) * n * od, rewards + t * n, vn->workspace, stream);
+        prev_done = done;
+        if (last)
+            rc = dl_vecnormalize_step(raw_obs, raw_rew, done, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od,
+                                      vn->gamma, vn->eps, vn->clip_obs, vn->clip_rew, vn->flags, next_obs, rewards + t * n, vn->workspace, stream);
+        else
+            rc = vn_reduce_launch(raw_obs, raw_rew, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od, vn->gamma, vn->flags, stream);
         if (rc) return rc;
     }
     return DL_OK;
@@ -990,7 +1019,7 @@ int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const fl
 int dl_adv_stats(const float* adv, int64_t n, double* out3, void* workspace, void* stream) {
     if (!adv || !out3 || !workspace || n <= 0) return fail(DL_E_INVAL, "dl_adv_stats: bad arguments");
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > ADV_MAXBLOCKS) blocks = ADV_MAXBLOCKS;
+    if (blocks > 128) blocks = 128;         // few blocks: the last-arriver reduction pays one contended device-scope atomic per block
     if (blocks < 1) blocks = 1;
     double* work = (double*)workspace;
     hipLaunchKernelGGL(k_adv_stats, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, adv, (long long)n, out3, work, (unsigned*)(work + 2 * ADV_MAXBLOCKS));

@@ -17,6 +17,7 @@
 //     ping-pong register sets loaded by inline asm one step ahead of the 64 MFMAs that consume them;
 //   layer 2: each wave owns hidden/NW output columns (NTW accumulator tiles); heads: the reduction is split over
 //     the waves and summed through LDS.
+// (With 4 waves x 64 lanes and hidden < 256 `tid < 256` covers the whole workgroup; the epilogue uses 256 lanes.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -51,35 +52,86 @@ __device__ __forceinline__ float pol_gauss(uint64_t seed, uint64_t counter, uint
 
 constexpr int POL_ROWS = 16;       // walkers per workgroup
 constexpr int POL_MAXT = 8;        // accumulator tiles per wave in the hidden layer (hidden <= 512)
+constexpr int POL_SLD = 36;        // row stride of a staged 16 x 32 activation block (floats)
+constexpr int POL_PLD = 20;        // row stride of a wave's private 16 x 16 tile
+// dynamic LDS of k_policy_forward<NTW, NW>: two staged activation blocks + per wave a private tile and a partial head tile
+constexpr size_t pol_lds_bytes(int nw) { return ((size_t)2 * POL_ROWS * POL_SLD + (size_t)nw * POL_ROWS * POL_PLD + (size_t)nw * 256) * sizeof(float); }
+
+// VecNormalize.step_wait's second half (k_vn_apply) folded into the policy's input stage: with raw_obs != NULL the kernel reads the
+// raw observation / reward of the last env step, normalises them with the (already updated) moments exactly as k_vn_apply does,
+// stores them where the rollout buffer wants them (obs_out = observations[t + 1], rew_out = rewards[t]) and runs the forward pass
+// on the normalised observation: one launch less per control step, the same bits.
+struct PolVnFuse {
+    const float* raw_obs; const float* raw_rew; const uint8_t* done;
+    const double* mean; const double* var; double* count;
+    double* ret; const double* ret_var; double* ret_count;
+    float* obs_out; float* rew_out;
+    double eps, clip_obs, clip_rew;
+    int flags;
+};
 
 // NTW = accumulator tiles per wave in the hidden layer, NW = waves per workgroup: hidden = 16 * NTW * NW (compile time, so
 // that the tile loops are straight-line code).  hidden = 512 runs as 8 waves x 4 tiles: two waves per SIMD, so that the LDS /
-// weight-load latency of one overlaps the MFMAs of the other (4 waves x 8 tiles left the matrix pipe idle for ~ 45 % of the
-// hidden layer).
+// weight-load latency of one overlaps the MFMAs of the other.
+// The activations never exist as whole [16, hidden] arrays in LDS: a wave keeps the 16 x 64 block of h1 (h2) it computed in
+// registers (accumulator layout) and the hidden layer's reduction walks over h1 in blocks of 32 columns that their owner
+// stages through a double-buffered 16 x 32 block (4.5 KB); the heads transpose h2 tile by tile through a private 16 x 16 tile
+// per wave.  23 KB of LDS per workgroup instead of 74 KB: the kernel fits next to four resident workgroups of the env-step
+// kernel on a CU (160 KB), which is what lets the policy of one half of the walkers run under the simulation of the other.
 template <int NTW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                         uint64_t seed, uint64_t counter, int index_base, int deterministic,
-                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp) {
+                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int H = 16 * NTW * NW, LDH = H + 4, ntw = NTW;
+    constexpr int H = 16 * NTW * NW, ntw = NTW;
     const int D = p.obs_dim, A = p.act_dim;
-    float* h1 = sm;
-    float* h2 = sm + POL_ROWS * LDH;
-    float* part = h2 + POL_ROWS * LDH;            // [NW][16][16] partial head tiles, then [16][16] log-prob terms
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
+    float* stage = sm;                                                     // [2][16][POL_SLD]
+    float* priv = sm + 2 * POL_ROWS * POL_SLD + wave * (POL_ROWS * POL_PLD);       // this wave's [16][POL_PLD]
+    float* part = sm + 2 * POL_ROWS * POL_SLD + NW * (POL_ROWS * POL_PLD);          // [NW][16][16] partial head tiles, then [16][16] log-prob terms
     const int row0 = blockIdx.x * POL_ROWS;
     constexpr int ncw = H / NW;
     const int n0w = wave * ncw;
+    auto wave_sync = [&]() {      // LDS operations of one wave execute in order: exchanging data inside the wave needs no s_barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // ---- reward normalisation / bookkeeping of the folded VecNormalize step (k_vn_apply's second half)
+    if (vf.raw_obs) {
+        if (tid < POL_ROWS && row0 + tid < n) {
+            const int r = row0 + tid;
+            double y = (double)vf.raw_rew[r];
+            if (vf.flags & 8) { y = y / sqrt(*vf.ret_var + vf.eps); y = y < -vf.clip_rew ? -vf.clip_rew : (y > vf.clip_rew ? vf.clip_rew : y); }
+            vf.rew_out[r] = (float)y;
+            if ((vf.flags & 4) && vf.done[r]) vf.ret[r] = 0;
+        }
+        if (blockIdx.x == 0 && tid == 0) { if (vf.flags & 1) *vf.count += (double)n; if (vf.flags & 4) *vf.ret_count += (double)n; }
+    }
     // ---- layer 1: [16, D] x [D, H].  D is small (29): all operand loads of the wave are issued before the first MFMA
-    // (one memory latency for the layer instead of one per tile)
+    // (one memory latency for the layer instead of one per tile).  h1 stays in registers (accumulator layout).
+    float h1r[NTW][4];
     {
         const int r = row0 + lm;
         constexpr int KB1 = 3;                                      // obs_dim <= 48 (checked by the host): 29 (straight walker), 47 (165 cm walker)
         float a1[KB1 * 4], b1v[NTW][KB1 * 4];
+        const float* src = vf.raw_obs ? vf.raw_obs : obs;
 #pragma unroll
         for (int q = 0; q < KB1 * 4; q++) {
             const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
-            a1[q] = (k < D && r < n) ? obs[(size_t)r * D + k] : 0.0f;
+            a1[q] = (k < D && r < n) ? src[(size_t)r * D + k] : 0.0f;
+        }
+        if (vf.raw_obs) {
+#pragma unroll
+            for (int q = 0; q < KB1 * 4; q++) {
+                const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
+                if (k < D && r < n) {
+                    double y = (double)a1[q];
+                    if (vf.flags & 2) { y = (y - vf.mean[k]) / sqrt(vf.var[k] + vf.eps); y = y < -vf.clip_obs ? -vf.clip_obs : (y > vf.clip_obs ? vf.clip_obs : y); }
+                    a1[q] = (float)y;
+                    if (wave == 0) vf.obs_out[(size_t)r * D + k] = a1[q];
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -92,19 +144,34 @@ __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_para
         }
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
-            if (t < ntw) {
-                const int ncol = n0w + t * 16 + lm;
-                pf4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int ncol = n0w + t * 16 + lm;
+            pf4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < KB1 * 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1v[t][q], acc, 0, 0, 0);
-                const float bias = p.b1[ncol];
+            for (int q = 0; q < KB1 * 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1v[t][q], acc, 0, 0, 0);
+            const float bias = p.b1[ncol];
 #pragma unroll
-                for (int i = 0; i < 4; i++) h1[(4 * lk + i) * LDH + ncol] = pol_tanh(acc[i] + bias);
-            }
+            for (int i = 0; i < 4; i++) h1r[t][i] = pol_tanh(acc[i] + bias);
         }
     }
-    __syncthreads();
+    // the two 16-column tiles of k pair kp, staged by the wave(s) that own them
+    auto publish = [&](int kp) {
+        float* buf = stage + (kp & 1) * (POL_ROWS * POL_SLD);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int tt = 2 * kp + half;
+            if (tt / NTW == wave) {
+                const int lt = tt % NTW;
+#pragma unroll
+                for (int t = 0; t < NTW; t++)
+                    if (t == lt) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) buf[(4 * lk + i) * POL_SLD + half * 16 + lm] = h1r[t][i];
+                    }
+            }
+        }
+    };
     // ---- layer 2: [16, H] x [H, H]; the weight rows of this wave's tiles stream from L2 one k block ahead
+    float h2r[NTW][4];
     {
         pf4 acc[NTW];
 #pragma unroll
@@ -138,52 +205,57 @@ __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_para
             for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(b[t][0]), "+v"(b[t][1]));
         };
         auto compute = [&](const pf4 (&b4)[NTW][2], int kp) {
-            const pf4 a4a = *(const pf4*)&h1[lm * LDH + kp * 32 + lk * 4], a4b = *(const pf4*)&h1[lm * LDH + kp * 32 + 16 + lk * 4];
+            const float* buf = stage + (kp & 1) * (POL_ROWS * POL_SLD);
+            const pf4 a4a = *(const pf4*)&buf[lm * POL_SLD + lk * 4], a4b = *(const pf4*)&buf[lm * POL_SLD + 16 + lk * 4];
             // k step outermost: consecutive MFMAs go to different accumulator tiles (no back-to-back dependent issue)
 #define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b4[t][H2].C, acc[t], 0, 0, 0);
             DL_POL_KSTEP(a4a.x, 0, x) DL_POL_KSTEP(a4a.y, 0, y) DL_POL_KSTEP(a4a.z, 0, z) DL_POL_KSTEP(a4a.w, 0, w)
             DL_POL_KSTEP(a4b.x, 1, x) DL_POL_KSTEP(a4b.y, 1, y) DL_POL_KSTEP(a4b.z, 1, z) DL_POL_KSTEP(a4b.w, 1, w)
 #undef DL_POL_KSTEP
         };
-        // DEPTH register sets, DEPTH - 1 of them in flight while one is consumed.  Measured: 4 sets are no faster than 2 (37 us for one
-        // workgroup either way, 149 vs 141 us for 16 384 rows) -- the hidden layer is bound by the matrix pipe (1024 MFMAs of 32 cycles
-        // per SIMD = 14 us) plus the L2 -> CU stream of the whole weight matrix per workgroup, not by the latency of a single load.
+        // DEPTH register sets, DEPTH - 1 of them in flight while one is consumed (4 sets were measured no faster than 2: the hidden
+        // layer is bound by the matrix pipe plus the L2 -> CU stream of the weight matrix, not by the latency of a single load).
         constexpr int DEPTH = 2;
         static_assert((H / 32) % DEPTH == 0, "steps come in groups of DEPTH");
         pf4 bs[DEPTH][NTW][2];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the compiler's own loads may be counted against the sets
 #pragma unroll
         for (int d = 0; d < DEPTH - 1; d++) load_set(bs[d], d);
+        publish(0);
+        __syncthreads();
         for (int kp0 = 0; kp0 < npair; kp0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) {
                 const int kp = kp0 + d, ahead = kp + DEPTH - 1;
                 if (ahead < npair) load_set(bs[(d + DEPTH - 1) % DEPTH], ahead);
+                if (kp + 1 < npair) publish(kp + 1);        // its buffer was last read in step kp - 1, which ended with the barrier below
                 const int left = npair - 1 - kp;
                 wait_set(bs[d], left < DEPTH - 1 ? left : DEPTH - 1);
                 compute(bs[d], kp);
+                __syncthreads();
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
-            if (t < ntw) {
-                const int ncol = n0w + t * 16 + lm;
-                const float bias = p.b2[ncol];
+            const float bias = p.b2[n0w + t * 16 + lm];
 #pragma unroll
-                for (int i = 0; i < 4; i++) h2[(4 * lk + i) * LDH + ncol] = pol_tanh(acc[t][i] + bias);
-            }
+            for (int i = 0; i < 4; i++) h2r[t][i] = pol_tanh(acc[t][i] + bias);
         }
     }
-    __syncthreads();
-    // ---- heads: one 16 x 16 tile (columns 0..A-1 action means, column A the value); reduction split over the waves
+    // ---- heads: one 16 x 16 tile (columns 0..A-1 action means, column A the value); the reduction is split over the waves, each
+    // over the h2 columns it owns: a tile goes from the accumulator layout to the A-operand layout through the wave's private tile
     {
         pf4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int kper = H / NW;
         const float* wrow = lm < A ? p.wa + (size_t)lm * H : (lm == A ? p.wv : nullptr);
-        for (int kb = 0; kb < kper / 16; kb++) {
-            const int k0 = wave * kper + kb * 16 + lk * 4;
-            const pf4 a4 = *(const pf4*)&h2[lm * LDH + k0];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 4; i++) priv[(4 * lk + i) * POL_PLD + lm] = h2r[t][i];
+            wave_sync();
+            const int k0 = n0w + t * 16 + lk * 4;
+            const pf4 a4 = *(const pf4*)&priv[lm * POL_PLD + lk * 4];
             const pf4 b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);

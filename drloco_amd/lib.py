@@ -10,7 +10,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libdrloco_hip.so')
+LIB_PATH = os.environ.get('DL_LIB_PATH') or os.path.join(CSRC, 'libdrloco_hip.so')      # DL_LIB_PATH: experiment builds (build_variants/), never the product
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 _SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.h')))
 
@@ -56,6 +56,7 @@ _SIGNATURES = {
     'dl_forward': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
     'dl_set_randomization': (C.c_int, [_V, _P, _P, _P]),
     'dl_set_push': (C.c_int, [_V, _P, _P]),
+    'dl_set_push_schedule': (C.c_int, [_V, _P, _P, _I, _I, _P]),
     'dl_terminate_early': (C.c_int, [_V, _P, _P]),
     'dl_stats_snapshot': (C.c_int, [_V, C.c_char_p, _P, _P]),
     'dl_profile': (C.c_int, [_V, _I]),

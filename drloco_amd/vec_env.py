@@ -203,6 +203,14 @@ class HipVecEnv(_VecEnvBase):
         lib.check(self._lib.dl_set_push(self._h, _ptr(f), _stream()))
         torch.cuda.current_stream().synchronize()
 
+    def set_push_schedule(self, force=None, phase=None, period=400, duration=20):
+        """Periodic pushes kept on the device: walker w is pushed with force[w] during the k-th control step from now iff
+        (k + phase[w]) % period < duration (defaults: 0.1 s every 2 s at 200 Hz).  force None switches the schedule off."""
+        f = None if force is None else torch.as_tensor(np.asarray(force, np.float32), device=self.device).contiguous()
+        ph = None if phase is None else torch.as_tensor(np.asarray(phase, np.int32), device=self.device).contiguous()
+        lib.check(self._lib.dl_set_push_schedule(self._h, _ptr(f), _ptr(ph), int(period), int(duration), _stream()))
+        torch.cuda.current_stream().synchronize()
+
     def do_terminate_early(self):
         """MimicEnv.do_terminate_early (mimic_env.py:652-702) for all walkers: bool [N, 4] =
         (terminate_early, com_height_too_low, trunk_ang_exceeded, is_drunk)."""

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 3   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace, DL_VN_WORKSPACE_BYTES grew (128 blocks) */
+#define DL_ABI_VERSION 3   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step needs none any more */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -225,6 +225,12 @@ int dl_set_randomization(dl_handle h, const float* mass_scale, const float* floo
 /* [3P] xfrc_applied on the torso: world-frame force float[N, 3] (device) acting at the torso's centre of mass during
  * every following mj_step until changed; NULL = no force.  16-lane kernels only. */
 int dl_set_push(dl_handle h, const float* force, void* stream);
+/* The same push as a per-walker SCHEDULE kept on the device, so that launches covering many control steps
+ * (dl_rollout_fixed) need no host round trip per step: force float[N, 3], phase int32[N] (device); during the k-th control
+ * step after this call walker w is pushed iff (k + phase[w]) % period < duration.  force == NULL switches the schedule off
+ * and clears the push.  (BASELINE config 5's "50 N push perturbations"; the reference's hook is a stub, mimic_env.py:492-524.) */
+int dl_set_push_schedule(dl_handle h, const float* force, const int32_t* phase, int32_t period, int32_t duration,
+                         void* stream);
 
 /* MimicEnv.do_terminate_early (mimic_env.py:652-702; the reference defines it but its call in step() is commented
  * out, :113-118) at the current state of every walker: flags int32[N, 4] device =
@@ -269,8 +275,7 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
  * moments (training), 8 normalise rewards.  obs/rew are not modified (get_original_obs / get_original_reward);
  * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
  * zero-initialised once by the caller and owned by this call sequence. */
-#define DL_VN_BLOCKS 128
-#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * DL_VN_BLOCKS * ((D) + 1) + 2))
+#define DL_VN_WORKSPACE_BYTES(D) 64      /* reserved: the reduction needs no scratch since ABI 3 (may be NULL) */
 int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean,
                          double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                          double* ret_count, int32_t B, int32_t D, double gamma, double eps, double clip_obs,

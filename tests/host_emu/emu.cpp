@@ -25,6 +25,8 @@ template <typename T, typename TP> struct Emu {
     GModel<T, TP> gm;                 // table-driven model of the 16-lane kernels
     bool gm_ok = false;
     std::vector<T> rnd, smem;
+    std::vector<int32_t> push_phase;
+    int push_step = 0;
 };
 
 template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
@@ -57,6 +59,7 @@ template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_
     e->work.assign((size_t)4 * TP::NV * n, 0);
     e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), e->work.data(), n};
     e->st.rnd = nullptr; e->st.dbgf = nullptr; e->st.dbg = nullptr; e->st.dbg_cap = 1 << 30;
+    e->st.push_phase = nullptr; e->st.push_period = 1; e->st.push_dur = 0; e->st.push_step0 = 0;
     e->gm_ok = fill_group_model<T, TP>(*d, e->gm, why);
     e->smem.assign((size_t)GW * GLds<TP>::TOTAL, 0);
     return e;
@@ -106,6 +109,7 @@ template <typename T, typename TP> static int emu_gstep(Emu<T, TP>* e, int nstep
     const int nwg = (e->n + GW - 1) / GW;
     bool armed = false;
     for (int i = 0; i < e->n; i++) armed = armed || e->inj_flags[i] != 0;
+    e->st.push_step0 = e->push_step; e->push_step += nsteps;
     for (int wg = 0; wg < nwg; wg++)
         dlemu::run_wave(64, [&](int lane) {
             g_wave_env_step<T, TP, false>(lane, g_block_of_workgroup(wg, nwg), wg, nwg, e->smem.data(), &e->gm, e->c, e->st, act, obs, rew, done, term, terms,
@@ -124,7 +128,15 @@ template <typename T, typename TP> static void emu_set_rnd(Emu<T, TP>* e, const 
     }
 }
 
+template <typename T, typename TP> static void emu_set_push_schedule(Emu<T, TP>* e, const float* force, const int32_t* phase, int period, int duration) {
+    emu_set_rnd<T, TP>(e, nullptr, nullptr, force);
+    e->push_phase.assign(phase, phase + e->n);
+    e->st.push_phase = e->push_phase.data(); e->st.push_period = period; e->st.push_dur = duration;
+    e->push_step = 0;
+}
+
 #define EMU_API(SUF, T, TP) \
+    extern "C" void dle_set_push_schedule_##SUF(void* h, const float* f, const int32_t* ph, int per, int dur) { emu_set_push_schedule<T, TP>((Emu<T, TP>*)h, f, ph, per, dur); } \
     extern "C" int dle_gforward_##SUF(void* h, const T* u, T* qa, int32_t* nc, int32_t* ne, int32_t* ni) { return emu_gforward<T, TP>((Emu<T, TP>*)h, u, qa, nc, ne, ni); } \
     extern "C" int dle_gstep_##SUF(void* h, int k, const float* a, float* o, float* r, uint8_t* d, float* t, float* tt, float* cu) { return emu_gstep<T, TP>((Emu<T, TP>*)h, k, a, o, r, d, t, tt, cu); } \
     extern "C" void dle_set_rnd_##SUF(void* h, const float* ms, const float* mu, const float* push) { emu_set_rnd<T, TP>((Emu<T, TP>*)h, ms, mu, push); } \

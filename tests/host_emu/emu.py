@@ -121,6 +121,10 @@ class EmuEnv:
         ms, mu, pu = f(mass_scale), f(floor_friction), f(push)
         self._f('set_rnd')(self.h, _p(ms, C.c_float), _p(mu, C.c_float), _p(pu, C.c_float))
 
+    def set_push_schedule(self, force, phase, period, duration):
+        f = np.ascontiguousarray(force, np.float32); ph = np.ascontiguousarray(phase, np.int32)
+        self._f('set_push_schedule')(self.h, _p(f, C.c_float), _p(ph, C.c_int32), C.c_int(period), C.c_int(duration))
+
     def glds_bytes(self):
         return self._f('glds_bytes')()
 

@@ -1151,3 +1151,158 @@ def test_G12_device_forward_matches_real_mujoco(torch_cuda, key, precision, tol)
     err = np.abs(qa - want) / (1 + np.abs(want))
     assert err.max() < tol, err.max()
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# f3 on the device: the mocap options of the reference -- mirrored reference steps, adapted
+# trajectories -- through the HIP path, against the reference's golden vectors G11
+@LANES
+def test_G11_mirrored_refs_on_device(torch_cuda, model, refs, lanes):
+    """RefTable.mirrored() (StraightWalkingTrajectories(mirror_refs=True), straight_walk_trajecs.py:128-139) through HipVecEnv: the
+    cursor words follow G11's trace bit for bit across a right -> mirrored-left rollover, and the reference sample the kernel looked
+    up is G11's (m_q, m_v): the reward terms it produces from an injected state are those computed from the golden sample."""
+    from drloco_amd.vec_env import HipVecEnv
+    with np.load(os.path.join(GOLDEN, 'G11_mocap_options.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    env = HipVecEnv(num_envs=1, precision=64, model=model, refs=refs.mirrored(), ep_dur_max=10 ** 9, lanes_per_walker=lanes)
+    cur = np.zeros((abi.DL_CUR_WORDS, 1), np.int32)
+    cur[abi.DL_CUR_I_STEP] = cur[abi.DL_CUR_READ_STEP] = cur[abi.DL_CUR_RSI_STEP] = int(g['m_start'][0]); cur[abi.DL_CUR_POS] = int(g['m_start'][1]); cur[abi.DL_CUR_COUNT] = 1
+    env.set_state(cursor=cur)
+    q_up = np.array(model.jnt_qpos0[:14]); q_up[3:] = 0.05 * np.arange(11)          # a pose that is not the reference's
+    v_in = 0.1 * np.arange(14)
+    for t in range(len(g['m_q'])):
+        env.debug_inject(qpos=q_up[:, None], qvel=v_in[:, None], flags=np.array([1], np.int32))
+        obs, rew, done, _ = env.step(np.zeros((1, 8), np.float32))
+        st = env.get_state()['cursor']
+        assert (st[abi.DL_CUR_I_STEP, 0], st[abi.DL_CUR_POS, 0]) == tuple(g['m_cur'][t]), t
+        assert not done[0]
+        terms = env.rew_terms.cpu().numpy()[0].astype(np.float64)
+        want_p = np.exp(-3 * ((q_up[3:] - g['m_q'][t][3:]) ** 2).sum()); want_v = np.exp(-0.05 * ((v_in[3:] - g['m_v'][t][3:]) ** 2).sum())
+        np.testing.assert_allclose(terms[:2], [want_p, want_v], rtol=2e-6)          # float32 outputs of a float64 evaluation
+        np.testing.assert_allclose(rew[0], 0.8 * want_p + 0.2 * want_v + 0.2, rtol=2e-6)
+    assert len(set(g['m_cur'][:, 0])) > 1
+    env.close()
+
+
+@LANES
+def test_G11_adapted_trajectories_on_device(torch_cuda, lanes):
+    """BaseReferenceTrajectories.adapt_trajectories (base_ref_trajecs.py:105-118) through the 19-dof walker's device path: with an
+    `adaptations=` table the kernel's reward terms are those of G11's adapted (a_q, a_v) rows, not of the plain table."""
+    from drloco_amd import mocap, models
+    from drloco_amd.vec_env import HipVecEnv
+    with np.load(os.path.join(GOLDEN, 'G11_mocap_options.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    ang, vel = mocap.synthetic_loco3d(L=int(g['a_L']), seed=int(g['a_seed']))
+    table = mocap.loco3d_table(ang, vel, adaptations=dict(zip(g['a_rows'].tolist(), g['a_scalars'].tolist())))
+    plain = mocap.loco3d_table(ang, vel)
+    m = models.make_model(models.WALKER_165CM)
+    env = HipVecEnv(models.WALKER_165CM, num_envs=1, precision=64, refs=table, ep_dur_max=10 ** 9, lanes_per_walker=lanes)
+    L = g['a_q'].shape[1]
+    cur = np.zeros((abi.DL_CUR_WORDS, 1), np.int32); cur[abi.DL_CUR_POS] = 100; cur[abi.DL_CUR_COUNT] = 1
+    env.set_state(cursor=cur)
+    q_in = np.array(m.jnt_qpos0[:19]) + 0.02 * np.arange(19); v_in = 0.05 * np.arange(19)
+    differs = 0
+    for t in range(12):
+        env.debug_inject(qpos=q_in[:, None], qvel=v_in[:, None], flags=np.array([1], np.int32))
+        obs, rew, done, _ = env.step(np.zeros((1, 13), np.float32))
+        pos = int(env.get_state()['cursor'][abi.DL_CUR_POS, 0])
+        assert pos == 100 + 5 * (t + 1) and pos < L
+        terms = env.rew_terms.cpu().numpy()[0].astype(np.float64)
+        qr, vr = g['a_q'][:, pos], g['a_v'][:, pos]
+        want_p = np.exp(-3 * ((q_in[3:] - qr[3:]) ** 2).sum()); want_v = np.exp(-0.05 * ((v_in[3:] - vr[3:]) ** 2).sum())
+        np.testing.assert_allclose(terms[:2], [want_p, want_v], rtol=2e-6)
+        plain_p = np.exp(-3 * ((q_in[3:] - plain.table[3:19, pos]) ** 2).sum())
+        differs += abs(plain_p - want_p) > 1e-4 * want_p
+    assert differs > 0
+    env.close()
+
+
+@LANES
+def test_G5_actions_on_device(torch_cuda, model, refs, lanes):
+    """_rescale_actions + mirror_action (mimic_env.py:170-192, 483-489) of the DEVICE step kernels against the reference's golden
+    vector G5: sim.data.ctrl as the kernel set it (dl_debug_last_ctrl).  The C-ABI takes float32 actions and the record is float32,
+    so values agree to 2 float32 ulp; signs (incl. the -0.0 of a zero action), saturation and the left-step permutation exactly."""
+    from drloco_amd.vec_env import HipVecEnv
+    if lanes == 1:
+        pytest.skip('the ctrl record is a hook of the 16-lane kernels (the lane-per-walker kernels are covered through the oracle)')
+    with np.load(os.path.join(GOLDEN, 'G5_actions.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    n = len(g['actions'])
+    for precision in (64, 32):
+        env = HipVecEnv(num_envs=2 * n, precision=precision, model=model, refs=refs, ep_dur_max=10 ** 9, lanes_per_walker=lanes)
+        cur = np.zeros((abi.DL_CUR_WORDS, 2 * n), np.int32)
+        cur[abi.DL_CUR_I_STEP] = np.concatenate([np.full(n, 4), np.full(n, 5)]); cur[abi.DL_CUR_READ_STEP] = cur[abi.DL_CUR_I_STEP]
+        cur[abi.DL_CUR_POS] = 10; cur[abi.DL_CUR_COUNT] = 1
+        env.set_state(cursor=cur)
+        assert (env.debug_last_ctrl() == 0).all()                     # enables the record
+        q_up = np.repeat(np.array(model.jnt_qpos0[:14])[:, None], 2 * n, 1)
+        env.debug_inject(qpos=q_up, qvel=np.zeros_like(q_up), flags=np.ones(2 * n, np.int32))
+        env.step(np.concatenate([g['actions'], g['actions']]).astype(np.float32))
+        ctrl = env.debug_last_ctrl().astype(np.float64)
+        want = np.concatenate([g['rescaled'], g['mirrored']])
+        np.testing.assert_allclose(ctrl, want, rtol=2.5e-7, atol=0)
+        assert np.array_equal(np.signbit(ctrl), np.signbit(want)) and np.array_equal(np.abs(ctrl) == 300, np.abs(want) == 300)
+        z0 = np.where((g['actions'] == 0).all(axis=1))[0][0]
+        assert np.signbit(ctrl[z0]).all()
+        env.close()
+
+
+def test_push_schedule_on_device(torch_cuda, oracle, model, refs):
+    """dl_set_push_schedule (BASELINE config 5 without a host round trip per control step): the device-resident periodic push inside
+    ONE multi-step launch of dl_rollout_fixed against the oracle stepped with the push switched on and off by hand (float64), and
+    identical (bit for bit) to per-step dl_set_push calls around single-step launches."""
+    import torch
+    n, T, period, dur = 256, 40, 10, 3
+    rng = np.random.default_rng(4)
+    force = np.zeros((n, 3), np.float32); force[:, 0] = 50 * np.cos(np.arange(n)); force[:, 1] = 50 * np.sin(np.arange(n)); force[::3] = 0
+    phase = rng.integers(0, period, n).astype(np.int32)
+    acts = np.clip(0.5 * rng.standard_normal((T, n, 8)), -1, 1).astype(np.float32)
+    dev, orc = make_pair(oracle, model, refs, n, 64, lanes_per_walker=16)
+    np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
+    st0 = dev.get_state()
+    dev.set_push_schedule(force, phase, period, dur)
+    om, rm, dm = dev.rollout_fixed(torch.as_tensor(acts, device='cuda'))
+    om, rm, dm = om.cpu().numpy(), rm.cpu().numpy(), dm.cpu().numpy()
+    for t in range(T):
+        on = ((t + phase) % period) < dur
+        orc.set_randomization(xfrc=(force * on[:, None]).astype(np.float64))
+        o1, r1, d1, _, _ = orc.step(acts[t].astype(np.float64))
+        assert np.array_equal(d1.astype(bool), dm[t].astype(bool)), t
+        np.testing.assert_allclose(om[t], o1, atol=5e-5, rtol=2e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(rm[t], r1, atol=1e-6)
+    # the same pushes issued from the host, one launch per control step
+    dev2, _ = make_pair(oracle, model, refs, n, 64, lanes_per_walker=16)
+    dev2.reset()
+    dev2.set_state(qpos=st0['qpos'], qvel=st0['qvel'], warm=st0['warm'], cursor=st0['cursor'], walked=st0['walked'])
+    for t in range(T):
+        on = ((t + phase) % period) < dur
+        dev2.set_push(force * on[:, None])
+        o2, r2, d2, _ = dev2.step(acts[t])
+        live = ~dm[t].astype(bool)
+        assert np.array_equal(o2[live], om[t][live]) and np.array_equal(r2, rm[t]) and np.array_equal(d2, dm[t].astype(bool)), t
+    # switching the schedule off clears the push
+    dev.set_push_schedule(None)
+    dev.close(); dev2.close()
+
+
+def test_loco3d_randomization_and_push(torch_cuda, oracle):
+    """dl_set_randomization / dl_set_push for the 19-dof walker: float64 forward dynamics against the oracle."""
+    n = 256
+    rng = np.random.default_rng(9)
+    ms = rng.uniform(0.8, 1.2, n).astype(np.float32); fr = rng.uniform(0.5, 1.1, n).astype(np.float32)
+    push = np.zeros((n, 3), np.float32); k = rng.random(n) < 0.6
+    ang = rng.uniform(0, 2 * np.pi, n); push[k, 0] = 50 * np.cos(ang[k]); push[k, 1] = 50 * np.sin(ang[k]); push[k, 2] = rng.uniform(-20, 20, k.sum())
+    for precision, tol in ((64, 1e-9), (32, 1e-2)):
+        dev, orc = _loco3d_pair(oracle, n, precision, lanes_per_walker=16)
+        q = np.array(dev.model.jnt_qpos0[:19])[:, None] + 0.2 * rng.standard_normal((19, n)); q[2] = rng.uniform(0.75, 1.2, n)
+        v = 1.5 * rng.standard_normal((19, n)); w = rng.standard_normal((19, n)); u = rng.uniform(-300, 300, (13, n))
+        dev.set_state(qpos=q, qvel=v, warm=w); orc.set_state(qpos=q, qvel=v, warm=w)
+        qa0, _, _, _ = orc.forward(u)
+        dev.set_randomization(ms, fr); dev.set_push(push)
+        orc.set_randomization(ms.astype(np.float64), fr.astype(np.float64), push.astype(np.float64))
+        qa, nc, ne, _ = orc.forward(u); qb, nc2, ne2, _ = dev.forward(u)
+        assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2)
+        err = np.abs(qa - qb) / (1 + np.abs(qa))
+        assert err.max() < tol, (precision, err.max())
+        assert np.abs(qa0 - qa).max() > 1.0
+        dev.close()

@@ -291,3 +291,29 @@ def test_group_kernel_source_on_host_ctrl_matches_G5(emu):
     assert np.array_equal(np.signbit(ctrl), np.signbit(want)) and np.array_equal(np.abs(ctrl) == 300, np.abs(want) == 300)
     z = np.where((g['actions'] == 0).all(axis=1))[0][0]
     assert np.signbit(ctrl[z]).all()
+
+
+def test_group_kernel_source_on_host_push_schedule(emu, oracle):
+    """dl_set_push_schedule: the periodic push kept on the device, inside a multi-step launch, against the oracle stepped with
+    the push switched on and off by hand (float64)."""
+    m, table, cfg = _walker('straight')
+    n, T, period, dur = 8, 12, 6, 2
+    rng = np.random.default_rng(4)
+    force = np.zeros((n, 3), np.float32); force[:, 0] = 50 * np.cos(np.arange(n)); force[:, 1] = 50 * np.sin(np.arange(n)); force[::3] = 0
+    phase = rng.integers(0, period, n).astype(np.int32)
+    o = oracle.OracleEnv(m, table, cfg, n); e = emu.EmuEnv(m, table, cfg, n, 64)
+    np.testing.assert_allclose(e.reset(), o.reset(), atol=2e-6)
+    e.set_push_schedule(force, phase, period, dur)
+    acts = np.clip(0.5 * rng.standard_normal((T, n, 8)), -1, 1).astype(np.float32)
+    om, rm, dm, _, _ = e.gstep(acts)                   # one launch of T control steps
+    pushed_steps = 0
+    for t in range(T):
+        on = ((t + phase) % period) < dur
+        pushed_steps += int((on & (np.abs(force).sum(1) > 0)).sum())
+        o.set_randomization(xfrc=(force * on[:, None]).astype(np.float64))
+        o1, r1, d1, _, _ = o.step(acts[t].astype(np.float64))
+        assert np.array_equal(d1, dm[t]), t
+        np.testing.assert_allclose(om[t], o1, atol=5e-5, rtol=2e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(rm[t], r1, atol=1e-6)
+    assert pushed_steps > 10
+    np.testing.assert_allclose(e.get_state()['qpos'], o.get_state()['qpos'], rtol=1e-7, atol=1e-8)
