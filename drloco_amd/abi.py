@@ -10,8 +10,8 @@ DL_ADV_WORKSPACE_BYTES = (2 * 512 + 2) * 8
 
 
 def vn_workspace_bytes(obs_dim):
-    """DL_VN_WORKSPACE_BYTES(D) of include/drloco_hip.h (reserved since ABI 3)"""
-    return 64
+    """DL_VN_WORKSPACE_BYTES(D) of include/drloco_hip.h"""
+    return 8 * (2 * 32 * (obs_dim + 1) + 2)
 
 DL_MAX_BODY, DL_MAX_DOF, DL_MAX_GEOM, DL_MAX_SITE, DL_MAX_ACT = 12, 20, 12, 8, 16
 DL_JNT_SLIDE, DL_JNT_HINGE = 0, 1

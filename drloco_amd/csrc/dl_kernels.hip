@@ -200,11 +200,11 @@ __global__ void k_reward_finish(float* rew, double* ret, const uint8_t* done, co
 // (ret = ret * gamma + r is advanced here) are column D.  RunningMeanStd's Chan update follows; the counts are read here and
 // advanced by k_vn_apply (stream order), so every merge sees the old count.
 constexpr int VN_THREADS = 1024;
-__global__ __launch_bounds__(VN_THREADS) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
-                                                          double* ret, double* ret_mean, double* ret_var, const double* ret_count,
-                                                          int B, int D, double gamma, int flags) {
-    __shared__ double sh[2][VN_THREADS];
-    __shared__ double sh2[VN_THREADS / 64];
+// one batch: the moments (mean, var, count of the observations / of the discounted returns) are read and updated through generic
+// pointers -- global memory in the single-step kernel, LDS in the multi-step kernel, same arithmetic
+__device__ __forceinline__ void vn_reduce_phase(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
+                                                double* ret, double* ret_mean, double* ret_var, const double* ret_count,
+                                                int B, int D, double gamma, int flags, double (*sh)[VN_THREADS], double* sh2) {
     const int t = threadIdx.x;
     double rs = 0, rss = 0;
     // ---- discounted returns first (their loads overlap the observation loads below)
@@ -220,12 +220,12 @@ __global__ __launch_bounds__(VN_THREADS) void k_vn_reduce(const float* __restric
         if (t < nthr) {
             const double K = mean[col];
             int row = rsub;
-            for (; row + 7 * rpb < B; row += 8 * rpb) {          // eight independent loads in flight
-                float a[8];
+            for (; row + 15 * rpb < B; row += 16 * rpb) {          // sixteen independent loads in flight: one CU has to cover the latency alone
+                float a[16];
 #pragma unroll
-                for (int k = 0; k < 8; k++) a[k] = x[(size_t)(row + k * rpb) * D + col];
+                for (int k = 0; k < 16; k++) a[k] = x[(size_t)(row + k * rpb) * D + col];
 #pragma unroll
-                for (int k = 0; k < 8; k++) { const double d = (double)a[k] - K; s += d; ss += d * d; }
+                for (int k = 0; k < 16; k++) { const double d = (double)a[k] - K; s += d; ss += d * d; }
             }
             for (; row < B; row += rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
         }
@@ -250,6 +250,71 @@ __global__ __launch_bounds__(VN_THREADS) void k_vn_reduce(const float* __restric
             *ret_var = M2 / tot;
         }
     }
+}
+__global__ __launch_bounds__(VN_THREADS) void k_vn_reduce(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
+                                                          double* ret, double* ret_mean, double* ret_var, const double* ret_count,
+                                                          int B, int D, double gamma, int flags) {
+    __shared__ double sh[2][VN_THREADS];
+    __shared__ double sh2[VN_THREADS / 64];
+    vn_reduce_phase(x, rew, mean, var, count, ret, ret_mean, ret_var, ret_count, B, D, gamma, flags, sh, sh2);
+}
+// The multi-block form of the reduction (flags bit 16): 32 blocks leave per-column partial sums, the last block to arrive merges them in
+// block order (deterministic).  Two device-scope fences and an atomic per block make it slower than the one-workgroup kernel when
+// a caller waits for it (20 vs 15 us), but its loads are spread over 32 CUs: on a side stream UNDER a running env-step kernel it
+// keeps its pace where the single workgroup, sharing one CU with four env-step waves, falls to 39 us -- the choice of the
+// overlapped fixed-action path (HipVecNormalize.enable_overlap).
+constexpr int VN_BLOCKS = 32;
+__global__ __launch_bounds__(256) void k_vn_reduce_mb(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
+                                                   double* ret, double* ret_mean, double* ret_var, const double* ret_count,
+                                                   int B, int D, double gamma, int flags, double* work, unsigned* arrive) {
+    __shared__ double sh[2][256];
+    __shared__ double sh2[4];
+    __shared__ bool is_last;
+    const int t = threadIdx.x, W = D + 1;
+    // ---- observations: per-column partial sums of this block's rows
+    if (flags & 1) {
+        const int rpb = blockDim.x / D, nthr = rpb * D;       // rows per pass of this block
+        double s = 0, ss = 0;
+        const int col = t % D, rsub = t / D;
+        if (t < nthr) {
+            const double K = mean[col];
+            for (int row = blockIdx.x * rpb + rsub; row < B; row += VN_BLOCKS * rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
+        }
+        sh[0][t] = s; sh[1][t] = ss;
+        __syncthreads();
+        if (t < D) {
+            for (int r = 1; r < rpb; r++) { s += sh[0][r * D + t]; ss += sh[1][r * D + t]; }
+            work[((size_t)blockIdx.x * W + t) * 2] = s; work[((size_t)blockIdx.x * W + t) * 2 + 1] = ss;
+        }
+    }
+    // ---- discounted returns: advance this block's slice, partial sums as column D
+    if (flags & 4) {
+        const int chunk = (B + VN_BLOCKS - 1) / VN_BLOCKS, lo = blockIdx.x * chunk, hi = lo + chunk < B ? lo + chunk : B;
+        const double K = *ret_mean;
+        double s = 0, ss = 0;
+        for (int i = lo + t; i < hi; i += blockDim.x) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; const double d = r - K; s += d; ss += d * d; }
+        s = block_sum(s, sh2); ss = block_sum(ss, sh2);
+        if (t == 0) { work[((size_t)blockIdx.x * W + D) * 2] = s; work[((size_t)blockIdx.x * W + D) * 2 + 1] = ss; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) is_last = atomicAdd(arrive, 1u) == (unsigned)(VN_BLOCKS - 1);
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const bool do_obs = t < D && (flags & 1), do_ret = t == D && (flags & 4);
+    if (do_obs || do_ret) {
+        double S = 0, SS = 0;
+        for (int b = 0; b < VN_BLOCKS; b++) { S += __builtin_nontemporal_load(&work[((size_t)b * W + t) * 2]); SS += __builtin_nontemporal_load(&work[((size_t)b * W + t) * 2 + 1]); }
+        double* m = do_obs ? mean + t : ret_mean;
+        double* v = do_obs ? var + t : ret_var;
+        const double K = *m, bm = K + S / B, bv = SS / B - (S / B) * (S / B);
+        const double cnt = do_obs ? *count : *ret_count, tot = cnt + B, delta = bm - K;
+        const double M2 = *v * cnt + bv * B + delta * delta * cnt * B / tot;
+        *m = K + delta * B / tot;
+        *v = M2 / tot;
+    }
+    if (t == 0) *arrive = 0;
 }
 // k_vn_apply: obs_out = clip((obs - mean)/sqrt(var + eps)); rew_out = clip(r/sqrt(ret_var + eps)); ret[done] = 0; counts += B
 __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, const float* __restrict__ rew, const uint8_t* __restrict__ done,
@@ -923,8 +988,13 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
     return DL_OK;
 }
 static int vn_reduce_launch(const float* obs, const float* rew, double* obs_mean, double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
-                            double* ret_count, int32_t B, int32_t D, double gamma, int32_t flags, void* stream) {
-    if (flags & 5)
+                            double* ret_count, int32_t B, int32_t D, double gamma, int32_t flags, void* workspace, void* stream) {
+    if ((flags & 5) && (flags & 16) && workspace) {
+        double* work = (double*)workspace;
+        unsigned* arrive = (unsigned*)(work + (size_t)2 * VN_BLOCKS * (D + 1));
+        hipLaunchKernelGGL(k_vn_reduce_mb, dim3(VN_BLOCKS), dim3(256), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
+                           (const double*)ret_count, B, D, gamma, flags, work, arrive);
+    } else if (flags & 5)
         hipLaunchKernelGGL(k_vn_reduce, dim3(1), dim3(VN_THREADS), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
                            (const double*)ret_count, B, D, gamma, flags);
     HIPCHK(hipGetLastError());
@@ -935,9 +1005,8 @@ int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done
                          double clip_obs, double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace, void* stream) {
     if (!obs || !rew || !done || !obs_mean || !obs_var || !obs_count || !ret || !ret_mean || !ret_var || !ret_count || !obs_out || !rew_out || B <= 0 || D <= 0 || D > 128)
         return fail(DL_E_INVAL, "dl_vecnormalize_step: bad arguments");
-    (void)workspace;              // reserved (ABI 2 used it for cross-block partial sums; the reduction is one workgroup now)
     {
-        const int rc = vn_reduce_launch(obs, rew, obs_mean, obs_var, obs_count, ret, ret_mean, ret_var, ret_count, B, D, gamma, flags, stream);
+        const int rc = vn_reduce_launch(obs, rew, obs_mean, obs_var, obs_count, ret, ret_mean, ret_var, ret_count, B, D, gamma, flags, workspace, stream);
         if (rc) return rc;
     }
     const size_t ne = (size_t)B * D;
@@ -1005,7 +1074,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
             rc = dl_vecnormalize_step(raw_obs, raw_rew, done, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od,
                                       vn->gamma, vn->eps, vn->clip_obs, vn->clip_rew, vn->flags, next_obs, rewards + t * n, vn->workspace, stream);
         else
-            rc = vn_reduce_launch(raw_obs, raw_rew, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od, vn->gamma, vn->flags, stream);
+            rc = vn_reduce_launch(raw_obs, raw_rew, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret, vn->ret_mean, vn->ret_var, vn->ret_count, (int32_t)n, (int32_t)od, vn->gamma, vn->flags, vn->workspace, stream);
         if (rc) return rc;
     }
     return DL_OK;

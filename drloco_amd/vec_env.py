@@ -406,6 +406,10 @@ class HipVecNormalize(_VecEnvWrapperBase):
         self.norm_rew_t = torch.zeros_like(venv.rew)
         self._vn_work = torch.zeros(abi.vn_workspace_bytes(venv.obs_dim) // 8, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
         self._ov = None                                   # overlap state (enable_overlap)
+        # form of the moment reduction (flags bit 16 of dl_vecnormalize_step): one workgroup (lowest latency when the next launch waits
+        # for it: a policy in the loop) or 32 blocks (keeps its pace on a side stream under a running env-step kernel: enable_overlap).
+        # Both are deterministic; they sum in different orders, i.e. their moments can differ in the last bit.
+        self.multi_block_reduce = False
 
     # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
     @property
@@ -430,7 +434,8 @@ class HipVecNormalize(_VecEnvWrapperBase):
     def _flags(self):
         # SB3 1.0 step_wait: obs_rms / ret_rms (and ret) advance whenever training is on, whatever norm_obs / norm_reward say
         # (the reference's load_env builds an evaluation env with norm_reward=False); the norm_* switches only gate the scaling
-        return (1 if self.training else 0) | (2 if self.norm_obs else 0) | (4 if self.training else 0) | (8 if self.norm_reward else 0)
+        return (1 if self.training else 0) | (2 if self.norm_obs else 0) | (4 if self.training else 0) | (8 if self.norm_reward else 0) | \
+               (16 if self.multi_block_reduce else 0)
 
     def state_struct(self):
         """dl_vecnorm_state for dl_rollout_policy: pointers to the device-resident moments of this object."""
@@ -502,6 +507,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         simulating.  Same kernels, same order of moment updates, same results; the outputs of step_tensors are complete
         only after `flush()` (call it before anything on the main stream reads them: GAE, the policy, a copy to the host)."""
         dev = self.venv.device
+        self.multi_block_reduce = True
         ev = lambda: torch.cuda.Event()
         # high priority: its own hardware-queue pool (a default-priority stream may share the main stream's queue once other
         # libraries -- RCCL -- have created streams) and the tiny launches are dispatched while the step kernel runs

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 3   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step needs none any more */
+#define DL_ABI_VERSION 3   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16 */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -272,15 +272,17 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
  *   obs_rms.update(obs); obs_out = clip((obs - mean)/sqrt(var + eps), +-clip_obs);
  *   ret = ret*gamma + rew; ret_rms.update(ret); rew_out = clip(rew/sqrt(ret_var + eps), +-clip_rew); ret[done] = 0.
  * flags: 1 update the observation moments (training), 2 normalise observations, 4 advance ret and update its
- * moments (training), 8 normalise rewards.  obs/rew are not modified (get_original_obs / get_original_reward);
+ * moments (training), 8 normalise rewards, 16 reduce with 32 blocks instead of one workgroup (for launches on a side stream
+ * under other kernels; both forms are deterministic, their summation orders differ).  obs/rew are not modified (get_original_obs / get_original_reward);
  * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
  * zero-initialised once by the caller and owned by this call sequence. */
-#define DL_VN_WORKSPACE_BYTES(D) 64      /* reserved: the reduction needs no scratch since ABI 3 (may be NULL) */
+#define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * ((D) + 1) + 2))   /* used by the multi-block reduction (flags bit 16) only */
 int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done, double* obs_mean,
                          double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                          double* ret_count, int32_t B, int32_t D, double gamma, double eps, double clip_obs,
                          double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace,
                          void* stream);
+
 /* RolloutBuffer.compute_returns_and_advantage: arrays are [T, N] time-major float;
  * ep_start[t] = "obs_t starts an episode"; last_val float[N]; last_done uint8[N]. */
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val,

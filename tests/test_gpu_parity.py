@@ -894,6 +894,7 @@ def test_overlapped_vecnormalize_is_identical(torch_cuda, model, refs):
     for overlap in (False, True):
         vn = HipVecNormalize(HipVecEnv(num_envs=n, seed=9, model=model, refs=refs))
         vn.reset()
+        vn.multi_block_reduce = True         # the form of the moment reduction enable_overlap() selects (same summation order on both sides)
         if overlap:
             vn.enable_overlap()
         obs = torch.zeros(T, n, 29, device='cuda'); rew = torch.zeros(T, n, device='cuda'); done = torch.zeros(T, n, dtype=torch.uint8, device='cuda')
@@ -992,6 +993,7 @@ def test_steps_fixed_runs_match_the_step_by_step_path(torch_cuda, model, refs):
     res = []
     for runs in (None, 64, 40):
         vn = HipVecNormalize(HipVecEnv(num_envs=n, seed=2, model=model, refs=refs))
+        vn.multi_block_reduce = True         # the form of the moment reduction enable_overlap() selects (same summation order in all three runs)
         buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
         buf.actions.copy_(acts)
         vn.reset()
