@@ -15,6 +15,11 @@
 Neither SB3 nor gym is installed here, so both layouts are restated from SB3 1.0's published source and are
 **unpinned by a reference artefact**: the reader below is tolerant (any class it cannot import becomes a plain attribute
 bag), the writer emits the SB3 class paths so that an SB3 installation unpickles real objects.
+
+What is interchangeable with the reference: `policy.pth` (the state dict, both directions) and the VecNormalize statistics
+(`obs_rms`, `ret_rms`, clip values, gamma, epsilon, the norm_* and training flags).  `write_policy_zip` does NOT produce a
+complete `PPO.load` archive: its `data` member lacks observation_space / action_space and the SB3-serialised policy class, and
+there is no `policy.optimizer.pth` -- SB3 users load the weights with `policy.load_state_dict(th.load(...))` instead.
 """
 import io
 import json
@@ -140,7 +145,8 @@ def load_policy_zip(path, **kw):
 
 
 def write_policy_zip(policy, path, data=None):
-    """Tensors of a HipPolicy (or any object with w1..log_std) -> model.zip with the SB3 1.0 member names."""
+    """Tensors of a HipPolicy (or any object with w1..log_std) -> a zip with `policy.pth` under SB3 1.0's member and key names (the
+    weights are interchangeable; the archive as a whole is not a complete PPO.load input, see the module docstring)."""
     sd = {}
     for k, name in _KEYS.items():
         sd[name] = getattr(policy, k).detach().cpu()

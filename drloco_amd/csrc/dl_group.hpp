@@ -54,7 +54,7 @@ template <typename TP> struct GD {
     static constexpr int NXA = NX > 0 ? NX : 1;           // array extent (no zero-length arrays)
     static constexpr int NL = NV - NX;                    // dofs that own a lane: lane l <-> dof l + NX
     static constexpr int MAXB = TP::NB;                   // bodies incl. world
-    static constexpr int MAXCON = TP::MAXCON <= 20 ? 20 : ((TP::MAXCON + 1) & ~1);     // even: contacts are processed in pairs
+    static constexpr int MAXCON = (TP::MAXCON + 1) & ~1;     // even: contacts are processed in pairs (straight walker 18: 29.3 KB of LDS per wave, five waves per CU)
     static constexpr int MAXROW = ((TP::NLIM + 4 * TP::MAXCON + 3) / 4) * 4;
     static constexpr int ncand_() { int n = 0; for (int g = 0; g < TP::NG; g++) n += TP::geom_type(g) ? 8 : 2; return n; }
     static constexpr int NCAND = ncand_();                // capsule end points / box corners in contact order

@@ -118,7 +118,7 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
                   f"mean episode length {res['mean_episode_duration'] * 3000:.0f}, stable walks {res['count_stable_walks']}/20, "
                   f"mean step reward (normalised) {res['mean_reward_means']:.2f}")
     if save_path:
-        # utils.save_model (drloco/common/utils.py:175-192): models/model_<ckpt>.zip + envs/env_<ckpt> in the SB3 1.0 layouts
+        # utils.save_model (drloco/common/utils.py:175-192): models/model_<ckpt>.zip (policy.pth under SB3 1.0's key names) + envs/env_<ckpt> (VecNormalize statistics)
         from drloco_amd import checkpoint
         os.makedirs(os.path.join(save_path, 'models'), exist_ok=True); os.makedirs(os.path.join(save_path, 'envs'), exist_ok=True)
         ckpt = f'{int(total / 1e5)}'
@@ -136,7 +136,7 @@ if __name__ == '__main__':
     ap.add_argument('--batch', type=int, default=16384, help='samples per update = envs x rollout steps (the reference: 16 384)')
     ap.add_argument('--minibatch', type=int, default=2048)
     ap.add_argument('--seed', type=int, default=1, help='seeds 1, 2, 3 learn to walk within 8 M steps with the current kernels, seed 0 plateaus (DESIGN.md 5.1)')
-    ap.add_argument('--save', default=None, help='directory for models/model_<ckpt>.zip and envs/env_<ckpt> (SB3 1.0 layouts, drloco_amd/checkpoint.py)')
+    ap.add_argument('--save', default=None, help='directory for models/model_<ckpt>.zip (policy.pth with SB3 1.0 key names) and envs/env_<ckpt> (VecNormalize statistics), drloco_amd/checkpoint.py')
     ap.add_argument('--no-norm-reward', action='store_true', help='VecNormalize(norm_reward=False)')
     args = ap.parse_args()
     train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward, evaluate=True, save_path=args.save)

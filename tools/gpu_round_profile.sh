@@ -1,18 +1,21 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/gpu_round_profile.sh <round-tag>
-# 1. bench.py default run -> gpurun_out/<tag>/bench.json
+# usage (GPU box, repo root): tools/gpu_round_profile.sh <round-tag> [walker]
+# 1. bench.py default run (for the walker) -> gpurun_out/<tag>/bench.json
 # 2. rocprofv3 --kernel-trace --stats of the same bench command -> kernel_stats csv
-# 3. PMC passes (each its own run) on tools/prof_step.py
-TAG=${1:-r01}
+# 3. PMC passes (each its own run, --kernel-trace only next to --pmc) on tools/prof_step.py, which issues the benchmark's launch schedule
+TAG=${1:-r02}
+WALKER=${2:-straight}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+BW=""; if [ "$WALKER" != "straight" ]; then BW="--walker $WALKER"; fi
+python3 bench.py $BW > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc1 -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py --steps 448 --warm 64 > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_IFETCH --kernel-trace --output-format csv -d $OUT/pmc2 -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py --steps 448 --warm 64 > $OUT/pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc3 -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py --steps 448 --warm 64 > $OUT/pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc4 -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py --steps 448 --warm 64 > $OUT/pmc4.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc5 -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py --steps 448 --warm 64 > $OUT/pmc5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $BW > $OUT/bench_trace.log 2>&1
+P="python3 $GRAFT_REPO_ROOT/tools/prof_step.py --walker $WALKER --steps 448 --warm 64"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc1 -- $P > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_IFETCH --kernel-trace --output-format csv -d $OUT/pmc2 -- $P > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc3 -- $P > $OUT/pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc4 -- $P > $OUT/pmc4.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc5 -- $P > $OUT/pmc5.log 2>&1
 cat $OUT/bench.json

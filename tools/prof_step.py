@@ -14,11 +14,17 @@ ap.add_argument('--steps', type=int, default=448)
 ap.add_argument('--warm', type=int, default=64)
 ap.add_argument('--single', action='store_true', help='one control step per launch (dl_step) instead of dl_rollout_fixed')
 ap.add_argument('--variant', type=int, default=0, help='lanes per walker: 0 auto, 1, 16')
+ap.add_argument('--walker', choices=['straight', 'loco3d'], default='straight')
 args = ap.parse_args()
-env = HipVecEnv(num_envs=args.envs, lanes_per_walker=args.variant)
+if args.walker == 'loco3d':
+    from drloco_amd import mocap, models
+    ang, vel = mocap.synthetic_loco3d(L=60000, seed=0)
+    env = HipVecEnv(models.WALKER_165CM, num_envs=args.envs, lanes_per_walker=args.variant, refs=mocap.loco3d_table(ang, vel))
+else:
+    env = HipVecEnv(num_envs=args.envs, lanes_per_walker=args.variant)
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
-acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, 8, device='cuda', generator=g), -1, 1)
+acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, env.nu, device='cuda', generator=g), -1, 1)
 if args.single:
     for t in range(args.warm + args.steps):
         env.step_tensors(acts[t])

@@ -9,13 +9,14 @@ import os
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+walker = sys.argv[4] if len(sys.argv) > 4 else 'straight'       # the straight walker's counters feed bench.py's roofline line (traffic_env_step.json)
 os.makedirs(dst, exist_ok=True)
 out = {}
 stats = glob.glob(os.path.join(src, 'bench_trace', '*', '*kernel_stats.csv'))
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (kernel_stats.csv, top rows)')
+    lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' + ('' if walker == 'straight' else f' --walker {walker}') + '   (kernel_stats.csv, top rows)')
     lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
     for r in rows[:14]:
         lines.append(f'{r["Name"][:70]:70s} {r["Calls"]:>7s} {float(r["AverageNs"]) / 1e3:12.2f} {float(r["MinNs"]) / 1e3:10.2f} {float(r["MaxNs"]) / 1e3:10.2f} {float(r["Percentage"]):7.2f}')
@@ -63,5 +64,5 @@ if 'hbm_bytes_per_launch' in out:
     from bench import kernel_sources_sha16          # the kernel sources these counters belong to: bench.py reports them only while they match
     json.dump({**extra, 'tag': tag, 'kernel_sources_sha16': kernel_sources_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
                'source': f'profiles/{tag}_summary.txt', 'correction': 'FETCH_SIZE doubled (gfx950: 128 B requests tallied at 64 B), WRITE_SIZE as reported'},
-              open(os.path.join(dst, 'traffic_env_step.json'), 'w'))
+              open(os.path.join(dst, 'traffic_env_step.json' if walker == 'straight' else f'traffic_env_step_{walker}.json'), 'w'))
 print('\n'.join(lines))
