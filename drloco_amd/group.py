@@ -6,12 +6,12 @@ the loop forbids.  Oversubscription hides it as well: two handles of 4096 walker
 env-steps/s with single-step launches (tools/diag_streams.py; the workgroups of one handle's step kernel fill the SIMDs
 the other handle's fast waves have left), against 17.8 M for one handle of 4096.
 
-Measured status WITH the policy in the loop (bench.py --policy --handles H, one MI355X): no gain yet -- 8192 walkers as
-2 handles 14.9 M env-steps/s, as one handle 15.6 M; 4096 walkers as 2 handles 9.4 M, as one 13.7 M.  The chains convoy:
-`k_policy_forward` needs 66 KB of LDS per workgroup, the resident step kernels leave 5 KB per CU, so a handle's policy
-launch waits until the other handle's step kernel has drained and the two step kernels end up alternating instead of
-overlapping.  What would lift it is a policy kernel (or a step kernel) with a smaller LDS footprint; the class is kept
-because the sharding and merge semantics below are what any such scheme needs, and they are tested.
+Measured WITH the policy in the loop (bench.py --policy --handles H, one MI355X, round 2): it pays as soon as there is more than
+one wave per SIMD -- 8192 walkers: 17.5 M env-steps/s as 2 handles against 15.8 M as one; 32 768: 20.7 M against 18.9 M; 65 536 as 4
+handles 21.0 M.  At 4096 walkers it does not (9.7 M as 2 handles against 14.0 M): a half-size launch still has one wave per SIMD it
+occupies and lasts as long as its slowest wave, so two half chains just alternate.  Round 1 saw no gain at any
+size because `k_policy_forward` needed 74 KB of LDS per workgroup and convoyed behind the resident step kernels; it needs 23 KB
+now and fits next to four of their workgroups per CU.
 
 Semantics: the handles are shards exactly like the ranks of a multi-GPU run: walker i of handle h is
 global walker `index_base + h * n_per_handle + i` for the RSI and policy-noise streams, so every handle's rollout is
