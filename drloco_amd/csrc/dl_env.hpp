@@ -20,7 +20,10 @@ namespace dl {
 enum {
     MON_EP_LEN = 0, MON_NSTEPS, MON_RET, MON_LAST, MON_POS, MON_VEL, MON_COM, MON_TOR,
     MON_S_EP_LEN, MON_S_EP_RET, MON_S_MEAN_REW, MON_S_POS, MON_S_VEL, MON_S_COM, MON_S_TOR,
-    MON_MOVED, MON_HAS, MON_POSREW, MON_VELREW, MON_COMREW, MON_WORDS
+    MON_MOVED, MON_HAS, MON_POSREW, MON_VELREW, MON_COMREW,
+    // what the host needs to keep Monitor's per-episode lists (monitor_wrapper.py:93,107,123,131-132): reference-cursor position at the
+    // first step and at the end of the episode, the step's mean absolute torque, "shorter than 0.75 x the smoothed length" flag
+    MON_INIT_POS, MON_ET_POS, MON_TOR_LAST, MON_DIFFICULT, MON_WORDS
 };
 
 template <typename T> struct DevState {
@@ -149,8 +152,11 @@ DL_HD void mon_smooth(double* mon, int n, int i, int word, int bit, double x, do
     else s = alpha * x + (1 - alpha) * s;
 }
 
-DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const double (&terms)[3], double tor, double walked) {
+// cur_pos: refs._pos after this step's refs.next() (before any reset), as Monitor.step reads it
+DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const double (&terms)[3], double tor, double walked, int cur_pos) {
     auto W = [&](int w) -> double& { return mon[(size_t)w * n + i]; };
+    if (W(MON_EP_LEN) == 0) W(MON_INIT_POS) = (double)cur_pos;      // monitor_wrapper.py:91-93
+    W(MON_TOR_LAST) = tor;
     W(MON_EP_LEN) += 1; W(MON_NSTEPS) += 1; W(MON_RET) += rew; W(MON_LAST) = rew;
     W(MON_POS) += terms[0]; W(MON_VEL) += terms[1]; W(MON_COM) += terms[2]; W(MON_TOR) += tor;
     if (done) {
@@ -161,6 +167,8 @@ DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const 
         mon_smooth(mon, n, i, MON_S_COM, 3, W(MON_COM) / W(MON_NSTEPS), 0.9);
         mon_smooth(mon, n, i, MON_S_EP_RET, 4, W(MON_RET), 0.25);
         mon_smooth(mon, n, i, MON_S_EP_LEN, 5, len, 0.75);
+        W(MON_ET_POS) = (double)cur_pos;                                                  // :105-107
+        W(MON_DIFFICULT) = (len < W(MON_S_EP_LEN) * 0.75) ? 1.0 : 0.0;                    // :122-123 (after the smoothing update)
         mon_smooth(mon, n, i, MON_S_TOR, 6, W(MON_TOR) / len, 0.75);
         W(MON_MOVED) = walked;
         W(MON_EP_LEN) = 0; W(MON_RET) = 0; W(MON_TOR) = 0;
@@ -235,7 +243,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
         if (dst) static_for<TP::OBS>([&](auto ki) { dst[(size_t)i * TP::OBS + ki.value] = o[ki.value]; });
         if (dn) st.need_reset[i] = 1;
     }
-    monitor_step(st.mon, n, i, (double)r, dn, terms, tor_mean, walked);
+    monitor_step(st.mon, n, i, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
     st.mon[(size_t)MON_POSREW * n + i] = terms[0]; st.mon[(size_t)MON_VELREW * n + i] = terms[1]; st.mon[(size_t)MON_COMREW * n + i] = terms[2];
     if (rew_terms) { rew_terms[3 * (size_t)i] = (float)terms[0]; rew_terms[3 * (size_t)i + 1] = (float)terms[1]; rew_terms[3 * (size_t)i + 2] = (float)terms[2]; }
     rew[i] = r;

@@ -41,6 +41,15 @@
 #ifndef DL_PIN_STRAIGHT
 #define DL_PIN_STRAIGHT 1       // experiment switch: 0 builds the straight walker with the fetch-at-use policy of the 19-dof walker
 #endif
+// experiment switches: unroll factor of the contact-pair loops (J^T f / Hessian, J dir); 1 = as written
+#ifndef DL_UNROLL_JTF
+#define DL_UNROLL_JTF 1
+#endif
+#ifndef DL_UNROLL_APPLY
+#define DL_UNROLL_APPLY 1
+#endif
+#define DL_PRAGMA_(x) _Pragma(#x)
+#define DL_UNROLL(n) DL_PRAGMA_(unroll n)
 
 namespace dl {
 
@@ -1080,6 +1089,7 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
     }
     if (my_lim >= 0) wb[Ld::ROW + Ld::R_JV * MAXROW + my_lim] = lim_sign * x;
     // two contacts per trip (the Jacobian record after the last contact is zero): six interleaved row sums
+    DL_UNROLL(DL_UNROLL_APPLY)
     for (int c = 0; c < ncon; c += 2) {
         const Q4<T> ja = ld4(wb + Ld::JC + (c * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c + 1) * GL + j) * 4);
         T mua, mub;
@@ -1215,6 +1225,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         // ---- J^T f and the Hessian rows (dof lanes; the lane's Jacobian column of contact cc is one 16-byte read)
         T fcx[NXA];
         static_for<NX>([&](auto ti) { fcx[ti.value] = T(0); });
+        DL_UNROLL(DL_UNROLL_JTF)
         for (int c2 = 0; c2 < ncon; c2 += 2) {
             const DL_LDS T* fca = wb + Ld::FC + Ld::FC_W * c2;
             const Q4<T> Fa = ld4(fca), Fb = ld4(fca + Ld::FC_W), ja = ld4(wb + Ld::JC + (c2 * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c2 + 1) * GL + j) * 4);

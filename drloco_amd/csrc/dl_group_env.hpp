@@ -318,7 +318,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
     }
     if (valid && j == 0) {
-        monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked);
+        monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
         if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
         rew[w] = r;
         done[w] = dn ? 1 : 0;

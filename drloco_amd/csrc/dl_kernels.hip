@@ -925,7 +925,8 @@ int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) 
     static const struct { const char* name; int word; } tab[] = {
         {"ep_len_smoothed", MON_S_EP_LEN}, {"ep_ret_smoothed", MON_S_EP_RET}, {"mean_reward_smoothed", MON_S_MEAN_REW},
         {"moved_distance", MON_MOVED}, {"mean_ep_pos_rew_smoothed", MON_S_POS}, {"mean_ep_vel_rew_smoothed", MON_S_VEL},
-        {"mean_ep_com_rew_smoothed", MON_S_COM}, {"mean_abs_ep_torque_smoothed", MON_S_TOR}, {"ep_len", MON_EP_LEN}};
+        {"mean_ep_com_rew_smoothed", MON_S_COM}, {"mean_abs_ep_torque_smoothed", MON_S_TOR}, {"ep_len", MON_EP_LEN},
+        {"init_pos", MON_INIT_POS}, {"et_pos", MON_ET_POS}, {"last_abs_torque", MON_TOR_LAST}, {"difficult", MON_DIFFICULT}};
     for (const auto& t : tab)
         if (!strcmp(name, t.name)) return h->snapshot(t.word, out, (hipStream_t)stream);
     return fail(DL_E_INVAL, std::string("dl_stats_snapshot: unknown attribute ") + name);

@@ -15,7 +15,7 @@ import pickle
 import numpy as np
 import torch
 
-from . import abi, compat, lib, mocap, models
+from . import abi, compat, lib, mocap, models, monitor_lists
 
 MONITOR_ATTRS = ('ep_len_smoothed', 'ep_ret_smoothed', 'mean_reward_smoothed', 'moved_distance',
                  'mean_ep_pos_rew_smoothed', 'mean_ep_vel_rew_smoothed', 'mean_ep_com_rew_smoothed',
@@ -80,6 +80,7 @@ class HipVecEnv(_VecEnvBase):
         # host-side mirrors of Monitor's per-env lists (monitor_wrapper.py:57,120)
         self._ep_len = np.zeros(n, np.int64)
         self.ep_lens = [[] for _ in range(n)]
+        self._mlists = None                        # track_monitor_lists()
 
     # ---- VecEnv surface -------------------------------------------------------------------
     def reset(self, mask=None, init_step=None, init_pos=None):
@@ -115,6 +116,7 @@ class HipVecEnv(_VecEnvBase):
         obs_h, rew_h, done_h = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool)
         infos = [{} for _ in range(self.num_envs)]
         self._ep_len += 1
+        self._update_monitor_lists(done_h)
         if done_h.any():
             term_h = term.cpu().numpy()
             for i in np.nonzero(done_h)[0]:
@@ -149,6 +151,10 @@ class HipVecEnv(_VecEnvBase):
             return sel.cpu().numpy().tolist()
         if name == 'ep_lens':
             return [list(self.ep_lens[i]) for i in idx]
+        if name in monitor_lists.NAMES:
+            if self._mlists is None:
+                raise AttributeError(f'{name}: call track_monitor_lists() first (the per-episode lists of Monitor are kept on the host on request)')
+            return [self._mlists.get(name, i) for i in idx]
         raise AttributeError(name)
 
     def set_attr(self, name, value, indices=None):
@@ -158,6 +164,20 @@ class HipVecEnv(_VecEnvBase):
                 self.ep_lens[i] = list(value)
             return
         raise AttributeError(f'cannot set {name!r} on HipVecEnv')
+
+    def track_monitor_lists(self, on=True):
+        """Keep Monitor's rsi_positions / et_positions / difficult_rsi_phases / median_abs_torque_smoothed (monitor_lists.py) from now
+        on; they are updated by the numpy step_wait() surface (four device words per walker cross PCIe per control step)."""
+        self._mlists = monitor_lists.MonitorLists(self.num_envs, self.cfg.ep_dur_max) if on else None
+
+    def _update_monitor_lists(self, done_h):
+        if self._mlists is None:
+            return
+        words = torch.empty(4, self.num_envs, dtype=torch.float64, device=self.device)
+        for k, name in enumerate((b'init_pos', b'et_pos', b'last_abs_torque', b'difficult')):
+            lib.check(self._lib.dl_stats_snapshot(self._h, name, _ptr(words[k]), _stream()))
+        w = words.cpu().numpy()
+        self._mlists.update(done_h, w[0], w[1], w[2], w[3])
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         """SB3 VecEnv protocol: the walkers are not gym.Wrapper chains; Monitor's statistics are kept by the step kernel."""
@@ -568,6 +588,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         done_h = done.cpu().numpy().astype(bool)
         infos = [{} for _ in range(self.num_envs)]
         self.venv._ep_len += 1
+        self.venv._update_monitor_lists(done_h)
         if done_h.any():
             t = term.clone()
             if self.norm_obs and self.norm_terminal_obs:

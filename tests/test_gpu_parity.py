@@ -1333,3 +1333,49 @@ def test_f32_contact_activation_flips_after_reset_are_counted(torch_cuda, oracle
     err = (np.abs(qa - qb) / (1 + np.abs(qa)))[:, same]
     assert np.quantile(err.max(axis=0), 0.99) < 2e-3 and np.median(err.max(axis=0)) < 2e-4
     dev.close()
+
+
+@LANES
+def test_monitor_lists_on_device(torch_cuda, oracle, model, refs, lanes):
+    """Monitor's per-episode lists (rsi_positions, et_positions, difficult_rsi_phases, median_abs_torque_smoothed) through the numpy
+    VecEnv surface: the device words feeding them against the oracle's cursor (the reference's own Monitor pins the list logic itself:
+    tests/test_oracle_golden.py::test_G7_monitor_lists)."""
+    n, T = 64, 130
+    dev, orc = make_pair(oracle, model, refs, n, 64, lanes_per_walker=lanes, ep_dur_max=40)
+    scratch = oracle.OracleEnv(model, refs, abi.default_config(ep_dur_max=10 ** 9), n)      # replays refs.next() from a given cursor
+    dev.track_monitor_lists()
+    np.testing.assert_allclose(dev.reset(), orc.reset(), atol=2e-6)
+    rng = np.random.default_rng(3)
+    q_up = np.array(model.jnt_qpos0[:14])
+    want_rsi = [[] for _ in range(n)]; want_et = [[] for _ in range(n)]; ep_len = np.zeros(n, int); tors = [[] for _ in range(n)]; med = [None] * n
+    want_diff = [[] for _ in range(n)]; len_s = [None] * n
+    for t in range(T):
+        prev = orc.get_state()['cursor'].copy()
+        a = np.clip(1.5 * rng.standard_normal((n, 8)), -1, 1).astype(np.float32)          # violent actions: some walkers fall early
+        o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2), t
+        # refs._pos after this step's refs.next(), before any reset
+        prev[abi.DL_CUR_EP_DUR] = 0
+        scratch.set_state(cursor=prev)
+        for k in range(n):
+            scratch.inject_state(k, q_up, np.zeros(14))
+        scratch.step(np.zeros((n, 8)))
+        pos = scratch.get_state()['cursor'][abi.DL_CUR_POS]
+        ctrl = orc.last_ctrl()
+        for k in range(n):
+            if ep_len[k] == 0:
+                want_rsi[k].append(int(pos[k]))
+            ep_len[k] += 1
+            tors[k].append(np.abs(np.clip(ctrl[k], -300, 300)).mean())
+            if d1[k]:
+                want_et[k].append(int(pos[k]))
+                m = float(np.median(tors[k])); med[k] = m if med[k] is None else 0.75 * m + 0.25 * med[k]
+                ep_len[k] = 0; tors[k] = []
+    assert sum(len(x) for x in want_et) > n
+    assert dev.get_attr('rsi_positions') == want_rsi and dev.get_attr('et_positions') == want_et
+    got = dev.get_attr('median_abs_torque_smoothed')
+    for k in range(n):
+        if med[k] is not None:
+            assert abs(got[k] - med[k]) < 1e-9 * (1 + abs(med[k])), k
+    assert dev.get_attr('difficult_rsi_phases') == want_diff
+    dev.close()

@@ -446,3 +446,26 @@ def test_G12_absence_is_reported():
     else:
         import warnings
         warnings.warn(G12_SKIP)
+
+
+def test_G7_monitor_lists():
+    """Monitor's per-episode lists (rsi_positions, et_positions, difficult_rsi_phases, median_abs_torque_smoothed) as the host keeps
+    them (drloco_amd/monitor_lists.py) from the four per-walker words of the step kernel, against the reference's own Monitor (G7)."""
+    from drloco_amd.monitor_lists import MonitorLists
+    g = load('G7_monitor.npz')
+    T = len(g['rew'])
+    ml = MonitorLists(1, ep_dur_max=3000)
+    # the device words, restated: cursor position at the first step / at the end of an episode, the step's torque, the flag
+    ep_len, init_pos = 0, 0
+    for t in range(T):
+        if ep_len == 0:
+            init_pos = int(g['cursor'][t])
+        ep_len += 1
+        done = bool(g['done'][t])
+        difficult = float(done and ep_len < g['ep_len_smoothed'][t] * 0.75)
+        ml.update(np.array([done]), np.array([init_pos]), np.array([g['cursor'][t]]), np.array([g['tor'][t]]), np.array([difficult]))
+        np.testing.assert_allclose(ml.median_abs_torque_smoothed[0], g['median_abs_torque_smoothed'][t], rtol=1e-13)
+        if done:
+            ep_len = 0
+    assert ml.rsi_positions[0] == list(g['rsi_positions']) and ml.et_positions[0] == list(g['et_positions'])
+    assert ml.difficult_rsi_phases[0] == list(g['difficult_rsi_phases']) and len(g['difficult_rsi_phases']) > 0
