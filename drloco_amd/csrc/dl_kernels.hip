@@ -278,7 +278,14 @@ __global__ __launch_bounds__(256) void k_vn_reduce_mb(const float* __restrict__ 
         const int col = t % D, rsub = t / D;
         if (t < nthr) {
             const double K = mean[col];
-            for (int row = blockIdx.x * rpb + rsub; row < B; row += VN_BLOCKS * rpb) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
+            const int stride = VN_BLOCKS * rpb;
+            int row = blockIdx.x * rpb + rsub;
+            for (; row + 3 * stride < B; row += 4 * stride) {       // four independent loads in flight, accumulated in row order
+                const float a0 = x[(size_t)row * D + col], a1 = x[(size_t)(row + stride) * D + col], a2 = x[(size_t)(row + 2 * stride) * D + col], a3 = x[(size_t)(row + 3 * stride) * D + col];
+                const double d0 = (double)a0 - K, d1 = (double)a1 - K, d2 = (double)a2 - K, d3 = (double)a3 - K;
+                s += d0; ss += d0 * d0; s += d1; ss += d1 * d1; s += d2; ss += d2 * d2; s += d3; ss += d3 * d3;
+            }
+            for (; row < B; row += stride) { const double d = (double)x[(size_t)row * D + col] - K; s += d; ss += d * d; }
         }
         sh[0][t] = s; sh[1][t] = ss;
         __syncthreads();

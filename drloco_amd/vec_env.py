@@ -427,9 +427,10 @@ class HipVecNormalize(_VecEnvWrapperBase):
         self._vn_work = torch.zeros(abi.vn_workspace_bytes(venv.obs_dim) // 8, dtype=torch.float64, device=dev)    # DL_VN_WORKSPACE_BYTES
         self._ov = None                                   # overlap state (enable_overlap)
         # form of the moment reduction (flags bit 16 of dl_vecnormalize_step): one workgroup (lowest latency when the next launch waits
-        # for it: a policy in the loop) or 32 blocks (keeps its pace on a side stream under a running env-step kernel: enable_overlap).
-        # Both are deterministic; they sum in different orders, i.e. their moments can differ in the last bit.
-        self.multi_block_reduce = False
+        # for it: a policy in the loop with <= 4096 walkers -- 14 us) or 32 blocks (keeps its pace on a side stream under a running
+        # env-step kernel: enable_overlap; and for large batches, where one CU's time grows with the batch: 236 us for 16 384 walkers
+        # under contention).  Both are deterministic; they sum in different orders, i.e. their moments can differ in the last bit.
+        self.multi_block_reduce = self.num_envs > 4096
 
     # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
     @property

@@ -10,18 +10,25 @@ from drloco_amd.vec_env import HipVecEnv, _ptr, _stream
 ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--warm', type=int, default=80)
+ap.add_argument('--walker', choices=['straight', 'loco3d'], default='straight')
 args = ap.parse_args()
 n = args.envs
-env = HipVecEnv(num_envs=n, lanes_per_walker=16, seed=1234)
+if args.walker == 'loco3d':
+    from drloco_amd import mocap, models
+    ang, vel = mocap.synthetic_loco3d(L=60000, seed=0)
+    env = HipVecEnv(models.WALKER_165CM, num_envs=n, lanes_per_walker=16, seed=1234, refs=mocap.loco3d_table(ang, vel))
+else:
+    env = HipVecEnv(num_envs=n, lanes_per_walker=16, seed=1234)
+nu, nv = env.nu, env.nv
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
-acts = torch.clamp(0.5 * torch.randn(args.warm, n, 8, device='cuda', generator=g), -1, 1)
+acts = torch.clamp(0.5 * torch.randn(args.warm, n, nu, device='cuda', generator=g), -1, 1)
 for t in range(args.warm):
     env.step_tensors(acts[t])
-ctrl = (300 * torch.clamp(0.5 * torch.randn(8, n, device='cuda', generator=g), -1, 1)).contiguous()
+ctrl = (300 * torch.clamp(0.5 * torch.randn(nu, n, device='cuda', generator=g), -1, 1)).contiguous()
 nb = (n + 3) // 4
 tim = torch.zeros(10, nb, dtype=torch.int64, device='cuda')
-qacc = torch.zeros(14, n, device='cuda')
+qacc = torch.zeros(nv, n, device='cuda')
 names = ['smooth dynamics', 'constraints', 'rows, J^T f, Hessian', 'factor + solve', 'J dir / M dir', 'line search + step', '(iterations)', '-']
 for rep in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,7 +47,7 @@ w = ni.reshape(-1, 4).max(1)
 print('per wave max iters: mean %.2f' % w.mean())
 
 # ---- the same sections inside whole control steps of the rollout (20 evaluations each)
-acts2 = torch.clamp(0.5 * torch.randn(30, n, 8, device='cuda', generator=g), -1, 1)
+acts2 = torch.clamp(0.5 * torch.randn(30, n, nu, device='cuda', generator=g), -1, 1)
 tot = np.zeros((10, nb))
 launch_max, launch_mean, per_launch = [], [], []
 for t in range(30):

@@ -16,7 +16,8 @@ stats = glob.glob(os.path.join(src, 'bench_trace', '*', '*kernel_stats.csv'))
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' + ('' if walker == 'straight' else f' --walker {walker}') + '   (kernel_stats.csv, top rows)')
+    flags = {'straight': '', 'policy': ' --policy', 'policy_32768_h2': ' --policy --envs-per-gpu 32768 --handles 2 --steps 2'}.get(walker, f' --walker {walker}')
+    lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' + flags + '   (kernel_stats.csv, top rows)')
     lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
     for r in rows[:14]:
         lines.append(f'{r["Name"][:70]:70s} {r["Calls"]:>7s} {float(r["AverageNs"]) / 1e3:12.2f} {float(r["MinNs"]) / 1e3:10.2f} {float(r["MaxNs"]) / 1e3:10.2f} {float(r["Percentage"]):7.2f}')
