@@ -53,7 +53,7 @@ lines.append(json.dumps({k: v for k, v in out.items() if k != 'pmc_per_launch'})
 b = os.path.join(src, 'bench.json')
 if os.path.exists(b):
     lines.append('')
-    lines.append('bench.py (default flags) on the same box:')
+    lines.append('bench.py (the same flags, with the CPU baselines) on the same box:')
     lines.append(open(b).read().strip())
 open(os.path.join(dst, f'{tag}_summary.txt'), 'w').write('\n'.join(lines) + '\n')
 if 'hbm_bytes_per_launch' in out:
