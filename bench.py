@@ -308,7 +308,7 @@ def main():
         n_prof = venv.num_envs                       # walkers of the handle whose launches were bracketed (all of the rank's unless --handles)
         algo_bytes = ALGO_BYTES_PER_ENV_STEP_LOCO3D if args.walker == 'loco3d' else ALGO_BYTES_PER_ENV_STEP
         achieved = algo_bytes * n_prof * steps_per_launch / avg_launch_s / 1e9
-        # counter-derived figures come from a committed rocprofv3 PMC pass (profiles/traffic_env_step.json, tools/gpu_traffic.sh): they are
+        # counter-derived figures come from a committed rocprofv3 PMC pass (profiles/traffic_env_step.json, tools/gpu_round_profile.sh): they are
         # reported only for the configuration that pass measured AND only while the kernel sources are the ones it measured
         traffic = valu_busy = prof_origin = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
