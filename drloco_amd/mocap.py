@@ -84,6 +84,22 @@ class RefTable:
         return cls(z['table'], z['step_off'], z['step_is_left'], z['step_vel'], int(z['stride']))
 
 
+def hip3d_qpos(qpos):
+    """StraightWalking3dHipTrajectories.get_qpos (straight_walk_hip3d_trajecs.py:8-12): the straight walker's 14 reference
+    positions with a constant frontal ("traversal") hip angle inserted per leg, -0.05 rad before the right knee row group and
+    +0.05 rad for the left leg -> 16 values.  No environment of the reference's env_map uses the class (a 16-dof walker is not in
+    the repository), so this is a data transformation only; pinned by golden G13."""
+    q = np.asarray(qpos, dtype=np.float64)
+    return np.concatenate([q[..., :8], np.full(q.shape[:-1] + (1,), -0.05), q[..., 8:12], np.full(q.shape[:-1] + (1,), 0.05), q[..., 12:]], axis=-1)
+
+
+def hip3d_qvel(qvel):
+    """StraightWalking3dHipTrajectories.get_qvel (straight_walk_hip3d_trajecs.py:14-19): zero velocity for the two added hip rows."""
+    v = np.asarray(qvel, dtype=np.float64)
+    z = np.zeros(v.shape[:-1] + (1,))
+    return np.concatenate([v[..., :8], z, v[..., 8:12], z, v[..., 12:]], axis=-1)
+
+
 def _sequential_mean(row):
     acc = 0.0
     for x in row.tolist():

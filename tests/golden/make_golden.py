@@ -20,6 +20,8 @@ Fixtures:
   G7_monitor.npz         Monitor smoothing traces
   G11_mocap_options.npz  StraightWalkingTrajectories(mirror_refs=True) table + cursor trace; adapt_trajectories on the
                          synthetic loco3d table (`python tests/golden/make_golden.py mocap` regenerates only this one)
+  G13_hip3d.npz          StraightWalking3dHipTrajectories.get_qpos / get_qvel (the 16-d padded rows) at a few cursors
+                         (`python tests/golden/make_golden.py hip3d` regenerates only this one)
   G10_policy_trunk.npz   CustomHiddenLayers (drloco/custom/policies.py:13-51): weights, inputs, latent outputs
                          (`python tests/golden/make_golden.py policy` regenerates only this one)
 
@@ -326,7 +328,27 @@ def make_mocap_options_golden():
     print('wrote G11_mocap_options.npz')
 
 
+def make_hip3d_golden():
+    """G13: the trajectory class with frontal hip rows added (straight_walk_hip3d_trajecs.py:8-19; no env in env_map builds it)."""
+    import contextlib, io
+    refs_mod, walker_mod, monitor_mod, utils, hypers, _ = _import_reference()
+    import drloco.ref_trajecs.straight_walk_hip3d_trajecs as h3
+    qpos_rows, qvel_rows = list(walker_mod.qpos_indices), list(walker_mod.qvel_indices)
+    refs = h3.StraightWalking3dHipTrajectories(qpos_rows, qvel_rows)
+    cursors = [(0, 0), (3, 17), (6, 120), (11, 5), (20, 199)]
+    q = np.zeros((len(cursors), 16)); v = np.zeros((len(cursors), 16))
+    for n, (i_step, pos) in enumerate(cursors):
+        set_refs_cursor(refs, i_step, pos)
+        with contextlib.redirect_stdout(io.StringIO()):          # get_qvel prints a notice
+            q[n], v[n] = np.asarray(refs.get_qpos(), float), np.asarray(refs.get_qvel(), float)
+    np.savez_compressed(os.path.join(OUT, 'G13_hip3d.npz'), cursors=np.array(cursors, dtype=np.int32), q=q, v=v)
+    print('wrote G13_hip3d.npz')
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'hip3d':
+        make_hip3d_golden()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'policy':
         make_policy_golden()
         return

@@ -342,6 +342,19 @@ def test_G11_adapt_trajectories():
     assert not np.array_equal(plain.table, t.table)
 
 
+def test_G13_hip3d_rows(oracle, model, refs):
+    """StraightWalking3dHipTrajectories (straight_walk_hip3d_trajecs.py:8-19): the 16-value rows the class returns at a few cursors,
+    from the oracle's reference lookup on the packaged table + mocap.hip3d_qpos / hip3d_qvel."""
+    from drloco_amd import mocap
+    g = load('G13_hip3d.npz')
+    env = make_env(oracle, model, refs, n=1, ep_dur_max=10 ** 9)
+    for n, (i_step, pos) in enumerate(g['cursors']):
+        env.set_state(cursor=cursor(int(i_step), int(pos)))
+        qr, vr = env.ref_lookup(0)
+        assert np.array_equal(mocap.hip3d_qpos(qr), g['q'][n]) and np.array_equal(mocap.hip3d_qvel(vr), g['v'][n]), n
+    assert mocap.hip3d_qpos(np.zeros((3, 14))).shape == (3, 16)
+
+
 # ---------------------------------------------------------------------------------------------
 # G12: vectors of the REAL MuJoCo (tools/dump_mujoco_vectors.py).  The file can only be produced where `import mujoco` or
 # `import mujoco_py` works -- not in the build container -- so these tests skip LOUDLY until somebody commits it; with it the
