@@ -130,6 +130,39 @@ def cpu_baseline_subproc(n_envs=4, n_steps=2048, seed=4321):
                 sample=f'{n_envs} worker processes x 1 env (oracle) + 1 learner process (VecNormalize every step, GAE at the end) over pipes, {n_steps}-step rollout, {dt:.2f} s')
 
 
+def _allcores_worker(barrier, q, seed, n_envs, n_steps):
+    import numpy as np
+    from drloco_amd import abi, mocap, models
+    from oracle import oracle as O
+    env = O.OracleEnv(models.make_model(), mocap.RefTable.load(), abi.default_config(seed=seed), n_envs)
+    env.reset()
+    acts = np.clip(0.5 * np.random.default_rng(seed).standard_normal((n_steps, n_envs, 8)), -1, 1)
+    barrier.wait()
+    t0 = time.time()
+    for t in range(n_steps):
+        env.step(acts[t])
+    q.put((t0, time.time()))
+
+
+def cpu_baseline_all_cores(n_envs=64, n_steps=256, max_procs=32):
+    """The same scalar oracle on many host cores at once (one process per core, up to 32, independent walker shards, no learner): what
+    the CPU path reaches on this box when the environments are the only cost.  (The GPU boxes report 256 cores but schedule a job on
+    about a dozen: 128 processes gave 120 k env-steps/s, 11 x one core.)"""
+    import multiprocessing as mp
+    ctx = mp.get_context('fork')
+    n_procs = max(1, min(os.cpu_count() or 1, max_procs))
+    barrier, q = ctx.Barrier(n_procs), ctx.Queue()
+    procs = [ctx.Process(target=_allcores_worker, args=(barrier, q, 1234 + i, n_envs, n_steps), daemon=True) for i in range(n_procs)]
+    for p in procs:
+        p.start()
+    spans = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=5)
+    dt = max(e for _, e in spans) - min(b for b, _ in spans)
+    return dict(value=n_procs * n_envs * n_steps / dt, unit='env-steps/s', cores=n_procs,
+                sample=f'{n_procs} processes x {n_envs} walkers x {n_steps} control steps (oracle, environments only), {dt:.1f} s')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -168,6 +201,10 @@ def main():
             cpu_base['subproc_vec_env_4'] = cpu_baseline_subproc(4, 2048)
         except Exception as e:      # a box that cannot fork workers still gets its benchmark line
             cpu_base['subproc_vec_env_4'] = {'error': repr(e)}
+        try:        # and the oracle on up to 32 host cores at once
+            cpu_base['all_host_cores'] = cpu_baseline_all_cores()
+        except Exception as e:
+            cpu_base['all_host_cores'] = {'error': repr(e)}
     if local_rank >= torch.cuda.device_count():      # test rigs with fewer GPUs than ranks (DL_BENCH_BACKEND=gloo): share the last device
         local_rank = torch.cuda.device_count() - 1
     torch.cuda.set_device(local_rank)
