@@ -40,7 +40,8 @@ HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def kernel_sources_sha16():
-    """Identity of the kernel sources a profile was taken with: sha256 over drloco_amd/csrc/*.{hip,hpp} and the C-ABI header."""
+    """Identity of the kernel build a profile was taken with: sha256 over drloco_amd/csrc/*.{hip,hpp}, the C-ABI header and the product
+    build's extra compiler flags."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'drloco_amd', 'csrc')
@@ -48,6 +49,8 @@ def kernel_sources_sha16():
         if f.endswith(('.hip', '.hpp')):
             h.update(f.encode()); h.update(open(os.path.join(csrc, f), 'rb').read())
     h.update(open(os.path.join(ROOT, 'include', 'drloco_hip.h'), 'rb').read())
+    from drloco_amd import lib
+    h.update(' '.join(lib.EXTRA_FLAGS).encode())          # the compiler flags of the product build are part of what was measured
     return h.hexdigest()[:16]
 
 

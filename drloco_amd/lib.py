@@ -15,7 +15,12 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 _SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.h')))
 
 _lib = None
-EXTRA_FLAGS = []          # compiler flags of the product build beyond -O3 (experiments: DL_EXTRA_FLAGS in the environment)
+# compiler flags of the product build beyond -O3 (experiments: DL_EXTRA_FLAGS in the environment).  Both are measured choices for the
+# step kernels, which run one wave per SIMD and are bound by the latency of their dependent instructions: the SLP vectoriser
+# packs scalar float arithmetic into v_pk_* instructions at the price of register shuffles that cost more issue slots than they save
+# (-fno-slp-vectorize: +1.6 % straight walker, +4.7 % 19-dof walker), and the ILP-driven machine scheduler orders the long straight-line
+# blocks better than the default occupancy-driven one, which has no occupancy to gain here (another +1.2 % / +3.3 %).
+EXTRA_FLAGS = ['-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=iterative-ilp']
 
 
 class DrlocoError(RuntimeError):
