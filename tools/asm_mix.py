@@ -10,8 +10,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = sys.argv[1] if len(sys.argv) > 1 else '/tmp/dl_kernels.s'
 if not os.path.exists(path):
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'drloco_amd', 'csrc'),
-                           '--cuda-device-only', '-S', os.path.join(ROOT, 'drloco_amd', 'csrc', 'dl_kernels.hip'), '-o', path])
+    sys.path.insert(0, ROOT)
+    from drloco_amd import lib            # the product build's flags
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'drloco_amd', 'csrc')] + lib.EXTRA_FLAGS +
+                          ['--cuda-device-only', '-S', os.path.join(ROOT, 'drloco_amd', 'csrc', 'dl_kernels.hip'), '-o', path])
 lines = open(path).read().split('\n')
 cur, bodies = None, collections.defaultdict(list)
 for ln in lines:
