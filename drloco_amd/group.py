@@ -8,7 +8,7 @@ the other handle's fast waves have left), against 17.8 M for one handle of 4096.
 
 Measured WITH the policy in the loop (bench.py --policy --handles H, one MI355X, round 2): it pays as soon as there is more than
 one wave per SIMD -- 8192 walkers: 18.1 M env-steps/s as 2 handles against 16.5 M as one; 32 768: 21.3 M against 20.0 M; 65 536 as 4
-handles 21.1 M.  At 4096 walkers it does not (9.7 M as 2 handles against 14.0 M): a half-size launch still has one wave per SIMD it
+handles 21.8 M.  At 4096 walkers it does not (9.7 M as 2 handles against 14.5 M): a half-size launch still has one wave per SIMD it
 occupies and lasts as long as its slowest wave, so two half chains just alternate.  Round 1 saw no gain at any
 size because `k_policy_forward` needed 74 KB of LDS per workgroup and convoyed behind the resident step kernels; it needs 23 KB
 now and fits next to four of their workgroups per CU.
