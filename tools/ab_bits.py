@@ -11,7 +11,10 @@ if sys.argv[1] == '--compare':
     for k in a.files:
         same = np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
         d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max()
-        print(f'{k:24s} identical={same}  max abs diff {d:.3e}')
+        first = ''
+        if a[k].ndim == 3 or (a[k].ndim == 2 and k.endswith(('_rew', '_done'))):          # [T, ...]: the first control step alone (before chaos amplifies the last bit)
+            first = f'   first step: max abs diff {np.abs(a[k][0].astype(np.float64) - b[k][0].astype(np.float64)).max():.3e}'
+        print(f'{k:24s} identical={same}  max abs diff {d:.3e}{first}')
         ok &= same
     sys.exit(0 if ok else 1)
 import torch
