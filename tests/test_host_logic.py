@@ -317,3 +317,16 @@ def test_group_kernel_source_on_host_push_schedule(emu, oracle):
         np.testing.assert_allclose(rm[t], r1, atol=1e-6)
     assert pushed_steps > 10
     np.testing.assert_allclose(e.get_state()['qpos'], o.get_state()['qpos'], rtol=1e-7, atol=1e-8)
+
+
+def test_bench_cpu_baselines_run(oracle):
+    """bench.py's CPU legs (the oracle on one core, in the reference's SubprocVecEnv process structure, on many cores at once) on tiny
+    samples: they fork worker processes before the benchmark touches the GPU, so they must keep working without one."""
+    import bench
+    one = bench.cpu_baseline(4, 3)
+    sub = bench.cpu_baseline_subproc(2, 8)
+    many = bench.cpu_baseline_all_cores(n_envs=4, n_steps=3, max_procs=2)
+    for d, cores in ((one, 1), (sub, 3), (many, 2)):
+        assert d['unit'] == 'env-steps/s' and d['value'] > 0 and d['cores'] == cores and isinstance(d['sample'], str)
+    assert one['kind'] == 'port'
+    assert len(bench.kernel_sources_sha16()) == 16
