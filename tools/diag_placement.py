@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Where do the waves of one env-step launch land?  Needs an experiment build whose step kernel writes HW_ID / XCC_ID into the debug counters
-(rows 1 and 3) -- selected with DL_LIB_PATH.  Prints how many waves share a SIMD and how many CUs / SIMDs are used."""
+(rows 1 and 3) -- selected with DL_LIB_PATH.  Prints how many waves share a SIMD and how many CUs / SIMDs are used.
+The experiment build: in dl_group_env.hpp, where the step kernel updates st.dbg, store
+    st.dbg[n + w] = (int)__builtin_amdgcn_s_getreg(0xF804);              // HW_ID, all 32 bits
+    st.dbg[3 * n + w] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+instead of the maximum iteration count / the diverged-step count, add __attribute__((amdgpu_waves_per_eu(2, 2))) to k_env_step_g16 for
+the register-capped variant, and build with the product flags into build_variants/."""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
