@@ -181,6 +181,8 @@ def main():
     ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: rollout length - 64, 64 -- one long launch, then a 64-step launch under which the normalisations of the long one execute on the side stream (tools/prof_step.py issues the same schedule for the PMC passes)')
     ap.add_argument('--handles', type=int, default=1, help='with --policy: split the walkers of a rank over this many env handles, each driving its policy -> step -> normalise chain on its own stream (drloco_amd/group.py); balanced single-step launches need >= 8192 walkers per GPU')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
+    ap.add_argument('--vn-single-steps', action='store_true', help='normalise the steps of a fixed-action run one dl_vecnormalize_step at a time instead of with dl_vecnormalize_steps (five launches per run)')
+    ap.add_argument('--no-split', action='store_true', help='keep the one-wave-per-four-walkers launch form of the step kernel (dl_set_split 0); the default switches the split workgroup on where it exists (straight walker, float32, 16 lanes, one handle)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -239,6 +241,9 @@ def main():
         venv = HipVecEnv(models.WALKER_165CM, num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, refs=mocap.loco3d_table(ang, vel), lanes_per_walker=args.lanes)
     else:
         venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
+    split = (not args.no_split) and args.walker == 'straight' and args.lanes in (0, 16) and not (args.policy and args.handles > 1)
+    if split:
+        venv.set_split(True)          # dynamics waves + constraint waves (include/drloco_hip.h: dl_set_split)
     vn = HipVecNormalize(venv)
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
     # what the policy would have produced lives where it would have written it: in the rollout buffer.  The tapes are keyed by the GLOBAL
@@ -253,6 +258,7 @@ def main():
     vn.reset()
     if not args.policy and not args.no_overlap:
         vn.enable_overlap(chunk=max(r for _, r in run_starts))      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
+        vn.batched_steps = not args.vn_single_steps                 # ... as one dl_vecnormalize_steps call per run
     last_obs = vn.norm_obs_t                                    # observation / episode-start flags that open the next rollout
     last_done = buf.next_starts                                 # row T of the episode-start array: the flags after the last step
     last_done.fill_(1)
@@ -352,7 +358,7 @@ def main():
         # reported only for the configuration that pass measured AND only while the kernel sources are the ones it measured
         traffic = valu_busy = prof_origin = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
-        default_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.policy and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs
+        default_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.policy and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs and not args.no_split and not args.vn_single_steps
         if os.path.exists(tfile) and default_cfg:
             try:
                 pj = json.load(open(tfile))
@@ -370,13 +376,14 @@ def main():
             'config': {'workload': ('loco3d 19-dof walker (synthetic mocap table), ' if args.walker == 'loco3d' else 'straight_walking 3D walker, ') + f'{n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
-                       'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else 'side stream, under the following run of env steps',
+                       'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else ('side stream, one dl_vecnormalize_steps call per run' if not args.vn_single_steps else 'side stream, under the following run of env steps'),
+                       'step_kernel_form': 'split workgroups: 4 dynamics + 4 constraint waves per 16 walkers (dl_set_split 1)' if split else 'one wave per 4 walkers',
                        'env_launches': 'one per control step' if (args.policy or args.no_overlap) else
                                        'dl_rollout_fixed, runs of ' + ' + '.join(str(r) for _, r in run_starts) + ' control steps per launch',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes on a device-resident schedule (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
-                                   ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else 'k_env_step_g16<float,TopoStraight>'), 'avg_launch_us': avg_launch_s * 1e6,
+                                   ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>')), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
                          'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},

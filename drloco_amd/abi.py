@@ -5,13 +5,18 @@ library's own view (dl_abi_sizeof) and that every declared symbol is exported.
 """
 import ctypes as C
 
-DL_ABI_VERSION = 3
+DL_ABI_VERSION = 4
 DL_ADV_WORKSPACE_BYTES = (2 * 512 + 2) * 8
 
 
 def vn_workspace_bytes(obs_dim):
     """DL_VN_WORKSPACE_BYTES(D) of include/drloco_hip.h"""
     return 8 * (2 * 32 * (obs_dim + 1) + 2)
+
+
+def vn_steps_workspace_bytes(k, b, obs_dim):
+    """DL_VN_STEPS_WORKSPACE_BYTES(K, B, D) of include/drloco_hip.h"""
+    return 8 * (k * b + k * 32 * (obs_dim + 1) * 2 + k * (obs_dim + 1) * 2)
 
 DL_MAX_BODY, DL_MAX_DOF, DL_MAX_GEOM, DL_MAX_SITE, DL_MAX_ACT = 12, 20, 12, 8, 16
 DL_JNT_SLIDE, DL_JNT_HINGE = 0, 1

@@ -27,11 +27,15 @@
 #define DL_VPIN(x) ((void)0)
 #define DL_SPIN(x) ((void)0)
 #define DL_CLOCK() 0ll
+#define DL_SLEEP() ((void)0)
+#define DL_WAKE() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define DL_VPIN(x) asm volatile("" : "+v"(x))
 #define DL_SPIN(x) asm volatile("" : "+s"(x))
 #define DL_CLOCK() ((long long)__builtin_readcyclecounter())
+#define DL_SLEEP() __builtin_amdgcn_s_sleep(16)        // a waiting wave of a split workgroup: ~1000 cycles, cut short by the partner's s_wakeup
+#define DL_WAKE() asm volatile("s_wakeup")
 #endif
 
 #include <type_traits>
@@ -370,6 +374,20 @@ template <typename T, typename TP> struct GCtx {
     const GLane<T, GD<TP>::NPASS>* ln;           // this lane's preloaded model data
     const GConst<T, TP>* c;                      // pinned uniform scalars
     const GWalk<T>* wk;                          // this walker's randomisation
+    DL_LDS T* mm;                                // mirror block of the mass matrix (GLds::MM inside the rows, or its own space in the split workgroup)
+    DL_LDS T* mbox;                              // split workgroup: this walker's mailbox between the dynamics wave and the constraint wave (else null)
+    DL_LDS T* mbox0;                             //                  the mailbox of the wave's first walker (sequence numbers of the wave pair)
+};
+// Split workgroup: a second wave builds the constraints of the same four walkers while the first runs the smooth dynamics.
+// Per walker, behind the regular region: the mirror block of M (which may no longer share the rows' space) and the mailbox.
+template <typename TP> struct GSplit {
+    using Ld = GLds<TP>;
+    static constexpr int MMX = Ld::TOTAL;                        // M mirror [16][MS]
+    static constexpr int MB = MMX + GL * Ld::MS;                 // mailbox
+    static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_DONESEQ = 67, MB_CMD = 68, MB_SIZE = 96;
+    static constexpr int TOTAL = MB + MB_SIZE;                   // per walker; 16 (mod 32) like GLds::TOTAL
+    static_assert(TOTAL % 32 == 16 && MB % 4 == 0, "walker regions keep their bank offset");
+    static constexpr int SPIN_LIMIT = 1 << 12;                   // polls before a wave gives up waiting for its partner (no hang on a protocol error)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -569,7 +587,7 @@ template <typename T> struct GKin { V3<T> X, Y, Z, pos, axis; T rootz; };
 // (s, c) = (0, 1), so no lane waits for another one and nothing goes through LDS except the body frames that the
 // collision stage reads (BFR) and rootz (MISC[0]).  qx: the replicated root translations (only the vertical one
 // matters: positions are relative to the root origin).
-template <typename T, typename TP>
+template <typename T, typename TP, bool PUBLISH = true>      // PUBLISH = false: registers only (the dynamics wave of a split workgroup; its partner publishes)
 __device__ __forceinline__ void g_fk(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, const GX<T, GD<TP>::NX>& qx, GKin<T>& k) {
     static_assert(GTopo<TP>::slides_first(), "slide joints must be world-aligned root joints");
     using Ld = GLds<TP>;
@@ -619,12 +637,14 @@ __device__ __forceinline__ void g_fk(const GCtx<T, TP>& g, const GLaneTopo<T>& l
     const int idx = ln.axis;
     const V3<T> col = idx == 0 ? X : (idx == 1 ? Y : Z);
     k.X = X; k.Y = Y; k.Z = Z; k.pos = pos; k.axis = ln.sign * col; k.rootz = rootz;
-    if (j < NL && lt.last) {
-        DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
-        st4(f, X.x, X.y, X.z, Y.x); st4(f + 4, Y.y, Y.z, Z.x, Z.y); st4(f + 8, Z.z, pos.x, pos.y, pos.z);
+    if constexpr (PUBLISH) {
+        if (j < NL && lt.last) {
+            DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
+            st4(f, X.x, X.y, X.z, Y.x); st4(f + 4, Y.y, Y.z, Z.x, Z.y); st4(f + 8, Z.z, pos.x, pos.y, pos.z);
+        }
+        if (j == 0) wb[Ld::MISC + 0] = rootz;
+        g_sync<T>();
     }
-    if (j == 0) wb[Ld::MISC + 0] = rootz;
-    g_sync<T>();
 }
 
 // height of the lowest foot-sole site above the floor at the configuration last passed to g_fk
@@ -668,7 +688,7 @@ template <typename T, typename TP> struct GSmooth {
 // The replicated root translations are ancestors of every lane: their velocity enters every twist, their composite
 // inertia / wrench is the whole walker's (the subtree of lane 0), M[j][t] = S_t . (Ic_j S_j) is one entry per lane.
 // Out: sm; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
-template <typename T, typename TP>
+template <typename T, typename TP, bool PUBLISH = true>
 __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx,
                                                   GKin<T>& k, GSmooth<T, TP>& sm) {
     using Ld = GLds<TP>;
@@ -676,7 +696,7 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     const auto& ln = *g.ln;
-    g_fk<T, TP>(g, lt, q, qx, k);
+    g_fk<T, TP, PUBLISH>(g, lt, q, qx, k);
     const bool isdof = j < NL;
     // motion subspace of dof j and its joint velocity contribution
     SV<T> S;
@@ -747,13 +767,13 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
         const T mjj = sdot(S, f);
         sm.mdiag = isdof ? mjj + ln.armature : T(1);
         sm.mcorr = isdof ? ln.armature - mjj : T(0);
-        DL_LDS T* row = wb + Ld::MM + j * Ld::MS;
+        DL_LDS T* row = g.mm + j * Ld::MS;
         st4(row, ml[0], ml[1], ml[2], ml[3]); st4(row + 4, ml[4], ml[5], ml[6], ml[7]);
         st4(row + 8, ml[8], ml[9], ml[10], ml[11]); st4(row + 12, ml[12], ml[13], ml[14], ml[15]);
     }
     g_sync<T>();
 #pragma unroll
-    for (int a = 0; a < GL; a++) sm.mrow[a] = (a < NL) ? ml[a] + wb[Ld::MM + a * Ld::MS + j] : T(0);
+    for (int a = 0; a < GL; a++) sm.mrow[a] = (a < NL) ? ml[a] + g.mm[a * Ld::MS + j] : T(0);
     // [3P] xfrc_applied on the torso (body 1): J^T of a world-frame force at its centre of mass
     T push_q = T(0);
     if (g.wk->pushed) {
@@ -996,7 +1016,47 @@ __device__ __forceinline__ int g_popc(uint64_t x) { return __popcll(x); }
 // [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
 // Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
 // x0 / x0x = B v + a (lane / replicated dofs): the start point of the solver, folded into the rows' J a - aref.
+// Second half of the constraint stage: the contact Jacobians and J x0 for the ncon contacts whose records are in LDS (needs the lane's
+// kinematics in registers, nothing else of the first half).
 template <typename T, typename TP>
+__device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int ncon, T x0, const T (&x0x)[GD<TP>::NXA]) {
+    using Ld = GLds<TP>;
+    constexpr int NX = GD<TP>::NX, MAXROW = Ld::MAXROW;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j;
+    const auto& ln = *g.ln;
+    // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
+    // every contact from its joint axis / anchor in registers (dofs that do not move the contact's body write zeros),
+    // two contacts per trip; the same trip adds J x0 to the contacts' rows (six interleaved row sums, expanded to the
+    // pyramid rows by lanes 0..7), so the Jacobian is not read back for the start point
+    for (int c = 0; c < ncon; c += 2) {
+        const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * c;
+        const Q4<T> A0 = ld4(cn), B0 = ld4(cn + 4), A1 = ld4(cn + Ld::CON_W), B1 = ld4(cn + Ld::CON_W + 4);
+        DL_LDS T* rja = wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * c + j;
+        const bool writer = j < 4 || (j < 8 && c + 1 < ncon);
+        const T base = writer ? *rja : T(0);
+        V3<T> w0 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A0.a, A0.b, A0.c) - kin.pos);
+        V3<T> w1 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A1.a, A1.b, A1.c) - kin.pos);
+        if (!((lt.bodies >> (int)A0.d) & 1u)) w0 = mk<T>(0, 0, 0);
+        if (!((lt.bodies >> (int)A1.d) & 1u)) w1 = mk<T>(0, 0, 0);
+        const T j0n = w0.z, j0a = B0.a * w0.x + B0.b * w0.y, j0b = -B0.b * w0.x + B0.a * w0.y;
+        const T j1n = w1.z, j1a = B1.a * w1.x + B1.b * w1.y, j1b = -B1.b * w1.x + B1.a * w1.y;
+        st4(wb + Ld::JC + (c * GL + j) * 4, j0n, j0a, j0b, T(0));
+        st4(wb + Ld::JC + ((c + 1) * GL + j) * 4, j1n, j1a, j1b, T(0));
+        T r[6] = {j0n * x0, j0a * x0, j0b * x0, j1n * x0, j1a * x0, j1b * x0};
+        gsum_n<6>(r);
+        if constexpr (NX > 0) { g_slide_jx<T, TP>(B0.a, B0.b, x0x, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1.a, B1.b, x0x, r[3], r[4], r[5]); }
+        if (writer) {
+            const bool second = j >= 4;
+            const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? B1.c : B0.c;
+            *rja = base + vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
+        }
+    }
+    g_sync<T>();
+}
+
+// WITH_J = false: stop after the contact records and rows (the caller -- the dynamics wave of a split workgroup -- runs g_contact_jacobians itself)
+template <typename T, typename TP, bool WITH_J = true>
 __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, T x0, const T (&x0x)[GD<TP>::NXA],
                                                    int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
     using Ld = GLds<TP>;
@@ -1112,34 +1172,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
         wb[Ld::ROW + Ld::R_TMP * MAXROW + r] = T(0);
     }
     g_sync<T>();
-    // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
-    // every contact from its joint axis / anchor in registers (dofs that do not move the contact's body write zeros),
-    // two contacts per trip; the same trip adds J x0 to the contacts' rows (six interleaved row sums, expanded to the
-    // pyramid rows by lanes 0..7), so the Jacobian is not read back for the start point
-    for (int c = 0; c < ncon; c += 2) {
-        const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * c;
-        const Q4<T> A0 = ld4(cn), B0 = ld4(cn + 4), A1 = ld4(cn + Ld::CON_W), B1 = ld4(cn + Ld::CON_W + 4);
-        DL_LDS T* rja = wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * c + j;
-        const bool writer = j < 4 || (j < 8 && c + 1 < ncon);
-        const T base = writer ? *rja : T(0);
-        V3<T> w0 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A0.a, A0.b, A0.c) - kin.pos);
-        V3<T> w1 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A1.a, A1.b, A1.c) - kin.pos);
-        if (!((lt.bodies >> (int)A0.d) & 1u)) w0 = mk<T>(0, 0, 0);
-        if (!((lt.bodies >> (int)A1.d) & 1u)) w1 = mk<T>(0, 0, 0);
-        const T j0n = w0.z, j0a = B0.a * w0.x + B0.b * w0.y, j0b = -B0.b * w0.x + B0.a * w0.y;
-        const T j1n = w1.z, j1a = B1.a * w1.x + B1.b * w1.y, j1b = -B1.b * w1.x + B1.a * w1.y;
-        st4(wb + Ld::JC + (c * GL + j) * 4, j0n, j0a, j0b, T(0));
-        st4(wb + Ld::JC + ((c + 1) * GL + j) * 4, j1n, j1a, j1b, T(0));
-        T r[6] = {j0n * x0, j0a * x0, j0b * x0, j1n * x0, j1a * x0, j1b * x0};
-        gsum_n<6>(r);
-        if constexpr (NX > 0) { g_slide_jx<T, TP>(B0.a, B0.b, x0x, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1.a, B1.b, x0x, r[3], r[4], r[5]); }
-        if (writer) {
-            const bool second = j >= 4;
-            const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? B1.c : B0.c;
-            *rja = base + vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
-        }
-    }
-    g_sync<T>();
+    if constexpr (WITH_J) g_contact_jacobians<T, TP>(g, lt, kin, ncon, x0, x0x);
     nlim_out = nlim; ncon_out = ncon;
 }
 
@@ -1204,10 +1237,13 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
 // changes state).  It is written with selects so that the 4 walkers of a wave do not serialise on it.
 // TIMED: accumulate shader-clock cycles per section into tacc[8] (diagnostics build only):
 // 0 smooth dynamics, 1 constraints, 2 rows/J^T f/Hessian, 3 factor + solve, 4 J dir / M dir, 5 line search + step, 6 #iterations of the wave
-template <typename T, typename TP, bool TIMED = false>
+// SPLIT: this wave is the dynamics wave of a split workgroup -- it hands (q, B v + a) to its partner, which runs g_fk + g_make_constraints
+// on the same LDS regions while this wave does the smooth dynamics, and picks the result up before the solver starts (split_seq: the
+// pair's command counter, kept by the caller).
+template <typename T, typename TP, bool TIMED = false, bool SPLIT = false>
 __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm,
                                        const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx, const GX<T, GD<TP>::NX>& warmx, GX<T, GD<TP>::NX>& qaccx,
-                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr) {
+                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr) {
     constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, NXA = GD<TP>::NXA;
     using Ld = GLds<TP>;
     constexpr int MAXROW = Ld::MAXROW;
@@ -1220,16 +1256,47 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
     const int j = g.j;
     GKin<T> kin;
     GSmooth<T, TP> sm;
-    g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
-    const T smooth = sm.smooth;
-    tick(0);
+    const GConst<T, TP>& cs = *g.c;
     int nlim, ncon, my_lim;
     T lim_sign;
-    const GConst<T, TP>& cs = *g.c;
+    if constexpr (SPLIT) {
+        static_assert(NX == 0, "the split workgroup is built for the lane-only walker");
+        using Sp = GSplit<TP>;
+        // hand the configuration and the solver's start point to the constraint wave, then do the smooth dynamics meanwhile
+        g.mbox[Sp::MB_Q + j] = q;
+        g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
+        g_sync<T>();
+        const int seq = ++*split_seq;
+        if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
+        DL_WAKE();
+#ifdef DL_EXP_SPLIT_PROF
+        const long long tp0 = DL_CLOCK();
+#endif
+        g_smooth_dynamics<T, TP, false>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
+        tick(0);
+#ifdef DL_EXP_SPLIT_PROF
+        const long long tp1 = DL_CLOCK();
+#endif
+        for (int it = 0; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_DONESEQ] != seq && it < Sp::SPIN_LIMIT; it++) DL_SLEEP();
+#ifdef DL_EXP_SPLIT_PROF
+        split_seq[1] += (int)((DL_CLOCK() - tp1) >> 4); split_seq[2] += (int)((tp1 - tp0) >> 4);
+#endif
+        g_sync<T>();
+        my_lim = (int)g.mbox[Sp::MB_LIM + j]; lim_sign = g.mbox[Sp::MB_SGN + j];
+        ncon = (int)g.mbox[Sp::MB_NCON]; nlim = (int)g.mbox[Sp::MB_NLIM];
+        {   // the contact Jacobians are this wave's part of the constraint stage (its partner is the slower of the two otherwise)
+            const T x0x[NXA] = {T(0)};
+            g_contact_jacobians<T, TP>(g, lt, kin, ncon, (j < N) ? cs.solB * v + warm : T(0), x0x);
+        }
+    } else {
+    g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
+    tick(0);
     // rows: D, jar = J a - aref at a = warm start (K imp r + J (B v + a)), cleared "active" flags (TMP) of the Hessian
     T x0x[NXA];
     static_for<NX>([&](auto ti) { constexpr int t = ti.value; x0x[t] = cs.solB * vx.x[t] + warmx.x[t]; });
     g_make_constraints<T, TP>(g, lt, kin, grp, q, (j < N) ? cs.solB * v + warm : T(0), x0x, nlim, ncon, my_lim, lim_sign);
+    }
+    const T smooth = sm.smooth;
     const int nefc = nlim + 4 * ncon;
     ncon_o = ncon; nefc_o = nefc;
     DL_LDS T* rD = wb + Ld::ROW + Ld::R_D * MAXROW;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
     g_load_const<T, TP>(*m, cst);
     GWalk<T> wk;
     g_load_walk<T, TP>(m, st, wi, wk);
-    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk};
+    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MM, nullptr, nullptr};
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < NL) {
         const size_t o = (size_t)(j + NX) * n + wi;
@@ -82,11 +82,61 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
     }
 }
 
+// The constraint wave of a split workgroup: serves the dynamics wave that owns the same four walkers (same LDS regions).  Per request
+// (q and the solver's start point B v + a in the mailbox) it runs the kinematics + collision + constraint construction of g_forward --
+// body frames, contacts, rows, contact Jacobians, all in the walker's LDS region -- and reports (ncon, nlim, the lanes' limit rows).
+// Waits are bounded polls: a protocol error ends in wrong numbers (caught by the tests), never in a hung GPU.
+#if !defined(DL_GROUP_EMU)
+template <typename T, typename TP>
+__device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevState<T>& st) {
+    using D = GD<TP>;
+    using Ld = GLds<TP>;
+    using Sp = GSplit<TP>;
+    static_assert(D::NX == 0, "the split workgroup is built for the lane-only walker");
+    const int grp = lane >> 4, j = lane & 15, n = st.n;
+    const int w0 = wblock * GW + grp;
+    const int w = w0 < n ? w0 : n - 1;
+    const DL_CONST GModel<T, TP>* m = (const DL_CONST GModel<T, TP>*)gm;
+    const GLane<T, D::NPASS> ln = m->lanes[j];
+    GConst<T, TP> cst;
+    g_load_const<T, TP>(*m, cst);
+    GWalk<T> wk;
+    g_load_walk<T, TP>(m, st, w, wk);
+    DL_LDS T* wb = smem + (size_t)grp * Sp::TOTAL;
+    GCtx<T, TP> g{wb, m, j, &ln, &cst, &wk, wb + Sp::MMX, wb + Sp::MB, smem + Sp::MB};
+    GLaneTopo<T> lt;
+    g_lane_topo<T, TP>(j, lt);
+    volatile DL_LDS int* flags = (volatile DL_LDS int*)g.mbox0;
+    int seq = 0;
+    for (;;) {
+        int cur = seq, it = 0;
+        while ((cur = flags[Sp::MB_CMDSEQ]) == seq && it < Sp::SPIN_LIMIT) { DL_SLEEP(); it++; }
+        if (cur == seq || flags[Sp::MB_CMD] == 0) break;          // released (or the partner is gone)
+        seq = cur;
+        g_sync<T>();
+        const T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j];
+        GKin<T> kin;
+        GX<T, 0> qx;
+        g_fk<T, TP, true>(g, lt, q, qx, kin);
+        int nlim, ncon, my_lim;
+        T lim_sign;
+        const T x0x[1] = {T(0)};
+        g_make_constraints<T, TP, false>(g, lt, kin, grp, q, x0, x0x, nlim, ncon, my_lim, lim_sign);
+        g.mbox[Sp::MB_LIM + j] = (T)my_lim; g.mbox[Sp::MB_SGN + j] = lim_sign;
+        if (j == 0) { g.mbox[Sp::MB_NCON] = (T)ncon; g.mbox[Sp::MB_NLIM] = (T)nlim; }
+        g_sync<T>();
+        if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
+        DL_WAKE();
+    }
+}
+#endif
+
 // `nsteps` control steps (time-major arrays: step s uses actions[s], writes obs[s], rew[s], done[s]).  More than one
 // step per launch is for callers whose actions do not depend on the observations (dl_rollout_fixed): the launch then
 // lasts as long as the wave with the largest SUM over the steps, not the sum of the per-step maxima.
 // TIMED: tim = [10][nwg]: 0-6 g_forward's sections, 7 whole kernel, 8 before the physics, 9 after it.
-template <typename T, typename TP, bool TIMED = false>
+// SPLIT: the dynamics wave of a split workgroup (its partner runs g_constraint_server on the same walkers); smem = the LDS of the wave pair.
+template <typename T, typename TP, bool TIMED = false, bool SPLIT = false>
 __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, int nwg, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevCfg<T>& c, const DevState<T>& st,
                                                 const float* __restrict__ actions_all, float* obs_all, float* rew_all, uint8_t* done_all, float* term_obs_all, float* rew_terms_all,
                                                 const T* inj_q, const T* inj_v, const int32_t* inj_flags, float* ctrl_out, int eval_mode, int nsteps, long long* tim) {
@@ -97,39 +147,49 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_begin = 0;
     if constexpr (TIMED) t_begin = DL_CLOCK();
+#ifdef DL_EXP_SPLIT_PROF
+    const long long t_begin0 = DL_CLOCK();
+#endif
     const int grp = lane >> 4, j = lane & 15, n = st.n;
     const int w0 = wblock * GW + grp;
     const bool valid = w0 < n;
-    const int w = valid ? w0 : n - 1;
+    const int w1 = valid ? w0 : n - 1;
     const DL_CONST GModel<T, TP>* m = (const DL_CONST GModel<T, TP>*)gm;
     const GLane<T, D::NPASS> ln = m->lanes[j];     // this lane's record of the model block (built on the host by g_load_lane)
     GConst<T, TP> cst;
     g_load_const<T, TP>(*m, cst);
     GWalk<T> wk;
-    g_load_walk<T, TP>(m, st, w, wk);
-    GCtx<T, TP> g{smem + (size_t)grp * Ld::TOTAL, m, j, &ln, &cst, &wk};
+    g_load_walk<T, TP>(m, st, w1, wk);
+    constexpr int WSTRIDE = SPLIT ? GSplit<TP>::TOTAL : Ld::TOTAL;         // LDS words per walker
+    GCtx<T, TP> g{smem + (size_t)grp * WSTRIDE, m, j, &ln, &cst, &wk,
+                  smem + (size_t)grp * WSTRIDE + (SPLIT ? GSplit<TP>::MMX : Ld::MM), SPLIT ? smem + (size_t)grp * WSTRIDE + GSplit<TP>::MB : nullptr, SPLIT ? smem + GSplit<TP>::MB : nullptr};
+    int split_seq[3] = {0, 0, 0};
     DL_LDS T* wb = g.wb;
     const bool isdof = j < NL;
     const int jd = j + NX;                         // dof of this lane
     GLaneTopo<T> lt;
     g_lane_topo<T, TP>(j, lt);
     T q = T(0), v = T(0), warm = T(0);
-    if (isdof) { const size_t o = (size_t)jd * n + w; q = st.qpos[o]; v = st.qvel[o]; warm = st.warm[o]; }
+    if (isdof) { const size_t o = (size_t)jd * n + w1; q = st.qpos[o]; v = st.qvel[o]; warm = st.warm[o]; }
     GX<T, NX> qx, vx, warmx;
-    static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w; qx.x[t] = st.qpos[o]; vx.x[t] = st.qvel[o]; warmx.x[t] = st.warm[o]; });
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w1; qx.x[t] = st.qpos[o]; vx.x[t] = st.qvel[o]; warmx.x[t] = st.warm[o]; });
     int32_t cur[DL_CUR_WORDS];
 #pragma unroll
-    for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w];
+    for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w1];
     // per-walker words of the environment logic live in registers across the control steps of this launch
-    double walked = st.walked[w];
-    T comz = st.comz_off[w];
-    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w], st.mon[(size_t)MON_VELREW * n + w], st.mon[(size_t)MON_COMREW * n + w]};
+    double walked = st.walked[w1];
+    T comz = st.comz_off[w1];
+    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w1], st.mon[(size_t)MON_VELREW * n + w1], st.mon[(size_t)MON_COMREW * n + w1]};
     long long t_phys_end = 0;
     // push schedule on the device (BASELINE config 5 without a host round trip per control step)
     const V3<T> push_force = wk.push;
-    const int push_phase = (st.push_phase && st.rnd) ? st.push_phase[w] : -1;
+    const int push_phase = (st.push_phase && st.rnd) ? st.push_phase[w1] : -1;
 #pragma unroll 1
     for (int step = 0; step < nsteps; step++) {
+    // the walker index is opaque per control step: address arithmetic on it (some sixty per-walker words of state, Monitor and output
+    // arrays) is then done where it is used instead of being hoisted out of the loop as sixty 64-bit pointers (100 registers)
+    int w = w1;
+    DL_VPIN(w);
     if (push_phase >= 0) {
         const bool on = ((st.push_step0 + step + push_phase) % st.push_period) < st.push_dur;
         wk.push = on ? push_force : mk<T>(0, 0, 0);
@@ -197,7 +257,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 GX<T, NX> startx = warmx, accx;
                 if (stage == 1 && kf > 0) { start = warm + (warm - acc_s2_prev); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s2_prev.x[t]); }); }
                 else if (stage == 3) { start = warm + (warm - acc_s0); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s0.x[t]); }); }
-                const T acc = g_forward<T, TP, TIMED>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc);
+                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq);
                 if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
                 if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
@@ -316,6 +376,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     }
     if (valid && j == 0 && st.dbg) {
         st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
+#ifdef DL_EXP_SPLIT_PROF
+        if constexpr (SPLIT) { st.dbg[(size_t)n + w] = split_seq[1]; st.dbg[(size_t)2 * n + w] = split_seq[2]; st.dbg[(size_t)3 * n + w] = (int)((DL_CLOCK() - t_begin0) >> 4); }
+#endif
     }
     if (valid && j == 0) {
         monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
@@ -363,15 +426,19 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         terms[0] = terms[1] = terms[2] = 1.0;       // reset_model's sanity check evaluates the reward terms at the init state (:562)
     }
     }   // control steps of this launch
-    if (valid && j == 0) {
-        st.comz_off[w] = comz;
-        st.mon[(size_t)MON_POSREW * n + w] = terms[0]; st.mon[(size_t)MON_VELREW * n + w] = terms[1]; st.mon[(size_t)MON_COMREW * n + w] = terms[2];
-        st.walked[w] = walked;
-#pragma unroll
-        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w] = cur[k];
-        static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w; st.qpos[o] = qx.x[t]; st.qvel[o] = vx.x[t]; st.warm[o] = warmx.x[t]; });
+    if constexpr (SPLIT) {      // release the constraint wave
+        if (lane == 0) { ((volatile DL_LDS int*)g.mbox0)[GSplit<TP>::MB_CMD] = 0; ((volatile DL_LDS int*)g.mbox0)[GSplit<TP>::MB_CMDSEQ] = split_seq[0] + 1; }
+        DL_WAKE();
     }
-    if (valid && isdof) { const size_t o = (size_t)jd * n + w; st.qpos[o] = q; st.qvel[o] = v; st.warm[o] = warm; }
+    if (valid && j == 0) {
+        st.comz_off[w1] = comz;
+        st.mon[(size_t)MON_POSREW * n + w1] = terms[0]; st.mon[(size_t)MON_VELREW * n + w1] = terms[1]; st.mon[(size_t)MON_COMREW * n + w1] = terms[2];
+        st.walked[w1] = walked;
+#pragma unroll
+        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w1] = cur[k];
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w1; st.qpos[o] = qx.x[t]; st.qvel[o] = vx.x[t]; st.warm[o] = warmx.x[t]; });
+    }
+    if (valid && isdof) { const size_t o = (size_t)jd * n + w1; st.qpos[o] = q; st.qvel[o] = v; st.warm[o] = warm; }
     if constexpr (TIMED) {
         const long long t_end = DL_CLOCK();
         tacc[7] = t_end - t_begin; tacc[9] = t_end - t_phys_end;

@@ -89,6 +89,37 @@ __global__ __launch_bounds__(64) void k_env_step_g16(const GModel<T, TP>* __rest
                                   term_obs_all, rew_terms_all, inj_q, inj_v, inj_flags, ctrl_out, eval_mode, nsteps, tim);
 }
 
+// The same control steps with a SPLIT workgroup (lane-only walker, float32): eight waves serve sixteen walkers -- waves 0..3 are
+// dynamics waves (the whole step, g_wave_env_step), waves 4..7 constraint waves (g_constraint_server), the hardware spreads the eight waves
+// over the four SIMDs two by two, and constraint wave s serves dynamics wave s + 1 so that a SIMD holds two different groups of walkers
+// (the constraint work of one falls into the solver stalls of the other).  Capped at 256 registers: two waves per SIMD.
+template <typename T, typename TP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_env_step_g16_split(const GModel<T, TP>* __restrict__ gm, const DevCfg<T> c, const DevState<T> st, const float* __restrict__ actions_all,
+                          float* obs_all, float* rew_all, uint8_t* done_all, float* term_obs_all, float* rew_terms_all,
+                          const T* inj_q, const T* inj_v, const int32_t* inj_flags, float* ctrl_out, int eval_mode, int nsteps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Sp = GSplit<TP>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, role = wave >> 2, slot = wave & 3;
+#ifndef DL_SPLIT_PAIR_OFFSET
+#define DL_SPLIT_PAIR_OFFSET 1
+#endif
+    const int gslot = role == 0 ? slot : ((slot + DL_SPLIT_PAIR_OFFSET) & 3);   // the group of four walkers this wave works for
+    DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
+    if (lane == 0) {               // both waves of a pair clear the pair's flags, then the one barrier of this kernel
+        volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
+        f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1;
+    }
+    __syncthreads();
+    const int vwg = blockIdx.x * 4 + gslot, nvwg = gridDim.x * 4;
+    const int wblock = g_block_of_workgroup(vwg, nvwg);
+    if (role == 0)
+        g_wave_env_step<T, TP, false, true>(lane, wblock, vwg, nvwg, base, gm, c, st, actions_all, obs_all, rew_all, done_all, term_obs_all, rew_terms_all,
+                                            inj_q, inj_v, inj_flags, ctrl_out, eval_mode, nsteps, nullptr);
+    else
+        g_constraint_server<T, TP>(lane, wblock, base, gm, st);
+}
+
 // row primitives of dl_group.hpp on known data (tests/test_gpu_parity.py::test_row_primitives)
 __global__ __launch_bounds__(64) void k_selftest(const float* in, float* out) {
     const int lane = threadIdx.x;
@@ -482,6 +513,7 @@ struct dl_env_s {
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
     virtual int last_ctrl(float* out, hipStream_t) = 0;
+    virtual int set_split(int on) = 0;
     virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
     virtual int step_timed(const float*, float*, float*, uint8_t*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
@@ -514,6 +546,9 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     std::vector<void*> allocs;
     GModel<T, TP>* gmd = nullptr;    // table-driven model of the 16-lane kernels
     static constexpr size_t GLDS = (size_t)GW * GLds<TP>::TOTAL * sizeof(T);      // LDS of one wave (four walkers) of the 16-lane kernels
+    static constexpr bool CAN_SPLIT = sizeof(T) == 4 && GD<TP>::NX == 0;             // the split workgroup exists for the lane-only walker in float32
+    static constexpr size_t SLDS = (size_t)4 * GW * GSplit<TP>::TOTAL * sizeof(T);   // LDS of a split workgroup (four wave pairs, sixteen walkers)
+    bool split = false;              // dl_set_split: step launches use k_env_step_g16_split
     float* ctrl_dbg = nullptr;       // test hook (dl_debug_last_ctrl): sim.data.ctrl of the last single-step launch, float[N, nu]
     T *inj_q = nullptr, *inj_v = nullptr;
     int32_t* inj_flags = nullptr;
@@ -600,6 +635,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 HIPCHK(hipMemcpy(gmd, &gmh, sizeof gmh, hipMemcpyHostToDevice));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_g16<T, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLDS));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16<T, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLDS));
+                if constexpr (CAN_SPLIT) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_step_g16_split<T, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SLDS));
             }
         }
         const unsigned g256 = (unsigned)((n + 255) / 256);
@@ -628,6 +664,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         const int k = nsteps < MULTI ? nsteps : MULTI;
         st.push_step0 = push_step; push_step += k;
         prof_begin(s);
+        if constexpr (CAN_SPLIT) {
+            if (split) hipLaunchKernelGGL((k_env_step_g16_split<T, TP>), dim3(((n + GW - 1) / GW + 3) / 4), dim3(512), SLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, (float*)nullptr,
+                                          (float*)nullptr, (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, (float*)nullptr, eval_mode, k);
+        }
+        if (!split)
         hipLaunchKernelGGL((k_env_step_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
                            (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, (float*)nullptr, eval_mode, k);
         if (prof_open) prof_steps += k;
@@ -640,6 +681,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (variant == 1 && gmd) {
             st.push_step0 = push_step; push_step += 1;
             prof_begin(s);
+            if constexpr (CAN_SPLIT) {
+                if (split) hipLaunchKernelGGL((k_env_step_g16_split<T, TP>), dim3(((n + GW - 1) / GW + 3) / 4), dim3(512), SLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, term, terms,
+                                              (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), ctrl_dbg, eval_mode, 1);
+            }
+            if (!split)
             hipLaunchKernelGGL((k_env_step_g16<T, TP>), dim3((n + GW - 1) / GW), dim3(64), GLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, term, terms,
                                (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), ctrl_dbg, eval_mode, 1);
             if (prof_open) prof_steps += 1;
@@ -766,6 +812,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             return DL_OK;
         }
         return fail(DL_E_INVAL, "dl_debug_step_timed: float32 only");
+    }
+    int set_split(int on) override {
+        if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels of the lane-only (straight) walker");
+        split = on != 0;
+        return DL_OK;
     }
     int last_ctrl(float* out, hipStream_t s) override {
         if (!(variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_debug_last_ctrl: implemented by the 16-lane kernels");
@@ -907,6 +958,10 @@ int dl_debug_capstate(dl_handle h, float* out, void* stream) {
 }
 /* sim.data.ctrl as the last dl_step set it (after _rescale_actions and mirror_action): float[N, nu] device; the first call
  * (out may be NULL) enables the record */
+int dl_set_split(dl_handle h, int32_t on) {
+    NEED(h);
+    return h->set_split(on);
+}
 int dl_debug_last_ctrl(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->last_ctrl(out, (hipStream_t)stream);
@@ -995,6 +1050,108 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
+// ---- K consecutive VecNormalize steps in five launches (dl_vecnormalize_steps): the per-step batch sums do not depend on each other once the
+// shift of the sums is fixed (the moments at the start of the run), only the Chan merge is sequential -- and that is K x (D + 1) scalars.
+//   k_vns_returns: ret_t = ret_{t-1} gamma + rew_t per walker (and the reset at episode ends), all K values kept for the sums
+//   k_vns_partial: per step and block the shifted sums of the observation columns and of ret_t (the layout of k_vn_reduce_mb)
+//   k_vns_merge:   per column the K merges in step order; leaves the running (mean, var) AFTER every step for k_vns_apply
+//   k_vns_apply:   the K normalisations
+__global__ __launch_bounds__(256) void k_vns_returns(const float* __restrict__ rew, const uint8_t* __restrict__ done, double* ret, double* rets, int K, int B, double gamma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double r = ret[i];
+    for (int t = 0; t < K; t++) {
+        r = r * gamma + (double)rew[(size_t)t * B + i];
+        rets[(size_t)t * B + i] = r;
+        if (done[(size_t)t * B + i]) r = 0;
+    }
+    ret[i] = r;
+}
+__global__ __launch_bounds__(256) void k_vns_partial(const float* __restrict__ x, const double* __restrict__ rets, const double* __restrict__ mean, const double* __restrict__ ret_mean,
+                                                  int B, int D, int flags, double* work) {
+    __shared__ double sh[2][256];
+    __shared__ double sh2[4];
+    const int t = threadIdx.x, W = D + 1, step = blockIdx.y;
+    double* wk = work + ((size_t)step * VN_BLOCKS + blockIdx.x) * W * 2;
+    if (flags & 1) {
+        const float* xs = x + (size_t)step * B * D;
+        const int rpb = blockDim.x / D, nthr = rpb * D;
+        double s = 0, ss = 0;
+        const int col = t % D, rsub = t / D;
+        if (t < nthr) {
+            const double K0 = mean[col];
+            const int stride = VN_BLOCKS * rpb;
+            int row = blockIdx.x * rpb + rsub;
+            for (; row + 3 * stride < B; row += 4 * stride) {
+                const float a0 = xs[(size_t)row * D + col], a1 = xs[(size_t)(row + stride) * D + col], a2 = xs[(size_t)(row + 2 * stride) * D + col], a3 = xs[(size_t)(row + 3 * stride) * D + col];
+                const double d0 = (double)a0 - K0, d1 = (double)a1 - K0, d2 = (double)a2 - K0, d3 = (double)a3 - K0;
+                s += d0; ss += d0 * d0; s += d1; ss += d1 * d1; s += d2; ss += d2 * d2; s += d3; ss += d3 * d3;
+            }
+            for (; row < B; row += stride) { const double d = (double)xs[(size_t)row * D + col] - K0; s += d; ss += d * d; }
+        }
+        sh[0][t] = s; sh[1][t] = ss;
+        __syncthreads();
+        if (t < D) {
+            for (int r = 1; r < rpb; r++) { s += sh[0][r * D + t]; ss += sh[1][r * D + t]; }
+            wk[t * 2] = s; wk[t * 2 + 1] = ss;
+        }
+    }
+    if (flags & 4) {
+        const int chunk = (B + VN_BLOCKS - 1) / VN_BLOCKS, lo = blockIdx.x * chunk, hi = lo + chunk < B ? lo + chunk : B;
+        const double K0 = *ret_mean;
+        const double* rs = rets + (size_t)step * B;
+        double s = 0, ss = 0;
+        for (int i = lo + t; i < hi; i += blockDim.x) { const double d = rs[i] - K0; s += d; ss += d * d; }
+        s = block_sum(s, sh2); ss = block_sum(ss, sh2);
+        if (t == 0) { wk[D * 2] = s; wk[D * 2 + 1] = ss; }
+    }
+}
+__global__ __launch_bounds__(128) void k_vns_merge(const double* __restrict__ work, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
+                                                int K, int B, int D, int flags, double* stats) {
+    const int d = threadIdx.x, W = D + 1;
+    const bool active = d < W, is_obs = d < D, upd = is_obs ? (flags & 1) != 0 : (flags & 4) != 0;
+    double* mp = is_obs ? mean + d : ret_mean;
+    double* vp = is_obs ? var + d : ret_var;
+    double m = 0, v = 0, cnt = 0;
+    if (active) { m = *mp; v = *vp; cnt = is_obs ? *count : *ret_count; }
+    __syncthreads();                           // every column has read the counts before one of them writes them back
+    if (!active) return;
+    const double K0 = m;                       // the shift of every step's sums
+    for (int t = 0; t < K; t++) {
+        if (upd) {
+            const double* wk = work + (size_t)t * VN_BLOCKS * W * 2;
+            double S = 0, SS = 0;
+            for (int b = 0; b < VN_BLOCKS; b++) { S += wk[((size_t)b * W + d) * 2]; SS += wk[((size_t)b * W + d) * 2 + 1]; }
+            const double bm = K0 + S / B, bv = SS / B - (S / B) * (S / B);
+            const double tot = cnt + B, delta = bm - m;
+            const double M2 = v * cnt + bv * B + delta * delta * cnt * B / tot;
+            m = m + delta * B / tot; v = M2 / tot; cnt = tot;
+        }
+        stats[((size_t)t * W + d) * 2] = m; stats[((size_t)t * W + d) * 2 + 1] = v;
+    }
+    *mp = m; *vp = v;
+    if (upd && (d == 0 || d == D)) { if (is_obs) *count = cnt; else *ret_count = cnt; }
+}
+__global__ __launch_bounds__(256) void k_vns_apply(const float* __restrict__ x, const float* __restrict__ rew, const double* __restrict__ stats, int K, int B, int D,
+                                                double eps, double clip_obs, double clip_rew, int flags, float* const* obs_out, float* const* rew_out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = (size_t)B * D;
+    const int W = D + 1;
+    if (idx < (size_t)K * per) {
+        const int t = (int)(idx / per);
+        const size_t e = idx - (size_t)t * per;
+        const int k = (int)(e % D);
+        double y = (double)x[idx];
+        if (flags & 2) { const double* st = stats + ((size_t)t * W + k) * 2; y = (y - st[0]) / sqrt(st[1] + eps); y = y < -clip_obs ? -clip_obs : (y > clip_obs ? clip_obs : y); }
+        obs_out[t][e] = (float)y;
+    }
+    if (idx < (size_t)K * B) {
+        const int t = (int)(idx / B);
+        const size_t e = idx - (size_t)t * B;
+        double y = (double)rew[idx];
+        if (flags & 8) { y = y / sqrt(stats[((size_t)t * W + D) * 2 + 1] + eps); y = y < -clip_rew ? -clip_rew : (y > clip_rew ? clip_rew : y); }
+        rew_out[t][e] = (float)y;
+    }
+}
 static int vn_reduce_launch(const float* obs, const float* rew, double* obs_mean, double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                             double* ret_count, int32_t B, int32_t D, double gamma, int32_t flags, void* workspace, void* stream) {
     if ((flags & 5) && (flags & 16) && workspace) {
@@ -1020,6 +1177,24 @@ int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done
     const size_t ne = (size_t)B * D;
     hipLaunchKernelGGL(k_vn_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, rew, done, (const double*)obs_mean, (const double*)obs_var, obs_count,
                        ret, (const double*)ret_var, ret_count, B, D, eps, clip_obs, clip_rew, flags, obs_out, rew_out);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_vecnormalize_steps(const dl_vecnorm_state* vn, int32_t K, const float* obs, const float* rew, const uint8_t* done, int32_t B, int32_t D,
+                          float* const* obs_out, float* const* rew_out, void* workspace, void* stream) {
+    if (!vn || !obs || !rew || !done || !obs_out || !rew_out || !workspace || K <= 0 || B <= 0 || D <= 0 || D > 127)
+        return fail(DL_E_INVAL, "dl_vecnormalize_steps: bad arguments");
+    if (!vn->obs_mean || !vn->obs_var || !vn->obs_count || !vn->ret || !vn->ret_mean || !vn->ret_var || !vn->ret_count) return fail(DL_E_INVAL, "dl_vecnormalize_steps: NULL state array");
+    const int W = D + 1, flags = vn->flags;
+    double* rets = (double*)workspace;                               // [K, B]
+    double* work = rets + (size_t)K * B;                             // [K, VN_BLOCKS, W, 2]
+    double* stats = work + (size_t)K * VN_BLOCKS * W * 2;            // [K, W, 2]
+    hipStream_t s = (hipStream_t)stream;
+    if (flags & 4) hipLaunchKernelGGL(k_vns_returns, dim3((B + 255) / 256), dim3(256), 0, s, rew, done, vn->ret, rets, K, B, vn->gamma);
+    if (flags & 5) hipLaunchKernelGGL(k_vns_partial, dim3(VN_BLOCKS, K), dim3(256), 0, s, obs, (const double*)rets, (const double*)vn->obs_mean, (const double*)vn->ret_mean, B, D, flags, work);
+    hipLaunchKernelGGL(k_vns_merge, dim3(1), dim3(128), 0, s, (const double*)work, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret_mean, vn->ret_var, vn->ret_count, K, B, D, flags, stats);
+    const size_t ne = (size_t)K * B * D;
+    hipLaunchKernelGGL(k_vns_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, obs, rew, (const double*)stats, K, B, D, vn->eps, vn->clip_obs, vn->clip_rew, flags, obs_out, rew_out);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

@@ -62,6 +62,7 @@ _SIGNATURES = {
     'dl_set_randomization': (C.c_int, [_V, _P, _P, _P]),
     'dl_set_push': (C.c_int, [_V, _P, _P]),
     'dl_set_push_schedule': (C.c_int, [_V, _P, _P, _I, _I, _P]),
+    'dl_set_split': (C.c_int, [_V, _I]),
     'dl_terminate_early': (C.c_int, [_V, _P, _P]),
     'dl_stats_snapshot': (C.c_int, [_V, C.c_char_p, _P, _P]),
     'dl_profile': (C.c_int, [_V, _I]),
@@ -71,6 +72,7 @@ _SIGNATURES = {
     'dl_normalize_obs': (C.c_int, [_P, _P, _P, _I, _I, C.c_double, C.c_double, _P]),
     'dl_normalize_reward': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, _P]),
     'dl_vecnormalize_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P, _P, _P]),
+    'dl_vecnormalize_steps': (C.c_int, [C.POINTER(abi.VecNormState), _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'dl_policy_forward': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _I, _P, C.c_uint64, C.c_uint64, _I, _I, _P, _P, _P, _P]),
     'dl_rollout_policy': (C.c_int, [_V, C.POINTER(abi.PolicyParams), C.c_uint64, C.c_uint64, _I, C.POINTER(abi.VecNormState), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'dl_gae': (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, _I, _I, _P, _P, _P]),

@@ -42,6 +42,9 @@ class HipVecEnv(_VecEnvBase):
                  model=None, refs=None, env_index_base=0, **config):
         if not torch.cuda.is_available():
             raise lib.DrlocoError('HipVecEnv needs a HIP device; there is no CPU fallback')
+        split = config.get('lanes_per_walker') == 'split'          # shorthand: 16 lanes per walker + set_split(True)
+        if split:
+            config['lanes_per_walker'] = 16
         self._lib = lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.env_id = env_id
@@ -81,6 +84,9 @@ class HipVecEnv(_VecEnvBase):
         self._ep_len = np.zeros(n, np.int64)
         self.ep_lens = [[] for _ in range(n)]
         self._mlists = None                        # track_monitor_lists()
+        self.split = False
+        if split:
+            self.set_split(True)
 
     # ---- VecEnv surface -------------------------------------------------------------------
     def reset(self, mask=None, init_step=None, init_pos=None):
@@ -222,6 +228,12 @@ class HipVecEnv(_VecEnvBase):
         f = None if force is None else torch.as_tensor(np.asarray(force, np.float32), device=self.device).contiguous()
         lib.check(self._lib.dl_set_push(self._h, _ptr(f), _stream()))
         torch.cuda.current_stream().synchronize()
+
+    def set_split(self, on=True):
+        """dl_set_split: the eight-wave workgroup form of the step kernel (dynamics waves + constraint waves; straight walker, float32,
+        16 lanes per walker).  Shorter launches, but nothing else runs next to it: for single-handle use (bench.py switches it on)."""
+        lib.check(self._lib.dl_set_split(self._h, int(bool(on))))
+        self.split = bool(on)
 
     def set_push_schedule(self, force=None, phase=None, period=400, duration=20):
         """Periodic pushes kept on the device: walker w is pushed with force[w] during the k-th control step from now iff
@@ -431,6 +443,9 @@ class HipVecNormalize(_VecEnvWrapperBase):
         # env-step kernel: enable_overlap; and for large batches, where one CU's time grows with the batch: 236 us for 16 384 walkers
         # under contention).  Both are deterministic; they sum in different orders, i.e. their moments can differ in the last bit.
         self.multi_block_reduce = self.num_envs > 4096
+        # fixed-action runs (steps_fixed): normalise the K steps of a run with dl_vecnormalize_steps (five launches) instead of K x
+        # dl_vecnormalize_step; the moments then agree with the step-by-step form to rounding (the shift of the sums differs), not bit for bit
+        self.batched_steps = False
 
     # the raw outputs of the last step stay in the env's own tensors (get_original_obs / get_original_reward)
     @property
@@ -514,11 +529,35 @@ class HipVecNormalize(_VecEnvWrapperBase):
         ov['stepped'][half].record(main)
         side.wait_event(ov['stepped'][half])
         with torch.cuda.stream(side):
-            for k, done, obs_out, rew_out in ov['pending']:
-                self._vn_launch(ov['raw'][k][0], ov['raw'][k][1], done, obs_out, rew_out)
+            if self.batched_steps and len(ov['pending']) > 1:
+                self._vn_launch_steps(ov['pending'])
+            else:
+                for k, done, obs_out, rew_out in ov['pending']:
+                    self._vn_launch(ov['raw'][k][0], ov['raw'][k][1], done, obs_out, rew_out)
             ov['read'][half] = ov['readev'][half]
             ov['read'][half].record(side)
         ov['pending'] = []
+
+    def _vn_launch_steps(self, pending):
+        """dl_vecnormalize_steps for a run of consecutive ring slots: five launches instead of two per control step (the moments agree
+        with the step-by-step form to rounding, include/drloco_hip.h).  pending: [(ring slot, done row, obs_out, rew_out)], slots consecutive."""
+        ov = self._ov
+        K, k0 = len(pending), pending[0][0]
+        n, d = self.venv.obs.shape
+        assert all(p[0] == k0 + i for i, p in enumerate(pending)) and pending[0][1].data_ptr() + (K - 1) * n == pending[-1][1].data_ptr()
+        need = abi.vn_steps_workspace_bytes(K, n, d)
+        if ov.get('steps_work') is None or ov['steps_work'].numel() < need:
+            ov['steps_work'] = torch.empty(need, dtype=torch.uint8, device=self.venv.device)
+        key = (k0, tuple(p[2].data_ptr() for p in pending), tuple(p[3].data_ptr() for p in pending))
+        ptrs = ov.setdefault('steps_ptrs', {})
+        if key not in ptrs:         # destinations of a rollout repeat from rollout to rollout: one upload per distinct run
+            if len(ptrs) > 16:
+                ptrs.clear()
+            ptrs[key] = (torch.tensor(key[1], dtype=torch.int64).to(self.venv.device), torch.tensor(key[2], dtype=torch.int64).to(self.venv.device))
+        po, pr = ptrs[key]
+        st = self.state_struct()
+        lib.check(self._lib.dl_vecnormalize_steps(C.byref(st), K, _ptr(ov['raw_obs'][k0]), _ptr(ov['raw_rew'][k0]), _ptr(pending[0][1]), n, d, _ptr(po), _ptr(pr),
+                                                  _ptr(ov['steps_work']), _stream()))
 
     def enable_overlap(self, chunk=8):
         """Software pipelining for callers whose next actions do not depend on this step's normalised observation

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 3   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16 */
+#define DL_ABI_VERSION 4   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -232,6 +232,14 @@ int dl_set_push(dl_handle h, const float* force, void* stream);
 int dl_set_push_schedule(dl_handle h, const float* force, const int32_t* phase, int32_t period, int32_t duration,
                          void* stream);
 
+/* Launch form of the step kernel for the straight walker in float32 (16 lanes per walker): on = 1 launches workgroups of eight waves for
+ * sixteen walkers -- four dynamics waves and four constraint waves that build the collision / contact / limit rows of the same walkers
+ * while the dynamics waves run the smooth dynamics (two waves per SIMD, registers capped at 256, 143 KB of LDS per workgroup) -- instead of
+ * one wave per four walkers.  6 % shorter launches at 4096 walkers; nothing else fits on the GPU next to it, so callers that overlap
+ * other kernels with the step (several handles with a policy in the loop) keep the default, 0.  Same algorithm; the float32 results of the
+ * two forms differ in the last bit (two instantiations).  Returns DL_E_INVAL for the other walker / float64 / one lane per walker. */
+int dl_set_split(dl_handle h, int32_t on);
+
 /* MimicEnv.do_terminate_early (mimic_env.py:652-702; the reference defines it but its call in step() is commented
  * out, :113-118) at the current state of every walker: flags int32[N, 4] device =
  * {terminate, COM height too low (< 0.75), trunk angle exceeded, |COM y| > 0.2}.  Straight walker only. */
@@ -325,6 +333,17 @@ typedef struct dl_vecnorm_state {
     double gamma, eps, clip_obs, clip_rew;
     int32_t flags;                                            /* as dl_vecnormalize_step */
 } dl_vecnorm_state;
+
+/* K consecutive dl_vecnormalize_step calls (SB3 1.0 VecNormalize.step_wait, K control steps of a fixed-action rollout) in five launches
+ * instead of 2 K: obs float[K, B, D], rew float[K, B], done uint8[K, B] (time-major, contiguous, DEVICE); obs_out / rew_out: DEVICE arrays of K
+ * pointers, the destination of every step (rollout-buffer slots).  The moments advance exactly as K single steps would advance them, up
+ * to rounding: the shifted sums of all K batches use the moments at the start of the run as their shift (the single steps use the moments
+ * of the step before), the merges are the same and run in step order; vn->flags bit 16 is irrelevant here.  workspace: caller-owned
+ * device memory of DL_VN_STEPS_WORKSPACE_BYTES(K, B, D), no initialisation needed. */
+#define DL_VN_STEPS_WORKSPACE_BYTES(K, B, D) (8 * ((size_t)(K) * (B) + (size_t)(K) * 32 * ((D) + 1) * 2 + (size_t)(K) * ((D) + 1) * 2))
+int dl_vecnormalize_steps(const dl_vecnorm_state* vn, int32_t K, const float* obs, const float* rew, const uint8_t* done,
+                          int32_t B, int32_t D, float* const* obs_out, float* const* rew_out, void* workspace,
+                          void* stream);
 
 /* SB3 1.0 OnPolicyAlgorithm.collect_rollouts for T steps in ONE call (constructed at
  * drloco/train.py:110-118, the loop SB3 runs between two PPO updates): for t = 0..T-1

@@ -27,6 +27,8 @@ def torch_cuda():
 
 
 LANES = pytest.mark.parametrize('lanes', [1, 16], ids=['lane-per-walker', '16-lanes-per-walker'])
+# float32 tests of the straight walker also run the split-workgroup launch form of the 16-lane kernels (dl_set_split)
+LANES_S = pytest.mark.parametrize('lanes', [1, 16, 'split'], ids=['lane-per-walker', '16-lanes-per-walker', '16-lanes-split-workgroups'])
 
 
 def make_pair(oracle, model, refs, n, precision, **cfg):
@@ -122,7 +124,7 @@ def test_rollout_f64_matches_oracle(torch_cuda, oracle, model, refs, lanes):
         np.testing.assert_allclose(dev.get_attr(name), orc.stats(name), rtol=1e-5, atol=1e-6, err_msg=name)
 
 
-@LANES
+@LANES_S
 def test_single_step_f32(torch_cuda, oracle, model, refs, lanes):
     """The product precision: one control step (5 RK4 substeps) from identical states."""
     n = 2048
@@ -153,7 +155,7 @@ def test_single_step_f32(torch_cuda, oracle, model, refs, lanes):
     assert rel.max() < 1e-4, rel.max()         # north_star: reward parity within 1e-4 relative
 
 
-@LANES
+@LANES_S
 def test_rollout_f32_statistics(torch_cuda, oracle, model, refs, lanes):
     """Over a horizon the fp32 and fp64 trajectories of a contact-rich system separate (chaos), so
     the horizon-level check is statistical: mean reward and mean episode length agree."""
@@ -220,7 +222,7 @@ def test_G4_step_traces_on_device(torch_cuda, model, refs, precision, case, lane
             np.testing.assert_allclose(infos[0]['terminal_observation'], G['obs'][t], **tol)
 
 
-@LANES
+@LANES_S
 def test_G2_cursor_on_device(torch_cuda, model, refs, lanes):
     from drloco_amd.vec_env import HipVecEnv
     with np.load(os.path.join(GOLDEN, 'G2_cursor_traces.npz')) as z:
@@ -375,7 +377,7 @@ def test_vecnormalize_matches_numpy(torch_cuda, oracle, model, refs):
     np.testing.assert_allclose(vn.ret_rms.var, rvar[0], rtol=1e-5)
 
 
-@LANES
+@LANES_S
 def test_full_size_properties(torch_cuda, model, refs, lanes):
     """BASELINE config 2 size (4096 walkers): size-independent properties."""
     import torch
@@ -1022,6 +1024,115 @@ def test_steps_fixed_runs_match_the_step_by_step_path(torch_cuda, model, refs):
     assert res[0][2].sum() > 100        # episodes ended inside the window
 
 
+def test_split_workgroups(torch_cuda, oracle, model, refs):
+    """dl_set_split (eight-wave workgroups: dynamics waves + constraint waves): ragged walker counts (partly filled and empty wave pairs),
+    a multi-step launch against single steps (bit for bit), randomisation + push schedule, and the refusals."""
+    import torch
+    from drloco_amd import lib as dl_lib, mocap, models
+    from drloco_amd.vec_env import HipVecEnv
+    # ragged sizes, float32, against the oracle from identical states
+    for n in (1, 5, 17, 70):
+        dev, orc = make_pair(oracle, model, refs, n, 32, lanes_per_walker='split')
+        assert dev.split
+        rng = np.random.default_rng(n)
+        orc.reset(); dev.reset()
+        for t in range(10):
+            orc.step(np.clip(0.3 * rng.standard_normal((n, 8)), -1, 1))
+        st = orc.get_state()
+        dev.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=st['warm'], cursor=st['cursor'], walked=st['walked'])
+        a = np.clip(0.5 * rng.standard_normal((n, 8)), -1, 1).astype(np.float32)
+        o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2)
+        live = ~d2
+        assert (np.abs(r1 - r2)[live] / np.abs(r1[live])).max() < 1e-4 if live.any() else True
+        np.testing.assert_allclose(o2[live], o1[live], atol=2e-2, rtol=1e-3)
+        dev.close()
+    # one launch of 37 control steps == 37 launches, bit for bit; with randomisation and a push schedule on
+    n, T = 200, 37
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    acts = torch.clamp(0.6 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
+    rng = np.random.default_rng(0)
+    outs = []
+    for multi in (False, True):
+        env = HipVecEnv(num_envs=n, seed=3, model=model, refs=refs, lanes_per_walker='split', ep_dur_max=20)       # episodes end (and reset) inside the window
+        env.set_randomization(rng.uniform(0.8, 1.2, n) * 0 + np.linspace(0.8, 1.2, n), np.linspace(0.5, 1.1, n))
+        ang = np.linspace(0, 6.28, n)
+        env.set_push_schedule(np.stack([50 * np.cos(ang), 50 * np.sin(ang), 0 * ang], 1), (np.arange(n) % 13).astype(np.int32), period=13, duration=3)
+        env.reset_tensors()
+        if multi:
+            o, r, d = env.rollout_fixed(acts)
+            outs.append((o.cpu().clone(), r.cpu().clone(), d.cpu().clone()))
+        else:
+            O, R, D = [], [], []
+            for t in range(T):
+                env.step_tensors(acts[t]); O.append(env.obs.cpu().clone()); R.append(env.rew.cpu().clone()); D.append(env.done.cpu().clone())
+            outs.append((torch.stack(O), torch.stack(R), torch.stack(D)))
+        env.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert outs[0][2].sum() > 0
+    # the form does not exist for float64, one lane per walker and the 19-dof walker
+    for kw in (dict(precision=64), dict(lanes_per_walker=1)):
+        env = HipVecEnv(num_envs=8, model=model, refs=refs, **kw)
+        with pytest.raises(dl_lib.DrlocoError):
+            env.set_split(True)
+        env.set_split(False)
+        env.close()
+    ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
+    env = HipVecEnv(models.WALKER_165CM, num_envs=8, refs=mocap.loco3d_table(ang, vel))
+    with pytest.raises(dl_lib.DrlocoError):
+        env.set_split(True)
+    env.close()
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_batched_vecnormalize_steps_match_single_steps(torch_cuda, model, refs, split):
+    """dl_vecnormalize_steps (the K normalisations of a fixed-action run in five launches) against K x dl_vecnormalize_step: same moments to
+    1e-12, same float32 outputs to one rounding of the normalisation; non-training and single-flag forms included.  split = True: both sides
+    simulate with the split-workgroup step kernel (dl_set_split: constraint waves next to the dynamics waves; its float32 results differ from
+    the one-wave kernel's in the last bit -- another instantiation -- so the comparison stays inside one form)."""
+    import torch
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    n, T, runs = 384, 96, 40
+    g = torch.Generator(device='cuda'); g.manual_seed(8)
+    acts = torch.clamp(0.6 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
+    for kw in (dict(), dict(training=False), dict(norm_reward=False), dict(norm_obs=False)):
+        res = []
+        for mode in ('single', 'batched'):
+            venv = HipVecEnv(num_envs=n, seed=2, model=model, refs=refs)
+            if split:
+                venv.set_split(True)
+            vn = HipVecNormalize(venv, **kw)
+            vn.batched_steps = mode != 'single'
+            buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+            buf.actions.copy_(acts)
+            vn.reset()
+            last_obs = vn.norm_obs_t.clone(); last_done = buf.next_starts; last_done.fill_(1)
+            vn.enable_overlap(chunk=runs)
+            for rollout in range(2):
+                buf.observations[0].copy_(last_obs); buf.episode_starts[0].copy_(last_done)
+                for t0 in range(0, T, runs):
+                    ts = range(t0, min(t0 + runs, T))
+                    vn.steps_fixed(buf.actions[t0:ts[-1] + 1], [buf.observations[t + 1] if t + 1 < T else last_obs for t in ts], [buf.rewards[t] for t in ts],
+                                   buf._starts[t0 + 1:ts[-1] + 2])
+                vn.flush()
+            torch.cuda.synchronize()
+            res.append(dict(obs=buf.observations.cpu().clone(), rew=buf.rewards.cpu().clone(), starts=buf._starts.cpu().clone(), last=last_obs.cpu().clone(),
+                            om=np.array(vn.obs_rms.mean), ov=np.array(vn.obs_rms.var), oc=float(vn.obs_rms.count), rm=float(np.array(vn.ret_rms.mean)), rv=float(np.array(vn.ret_rms.var)),
+                            rc=float(vn.ret_rms.count), raw=torch.as_tensor(vn.get_original_obs()).clone()))
+        a = res[0]
+        for b in res[1:]:
+            assert torch.equal(a['starts'], b['starts']) and torch.equal(a['raw'], b['raw']), kw        # the simulation itself is untouched
+            np.testing.assert_allclose(b['om'], a['om'], rtol=1e-12, atol=1e-13, err_msg=str(kw)); np.testing.assert_allclose(b['ov'], a['ov'], rtol=1e-11, err_msg=str(kw))
+            assert b['oc'] == a['oc'] and b['rc'] == a['rc']
+            np.testing.assert_allclose([b['rm'], b['rv']], [a['rm'], a['rv']], rtol=1e-11)
+            np.testing.assert_allclose(b['obs'].numpy(), a['obs'].numpy(), rtol=0, atol=2e-6, err_msg=str(kw))
+            np.testing.assert_allclose(b['rew'].numpy(), a['rew'].numpy(), rtol=0, atol=2e-6, err_msg=str(kw))
+            np.testing.assert_allclose(b['last'].numpy(), a['last'].numpy(), rtol=0, atol=2e-6)
+        assert a['starts'].sum() > 100
+
+
 def test_env_group_handles_are_shards(torch_cuda, model, refs):
     """HipEnvGroup (several handles, each with its policy -> step -> normalise chain on its own stream): every handle's
     rollout is exactly what that shard produces when run on its own, the moment merge is the exact Chan merge of the
@@ -1310,7 +1421,7 @@ def test_loco3d_randomization_and_push(torch_cuda, oracle):
         dev.close()
 
 
-@LANES
+@LANES_S
 def test_f32_contact_activation_flips_after_reset_are_counted(torch_cuda, oracle, model, refs, lanes):
     """Quantifies the one systematic float32 effect: right after a reset the lowest foot corner sits exactly ON the
     floor (reset_model shifts the walker by the lowest site's height), so whether that contact is active is decided by the last bit.
@@ -1326,7 +1437,7 @@ def test_f32_contact_activation_flips_after_reset_are_counted(torch_cuda, oracle
     qa, nc, ne, _ = orc.forward(u); qb, nc2, ne2, _ = dev.forward(u)
     flip = nc != nc2
     frac = flip.mean()
-    print('post-reset contact-set flips (lanes %d): %d of %d walkers (%.2f %%), |dncon| max %d' % (lanes, flip.sum(), n, 100 * frac, np.abs(nc - nc2).max()))
+    print('post-reset contact-set flips (lanes %s): %d of %d walkers (%.2f %%), |dncon| max %d' % (lanes, flip.sum(), n, 100 * frac, np.abs(nc - nc2).max()))
     assert frac < 0.01 and np.abs(nc - nc2).max() <= 2
     same = ~flip
     assert np.array_equal(ne[same], ne2[same])

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Split workgroup (DL_SPLIT=1, experiment build with -DDL_EXP_SPLIT_PROF): cycles the dynamics wave spends in the smooth dynamics and waiting
+for its constraint wave, per control step."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from drloco_amd.vec_env import HipVecEnv
+n, T = 4096, 64
+env = HipVecEnv(num_envs=n, seed=1)
+env.reset_tensors()
+g = torch.Generator(device='cuda'); g.manual_seed(3)
+acts = torch.clamp(0.5 * torch.randn(T, n, env.nu, device='cuda', generator=g), -1, 1)
+env.rollout_fixed(acts)              # warm-up: walkers spread over the gait
+env.debug_counters()
+env.rollout_fixed(acts)
+c = env.debug_counters().astype(np.float64) * 16
+wait, smooth, total = c[1][::4] / T, c[2][::4] / T, c[3][::4] / T
+print(f'per control step and dynamics wave (cycles): whole {total.mean():.0f} (max {total.max():.0f}), smooth dynamics {smooth.mean():.0f}, waiting for the constraint wave {wait.mean():.0f} (max {wait.max():.0f})')

@@ -15,6 +15,7 @@ ap.add_argument('--warm', type=int, default=64)
 ap.add_argument('--single', action='store_true', help='one control step per launch (dl_step) instead of dl_rollout_fixed')
 ap.add_argument('--variant', type=int, default=0, help='lanes per walker: 0 auto, 1, 16')
 ap.add_argument('--walker', choices=['straight', 'loco3d'], default='straight')
+ap.add_argument('--no-split', action='store_true', help='one wave per four walkers instead of the split workgroups bench.py uses for the straight walker')
 args = ap.parse_args()
 if args.walker == 'loco3d':
     from drloco_amd import mocap, models
@@ -22,6 +23,8 @@ if args.walker == 'loco3d':
     env = HipVecEnv(models.WALKER_165CM, num_envs=args.envs, lanes_per_walker=args.variant, refs=mocap.loco3d_table(ang, vel))
 else:
     env = HipVecEnv(num_envs=args.envs, lanes_per_walker=args.variant)
+    if args.variant in (0, 16) and not args.no_split:
+        env.set_split(True)          # the launch form of the benchmark
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
 acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, env.nu, device='cuda', generator=g), -1, 1)
