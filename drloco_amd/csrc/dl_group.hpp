@@ -688,7 +688,7 @@ template <typename T, typename TP> struct GSmooth {
 // The replicated root translations are ancestors of every lane: their velocity enters every twist, their composite
 // inertia / wrench is the whole walker's (the subtree of lane 0), M[j][t] = S_t . (Ic_j S_j) is one entry per lane.
 // Out: sm; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
-template <typename T, typename TP, bool PUBLISH = true>
+template <typename T, typename TP, bool PUBLISH = true, bool HAVE_KIN = false>      // HAVE_KIN: the caller has run g_fk already (k is an input)
 __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx,
                                                   GKin<T>& k, GSmooth<T, TP>& sm) {
     using Ld = GLds<TP>;
@@ -696,7 +696,7 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     const auto& ln = *g.ln;
-    g_fk<T, TP, PUBLISH>(g, lt, q, qx, k);
+    if constexpr (!HAVE_KIN) g_fk<T, TP, PUBLISH>(g, lt, q, qx, k);
     const bool isdof = j < NL;
     // motion subspace of dof j and its joint velocity contribution
     SV<T> S;
@@ -1262,17 +1262,18 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
     if constexpr (SPLIT) {
         static_assert(NX == 0, "the split workgroup is built for the lane-only walker");
         using Sp = GSplit<TP>;
-        // hand the configuration and the solver's start point to the constraint wave, then do the smooth dynamics meanwhile
+        // the kinematics first: body frames and root height go to LDS for the constraint wave, which then needs no kinematics of its own;
+        // with them the configuration and the solver's start point; then the rest of the smooth dynamics while the partner works
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
-        g_sync<T>();
+        g_fk<T, TP, true>(g, lt, q, qx, kin);
         const int seq = ++*split_seq;
         if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
         DL_WAKE();
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp0 = DL_CLOCK();
 #endif
-        g_smooth_dynamics<T, TP, false>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
+        g_smooth_dynamics<T, TP, false, true>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
         tick(0);
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp1 = DL_CLOCK();

@@ -83,8 +83,9 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
 }
 
 // The constraint wave of a split workgroup: serves the dynamics wave that owns the same four walkers (same LDS regions).  Per request
-// (q and the solver's start point B v + a in the mailbox) it runs the kinematics + collision + constraint construction of g_forward --
-// body frames, contacts, rows, contact Jacobians, all in the walker's LDS region -- and reports (ncon, nlim, the lanes' limit rows).
+// (q and the solver's start point B v + a in the mailbox, body frames and root height in the walker's LDS region) it runs the first half of
+// g_forward's constraint stage -- collision, contact records, limit and contact rows, all in the walker's LDS region -- and reports
+// (ncon, nlim, the lanes' limit rows); the contact Jacobians are the dynamics wave's.
 // Waits are bounded polls: a protocol error ends in wrong numbers (caught by the tests), never in a hung GPU.
 #if !defined(DL_GROUP_EMU)
 template <typename T, typename TP>
@@ -115,9 +116,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         seq = cur;
         g_sync<T>();
         const T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j];
-        GKin<T> kin;
-        GX<T, 0> qx;
-        g_fk<T, TP, true>(g, lt, q, qx, kin);
+        GKin<T> kin{};                 // the first half of the constraint stage reads the body frames its partner left in LDS, not the lane's kinematics
         int nlim, ncon, my_lim;
         T lim_sign;
         const T x0x[1] = {T(0)};

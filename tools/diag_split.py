@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from drloco_amd.vec_env import HipVecEnv
 n, T = 4096, 64
-env = HipVecEnv(num_envs=n, seed=1)
+env = HipVecEnv(num_envs=n, seed=1, lanes_per_walker="split")
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(3)
 acts = torch.clamp(0.5 * torch.randn(T, n, env.nu, device='cuda', generator=g), -1, 1)
