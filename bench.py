@@ -241,7 +241,9 @@ def main():
         venv = HipVecEnv(models.WALKER_165CM, num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, refs=mocap.loco3d_table(ang, vel), lanes_per_walker=args.lanes)
     else:
         venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
-    split = (not args.no_split) and args.walker == 'straight' and args.lanes in (0, 16) and not (args.policy and args.handles > 1)
+    # the split workgroups fill the GPU: good for the policy-free rollout at any size and for a policy in the loop at the benchmark size;
+    # with a policy and more walkers the one-wave form leaves room for the policy kernel next to the env steps (measured: 18.7 vs 20.0 M at 32 768)
+    split = (not args.no_split) and args.walker == 'straight' and args.lanes in (0, 16) and not (args.policy and (args.handles > 1 or n > 4096))
     if split:
         venv.set_split(True)          # dynamics waves + constraint waves (include/drloco_hip.h: dl_set_split)
     vn = HipVecNormalize(venv)
@@ -363,7 +365,7 @@ def main():
             try:
                 pj = json.load(open(tfile))
                 if pj.get('kernel_sources_sha16') == kernel_sources_sha16():
-                    traffic, valu_busy = pj.get('hbm_bytes_per_launch'), pj.get('valu_busy_frac')
+                    traffic, valu_busy = pj.get('hbm_bytes_per_launch'), (pj.get('valu_busy_frac_simd') if split else pj.get('valu_busy_frac'))
                     prof_origin = {'file': 'profiles/traffic_env_step.json', 'tag': pj.get('tag'), 'kernel_sources_sha16': pj.get('kernel_sources_sha16')}
                 else:
                     prof_origin = {'file': 'profiles/traffic_env_step.json', 'stale': True, 'measured_sha16': pj.get('kernel_sources_sha16'), 'built_sha16': kernel_sources_sha16()}
@@ -386,7 +388,7 @@ def main():
                                    ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>')), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
                          'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
-                         'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
+                         'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
         out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'backend': dist.get_backend() if use_dist else None,
                               'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None}

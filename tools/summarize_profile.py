@@ -61,6 +61,10 @@ if 'hbm_bytes_per_launch' in out:
     if 'SQ_ACTIVE_INST_VALU' in pmc and 'SQ_WAVE_CYCLES' in pmc:
         extra = {'valu_busy_frac': pmc['SQ_ACTIVE_INST_VALU'] / pmc['SQ_WAVE_CYCLES'], 'wait_frac': pmc.get('SQ_WAIT_ANY', 0.0) / pmc['SQ_WAVE_CYCLES'],
                  'valu_insts_per_launch': pmc.get('SQ_INSTS_VALU')}
+        if 'GRBM_GUI_ACTIVE' in pmc:
+            # the same against the SIMDs' time instead of the waves': GRBM_GUI_ACTIVE sums the 8 XCDs' clocks over the launch, the SQ cycle counters tick
+            # every 4 clocks, 1024 SIMDs -- the figure that stays meaningful when a SIMD holds two waves of which one mostly sleeps (split workgroups)
+            extra['valu_busy_frac_simd'] = pmc['SQ_ACTIVE_INST_VALU'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 32)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_sources_sha16          # the kernel sources these counters belong to: bench.py reports them only while they match
     json.dump({**extra, 'tag': tag, 'kernel_sources_sha16': kernel_sources_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
