@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Split workgroup (DL_SPLIT=1, experiment build with -DDL_EXP_SPLIT_PROF): cycles the dynamics wave spends in the smooth dynamics and waiting
+"""Split workgroups (dl_set_split; needs a build with -DDL_EXP_SPLIT_PROF, selected with DL_LIB_PATH): cycles the dynamics wave spends in the smooth dynamics and waiting
 for its constraint wave, per control step."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
