@@ -529,7 +529,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         ov['stepped'][half].record(main)
         side.wait_event(ov['stepped'][half])
         with torch.cuda.stream(side):
-            if self.batched_steps and len(ov['pending']) > 1:
+            if (self.batched_steps or getattr(self.venv, 'split', False)) and len(ov['pending']) > 1:       # nothing hides under split workgroups: always the five-launch form
                 self._vn_launch_steps(ov['pending'])
             else:
                 for k, done, obs_out, rew_out in ov['pending']:

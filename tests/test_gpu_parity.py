@@ -1105,6 +1105,8 @@ def test_batched_vecnormalize_steps_match_single_steps(torch_cuda, model, refs, 
                 venv.set_split(True)
             vn = HipVecNormalize(venv, **kw)
             vn.batched_steps = mode != 'single'
+            if mode == 'single':
+                venv.split_hint = venv.split; venv.split = False      # (python-side flag only: keeps _submit_pending on the step-by-step form)
             buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
             buf.actions.copy_(acts)
             vn.reset()

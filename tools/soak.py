@@ -8,7 +8,7 @@ from drloco_amd.vec_env import HipVecEnv
 import os
 n, T, R = 4096, 500, int(os.environ.get("SOAK_R", "10"))
 PREC = int(os.environ.get("SOAK_PREC", "32"))
-env = HipVecEnv(num_envs=n, seed=4242, precision=PREC)
+env = HipVecEnv(num_envs=n, seed=4242, precision=PREC, **({'lanes_per_walker': 'split'} if os.environ.get('SOAK_SPLIT') == '1' else {}))      # SOAK_SPLIT=1: the split-workgroup launch form
 env.reset_tensors(); env.debug_counters()
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 tot_done = 0
