@@ -343,6 +343,27 @@ def main():
     tot_ms, launches = C.c_double(), C.c_int32()
     lib.check(venv._lib.dl_profile_read(venv._h, C.byref(tot_ms), C.byref(launches)))
     lib.check(venv._lib.dl_profile(venv._h, 0))
+    # ---- self-check of what the timed region produced (outside the timed region): a broken kernel must not print a number
+    checks = {}
+    if group is None:
+        lib.check(venv._lib.dl_fault_check(venv._h, None))          # raises if a split-workgroup hand-over timed out (DL_E_FAULT)
+        starts = buf._starts[1:T + 1]
+        n_done = int(starts.sum().item())
+        fin = bool(torch.isfinite(buf.observations).all().item() and torch.isfinite(buf.rewards).all().item() and torch.isfinite(buf.advantages).all().item()
+                   and torch.isfinite(buf.returns).all().item())
+        obs_absmax = float(buf.observations.abs().max().item())
+        if vn._ov is not None:           # raw (un-normalised) step outputs of the last rollout: the ring the long launches wrote
+            raw_rew, raw_obs = vn._ov['raw_rew'], vn._ov['raw_obs']
+        else:
+            raw_rew, raw_obs = vn.old_rew, vn.old_obs
+        rmin, rmax = float(raw_rew.min().item()), float(raw_rew.max().item())
+        fin = fin and bool(torch.isfinite(raw_obs).all().item() and torch.isfinite(raw_rew).all().item())
+        checks = {'finite': fin, 'raw_reward_min': rmin, 'raw_reward_max': rmax, 'episodes_ended_last_rollout': n_done, 'normalised_obs_absmax': obs_absmax}
+        # MimicEnv.step: reward = 0 on done, else imitation (<= 1) + 0.2 alive bonus (mimic_env.py:142-168); VecNormalize clips at 10
+        assert fin, f'bench self-check: non-finite values in the rollout buffer {checks}'
+        assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'
+        assert 0 < n_done < n * T, f'bench self-check: implausible number of episode ends {checks}'
+        assert obs_absmax <= 10.0 + 1e-5, f'bench self-check: normalised observations beyond the clip {checks}'
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -392,6 +413,7 @@ def main():
         }
         out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'backend': dist.get_backend() if use_dist else None,
                               'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None}
+        out['self_check'] = checks
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_base
         print(json.dumps(out))

@@ -62,6 +62,9 @@ def minibatch_adv_normalize(adv_local, group=None):
 def shard_minibatch(idx_global, n_global, rank, world):
     """idx_global: flat indices t * n_global + i into the time-major [T, n_global] rollout of ALL walkers (the same permutation
     on every rank).  Returns the flat indices t * n_local + (i - lo) of the samples whose walker belongs to this rank."""
+    if n_global % world:
+        raise ValueError(f'shard_minibatch: {n_global} walkers do not divide over {world} ranks (contiguous equal index ranges, DESIGN.md 6); '
+                         'the samples of the remainder would silently drop out of every minibatch')
     n_local = n_global // world
     lo = rank * n_local
     t, i = idx_global // n_global, idx_global % n_global

@@ -44,6 +44,10 @@ template <typename T> struct DevState {
     float* dbgf;             // [3*16][N] or NULL: stage input (q, v, solver start) of the last evaluation with >= dbg_cap iterations
     int dbg_cap;             // default: the iteration cap of the model (env DL_DEBUG_CAP_ITERS overrides; diagnostics)
     int32_t* dbg;            // [4][N] or NULL: solver diagnostics of the 16-lane step kernel (sum iters, max iters, sum rows, diverged)
+    // fault word of the handle (host-pinned, written by the device with system scope; NULL = none): a wave of a split workgroup that leaves a
+    // bounded poll by TIMEOUT ors its reason in (DL_FAULT_*); the host raises DL_E_FAULT at its next call (dl_fault_check)
+    int32_t* fault;
+    int32_t spin_dyn, spin_srv;   // polls before a dynamics wave / a constraint wave of a split workgroup gives up (dl_debug_set_spin_limit)
 };
 
 DL_HD uint64_t splitmix64(uint64_t x) {

@@ -29,6 +29,9 @@
 #define DL_CLOCK() 0ll
 #define DL_SLEEP() ((void)0)
 #define DL_WAKE() ((void)0)
+#define DL_WG_RELEASE() ((void)0)
+#define DL_WG_ACQUIRE() ((void)0)
+#define DL_FAULT_OR(p, code) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define DL_VPIN(x) asm volatile("" : "+v"(x))
@@ -36,7 +39,15 @@
 #define DL_CLOCK() ((long long)__builtin_readcyclecounter())
 #define DL_SLEEP() __builtin_amdgcn_s_sleep(16)        // a waiting wave of a split workgroup: ~1000 cycles, cut short by the partner's s_wakeup
 #define DL_WAKE() asm volatile("s_wakeup")
+// the hand-over between the two waves of a split pair is the one place where DIFFERENT waves exchange data through LDS: workgroup-scope
+// release before the flag store, acquire after the successful poll (g_sync's wavefront scope orders a wave against itself only)
+#define DL_WG_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define DL_WG_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+#define DL_FAULT_OR(p, code) __hip_atomic_fetch_or((p), (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #endif
+// reasons in a handle's fault word (include/drloco_hip.h: dl_fault_check)
+#define DL_FAULT_DYN_TIMEOUT 1      // a dynamics wave gave up waiting for its constraint wave
+#define DL_FAULT_SRV_TIMEOUT 2      // a constraint wave gave up waiting for a request
 
 #include <type_traits>
 
@@ -377,6 +388,8 @@ template <typename T, typename TP> struct GCtx {
     DL_LDS T* mm;                                // mirror block of the mass matrix (GLds::MM inside the rows, or its own space in the split workgroup)
     DL_LDS T* mbox;                              // split workgroup: this walker's mailbox between the dynamics wave and the constraint wave (else null)
     DL_LDS T* mbox0;                             //                  the mailbox of the wave's first walker (sequence numbers of the wave pair)
+    int32_t* fault;                              //                  the handle's fault word (or null) and the poll budget of this wave's waits
+    int spin_limit;
 };
 // Split workgroup: a second wave builds the constraints of the same four walkers while the first runs the smooth dynamics.
 // Per walker, behind the regular region: the mirror block of M (which may no longer share the rows' space) and the mailbox.
@@ -387,7 +400,9 @@ template <typename TP> struct GSplit {
     static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_DONESEQ = 67, MB_CMD = 68, MB_SIZE = 96;
     static constexpr int TOTAL = MB + MB_SIZE;                   // per walker; 16 (mod 32) like GLds::TOTAL
     static_assert(TOTAL % 32 == 16 && MB % 4 == 0, "walker regions keep their bank offset");
-    static constexpr int SPIN_LIMIT = 1 << 12;                   // polls before a wave gives up waiting for its partner (no hang on a protocol error)
+    // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
+    // wave sets the handle's fault word, its walkers take the reference's exception path (mimic_env.py:86-91) and the host raises DL_E_FAULT
+    static constexpr int SPIN_LIMIT = 1 << 16;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1262,12 +1277,15 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
     if constexpr (SPLIT) {
         static_assert(NX == 0, "the split workgroup is built for the lane-only walker");
         using Sp = GSplit<TP>;
+        // a pair whose hand-over has failed once (split_seq[3]) takes no further part in the protocol: its walkers are on the exception path
+        if (split_seq[3]) { ncon_o = 0; nefc_o = 0; niter_o = 0; return warm; }
         // the kinematics first: body frames and root height go to LDS for the constraint wave, which then needs no kinematics of its own;
         // with them the configuration and the solver's start point; then the rest of the smooth dynamics while the partner works
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
         g_fk<T, TP, true>(g, lt, q, qx, kin);
         const int seq = ++*split_seq;
+        DL_WG_RELEASE();
         if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
         DL_WAKE();
 #ifdef DL_EXP_SPLIT_PROF
@@ -1278,10 +1296,18 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp1 = DL_CLOCK();
 #endif
-        for (int it = 0; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_DONESEQ] != seq && it < Sp::SPIN_LIMIT; it++) DL_SLEEP();
+        bool answered = false;
+        for (int it = 0; !(answered = ((volatile DL_LDS int*)g.mbox0)[Sp::MB_DONESEQ] == seq) && it < g.spin_limit; it++) DL_SLEEP();
 #ifdef DL_EXP_SPLIT_PROF
         split_seq[1] += (int)((DL_CLOCK() - tp1) >> 4); split_seq[2] += (int)((tp1 - tp0) >> 4);
 #endif
+        if (!answered) {      // timeout (wave-uniform): never carry on with stale rows -- fault word, exception path for the four walkers
+            split_seq[3] = 1;
+            if (grp == 0 && j == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_DYN_TIMEOUT);
+            ncon_o = 0; nefc_o = 0; niter_o = 0;
+            return warm;
+        }
+        DL_WG_ACQUIRE();
         g_sync<T>();
         my_lim = (int)g.mbox[Sp::MB_LIM + j]; lim_sign = g.mbox[Sp::MB_SGN + j];
         ncon = (int)g.mbox[Sp::MB_NCON]; nlim = (int)g.mbox[Sp::MB_NLIM];

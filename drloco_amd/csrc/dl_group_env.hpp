@@ -56,7 +56,7 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
     g_load_const<T, TP>(*m, cst);
     GWalk<T> wk;
     g_load_walk<T, TP>(m, st, wi, wk);
-    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MM, nullptr, nullptr};
+    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MM, nullptr, nullptr, nullptr, 0};
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < NL) {
         const size_t o = (size_t)(j + NX) * n + wi;
@@ -86,7 +86,8 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
 // (q and the solver's start point B v + a in the mailbox, body frames and root height in the walker's LDS region) it runs the first half of
 // g_forward's constraint stage -- collision, contact records, limit and contact rows, all in the walker's LDS region -- and reports
 // (ncon, nlim, the lanes' limit rows); the contact Jacobians are the dynamics wave's.
-// Waits are bounded polls: a protocol error ends in wrong numbers (caught by the tests), never in a hung GPU.
+// Waits are bounded polls (never a hung GPU); a wait that runs out sets the handle's fault word and ends this wave -- the dynamics wave's
+// next request then runs out too, its walkers take the exception path and the host raises DL_E_FAULT (dl_fault_check).
 #if !defined(DL_GROUP_EMU)
 template <typename T, typename TP>
 __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevState<T>& st) {
@@ -104,15 +105,20 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     GWalk<T> wk;
     g_load_walk<T, TP>(m, st, w, wk);
     DL_LDS T* wb = smem + (size_t)grp * Sp::TOTAL;
-    GCtx<T, TP> g{wb, m, j, &ln, &cst, &wk, wb + Sp::MMX, wb + Sp::MB, smem + Sp::MB};
+    GCtx<T, TP> g{wb, m, j, &ln, &cst, &wk, wb + Sp::MMX, wb + Sp::MB, smem + Sp::MB, st.fault, st.spin_srv};
     GLaneTopo<T> lt;
     g_lane_topo<T, TP>(j, lt);
     volatile DL_LDS int* flags = (volatile DL_LDS int*)g.mbox0;
     int seq = 0;
     for (;;) {
         int cur = seq, it = 0;
-        while ((cur = flags[Sp::MB_CMDSEQ]) == seq && it < Sp::SPIN_LIMIT) { DL_SLEEP(); it++; }
-        if (cur == seq || flags[Sp::MB_CMD] == 0) break;          // released (or the partner is gone)
+        while ((cur = flags[Sp::MB_CMDSEQ]) == seq && it < g.spin_limit) { DL_SLEEP(); it++; }
+        if (cur == seq) {         // timeout: the partner never asked and never released -- say so (the partner's next request then times out as well)
+            if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
+            break;
+        }
+        if (flags[Sp::MB_CMD] == 0) break;          // released
+        DL_WG_ACQUIRE();
         seq = cur;
         g_sync<T>();
         const T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j];
@@ -124,6 +130,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         g.mbox[Sp::MB_LIM + j] = (T)my_lim; g.mbox[Sp::MB_SGN + j] = lim_sign;
         if (j == 0) { g.mbox[Sp::MB_NCON] = (T)ncon; g.mbox[Sp::MB_NLIM] = (T)nlim; }
         g_sync<T>();
+        DL_WG_RELEASE();
         if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
         DL_WAKE();
     }
@@ -161,8 +168,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     g_load_walk<T, TP>(m, st, w1, wk);
     constexpr int WSTRIDE = SPLIT ? GSplit<TP>::TOTAL : Ld::TOTAL;         // LDS words per walker
     GCtx<T, TP> g{smem + (size_t)grp * WSTRIDE, m, j, &ln, &cst, &wk,
-                  smem + (size_t)grp * WSTRIDE + (SPLIT ? GSplit<TP>::MMX : Ld::MM), SPLIT ? smem + (size_t)grp * WSTRIDE + GSplit<TP>::MB : nullptr, SPLIT ? smem + GSplit<TP>::MB : nullptr};
-    int split_seq[3] = {0, 0, 0};
+                  smem + (size_t)grp * WSTRIDE + (SPLIT ? GSplit<TP>::MMX : Ld::MM), SPLIT ? smem + (size_t)grp * WSTRIDE + GSplit<TP>::MB : nullptr, SPLIT ? smem + GSplit<TP>::MB : nullptr,
+                  st.fault, st.spin_dyn};
+    int split_seq[4] = {0, 0, 0, 0};         // [0] command counter of the wave pair, [1], [2] cycle counters of the profiling build, [3] the hand-over has failed
     DL_LDS T* wb = g.wb;
     const bool isdof = j < NL;
     const int jd = j + NX;                         // dof of this lane
@@ -257,6 +265,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 if (stage == 1 && kf > 0) { start = warm + (warm - acc_s2_prev); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s2_prev.x[t]); }); }
                 else if (stage == 3) { start = warm + (warm - acc_s0); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s0.x[t]); }); }
                 const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq);
+                if constexpr (SPLIT) { if (split_seq[3] && simulate) exc = true; }      // the hand-over with the constraint wave failed: MujocoException path
                 if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
                 if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;

@@ -111,8 +111,10 @@ void k_env_step_g16_split(const GModel<T, TP>* __restrict__ gm, const DevCfg<T> 
         f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1;
     }
     __syncthreads();
+    // the XCD-aware permutation acts on WORKGROUPS (workgroup b runs on XCD b % 8): a workgroup owns sixteen consecutive walkers = one full
+    // 64-byte line of every SoA state row, and neighbouring walker blocks stay on one XCD
     const int vwg = blockIdx.x * 4 + gslot, nvwg = gridDim.x * 4;
-    const int wblock = g_block_of_workgroup(vwg, nvwg);
+    const int wblock = g_block_of_workgroup(blockIdx.x, gridDim.x) * 4 + gslot;
     if (role == 0)
         g_wave_env_step<T, TP, false, true>(lane, wblock, vwg, nvwg, base, gm, c, st, actions_all, obs_all, rew_all, done_all, term_obs_all, rew_terms_all,
                                             inj_q, inj_v, inj_flags, ctrl_out, eval_mode, nsteps, nullptr);
@@ -494,7 +496,19 @@ static int fail(int code, const std::string& what) { g_err = what; return code; 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(DL_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct dl_env_s {
-    virtual ~dl_env_s() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    virtual ~dl_env_s() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); if (fault_host) (void)hipHostFree(fault_host); }
+    // fault word: host-pinned, mapped into the device; a wave of a split workgroup that leaves a bounded poll by timeout ors its reason in
+    // (dl_group.hpp DL_FAULT_*).  Sticky until dl_fault_clear: every entry point that launches or reads results returns DL_E_FAULT while set.
+    int32_t* fault_host = nullptr;
+    int32_t* fault_dev = nullptr;
+    int fault_alloc() {
+        if (hipHostMalloc((void**)&fault_host, sizeof(int32_t), hipHostMallocMapped) != hipSuccess) { fault_host = nullptr; return DL_E_NOMEM; }
+        *fault_host = 0;
+        if (hipHostGetDevicePointer((void**)&fault_dev, fault_host, 0) != hipSuccess) return DL_E_HIP;
+        return DL_OK;
+    }
+    int fault_code() const { return fault_host ? __atomic_load_n(fault_host, __ATOMIC_RELAXED) : 0; }
+    virtual void set_spin_limits(int dyn, int srv) = 0;
     int n = 0, device = 0, real_size = 4, eval_mode = 0, obs_dim = 0, act_dim = 0, variant = 0;
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
@@ -610,6 +624,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         }
         // per-walker state
         st.n = n;
+        if ((rc = fault_alloc())) return fail(rc, "dl_create: cannot allocate the fault word (pinned host memory)");
+        st.fault = fault_dev; st.spin_dyn = GSplit<TP>::SPIN_LIMIT; st.spin_srv = GSplit<TP>::SPIN_LIMIT;
         if ((rc = dalloc(&st.qpos, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&st.qvel, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&st.warm, (size_t)TP::NV * n))) return rc;
@@ -813,6 +829,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         }
         return fail(DL_E_INVAL, "dl_debug_step_timed: float32 only");
     }
+    void set_spin_limits(int dyn, int srv) override { st.spin_dyn = dyn >= 0 ? dyn : GSplit<TP>::SPIN_LIMIT; st.spin_srv = srv >= 0 ? srv : GSplit<TP>::SPIN_LIMIT; }
     int set_split(int on) override {
         if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels of the lane-only (straight) walker");
         split = on != 0;
@@ -885,6 +902,34 @@ int32_t dl_act_dim(dl_handle h) { return h ? h->act_dim : 0; }
 int32_t dl_real_size(dl_handle h) { return h ? h->real_size : 0; }
 
 #define NEED(h) do { if (!(h)) return fail(DL_E_INVAL, "null handle"); } while (0)
+static int fault_error(dl_handle h) {
+    const int code = h->fault_code();
+    std::string why = "device fault " + std::to_string(code) + ":";
+    if (code & DL_FAULT_DYN_TIMEOUT) why += " a dynamics wave of a split workgroup gave up waiting for its constraint wave;";
+    if (code & DL_FAULT_SRV_TIMEOUT) why += " a constraint wave of a split workgroup gave up waiting for a request;";
+    return fail(DL_E_FAULT, why + " the walkers of the affected waves took the exception path (reward 0, episode ended, reset) -- results since the fault are "
+                "not a valid rollout; dl_fault_clear + dl_reset to continue");
+}
+// a fault raised by an EARLIER launch that has completed is reported by the next call (the word is host memory: no synchronisation needed)
+#define NOFAULT(h) do { if ((h)->fault_code()) return fault_error(h); } while (0)
+int dl_fault_check(dl_handle h, int32_t* code) {
+    NEED(h);
+    if (code) *code = h->fault_code();
+    NOFAULT(h);
+    return DL_OK;
+}
+int dl_fault_clear(dl_handle h) {
+    NEED(h);
+    if (h->fault_host) __atomic_store_n(h->fault_host, 0, __ATOMIC_RELAXED);
+    return DL_OK;
+}
+/* test hook: poll budgets of the split workgroup's two wave roles (negative = default); 0 for the constraint waves makes them leave at once,
+ * so that every dynamics wave's first request times out */
+int dl_debug_set_spin_limit(dl_handle h, int32_t dyn, int32_t srv) {
+    NEED(h);
+    h->set_spin_limits(dyn, srv);
+    return DL_OK;
+}
 
 int dl_reset(dl_handle h, const uint8_t* mask, const int32_t* init_step, const int32_t* init_pos, float* obs_out, void* stream) {
     NEED(h);
@@ -897,10 +942,12 @@ int dl_set_eval(dl_handle h, int32_t on) {
 }
 int dl_step(dl_handle h, const float* actions, float* obs, float* rew, uint8_t* done, float* term_obs, float* rew_terms, void* stream) {
     NEED(h);
+    NOFAULT(h);
     return h->step(actions, obs, rew, done, term_obs, rew_terms, (hipStream_t)stream);
 }
 int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, float* rew, uint8_t* done, void* stream) {
     NEED(h);
+    NOFAULT(h);
     if (T <= 0 || !actions || !obs || !rew || !done) return fail(DL_E_INVAL, "dl_rollout_fixed: bad arguments");
     const size_t n = (size_t)h->n;
     for (int32_t t = 0; t < T;) {
@@ -912,6 +959,7 @@ int dl_rollout_fixed(dl_handle h, int32_t T, const float* actions, float* obs, f
 }
 int dl_get_state(dl_handle h, void* qpos, void* qvel, void* qacc_warm, int32_t* cursor, double* walked, void* stream) {
     NEED(h);
+    NOFAULT(h);
     return h->get_state(qpos, qvel, qacc_warm, cursor, walked, (hipStream_t)stream);
 }
 int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qacc_warm, const int32_t* cursor, const double* walked, void* stream) {
@@ -1018,6 +1066,7 @@ int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches) {
     h->prof_last_steps = h->prof_steps;
     h->prof_steps = 0;
     h->ev_used = 0;
+    NOFAULT(h);                 // a host sync point: the bracketed launches have completed
     return DL_OK;
 }
 
@@ -1230,6 +1279,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
                       float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
                       float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, void* stream) {
     NEED(h);
+    NOFAULT(h);
     if (!pol || !vn || T <= 0 || !observations || !actions || !values || !log_probs || !rewards || !episode_starts || !next_obs || !next_done || !raw_obs || !raw_rew)
         return fail(DL_E_INVAL, "dl_rollout_policy: bad arguments");
     const size_t n = (size_t)h->n, od = (size_t)h->obs_dim, ad = (size_t)h->act_dim;

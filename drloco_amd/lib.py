@@ -27,6 +27,10 @@ class DrlocoError(RuntimeError):
     pass
 
 
+class DrlocoFault(DrlocoError):
+    """DL_E_FAULT: a kernel of the handle reported a fault (include/drloco_hip.h: dl_fault_check)."""
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 of the kernels + C-ABI into an in-tree shared library."""
     srcs = [os.path.join(CSRC, s) for s in _SOURCES] + [os.path.join(INCLUDE, 'drloco_hip.h')]
@@ -63,6 +67,8 @@ _SIGNATURES = {
     'dl_set_push': (C.c_int, [_V, _P, _P]),
     'dl_set_push_schedule': (C.c_int, [_V, _P, _P, _I, _I, _P]),
     'dl_set_split': (C.c_int, [_V, _I]),
+    'dl_fault_check': (C.c_int, [_V, C.POINTER(_I)]),
+    'dl_fault_clear': (C.c_int, [_V]),
     'dl_terminate_early': (C.c_int, [_V, _P, _P]),
     'dl_stats_snapshot': (C.c_int, [_V, C.c_char_p, _P, _P]),
     'dl_profile': (C.c_int, [_V, _I]),
@@ -83,6 +89,7 @@ _EXTRA = {
     'dl_abi_sizeof': (C.c_int, [C.c_int]),
     'dl_debug_inject': (C.c_int, [_V, _P, _P, _P, _P, _P]),
     'dl_debug_counters': (C.c_int, [_V, _P, _I, _P]),
+    'dl_debug_set_spin_limit': (C.c_int, [_V, _I, _I]),
     'dl_debug_capstate': (C.c_int, [_V, _P, _P]),
     'dl_debug_last_ctrl': (C.c_int, [_V, _P, _P]),
     'dl_debug_selftest': (C.c_int, [_P, _P, _P]),
@@ -113,5 +120,7 @@ def load():
 
 
 def check(rc):
+    if rc == abi.DL_E_FAULT:
+        raise DrlocoFault(f'drloco_hip fault: {load().dl_last_error().decode()}')
     if rc != 0:
         raise DrlocoError(f'drloco_hip error {rc}: {load().dl_last_error().decode()}')

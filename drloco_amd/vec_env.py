@@ -528,15 +528,21 @@ class HipVecNormalize(_VecEnvWrapperBase):
         half = ov['pending'][0][0] // ov['chunk']
         ov['stepped'][half].record(main)
         side.wait_event(ov['stepped'][half])
+        pending, ov['pending'] = ov['pending'], []         # cleared whatever happens below: a failed hand-over must not be re-issued
         with torch.cuda.stream(side):
-            if (self.batched_steps or getattr(self.venv, 'split', False)) and len(ov['pending']) > 1:       # nothing hides under split workgroups: always the five-launch form
-                self._vn_launch_steps(ov['pending'])
+            # the five-launch form needs consecutive ring slots and one contiguous block of done rows (steps_fixed produces exactly that;
+            # step_tensors callers that pass their own done_out slots may not): otherwise one dl_vecnormalize_step per step
+            if self.batched_steps and len(pending) > 1 and self._run_is_contiguous(pending):
+                self._vn_launch_steps(pending)
             else:
-                for k, done, obs_out, rew_out in ov['pending']:
+                for k, done, obs_out, rew_out in pending:
                     self._vn_launch(ov['raw'][k][0], ov['raw'][k][1], done, obs_out, rew_out)
             ov['read'][half] = ov['readev'][half]
             ov['read'][half].record(side)
-        ov['pending'] = []
+
+    def _run_is_contiguous(self, pending):
+        n, k0 = self.venv.num_envs, pending[0][0]
+        return all(p[0] == k0 + i and p[1].is_contiguous() and p[1].data_ptr() == pending[0][1].data_ptr() + i * n for i, p in enumerate(pending))
 
     def _vn_launch_steps(self, pending):
         """dl_vecnormalize_steps for a run of consecutive ring slots: five launches instead of two per control step (the moments agree
@@ -544,7 +550,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         ov = self._ov
         K, k0 = len(pending), pending[0][0]
         n, d = self.venv.obs.shape
-        assert all(p[0] == k0 + i for i, p in enumerate(pending)) and pending[0][1].data_ptr() + (K - 1) * n == pending[-1][1].data_ptr()
+        assert self._run_is_contiguous(pending)
         need = abi.vn_steps_workspace_bytes(K, n, d)
         if ov.get('steps_work') is None or ov['steps_work'].numel() < need:
             ov['steps_work'] = torch.empty(need, dtype=torch.uint8, device=self.venv.device)
@@ -568,6 +574,10 @@ class HipVecNormalize(_VecEnvWrapperBase):
         only after `flush()` (call it before anything on the main stream reads them: GAE, the policy, a copy to the host)."""
         dev = self.venv.device
         self.multi_block_reduce = True
+        if getattr(self.venv, 'split', False):
+            # nothing hides under split workgroups (they fill the GPU): the normalisations of a run go through dl_vecnormalize_steps (five
+            # launches per run; moments agree with the step-by-step form to rounding, not bit for bit).  Set batched_steps = False to opt out.
+            self.batched_steps = True
         ev = lambda: torch.cuda.Event()
         # high priority: its own hardware-queue pool (a default-priority stream may share the main stream's queue once other
         # libraries -- RCCL -- have created streams) and the tiny launches are dispatched while the step kernel runs

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 4   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split */
+#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -45,6 +45,7 @@ extern "C" {
 #define DL_E_NODEVICE (-2)  /* no HIP device */
 #define DL_E_HIP (-3)       /* a HIP runtime call failed */
 #define DL_E_NOMEM (-4)
+#define DL_E_FAULT (-5)     /* a kernel of this handle reported a fault (dl_fault_check): results since then are not a valid rollout */
 
 /* environment kinds (the reference's env_map, drloco/mujoco/config.py:9-10) */
 #define DL_ENV_STRAIGHT 0
@@ -239,6 +240,18 @@ int dl_set_push_schedule(dl_handle h, const float* force, const int32_t* phase, 
  * other kernels with the step (several handles with a policy in the loop) keep the default, 0.  Same algorithm; the float32 results of the
  * two forms differ in the last bit (two instantiations).  Returns DL_E_INVAL for the other walker / float64 / one lane per walker. */
 int dl_set_split(dl_handle h, int32_t on);
+
+/* Device faults.  The reference turns a diverging simulation into an ended episode (MujocoException -> reward 0, done, reset:
+ * mimic_env.py:86-91) and lets every other error raise; the kernels do the same.  The one failure a launch can detect but not repair is the
+ * hand-over between the two waves of a split workgroup running out of its (bounded, ~30 ms) poll budget: the wave then ors a reason into the
+ * handle's fault word (host-pinned memory: 1 = a dynamics wave gave up on its constraint wave, 2 = a constraint wave gave up waiting for a
+ * request), takes no further part in the protocol, and its four walkers take the exception path on every remaining step of the launch --
+ * never a silent continuation on stale constraint rows.  The word is sticky: dl_step, dl_rollout_fixed, dl_rollout_policy, dl_get_state and
+ * dl_profile_read return DL_E_FAULT (text in dl_last_error) as soon as a completed launch has left it set.  dl_fault_check reads it (after the
+ * caller has synchronised with the stream it sees every fault of the enqueued work); *code may be NULL.  dl_fault_clear resets it (then
+ * dl_reset the walkers). */
+int dl_fault_check(dl_handle h, int32_t* code);
+int dl_fault_clear(dl_handle h);
 
 /* MimicEnv.do_terminate_early (mimic_env.py:652-702; the reference defines it but its call in step() is commented
  * out, :113-118) at the current state of every walker: flags int32[N, 4] device =

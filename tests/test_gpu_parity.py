@@ -1104,14 +1104,12 @@ def test_batched_vecnormalize_steps_match_single_steps(torch_cuda, model, refs, 
             if split:
                 venv.set_split(True)
             vn = HipVecNormalize(venv, **kw)
-            vn.batched_steps = mode != 'single'
-            if mode == 'single':
-                venv.split_hint = venv.split; venv.split = False      # (python-side flag only: keeps _submit_pending on the step-by-step form)
             buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
             buf.actions.copy_(acts)
             vn.reset()
             last_obs = vn.norm_obs_t.clone(); last_done = buf.next_starts; last_done.fill_(1)
             vn.enable_overlap(chunk=runs)
+            vn.batched_steps = mode != 'single'          # (enable_overlap switches the batched form on under split workgroups)
             for rollout in range(2):
                 buf.observations[0].copy_(last_obs); buf.episode_starts[0].copy_(last_done)
                 for t0 in range(0, T, runs):
