@@ -26,6 +26,7 @@ DL_GEOM_CAPSULE, DL_GEOM_BOX = 0, 1
  DL_CUR_EPISODE, DL_CUR_READ_STEP, DL_CUR_EVAL_K) = range(9)
 DL_CUR_WORDS = 9
 EVAL_N_TIMES = 20        # drloco/config/config.py:23
+DL_ROLLOUT_PERSISTENT, DL_ROLLOUT_MOMENTS_PER_ROLLOUT = 1, 2
 DL_OK, DL_E_INVAL, DL_E_NODEVICE, DL_E_HIP, DL_E_NOMEM, DL_E_FAULT = 0, -1, -2, -3, -4, -5
 
 _d, _i = C.c_double, C.c_int32

@@ -41,8 +41,13 @@
 #define DL_WAKE() asm volatile("s_wakeup")
 // the hand-over between the two waves of a split pair is the one place where DIFFERENT waves exchange data through LDS: workgroup-scope
 // release before the flag store, acquire after the successful poll (g_sync's wavefront scope orders a wave against itself only)
+#ifdef DL_EXP_NO_WG_FENCE       // experiment switch: wavefront scope only (the round-2 form)
+#define DL_WG_RELEASE() ((void)0)
+#define DL_WG_ACQUIRE() ((void)0)
+#else
 #define DL_WG_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 #define DL_WG_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+#endif
 #define DL_FAULT_OR(p, code) __hip_atomic_fetch_or((p), (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #endif
 // reasons in a handle's fault word (include/drloco_hip.h: dl_fault_check)

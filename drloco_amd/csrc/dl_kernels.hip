@@ -114,7 +114,11 @@ void k_env_step_g16_split(const GModel<T, TP>* __restrict__ gm, const DevCfg<T> 
     // the XCD-aware permutation acts on WORKGROUPS (workgroup b runs on XCD b % 8): a workgroup owns sixteen consecutive walkers = one full
     // 64-byte line of every SoA state row, and neighbouring walker blocks stay on one XCD
     const int vwg = blockIdx.x * 4 + gslot, nvwg = gridDim.x * 4;
+#ifdef DL_EXP_OLD_XCD            // experiment switch: the round-2 mapping (permutation of the wave pairs)
+    const int wblock = g_block_of_workgroup(vwg, nvwg);
+#else
     const int wblock = g_block_of_workgroup(blockIdx.x, gridDim.x) * 4 + gslot;
+#endif
     if (role == 0)
         g_wave_env_step<T, TP, false, true>(lane, wblock, vwg, nvwg, base, gm, c, st, actions_all, obs_all, rew_all, done_all, term_obs_all, rew_terms_all,
                                             inj_q, inj_v, inj_flags, ctrl_out, eval_mode, nsteps, nullptr);
@@ -365,14 +369,10 @@ __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, c
     if (idx == 0) { if (flags & 1) *count += (double)B; if (flags & 4) *ret_count += (double)B; }
     if (idx < (size_t)B * D) {
         const int k = (int)(idx % D);
-        double y = (double)x[idx];
-        if (flags & 2) { y = (y - mean[k]) / sqrt(var[k] + eps); y = y < -clip_obs ? -clip_obs : (y > clip_obs ? clip_obs : y); }
-        obs_out[idx] = (float)y;
+        obs_out[idx] = (flags & 2) ? vn_norm_obs(x[idx], mean[k], var[k], eps, clip_obs) : x[idx];
     }
     if (idx < (size_t)B) {
-        double y = (double)rew[idx];
-        if (flags & 8) { y = y / sqrt(*ret_var + eps); y = y < -clip_rew ? -clip_rew : (y > clip_rew ? clip_rew : y); }
-        rew_out[idx] = (float)y;
+        rew_out[idx] = (flags & 8) ? vn_norm_rew(rew[idx], *ret_var, eps, clip_rew) : rew[idx];
         if ((flags & 4) && done[idx]) ret[idx] = 0;
     }
 }
@@ -489,6 +489,262 @@ __global__ void k_adv_normalize(float* a, long long n, const double* s3) {
     a[i] = (float)(((double)a[i] - mean) / (sqrt(var) + 1e-8));
 }
 
+
+// ---- the "blocked" order of the moment reduction (flags bit 32 of dl_vecnormalize_step) ----------------------------------------
+// One canonical summation order that a single launch AND the persistent rollout kernel (k_rollout_persistent: one workgroup per sixteen
+// walkers, a grid-wide exchange per control step) can both follow, so that the two produce the same bits:
+//   rows are cut into blocks of 16 (block b = rows 16 b ..), blocks into <= 8 contiguous groups of gsize = ceil(nblk / 8) blocks;
+//   S_b   = the block's shifted sums, rows in order          (s += d; ss = fma(d, d, ss); d = x - K, K = the mean before the update)
+//   X_g   = sum of S_b over the group's blocks in order,  total = sum of X_g over the groups in order;  then the Chan merge below.
+// The discounted returns are column D: ret = fma(ret, gamma, rew) is advanced first.
+struct VnBlk { int nblk, gsize, ngrp; };
+__host__ __device__ inline VnBlk vn_blk(int B) { VnBlk v; v.nblk = (B + 15) / 16; v.gsize = (v.nblk + 7) / 8; v.ngrp = (v.nblk + v.gsize - 1) / v.gsize; return v; }
+// RunningMeanStd.update_from_moments for one column from the shifted sums (S, SS) of a batch of B rows
+__device__ __forceinline__ void vn_chan_merge_d(double& mean, double& var, double cnt, double S, double SS, double B) {
+#pragma clang fp contract(off)
+    const double K = mean, sb = S / B, bm = K + sb, bv = SS / B - sb * sb;
+    const double tot = cnt + B, delta = bm - K;
+    const double M2 = var * cnt + bv * B + delta * delta * cnt * B / tot;
+    mean = K + delta * B / tot;
+    var = M2 / tot;
+}
+__device__ __forceinline__ void vn_chan_merge(double& mean, double& var, double cnt, double S, double SS, int B) { vn_chan_merge_d(mean, var, cnt, S, SS, (double)B); }
+// shifted sums of column k over rows [r0, r1) of x[B, D] (k < D) or of the advanced returns (k == D; also stores them)
+__device__ __forceinline__ void vn_block_sums(const float* __restrict__ x, const float* __restrict__ rew, double* ret, int D, int k, int r0, int r1, double K, double gamma,
+                                              double& s_out, double& ss_out) {
+    double s = 0, ss = 0;
+    if (k < D) {
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = r0 + r < r1 ? x[(size_t)(r0 + r) * D + k] : 0.0f;       // all loads in flight, then the sums in row order
+#pragma unroll
+        for (int r = 0; r < 16; r++) if (r0 + r < r1) { const double d = (double)a[r] - K; s += d; ss = fma(d, d, ss); }
+    } else {
+        for (int r = r0; r < r1; r++) { const double rn = fma(ret[r], gamma, (double)rew[r]); ret[r] = rn; const double d = rn - K; s += d; ss = fma(d, d, ss); }
+    }
+    s_out = s; ss_out = ss;
+}
+// single launch, one workgroup: a chunk of 32 blocks at a time (block sums in parallel -> LDS -> sequential accumulation per column)
+__global__ __launch_bounds__(1024) void k_vn_reduce_blk(const float* __restrict__ x, const float* __restrict__ rew, double* mean, double* var, const double* count,
+                                                        double* ret, double* ret_mean, double* ret_var, const double* ret_count, int B, int D, double gamma, int flags) {
+    constexpr int CH = 32;
+    __shared__ double sh[CH][2][32];           // [block of the chunk][s / ss][column] (D + 1 <= 32 columns per pass of 32)
+    const int t = threadIdx.x, W = D + 1;
+    const VnBlk vb = vn_blk(B);
+    for (int k0 = 0; k0 < W; k0 += 32) {       // column passes (D + 1 <= 32: one pass for the straight walker; 48 columns: two)
+        const int kl = t & 31, bl = t >> 5, k = k0 + kl;
+        const bool colok = k < W && ((k < D) ? (flags & 1) != 0 : (flags & 4) != 0);
+        const double K = colok ? (k < D ? mean[k] : *ret_mean) : 0.0;
+        double tot_s = 0, tot_ss = 0;
+        for (int g = 0; g < vb.ngrp; g++) {
+            const int b0 = g * vb.gsize, b1 = b0 + vb.gsize < vb.nblk ? b0 + vb.gsize : vb.nblk;
+            double xs = 0, xss = 0;
+            for (int c0 = b0; c0 < b1; c0 += CH) {
+                const int b = c0 + bl;
+                if (colok && b < b1) vn_block_sums(x, rew, ret, D, k, 16 * b, 16 * b + 16 < B ? 16 * b + 16 : B, K, gamma, sh[bl][0][kl], sh[bl][1][kl]);
+                __syncthreads();
+                if (bl == 0 && colok) { const int nb = b1 - c0 < CH ? b1 - c0 : CH; for (int i = 0; i < nb; i++) { xs += sh[i][0][kl]; xss += sh[i][1][kl]; } }
+                __syncthreads();
+            }
+            tot_s += xs; tot_ss += xss;
+        }
+        if (bl == 0 && colok) {
+            double m = K, v = k < D ? var[k] : *ret_var;
+            vn_chan_merge(m, v, k < D ? *count : *ret_count, tot_s, tot_ss, B);
+            if (k < D) { mean[k] = m; var[k] = v; } else { *ret_mean = m; *ret_var = v; }
+        }
+    }
+}
+
+// ---- SB3 collect_rollouts as ONE launch (dl_collect_rollouts, DL_ROLLOUT_PERSISTENT) ---------------------------------------------
+// A persistent workgroup of eight waves owns sixteen walkers for all T control steps of the rollout -- the split workgroup of the step
+// kernel (4 dynamics + 4 constraint waves) and the policy workgroup (8 waves x 16 rows) have the same shape, and one such workgroup fits
+// per CU (143 KB of LDS), so a grid of <= one workgroup per CU is co-resident by construction.  Per control step:
+//   P  policy forward for the workgroup's own 16 rows (pol_forward_rows: MFMA), with the normalisation of the last step's raw outputs folded
+//      into its input stage exactly as in dl_rollout_policy; the moments live in LDS, replicated per workgroup;
+//   E  MimicEnv.step for the 16 walkers (g_wave_env_step / g_constraint_server, the code of k_env_step_g16_split);
+//   R  VecNormalize's moment update: the workgroup's block sums (blocked order, above) go to HBM, ONE grid-wide exchange -- group
+//      counter -> the group's last arriver adds the group's blocks -> top counter -> everybody reads the <= 8 group sums and performs the
+//      same merge -- and every workgroup holds the moments SB3 would have after this step.  Exact SB3 semantics.
+// per_rollout != 0 (DL_ROLLOUT_MOMENTS_PER_ROLLOUT, opt-in): the moments are frozen at their start-of-rollout values, every workgroup
+// accumulates its shifted sums over the whole rollout, nothing is exchanged during the rollout (workgroups run free: the launch lasts as
+// long as the slowest SUM, not the sum of every step's slowest workgroup) and k_vn_merge_rollout performs one exact Chan merge of all
+// T x N samples afterwards -- the relaxation collective C3 already applies across ranks.
+// Hand-offs follow /opt/skills/guides/cdna_hip_programming.md guideline 16: plain stores -> __syncthreads -> one lane: agent-scope release,
+// drained, relaxed agent atomic; consumers: one lane polls relaxed, ONE agent-scope acquire, __syncthreads, plain loads.  Counters are
+// monotonic over the steps of a launch (epoch = step + 1) and zeroed by the host before every launch.  Every poll is bounded: a timeout
+// sets the handle's fault word (DL_FAULT_GRID_TIMEOUT) and ends the workgroup.
+#define DL_FAULT_GRID_TIMEOUT 4
+struct RolloutP {
+    dl_policy_params pol;
+    uint64_t seed, counter0;
+    double *obs_mean, *obs_var, *obs_count, *ret, *ret_mean, *ret_var, *ret_count;
+    double gamma, eps, clip_obs, clip_rew;
+    float *observations, *actions, *values, *log_probs, *rewards, *next_obs, *raw_obs, *raw_rew;
+    uint8_t *episode_starts, *next_done;
+    double *partial, *xpart;      // [nblk][W][2], [2][8][W][2] (group sums, double-buffered by step parity: a group may not overwrite what another group's workgroups still read)
+    unsigned* sync;               // group counters at [16 g], top counter at [128]
+    int32_t index_base, flags, T, per_rollout, spin_grid;
+};
+constexpr int RP_SYNC_WORDS = 160;
+template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2) * sizeof(double) + 64; }
+
+template <typename TP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg<float> c, const DevState<float> st0, const RolloutP a, int eval_mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using T = float;
+    using Sp = GSplit<TP>;
+    constexpr int D = TP::OBS, W = D + 1, NU = TP::NU;
+    constexpr size_t ENV_LDS = (size_t)4 * GW * Sp::TOTAL * sizeof(T);
+    static_assert(pol_lds_bytes(8) <= ENV_LDS, "the policy's LDS aliases the walkers' regions between two env steps");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = wave >> 2, slot = wave & 3;
+    const int gslot = role == 0 ? slot : ((slot + DL_SPLIT_PAIR_OFFSET) & 3);
+    DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
+    double* vm = (double*)(smem + ENV_LDS);                 // mean[W] (column D: the returns'), var[W], count, ret_count
+    int* shf = (int*)(vm + 2 * W + 2);                      // [0] group-last flag, [1] exchange ok
+    const int n = st0.n, nblk = gridDim.x;
+    const int blk = g_block_of_workgroup(blockIdx.x, gridDim.x);
+    const int row0 = blk * 16, row1 = row0 + 16 < n ? row0 + 16 : n;
+    const VnBlk vb = vn_blk(n);
+    const int grp = blk / vb.gsize, gb0 = grp * vb.gsize, gb1 = gb0 + vb.gsize < nblk ? gb0 + vb.gsize : nblk;
+    const int flags = a.flags;
+    const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !a.per_rollout;
+    if (tid < D) { vm[tid] = a.obs_mean[tid]; vm[W + tid] = a.obs_var[tid]; }
+    if (tid == D) { vm[D] = *a.ret_mean; vm[W + D] = *a.ret_var; vm[2 * W] = *a.obs_count; vm[2 * W + 1] = *a.ret_count; }
+    double acc_s = 0, acc_ss = 0;                           // per_rollout: this thread's column sums over the whole rollout
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < a.T; t++) {
+        // ---- P: actions, values, log-probs of step t (and observations[t], rewards[t - 1] from the raw outputs of step t - 1)
+        {
+            PolVnFuse vf{};
+            if (t > 0) {
+                vf.raw_obs = a.raw_obs; vf.raw_rew = a.raw_rew; vf.done = a.episode_starts + (size_t)t * n;
+                vf.mean = vm; vf.var = vm + W; vf.count = nullptr; vf.ret = a.ret; vf.ret_var = vm + W + D; vf.ret_count = nullptr;
+                vf.obs_out = a.observations + (size_t)t * n * D; vf.rew_out = a.rewards + (size_t)(t - 1) * n;
+                vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
+            }
+            pol_forward_rows<4, 8>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
+                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false);
+        }
+        __syncthreads();          // the actions of the workgroup's rows are in memory (workgroup scope); the policy's LDS is free again
+        // ---- E: one control step of the sixteen walkers
+        if (lane == 0) {
+            volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
+            f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1;
+        }
+        __syncthreads();
+        {
+            DevState<T> st = st0;
+            st.push_step0 = st0.push_step0 + t;
+            uint8_t* done = t + 1 == a.T ? a.next_done : a.episode_starts + (size_t)(t + 1) * n;
+            const int wblock = blk * 4 + gslot;
+            if (role == 0)
+                g_wave_env_step<T, TP, false, true>(lane, wblock, 0, 1, base, gm, c, st, a.actions + (size_t)t * n * NU, a.raw_obs, a.raw_rew, done, (float*)nullptr, (float*)nullptr,
+                                                    (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, eval_mode, 1, nullptr);
+            else
+                g_constraint_server<T, TP>(lane, wblock, base, gm, st);
+        }
+        __syncthreads();          // raw observation / reward / done of the workgroup's rows are in memory
+        // ---- R: VecNormalize's moment update
+        if (upd_obs || upd_ret) {
+            const bool mine = tid < W && (tid < D ? upd_obs : upd_ret);
+            if (mine) {
+                double s, ss;
+                vn_block_sums(a.raw_obs, a.raw_rew, a.ret, D, tid, row0, row1, vm[tid], a.gamma, s, ss);
+                if (exchange) { a.partial[((size_t)blk * W + tid) * 2] = s; a.partial[((size_t)blk * W + tid) * 2 + 1] = ss; }
+                else { acc_s += s; acc_ss += ss; }
+            }
+        }
+        if (exchange) {
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned old = __hip_atomic_fetch_add(a.sync + 16 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = old + 1u == (unsigned)(gb1 - gb0) * (unsigned)(t + 1);
+                if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                shf[0] = last ? 1 : 0;
+            }
+            __syncthreads();
+            if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order
+                if (tid < 2 * W) {
+                    double x = 0;
+                    for (int b = gb0; b < gb1; b++) x += a.partial[(size_t)b * W * 2 + tid];
+                    a.xpart[((size_t)(t & 1) * 8 + grp) * W * 2 + tid] = x;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(a.sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (tid == 0) {
+                const unsigned want = (unsigned)vb.ngrp * (unsigned)(t + 1);
+                bool ok = false;
+                for (int it = 0; it < a.spin_grid; it++) {
+                    if (__hip_atomic_load(a.sync + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                else if (st0.fault) DL_FAULT_OR(st0.fault, DL_FAULT_GRID_TIMEOUT);
+                shf[1] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!shf[1]) return;          // (uniform) the grid never completed this step: fault word set, nothing further is written
+            if (tid < W && (tid < D ? upd_obs : upd_ret)) {
+                double S = 0, SS = 0;
+                const double* xp = a.xpart + (size_t)(t & 1) * 8 * W * 2;
+                for (int g = 0; g < vb.ngrp; g++) { S += xp[((size_t)g * W + tid) * 2]; SS += xp[((size_t)g * W + tid) * 2 + 1]; }
+                double m = vm[tid], v = vm[W + tid];
+                vn_chan_merge(m, v, tid < D ? vm[2 * W] : vm[2 * W + 1], S, SS, n);
+                vm[tid] = m; vm[W + tid] = v;
+            }
+            __syncthreads();
+            if (tid == 0) { if (upd_obs) vm[2 * W] += (double)n; if (upd_ret) vm[2 * W + 1] += (double)n; }
+        }
+        __syncthreads();
+    }
+    // ---- VecNormalize of the last step's outputs (k_vn_apply's work for the workgroup's rows): next_obs, rewards[T - 1], ret
+    for (int idx = tid; idx < (row1 - row0) * D; idx += 512) {
+        const size_t e = (size_t)row0 * D + idx;
+        const int k = idx % D;
+        a.next_obs[e] = (flags & 2) ? vn_norm_obs(a.raw_obs[e], vm[k], vm[W + k], a.eps, a.clip_obs) : a.raw_obs[e];
+    }
+    if (tid < row1 - row0) {
+        const int r = row0 + tid;
+        a.rewards[(size_t)(a.T - 1) * n + r] = (flags & 8) ? vn_norm_rew(a.raw_rew[r], vm[W + D], a.eps, a.clip_rew) : a.raw_rew[r];
+        if (upd_ret && a.next_done[r]) a.ret[r] = 0;
+    }
+    if (a.per_rollout) {          // the workgroup's sums over the whole rollout, merged by k_vn_merge_rollout
+        if (tid < W) { a.partial[((size_t)blk * W + tid) * 2] = acc_s; a.partial[((size_t)blk * W + tid) * 2 + 1] = acc_ss; }
+    } else if (blk == 0) {        // every workgroup holds the same moments: one of them hands them back
+        if (tid < D) { a.obs_mean[tid] = vm[tid]; a.obs_var[tid] = vm[W + tid]; }
+        if (tid == D) { *a.ret_mean = vm[D]; *a.ret_var = vm[W + D]; *a.obs_count = vm[2 * W]; *a.ret_count = vm[2 * W + 1]; }
+    }
+}
+// per_rollout: one exact Chan merge of the T x N samples of a rollout from the workgroups' shifted sums (groups, then blocks, in order)
+__global__ __launch_bounds__(64) void k_vn_merge_rollout(const double* __restrict__ partial, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
+                                                       int nblk, int D, long long samples, int flags) {
+    const int k = threadIdx.x, W = D + 1;
+    const bool mine = k < W && (k < D ? (flags & 1) != 0 : (flags & 4) != 0);
+    double cnt = 0;
+    if (mine) cnt = k < D ? *count : *ret_count;
+    __syncthreads();
+    if (!mine) return;
+    double S = 0, SS = 0;
+    for (int b = 0; b < nblk; b++) { S += partial[((size_t)b * W + k) * 2]; SS += partial[((size_t)b * W + k) * 2 + 1]; }
+    double* mp = k < D ? mean + k : ret_mean;
+    double* vp = k < D ? var + k : ret_var;
+    double m = *mp, v = *vp;
+    vn_chan_merge_d(m, v, cnt, S, SS, (double)samples);
+    *mp = m; *vp = v;
+    if (k == 0) *count = cnt + (double)samples;
+    if (k == D) *ret_count = cnt + (double)samples;
+}
+
 // ------------------------------------------------------------------------------------------
 // handle
 static thread_local std::string g_err;
@@ -528,6 +784,10 @@ struct dl_env_s {
     virtual int capstate(float* out, hipStream_t) = 0;
     virtual int last_ctrl(float* out, hipStream_t) = 0;
     virtual int set_split(int on) = 0;
+    virtual int persistent_ok(int hidden, std::string* why) = 0;
+    virtual int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t T, float* observations,
+                                   float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
+                                   float* raw_rew, int per_rollout, hipStream_t s) = 0;
     virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
     virtual int step_timed(const float*, float*, float*, uint8_t*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
@@ -834,6 +1094,61 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels of the lane-only (straight) walker");
         split = on != 0;
         return DL_OK;
+    }
+
+    // ---- dl_collect_rollouts(DL_ROLLOUT_PERSISTENT): the whole rollout as one launch of k_rollout_persistent
+    double* rp_partial = nullptr; double* rp_xpart = nullptr; unsigned* rp_sync = nullptr;
+    int n_cus = 0;
+    int spin_grid = 1 << 22;      // polls of the grid exchange before a workgroup gives up (~2 s)
+    int persistent_ok(int hidden, std::string* why) override {
+        auto no = [&](const char* w) { if (why) *why = w; return 0; };
+        if constexpr (!CAN_SPLIT) return no("the persistent rollout kernel exists for the 16-lane float32 kernels of the lane-only (straight) walker");
+        else {
+            if (!(variant == 1 && gmd)) return no("the persistent rollout kernel needs the 16-lane kernels (lanes_per_walker = 16)");
+            if (hidden != 512) return no("the persistent rollout kernel is built for hidden = 512 (eight waves per workgroup)");
+            if (inj_armed) return no("injected states are pending");
+            if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cus = 0; }
+            if ((n + 15) / 16 > n_cus) return no("more than sixteen walkers per CU: the workgroups of one launch would not be co-resident");
+            return 1;
+        }
+    }
+    int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t nT, float* observations,
+                           float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
+                           float* raw_rew, int per_rollout, hipStream_t s) override {
+        if constexpr (!CAN_SPLIT) return fail(DL_E_INVAL, "dl_collect_rollouts: no persistent form for this walker / precision");
+        else {
+            std::string why;
+            if (!persistent_ok(pol.hidden, &why)) return fail(DL_E_INVAL, "dl_collect_rollouts: " + why);
+            constexpr int W = TP::OBS + 1;
+            const int nblk = (n + 15) / 16;
+            int rc;
+            if (!rp_partial) {
+                if ((rc = dalloc(&rp_partial, (size_t)nblk * W * 2))) return rc;
+                if ((rc = dalloc(&rp_xpart, (size_t)2 * 8 * W * 2))) return rc;
+                if ((rc = dalloc(&rp_sync, (size_t)RP_SYNC_WORDS))) return rc;
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
+            }
+            RolloutP a{};
+            a.pol = pol; a.seed = seed; a.counter0 = counter0; a.index_base = index_base;
+            a.obs_mean = vn.obs_mean; a.obs_var = vn.obs_var; a.obs_count = vn.obs_count; a.ret = vn.ret; a.ret_mean = vn.ret_mean; a.ret_var = vn.ret_var; a.ret_count = vn.ret_count;
+            a.gamma = vn.gamma; a.eps = vn.eps; a.clip_obs = vn.clip_obs; a.clip_rew = vn.clip_rew; a.flags = vn.flags;
+            a.observations = observations; a.actions = actions; a.values = values; a.log_probs = log_probs; a.rewards = rewards; a.next_obs = next_obs; a.raw_obs = raw_obs; a.raw_rew = raw_rew;
+            a.episode_starts = episode_starts; a.next_done = next_done;
+            a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync;
+            a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid;
+            HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
+            st.push_step0 = push_step; push_step += nT;
+            prof_begin(s);
+            hipLaunchKernelGGL((k_rollout_persistent<TP>), dim3(nblk), dim3(512), SLDS + rollout_lds_extra<TP>(), s, (const GModel<float, TP>*)gmd, c, st, a, eval_mode);
+            if (prof_open) prof_steps += nT;
+            prof_end(s);
+            HIPCHK(hipGetLastError());
+            if (per_rollout && (vn.flags & 5))
+                hipLaunchKernelGGL(k_vn_merge_rollout, dim3(1), dim3(64), 0, s, (const double*)rp_partial, vn.obs_mean, vn.obs_var, vn.obs_count, vn.ret_mean, vn.ret_var, vn.ret_count,
+                                   nblk, (int)TP::OBS, (long long)n * nT, vn.flags);
+            HIPCHK(hipGetLastError());
+            return DL_OK;
+        }
     }
     int last_ctrl(float* out, hipStream_t s) override {
         if (!(variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_debug_last_ctrl: implemented by the 16-lane kernels");
@@ -1189,21 +1504,23 @@ __global__ __launch_bounds__(256) void k_vns_apply(const float* __restrict__ x, 
         const int t = (int)(idx / per);
         const size_t e = idx - (size_t)t * per;
         const int k = (int)(e % D);
-        double y = (double)x[idx];
-        if (flags & 2) { const double* st = stats + ((size_t)t * W + k) * 2; y = (y - st[0]) / sqrt(st[1] + eps); y = y < -clip_obs ? -clip_obs : (y > clip_obs ? clip_obs : y); }
-        obs_out[t][e] = (float)y;
+        const double* st = stats + ((size_t)t * W + k) * 2;
+        obs_out[t][e] = (flags & 2) ? vn_norm_obs(x[idx], st[0], st[1], eps, clip_obs) : x[idx];
     }
     if (idx < (size_t)K * B) {
         const int t = (int)(idx / B);
         const size_t e = idx - (size_t)t * B;
-        double y = (double)rew[idx];
-        if (flags & 8) { y = y / sqrt(stats[((size_t)t * W + D) * 2 + 1] + eps); y = y < -clip_rew ? -clip_rew : (y > clip_rew ? clip_rew : y); }
-        rew_out[t][e] = (float)y;
+        rew_out[t][e] = (flags & 8) ? vn_norm_rew(rew[idx], stats[((size_t)t * W + D) * 2 + 1], eps, clip_rew) : rew[idx];
     }
 }
+
 static int vn_reduce_launch(const float* obs, const float* rew, double* obs_mean, double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                             double* ret_count, int32_t B, int32_t D, double gamma, int32_t flags, void* workspace, void* stream) {
-    if ((flags & 5) && (flags & 16) && workspace) {
+    if ((flags & 5) && (flags & 32)) {
+        if (D > 63) return fail(DL_E_INVAL, "dl_vecnormalize_step: the blocked reduction order (flag 32) takes at most 63 observation columns");
+        hipLaunchKernelGGL(k_vn_reduce_blk, dim3(1), dim3(1024), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
+                           (const double*)ret_count, B, D, gamma, flags);
+    } else if ((flags & 5) && (flags & 16) && workspace) {
         double* work = (double*)workspace;
         unsigned* arrive = (unsigned*)(work + (size_t)2 * VN_BLOCKS * (D + 1));
         hipLaunchKernelGGL(k_vn_reduce_mb, dim3(VN_BLOCKS), dim3(256), 0, (hipStream_t)stream, obs, rew, obs_mean, obs_var, (const double*)obs_count, ret, ret_mean, ret_var,
@@ -1311,6 +1628,28 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
         if (rc) return rc;
     }
     return DL_OK;
+}
+int dl_rollout_persistent_ok(dl_handle h, const dl_policy_params* pol) {
+    if (!h || !pol) return 0;
+    return h->persistent_ok(pol->hidden, nullptr);
+}
+int dl_collect_rollouts(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
+                        float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
+                        float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, int32_t mode, void* stream) {
+    NEED(h);
+    NOFAULT(h);
+    if (mode & ~(DL_ROLLOUT_PERSISTENT | DL_ROLLOUT_MOMENTS_PER_ROLLOUT)) return fail(DL_E_INVAL, "dl_collect_rollouts: unknown mode bits");
+    if (!(mode & DL_ROLLOUT_PERSISTENT)) {
+        if (mode & DL_ROLLOUT_MOMENTS_PER_ROLLOUT) return fail(DL_E_INVAL, "dl_collect_rollouts: per-rollout moments exist in the persistent form only");
+        return dl_rollout_policy(h, pol, seed, counter0, index_base, vn, T, observations, actions, values, log_probs, rewards, episode_starts, next_obs, next_done, raw_obs, raw_rew, stream);
+    }
+    if (!pol || !vn || T <= 0 || !observations || !actions || !values || !log_probs || !rewards || !episode_starts || !next_obs || !next_done || !raw_obs || !raw_rew)
+        return fail(DL_E_INVAL, "dl_collect_rollouts: bad arguments");
+    if (pol->obs_dim != h->obs_dim || pol->act_dim != h->act_dim) return fail(DL_E_INVAL, "dl_collect_rollouts: the policy's observation / action sizes are not the environment's");
+    if (!pol->w1 || !pol->b1 || !pol->w2 || !pol->b2 || !pol->wa || !pol->ba || !pol->wv || !pol->bv || !pol->log_std) return fail(DL_E_INVAL, "dl_collect_rollouts: NULL parameter array");
+    if (!vn->obs_mean || !vn->obs_var || !vn->obs_count || !vn->ret || !vn->ret_mean || !vn->ret_var || !vn->ret_count) return fail(DL_E_INVAL, "dl_collect_rollouts: NULL state array");
+    return h->collect_persistent(*pol, seed, counter0, index_base, *vn, T, observations, actions, values, log_probs, rewards, episode_starts, next_obs, next_done, raw_obs, raw_rew,
+                                 (mode & DL_ROLLOUT_MOMENTS_PER_ROLLOUT) != 0, (hipStream_t)stream);
 }
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val, const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv, float* ret, void* stream) {
     if (!rew || !val || !ep_start || !last_val || !last_done || !adv || !ret || T <= 0 || N <= 0) return fail(DL_E_INVAL, "dl_gae: bad arguments");

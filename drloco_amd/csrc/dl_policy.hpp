@@ -70,6 +70,19 @@ struct PolVnFuse {
     int flags;
 };
 
+// VecNormalize's two scalings, one definition for every kernel that applies them (k_vn_apply / k_vns_apply, the policy's folded input
+// stage, the persistent rollout kernel): the same float64 expression -> the same bits wherever a value is normalised
+__device__ __forceinline__ float vn_norm_obs(float x, double mean, double var, double eps, double clip) {
+    double y = ((double)x - mean) / sqrt(var + eps);
+    y = y < -clip ? -clip : (y > clip ? clip : y);
+    return (float)y;
+}
+__device__ __forceinline__ float vn_norm_rew(float r, double ret_var, double eps, double clip) {
+    double y = (double)r / sqrt(ret_var + eps);
+    y = y < -clip ? -clip : (y > clip ? clip : y);
+    return (float)y;
+}
+
 // NTW = accumulator tiles per wave in the hidden layer, NW = waves per workgroup: hidden = 16 * NTW * NW (compile time, so
 // that the tile loops are straight-line code).  hidden = 512 runs as 8 waves x 4 tiles: two waves per SIMD, so that the LDS /
 // weight-load latency of one overlaps the MFMAs of the other.
@@ -78,18 +91,21 @@ struct PolVnFuse {
 // stages through a double-buffered 16 x 32 block (4.5 KB); the heads transpose h2 tile by tile through a private 16 x 16 tile
 // per wave.  23 KB of LDS per workgroup instead of 74 KB: the kernel fits next to four resident workgroups of the env-step
 // kernel on a CU (160 KB), which is what lets the policy of one half of the walkers run under the simulation of the other.
+// The forward pass for the POL_ROWS rows starting at row0, executed by the 64 * NW lanes of a workgroup (device function: k_policy_forward
+// wraps it one workgroup per 16 rows; the persistent rollout kernel k_rollout_persistent calls it once per control step for the rows of its
+// own sixteen walkers).  sm: pol_lds_bytes(NW) bytes of LDS.  count_owner: this workgroup advances the moment counts of a folded
+// VecNormalize step (exactly one workgroup of a launch does).
 template <int NTW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
-                                                        uint64_t seed, uint64_t counter, int index_base, int deterministic,
-                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
+                                                 uint64_t seed, uint64_t counter, int index_base, int deterministic,
+                                                 float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse& vf,
+                                                 float* sm, int row0, bool count_owner) {
     constexpr int H = 16 * NTW * NW, ntw = NTW;
     const int D = p.obs_dim, A = p.act_dim;
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
     float* stage = sm;                                                     // [2][16][POL_SLD]
     float* priv = sm + 2 * POL_ROWS * POL_SLD + wave * (POL_ROWS * POL_PLD);       // this wave's [16][POL_PLD]
     float* part = sm + 2 * POL_ROWS * POL_SLD + NW * (POL_ROWS * POL_PLD);          // [NW][16][16] partial head tiles, then [16][16] log-prob terms
-    const int row0 = blockIdx.x * POL_ROWS;
     constexpr int ncw = H / NW;
     const int n0w = wave * ncw;
     auto wave_sync = [&]() {      // LDS operations of one wave execute in order: exchanging data inside the wave needs no s_barrier
@@ -101,12 +117,11 @@ __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_para
     if (vf.raw_obs) {
         if (tid < POL_ROWS && row0 + tid < n) {
             const int r = row0 + tid;
-            double y = (double)vf.raw_rew[r];
-            if (vf.flags & 8) { y = y / sqrt(*vf.ret_var + vf.eps); y = y < -vf.clip_rew ? -vf.clip_rew : (y > vf.clip_rew ? vf.clip_rew : y); }
-            vf.rew_out[r] = (float)y;
+            const float x = vf.raw_rew[r];
+            vf.rew_out[r] = (vf.flags & 8) ? vn_norm_rew(x, *vf.ret_var, vf.eps, vf.clip_rew) : x;
             if ((vf.flags & 4) && vf.done[r]) vf.ret[r] = 0;
         }
-        if (blockIdx.x == 0 && tid == 0) { if (vf.flags & 1) *vf.count += (double)n; if (vf.flags & 4) *vf.ret_count += (double)n; }
+        if (count_owner && tid == 0) { if (vf.flags & 1) *vf.count += (double)n; if (vf.flags & 4) *vf.ret_count += (double)n; }
     }
     // ---- layer 1: [16, D] x [D, H].  D is small (29): all operand loads of the wave are issued before the first MFMA
     // (one memory latency for the layer instead of one per tile).  h1 stays in registers (accumulator layout).
@@ -126,9 +141,7 @@ __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_para
             for (int q = 0; q < KB1 * 4; q++) {
                 const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
                 if (k < D && r < n) {
-                    double y = (double)a1[q];
-                    if (vf.flags & 2) { y = (y - vf.mean[k]) / sqrt(vf.var[k] + vf.eps); y = y < -vf.clip_obs ? -vf.clip_obs : (y > vf.clip_obs ? vf.clip_obs : y); }
-                    a1[q] = (float)y;
+                    if (vf.flags & 2) a1[q] = vn_norm_obs(a1[q], vf.mean[k], vf.var[k], vf.eps, vf.clip_obs);
                     if (wave == 0) vf.obs_out[(size_t)r * D + k] = a1[q];
                 }
             }
@@ -290,6 +303,14 @@ __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_para
         for (int a = 0; a < A; a++) s += part[row * 16 + a];
         logp[r] = s;
     }
+}
+
+template <int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
+                                                        uint64_t seed, uint64_t counter, int index_base, int deterministic,
+                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    pol_forward_rows<NTW, NW>(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, vf, sm, (int)blockIdx.x * POL_ROWS, blockIdx.x == 0);
 }
 
 }  // namespace dl

@@ -36,21 +36,33 @@ class HipRolloutBuffer:
         self.episode_starts[t].copy_(episode_start); self.values[t].copy_(value); self.log_probs[t].copy_(log_prob)
         self.pos += 1
 
-    def collect_rollouts(self, vn, policy, last_obs, last_done):
-        """SB3 1.0 OnPolicyAlgorithm.collect_rollouts (the loop between two PPO updates) as ONE C-ABI call,
-        dl_rollout_policy: T x (policy forward -> env step -> VecNormalize) enqueued back to back, every result written
-        straight into this buffer.  vn: HipVecNormalize; policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]:
-        the normalised observation and episode-start flags that open this rollout -- overwritten with the ones that open
-        the next (SB3's _last_obs / _last_episode_starts)."""
+    def collect_rollouts(self, vn, policy, last_obs, last_done, persistent=None, moments='per_step'):
+        """SB3 1.0 OnPolicyAlgorithm.collect_rollouts (the loop between two PPO updates) as ONE C-ABI call, dl_collect_rollouts:
+        T x (policy forward -> env step -> VecNormalize), every result written straight into this buffer.  vn: HipVecNormalize;
+        policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]: the normalised observation and episode-start flags that
+        open this rollout -- overwritten with the ones that open the next (SB3's _last_obs / _last_episode_starts).
+        persistent: True = ONE launch for the whole rollout (a persistent workgroup per sixteen walkers, one grid-wide exchange per control
+        step; straight walker, float32, <= 16 walkers per CU), False = three launches per control step, None = persistent where it exists.
+        moments: 'per_step' (SB3's semantics, default) or 'per_rollout' (opt-in relaxation, persistent form only: the whole rollout is
+        normalised with the moments at its start, which are advanced once, by all T x N samples, at its end -- include/drloco_hip.h)."""
+        if moments not in ('per_step', 'per_rollout'):
+            raise ValueError("moments must be 'per_step' or 'per_rollout'")
         self.reset()
         self.observations[0].copy_(last_obs)
         self.episode_starts[0].copy_(last_done)
         p, st = policy._params(), vn.state_struct()
-        lib.check(self._lib.dl_rollout_policy(vn.venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), self.T,
-                                              _ptr(self.observations), _ptr(self.actions), _ptr(self.values), _ptr(self.log_probs), _ptr(self.rewards),
-                                              _ptr(self.episode_starts), _ptr(last_obs), _ptr(last_done), _ptr(vn.venv.obs), _ptr(vn.venv.rew), _stream()))
+        ok = bool(self._lib.dl_rollout_persistent_ok(vn.venv._h, C.byref(p)))
+        if persistent is None:
+            persistent = ok
+        if moments == 'per_rollout' and not persistent:
+            raise lib.DrlocoError("moments='per_rollout' exists in the persistent form of collect_rollouts only")
+        mode = (abi.DL_ROLLOUT_PERSISTENT if persistent else 0) | (abi.DL_ROLLOUT_MOMENTS_PER_ROLLOUT if moments == 'per_rollout' else 0)
+        lib.check(self._lib.dl_collect_rollouts(vn.venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), self.T,
+                                                _ptr(self.observations), _ptr(self.actions), _ptr(self.values), _ptr(self.log_probs), _ptr(self.rewards),
+                                                _ptr(self.episode_starts), _ptr(last_obs), _ptr(last_done), _ptr(vn.venv.obs), _ptr(vn.venv.rew), mode, _stream()))
         policy.counter += self.T
         self.pos = self.T
+        self.last_form = 'persistent' if persistent else 'launches'
 
     def compute_returns_and_advantage(self, last_values, dones):
         lv = last_values.to(torch.float32).contiguous()

@@ -443,6 +443,9 @@ class HipVecNormalize(_VecEnvWrapperBase):
         # env-step kernel: enable_overlap; and for large batches, where one CU's time grows with the batch: 236 us for 16 384 walkers
         # under contention).  Both are deterministic; they sum in different orders, i.e. their moments can differ in the last bit.
         self.multi_block_reduce = self.num_envs > 4096
+        # flags bit 32: the "blocked" summation order (blocks of 16 rows -> <= 8 groups -> total), which the persistent rollout kernel of
+        # dl_collect_rollouts follows by construction: with it a launch-per-step rollout and a persistent one agree bit for bit
+        self.blocked_reduce = False
         # fixed-action runs (steps_fixed): normalise the K steps of a run with dl_vecnormalize_steps (five launches) instead of K x
         # dl_vecnormalize_step; the moments then agree with the step-by-step form to rounding (the shift of the sums differs), not bit for bit
         self.batched_steps = False
@@ -471,7 +474,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         # SB3 1.0 step_wait: obs_rms / ret_rms (and ret) advance whenever training is on, whatever norm_obs / norm_reward say
         # (the reference's load_env builds an evaluation env with norm_reward=False); the norm_* switches only gate the scaling
         return (1 if self.training else 0) | (2 if self.norm_obs else 0) | (4 if self.training else 0) | (8 if self.norm_reward else 0) | \
-               (16 if self.multi_block_reduce else 0)
+               (32 if self.blocked_reduce else (16 if self.multi_block_reduce else 0))
 
     def state_struct(self):
         """dl_vecnorm_state for dl_rollout_policy: pointers to the device-resident moments of this object."""

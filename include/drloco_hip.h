@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear */
+#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32 */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -294,7 +294,8 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
  *   ret = ret*gamma + rew; ret_rms.update(ret); rew_out = clip(rew/sqrt(ret_var + eps), +-clip_rew); ret[done] = 0.
  * flags: 1 update the observation moments (training), 2 normalise observations, 4 advance ret and update its
  * moments (training), 8 normalise rewards, 16 reduce with 32 blocks instead of one workgroup (for launches on a side stream
- * under other kernels; both forms are deterministic, their summation orders differ).  obs/rew are not modified (get_original_obs / get_original_reward);
+ * under other kernels), 32 reduce in the "blocked" order -- sums over blocks of 16 rows, blocks over <= 8 groups, groups in order: the order
+ * dl_collect_rollouts' persistent kernel follows, so that the two agree bit for bit (all forms are deterministic, their summation orders differ).  obs/rew are not modified (get_original_obs / get_original_reward);
  * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
  * zero-initialised once by the caller and owned by this call sequence. */
 #define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * ((D) + 1) + 2))   /* used by the multi-block reduction (flags bit 16) only */
@@ -376,6 +377,28 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
                       float* actions, float* values, float* log_probs, float* rewards,
                       uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
                       float* raw_rew, void* stream);
+
+/* dl_rollout_policy with a choice of execution form (`mode`):
+ *   0                                   T x 3 launches (= dl_rollout_policy);
+ *   DL_ROLLOUT_PERSISTENT               ONE launch for the whole rollout: a persistent workgroup of eight waves per sixteen walkers runs, per
+ *       control step, the policy forward of its own rows (matrix cores), MimicEnv.step of its walkers (the split-workgroup step kernel's code)
+ *       and VecNormalize's moment update through one grid-wide exchange.  Exact SB3 semantics (every step normalises with the moments of all
+ *       walkers up to that step); bit-identical to mode 0 when `vn->flags` selects the blocked reduction order (bit 32) and dl_set_split is on.
+ *       Needs: straight walker, float32, 16 lanes per walker, hidden = 512, at most 16 walkers per CU (4096 on an MI355X) -- query with
+ *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  A grid exchange that does not complete within its (bounded, ~2 s) poll budget
+ *       raises the handle's fault word (bit 4, dl_fault_check).
+ *   DL_ROLLOUT_PERSISTENT | DL_ROLLOUT_MOMENTS_PER_ROLLOUT   opt-in relaxation: observations and rewards of the whole rollout are normalised
+ *       with the moments at its START, workgroups exchange nothing during the rollout (they run free; a rollout lasts as long as its slowest
+ *       workgroup's sum of steps), and ONE exact Chan merge of all T x N samples follows -- RunningMeanStd.update fed the rollout as one batch.
+ *       Not SB3's per-step update; the same relaxation the cross-rank merge C3 applies. */
+#define DL_ROLLOUT_PERSISTENT 1
+#define DL_ROLLOUT_MOMENTS_PER_ROLLOUT 2
+int dl_rollout_persistent_ok(dl_handle h, const dl_policy_params* policy);
+int dl_collect_rollouts(dl_handle h, const dl_policy_params* policy, uint64_t seed, uint64_t counter0,
+                        int32_t index_base, const dl_vecnorm_state* vn, int32_t T, float* observations,
+                        float* actions, float* values, float* log_probs, float* rewards,
+                        uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
+                        float* raw_rew, int32_t mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -145,7 +145,7 @@ def test_loco3d_full_size_properties(torch_cuda):
     torch.cuda.synchronize()
     assert obs.shape == (T, n, 47) and torch.isfinite(obs).all() and torch.isfinite(rew).all()
     d = done.bool()
-    assert (rew[d] == 0).all() and (rew[~d] > 0.2).all() and (rew[~d] <= 1.2 + 1e-6).all()
+    assert (rew[d] == 0).all() and (rew[~d] >= 0.2).all() and (rew[~d] <= 1.2 + 1e-6).all()      # (far from the reference the imitation terms underflow: exactly the alive bonus)
     env2 = mk(n); env2.reset_tensors()
     obs2, rew2, done2 = env2.rollout_fixed(acts)
     assert torch.equal(obs, obs2) and torch.equal(rew, rew2) and torch.equal(done, done2)             # deterministic

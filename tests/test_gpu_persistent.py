@@ -1,0 +1,173 @@
+"""GPU tests of dl_collect_rollouts' persistent form (k_rollout_persistent: SB3's collect_rollouts -- drloco/train.py:110-133 with the policy of
+drloco/custom/policies.py:13-51 -- as ONE launch: per control step the policy forward of a workgroup's own sixteen rows, MimicEnv.step of its
+sixteen walkers and VecNormalize's moment update through one grid-wide exchange).
+  * exact mode: bit-identical to the launch-per-step form (dl_rollout_policy: 3 launches per control step) when that form simulates with the
+    split workgroups and reduces the moments in the blocked order the persistent kernel follows (dl_vecnormalize_step flag 32);
+  * per-rollout moments (opt-in): every output is re-derived from a replay -- the recorded actions through dl_rollout_fixed give the raw
+    observations / rewards, the start-of-rollout moments give their normalisation, dl_policy_forward on the recorded observations gives the
+    actions, and numpy's one-batch RunningMeanStd.update gives the moments after the rollout."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return torch
+
+
+def _setup(torch, model, refs, n, T, seed=21, **vn_kw):
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    venv = HipVecEnv(num_envs=n, seed=seed, model=model, refs=refs, ep_dur_max=60)        # episodes end by time-out (and by falls) inside the window
+    venv.set_split(True)
+    vn = HipVecNormalize(venv, **vn_kw)
+    vn.blocked_reduce = True
+    pol = HipPolicy(hidden=512, seed=4)
+    buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+    vn.reset()
+    return venv, vn, pol, buf, vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
+
+
+@pytest.mark.parametrize('n,T', [(4096, 40), (1000, 33), (16, 25), (5, 9)], ids=['full-size', 'ragged-63-workgroups', 'one-workgroup', 'partly-filled-workgroup'])
+def test_persistent_rollout_is_the_launch_path_bit_for_bit(torch_cuda, model, refs, n, T):
+    torch = torch_cuda
+    res = []
+    for persistent in (False, True):
+        venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
+        for rollout in range(2):                                # the second rollout starts from the first one's last observation and moments
+            buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=persistent)
+            assert buf.last_form == ('persistent' if persistent else 'launches')
+        torch.cuda.synchronize()
+        from drloco_amd import lib as L
+        L.check(venv._lib.dl_fault_check(venv._h, None))
+        st = venv.get_state()
+        res.append(dict(observations=buf.observations.cpu().clone(), actions=buf.actions.cpu().clone(), values=buf.values.cpu().clone(), log_probs=buf.log_probs.cpu().clone(),
+                        rewards=buf.rewards.cpu().clone(), episode_starts=buf.episode_starts.cpu().clone(), last_obs=last_obs.cpu().clone(), last_done=last_done.cpu().clone(),
+                        om=torch.as_tensor(vn.obs_rms.mean), ov=torch.as_tensor(vn.obs_rms.var), oc=torch.tensor(vn.obs_rms.count), rm=torch.as_tensor(vn.ret_rms.mean),
+                        rv=torch.as_tensor(vn.ret_rms.var), rc=torch.tensor(vn.ret_rms.count), ret=vn.ret.cpu().clone(), raw_obs=torch.as_tensor(vn.get_original_obs()),
+                        raw_rew=torch.as_tensor(vn.get_original_reward()), counter=torch.tensor(pol.counter), **{'state_' + k: torch.as_tensor(v) for k, v in st.items()},
+                        ep_len=torch.as_tensor(venv.get_attr('ep_len_smoothed')), moved=torch.as_tensor(venv.get_attr('moved_distance'))))
+        venv.close()
+    a, b = res
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].double() - b[k].double()).abs().max()))
+    assert a['episode_starts'].sum() > 0 and a['counter'] == 2 * T
+
+
+@pytest.mark.parametrize('kw', [dict(training=False), dict(norm_reward=False), dict(norm_obs=False)], ids=['frozen', 'raw-rewards', 'raw-observations'])
+def test_persistent_rollout_flag_combinations(torch_cuda, model, refs, kw):
+    """VecNormalize's switches (load_env's evaluation env: training = False / norm_reward = False, drloco/common/utils.py:234-240) in both forms."""
+    torch = torch_cuda
+    n, T = 300, 20
+    res = []
+    for persistent in (False, True):
+        venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T, **kw)
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=persistent)
+        torch.cuda.synchronize()
+        res.append([buf.observations.cpu().clone(), buf.actions.cpu().clone(), buf.rewards.cpu().clone(), buf.episode_starts.cpu().clone(), last_obs.cpu().clone(),
+                    torch.as_tensor(vn.obs_rms.mean), torch.as_tensor(vn.ret_rms.var), torch.tensor(vn.obs_rms.count), vn.ret.cpu().clone()])
+        venv.close()
+    for x, y in zip(*res):
+        assert torch.equal(x, y), kw
+
+
+def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs):
+    torch = torch_cuda
+    from drloco_amd.vec_env import HipVecEnv
+    n, T = 1000, 48
+    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
+    # give the moments a non-trivial start: one exact rollout first
+    buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+    torch.cuda.synchronize()
+    om0, ov0, oc0 = vn.obs_rms.mean.copy(), vn.obs_rms.var.copy(), vn.obs_rms.count
+    rm0, rv0, rc0 = float(vn.ret_rms.mean), float(vn.ret_rms.var), vn.ret_rms.count
+    ret0 = vn.ret.cpu().numpy().copy()
+    st0 = venv.get_state()
+    obs0 = last_obs.cpu().numpy().copy()
+    counter0 = pol.counter
+    buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True, moments='per_rollout')
+    torch.cuda.synchronize()
+    from drloco_amd import lib as L
+    L.check(venv._lib.dl_fault_check(venv._h, None))
+    # (1) replay: the recorded actions from the recorded start state, one launch per control step with the same (split) step kernel
+    rep = HipVecEnv(num_envs=n, seed=21, model=model, refs=refs, ep_dur_max=60)
+    rep.set_split(True)
+    rep.reset_tensors()
+    rep.set_state(qpos=st0['qpos'], qvel=st0['qvel'], warm=st0['warm'], cursor=st0['cursor'], walked=st0['walked'])
+    raw_o = torch.zeros(T, n, 29, device='cuda'); raw_r = torch.zeros(T, n, device='cuda'); dn = torch.zeros(T, n, dtype=torch.uint8, device='cuda')
+    for t in range(T):
+        rep.step_tensors(buf.actions[t], obs_out=raw_o[t], rew_out=raw_r[t], done_out=dn[t])
+    torch.cuda.synchronize()
+    assert torch.equal(dn[:-1], buf.episode_starts[1:]) and torch.equal(dn[-1], last_done)
+    assert dn.sum() > 0
+    # (2) the whole rollout is normalised with the moments at its start
+    ro, rr = raw_o.cpu().numpy().astype(np.float64), raw_r.cpu().numpy().astype(np.float64)
+    exp_obs = np.clip((ro - om0) / np.sqrt(ov0 + 1e-8), -10, 10).astype(np.float32)
+    exp_rew = np.clip(rr / np.sqrt(rv0 + 1e-8), -10, 10).astype(np.float32)
+    got_obs = np.concatenate([buf.observations[1:].cpu().numpy(), last_obs.cpu().numpy()[None]])
+    assert np.array_equal(buf.observations[0].cpu().numpy(), obs0)
+    np.testing.assert_allclose(got_obs, exp_obs, rtol=0, atol=1e-6)         # float64 formula on both sides; one float32 rounding
+    np.testing.assert_allclose(buf.rewards.cpu().numpy(), exp_rew, rtol=0, atol=1e-6)
+    # (3) the policy's outputs are those of dl_policy_forward on the recorded observations (same counter stream)
+    from drloco_amd.policy import HipPolicy
+    p2 = HipPolicy(hidden=512, seed=4)
+    p2.counter = counter0
+    for t in (0, 1, T - 1):
+        p2.counter = counter0 + t
+        a, v, lp = p2.forward(buf.observations[t])
+        assert torch.equal(a, buf.actions[t]) and torch.equal(v, buf.values[t]) and torch.equal(lp, buf.log_probs[t]), t
+    # (4) moments after the rollout: RunningMeanStd.update fed all T x N samples as ONE batch; discounted returns advance per step
+    def upd(m, v, c, x):
+        bm, bv, bc = x.mean(0), x.var(0), x.shape[0]
+        d, tot = bm - m, c + bc
+        return m + d * bc / tot, (v * c + bv * bc + d * d * c * bc / tot) / tot, tot
+    m1, v1, c1 = upd(om0, ov0, oc0, raw_o.cpu().numpy().astype(np.float64).reshape(T * n, 29))
+    ret, rets = ret0.copy(), []
+    dnh = dn.cpu().numpy()
+    for t in range(T):
+        ret = ret * 0.99 + rr[t]
+        rets.append(ret.copy())
+        ret[dnh[t] != 0] = 0
+    rm1, rv1, rc1 = upd(rm0, rv0, rc0, np.concatenate(rets))
+    np.testing.assert_allclose(vn.obs_rms.mean, m1, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(vn.obs_rms.var, v1, rtol=1e-10)
+    assert vn.obs_rms.count == c1 and vn.ret_rms.count == rc1
+    np.testing.assert_allclose([float(vn.ret_rms.mean), float(vn.ret_rms.var)], [rm1, rv1], rtol=1e-10)
+    np.testing.assert_allclose(vn.ret.cpu().numpy(), ret, rtol=1e-12, atol=1e-12)
+    venv.close(); rep.close()
+
+
+def test_persistent_form_refusals(torch_cuda, model, refs):
+    torch = torch_cuda
+    from drloco_amd import lib as L, mocap, models
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    def attempt(venv, pol, **kw):
+        vn = HipVecNormalize(venv)
+        vn.reset()
+        buf = HipRolloutBuffer(4, venv.num_envs, venv.obs_dim, venv.nu, torch.device('cuda'))
+        buf.collect_rollouts(vn, pol, vn.norm_obs_t.clone(), torch.ones(venv.num_envs, dtype=torch.uint8, device='cuda'), **kw)
+        torch.cuda.synchronize()
+        return buf.last_form
+    # other hidden sizes, float64, one lane per walker, too many walkers: the automatic choice is the launch form, an explicit request raises
+    for venv, pol in ((HipVecEnv(num_envs=64, model=model, refs=refs), HipPolicy(hidden=128)), (HipVecEnv(num_envs=64, model=model, refs=refs, precision=64), HipPolicy(hidden=512)),
+                      (HipVecEnv(num_envs=64, model=model, refs=refs, lanes_per_walker=1), HipPolicy(hidden=512)), (HipVecEnv(num_envs=4112, model=model, refs=refs), HipPolicy(hidden=512))):
+        assert attempt(venv, pol) == 'launches'
+        with pytest.raises(L.DrlocoError):
+            attempt(venv, pol, persistent=True)
+        with pytest.raises(L.DrlocoError):
+            attempt(venv, pol, persistent=False, moments='per_rollout')
+        venv.close()
+    ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
+    venv = HipVecEnv(models.WALKER_165CM, num_envs=32, refs=mocap.loco3d_table(ang, vel))
+    assert attempt(venv, HipPolicy(obs_dim=47, act_dim=13, hidden=512)) == 'launches'
+    venv.close()
+    venv = HipVecEnv(num_envs=64, model=model, refs=refs)
+    assert attempt(venv, HipPolicy(hidden=512)) == 'persistent'          # (dl_set_split need not be on: the persistent kernel IS the split form)
+    venv.close()

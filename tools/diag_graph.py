@@ -19,7 +19,7 @@ last_done.fill_(1)
 
 
 def direct():
-    buf.collect_rollouts(vn, policy, last_obs, last_done)
+    buf.collect_rollouts(vn, policy, last_obs, last_done, persistent=False)        # the launch-per-step form is what a graph would shorten
 
 
 def timeit(f, k=3):
