@@ -589,35 +589,59 @@ struct RolloutP {
 constexpr int RP_SYNC_WORDS = 160;
 template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2) * sizeof(double) + 64; }
 
+// All arguments travel as ONE by-value struct: the kernel reads them through the kernarg segment pointer, made opaque at the start of every
+// phase of every control step.  Passed as separate by-value parameters the ~150 uniform words (reference table, state arrays, rollout-buffer
+// pointers, policy parameters) are values the compiler keeps alive in SGPRs across the WHOLE step loop -- policy phase, env phase and
+// exchange -- and pays for with v_writelane / v_readlane spills inside the solver loops (measured: 471 SGPR + 188 VGPR spills, 40 us per
+// control step); loaded per phase they live exactly as long as the phase.
+template <typename TP> struct RolloutArgs {
+    const GModel<float, TP>* gm;
+    DevCfg<float> c;
+    DevState<float> st;
+    RolloutP a;
+    int32_t eval_mode;
+};
 template <typename TP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg<float> c, const DevState<float> st0, const RolloutP a, int eval_mode) {
+void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using T = float;
     using Sp = GSplit<TP>;
+    using Args = RolloutArgs<TP>;
     constexpr int D = TP::OBS, W = D + 1, NU = TP::NU;
     constexpr size_t ENV_LDS = (size_t)4 * GW * Sp::TOTAL * sizeof(T);
     static_assert(pol_lds_bytes(8) <= ENV_LDS, "the policy's LDS aliases the walkers' regions between two env steps");
+    // the first (only) explicit argument sits at offset 0 of the kernarg segment (HSA ABI)
+    const DL_CONST Args* const ap0 = (const DL_CONST Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto args = [&]() { const DL_CONST Args* q = ap0; DL_SPIN(q); return q; };       // a fresh, opaque view: loads through it are not merged with earlier ones
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = wave >> 2, slot = wave & 3;
     const int gslot = role == 0 ? slot : ((slot + DL_SPLIT_PAIR_OFFSET) & 3);
     DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
     double* vm = (double*)(smem + ENV_LDS);                 // mean[W] (column D: the returns'), var[W], count, ret_count
     int* shf = (int*)(vm + 2 * W + 2);                      // [0] group-last flag, [1] exchange ok
-    const int n = st0.n, nblk = gridDim.x;
+    const int nblk = gridDim.x;
     const int blk = g_block_of_workgroup(blockIdx.x, gridDim.x);
+    int n, nT, flags, per_rollout;
+    {
+        const DL_CONST Args* p = args();
+        n = p->st.n; nT = p->a.T; flags = p->a.flags; per_rollout = p->a.per_rollout;
+        if (tid < D) { vm[tid] = p->a.obs_mean[tid]; vm[W + tid] = p->a.obs_var[tid]; }
+        if (tid == D) { vm[D] = *p->a.ret_mean; vm[W + D] = *p->a.ret_var; vm[2 * W] = *p->a.obs_count; vm[2 * W + 1] = *p->a.ret_count; }
+    }
     const int row0 = blk * 16, row1 = row0 + 16 < n ? row0 + 16 : n;
     const VnBlk vb = vn_blk(n);
     const int grp = blk / vb.gsize, gb0 = grp * vb.gsize, gb1 = gb0 + vb.gsize < nblk ? gb0 + vb.gsize : nblk;
-    const int flags = a.flags;
-    const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !a.per_rollout;
-    if (tid < D) { vm[tid] = a.obs_mean[tid]; vm[W + tid] = a.obs_var[tid]; }
-    if (tid == D) { vm[D] = *a.ret_mean; vm[W + D] = *a.ret_var; vm[2 * W] = *a.obs_count; vm[2 * W + 1] = *a.ret_count; }
+    const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !per_rollout;
     double acc_s = 0, acc_ss = 0;                           // per_rollout: this thread's column sums over the whole rollout
     __syncthreads();
 #pragma unroll 1
-    for (int t = 0; t < a.T; t++) {
+    for (int t = 0; t < nT; t++) {
         // ---- P: actions, values, log-probs of step t (and observations[t], rewards[t - 1] from the raw outputs of step t - 1)
         {
+            const DL_CONST Args* p = args();
+            const RolloutP a = p->a;
+            int tid_t = tid;
+            DL_VPIN(tid_t);           // per-step opaque: the policy's per-lane index arithmetic is not kept alive across the env phase
             PolVnFuse vf{};
             if (t > 0) {
                 vf.raw_obs = a.raw_obs; vf.raw_rew = a.raw_rew; vf.done = a.episode_starts + (size_t)t * n;
@@ -626,7 +650,7 @@ void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
             pol_forward_rows<4, 8>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
-                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false);
+                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t);
         }
         __syncthreads();          // the actions of the workgroup's rows are in memory (workgroup scope); the policy's LDS is free again
         // ---- E: one control step of the sixteen walkers
@@ -636,33 +660,42 @@ void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg
         }
         __syncthreads();
         {
-            DevState<T> st = st0;
-            st.push_step0 = st0.push_step0 + t;
-            uint8_t* done = t + 1 == a.T ? a.next_done : a.episode_starts + (size_t)(t + 1) * n;
+            const DL_CONST Args* p = args();
+            DevState<T> st = p->st;
+            st.push_step0 += t;
+            const DevCfg<T> c = p->c;
+            uint8_t* done = t + 1 == nT ? p->a.next_done : p->a.episode_starts + (size_t)(t + 1) * n;
             const int wblock = blk * 4 + gslot;
+            int lane_t = lane;
+            DL_VPIN(lane_t);          // per-step opaque (as above): lane topology, lane records and pinned constants are this phase's only
             if (role == 0)
-                g_wave_env_step<T, TP, false, true>(lane, wblock, 0, 1, base, gm, c, st, a.actions + (size_t)t * n * NU, a.raw_obs, a.raw_rew, done, (float*)nullptr, (float*)nullptr,
-                                                    (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, eval_mode, 1, nullptr);
+                g_wave_env_step<T, TP, false, true>(lane_t, wblock, 0, 1, base, p->gm, c, st, p->a.actions + (size_t)t * n * NU, p->a.raw_obs, p->a.raw_rew, done, (float*)nullptr, (float*)nullptr,
+                                                    (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, p->eval_mode, 1, nullptr);
             else
-                g_constraint_server<T, TP>(lane, wblock, base, gm, st);
+                g_constraint_server<T, TP>(lane_t, wblock, base, p->gm, st);
         }
         __syncthreads();          // raw observation / reward / done of the workgroup's rows are in memory
         // ---- R: VecNormalize's moment update
         if (upd_obs || upd_ret) {
+            const DL_CONST Args* p = args();
             const bool mine = tid < W && (tid < D ? upd_obs : upd_ret);
             if (mine) {
                 double s, ss;
-                vn_block_sums(a.raw_obs, a.raw_rew, a.ret, D, tid, row0, row1, vm[tid], a.gamma, s, ss);
-                if (exchange) { a.partial[((size_t)blk * W + tid) * 2] = s; a.partial[((size_t)blk * W + tid) * 2 + 1] = ss; }
+                vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, tid, row0, row1, vm[tid], p->a.gamma, s, ss);
+                if (exchange) { p->a.partial[((size_t)blk * W + tid) * 2] = s; p->a.partial[((size_t)blk * W + tid) * 2 + 1] = ss; }
                 else { acc_s += s; acc_ss += ss; }
             }
         }
         if (exchange) {
+            const DL_CONST Args* p = args();
+            unsigned* sync = p->a.sync;
+            const double* partial = p->a.partial;
+            double* xpart = p->a.xpart + (size_t)(t & 1) * 8 * W * 2;
             __syncthreads();
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned old = __hip_atomic_fetch_add(a.sync + 16 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned old = __hip_atomic_fetch_add(sync + 16 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool last = old + 1u == (unsigned)(gb1 - gb0) * (unsigned)(t + 1);
                 if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 shf[0] = last ? 1 : 0;
@@ -671,33 +704,33 @@ void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg
             if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order
                 if (tid < 2 * W) {
                     double x = 0;
-                    for (int b = gb0; b < gb1; b++) x += a.partial[(size_t)b * W * 2 + tid];
-                    a.xpart[((size_t)(t & 1) * 8 + grp) * W * 2 + tid] = x;
+                    for (int b = gb0; b < gb1; b++) x += partial[(size_t)b * W * 2 + tid];
+                    xpart[(size_t)grp * W * 2 + tid] = x;
                 }
                 __syncthreads();
                 if (tid == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(a.sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (tid == 0) {
                 const unsigned want = (unsigned)vb.ngrp * (unsigned)(t + 1);
+                const int budget = p->a.spin_grid;
                 bool ok = false;
-                for (int it = 0; it < a.spin_grid; it++) {
-                    if (__hip_atomic_load(a.sync + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
+                for (int it = 0; it < budget; it++) {
+                    if (__hip_atomic_load(sync + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                else if (st0.fault) DL_FAULT_OR(st0.fault, DL_FAULT_GRID_TIMEOUT);
+                else if (p->st.fault) DL_FAULT_OR(p->st.fault, DL_FAULT_GRID_TIMEOUT);
                 shf[1] = ok ? 1 : 0;
             }
             __syncthreads();
             if (!shf[1]) return;          // (uniform) the grid never completed this step: fault word set, nothing further is written
             if (tid < W && (tid < D ? upd_obs : upd_ret)) {
                 double S = 0, SS = 0;
-                const double* xp = a.xpart + (size_t)(t & 1) * 8 * W * 2;
-                for (int g = 0; g < vb.ngrp; g++) { S += xp[((size_t)g * W + tid) * 2]; SS += xp[((size_t)g * W + tid) * 2 + 1]; }
+                for (int g = 0; g < vb.ngrp; g++) { S += xpart[((size_t)g * W + tid) * 2]; SS += xpart[((size_t)g * W + tid) * 2 + 1]; }
                 double m = vm[tid], v = vm[W + tid];
                 vn_chan_merge(m, v, tid < D ? vm[2 * W] : vm[2 * W + 1], S, SS, n);
                 vm[tid] = m; vm[W + tid] = v;
@@ -708,6 +741,8 @@ void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg
         __syncthreads();
     }
     // ---- VecNormalize of the last step's outputs (k_vn_apply's work for the workgroup's rows): next_obs, rewards[T - 1], ret
+    const DL_CONST Args* p = args();
+    const RolloutP a = p->a;
     for (int idx = tid; idx < (row1 - row0) * D; idx += 512) {
         const size_t e = (size_t)row0 * D + idx;
         const int k = idx % D;
@@ -715,10 +750,10 @@ void k_rollout_persistent(const GModel<float, TP>* __restrict__ gm, const DevCfg
     }
     if (tid < row1 - row0) {
         const int r = row0 + tid;
-        a.rewards[(size_t)(a.T - 1) * n + r] = (flags & 8) ? vn_norm_rew(a.raw_rew[r], vm[W + D], a.eps, a.clip_rew) : a.raw_rew[r];
+        a.rewards[(size_t)(nT - 1) * n + r] = (flags & 8) ? vn_norm_rew(a.raw_rew[r], vm[W + D], a.eps, a.clip_rew) : a.raw_rew[r];
         if (upd_ret && a.next_done[r]) a.ret[r] = 0;
     }
-    if (a.per_rollout) {          // the workgroup's sums over the whole rollout, merged by k_vn_merge_rollout
+    if (per_rollout) {            // the workgroup's sums over the whole rollout, merged by k_vn_merge_rollout
         if (tid < W) { a.partial[((size_t)blk * W + tid) * 2] = acc_s; a.partial[((size_t)blk * W + tid) * 2 + 1] = acc_ss; }
     } else if (blk == 0) {        // every workgroup holds the same moments: one of them hands them back
         if (tid < D) { a.obs_mean[tid] = vm[tid]; a.obs_var[tid] = vm[W + tid]; }
@@ -1139,7 +1174,9 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
-            hipLaunchKernelGGL((k_rollout_persistent<TP>), dim3(nblk), dim3(512), SLDS + rollout_lds_extra<TP>(), s, (const GModel<float, TP>*)gmd, c, st, a, eval_mode);
+            RolloutArgs<TP> ra{};
+            ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
+            hipLaunchKernelGGL((k_rollout_persistent<TP>), dim3(nblk), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
             prof_end(s);
             HIPCHK(hipGetLastError());

@@ -94,15 +94,16 @@ __device__ __forceinline__ float vn_norm_rew(float r, double ret_var, double eps
 // The forward pass for the POL_ROWS rows starting at row0, executed by the 64 * NW lanes of a workgroup (device function: k_policy_forward
 // wraps it one workgroup per 16 rows; the persistent rollout kernel k_rollout_persistent calls it once per control step for the rows of its
 // own sixteen walkers).  sm: pol_lds_bytes(NW) bytes of LDS.  count_owner: this workgroup advances the moment counts of a folded
-// VecNormalize step (exactly one workgroup of a launch does).
+// VecNormalize step (exactly one workgroup of a launch does).  tid: threadIdx.x (a parameter so that a caller looping over control steps can
+// pass it opaque per step: the lane's index arithmetic is then redone per step instead of being kept in registers across the other phases).
 template <int NTW, int NW>
 __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                  uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                  float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse& vf,
-                                                 float* sm, int row0, bool count_owner) {
+                                                 float* sm, int row0, bool count_owner, int tid) {
     constexpr int H = 16 * NTW * NW, ntw = NTW;
     const int D = p.obs_dim, A = p.act_dim;
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
+    const int wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
     float* stage = sm;                                                     // [2][16][POL_SLD]
     float* priv = sm + 2 * POL_ROWS * POL_SLD + wave * (POL_ROWS * POL_PLD);       // this wave's [16][POL_PLD]
     float* part = sm + 2 * POL_ROWS * POL_SLD + NW * (POL_ROWS * POL_PLD);          // [NW][16][16] partial head tiles, then [16][16] log-prob terms
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_para
                                                         uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                         float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    pol_forward_rows<NTW, NW>(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, vf, sm, (int)blockIdx.x * POL_ROWS, blockIdx.x == 0);
+    pol_forward_rows<NTW, NW>(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, vf, sm, (int)blockIdx.x * POL_ROWS, blockIdx.x == 0, (int)threadIdx.x);
 }
 
 }  // namespace dl
