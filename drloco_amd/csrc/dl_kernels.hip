@@ -520,7 +520,11 @@ __device__ __forceinline__ void vn_block_sums(const float* __restrict__ x, const
 #pragma unroll
         for (int r = 0; r < 16; r++) if (r0 + r < r1) { const double d = (double)a[r] - K; s += d; ss = fma(d, d, ss); }
     } else {
-        for (int r = r0; r < r1; r++) { const double rn = fma(ret[r], gamma, (double)rew[r]); ret[r] = rn; const double d = rn - K; s += d; ss = fma(d, d, ss); }
+        double o[16]; float w[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { o[r] = r0 + r < r1 ? ret[r0 + r] : 0.0; w[r] = r0 + r < r1 ? rew[r0 + r] : 0.0f; }
+#pragma unroll
+        for (int r = 0; r < 16; r++) if (r0 + r < r1) { const double rn = fma(o[r], gamma, (double)w[r]); ret[r0 + r] = rn; const double d = rn - K; s += d; ss = fma(d, d, ss); }
     }
     s_out = s; ss_out = ss;
 }
@@ -570,8 +574,9 @@ __global__ __launch_bounds__(1024) void k_vn_reduce_blk(const float* __restrict_
 // accumulates its shifted sums over the whole rollout, nothing is exchanged during the rollout (workgroups run free: the launch lasts as
 // long as the slowest SUM, not the sum of every step's slowest workgroup) and k_vn_merge_rollout performs one exact Chan merge of all
 // T x N samples afterwards -- the relaxation collective C3 already applies across ranks.
-// Hand-offs follow /opt/skills/guides/cdna_hip_programming.md guideline 16: plain stores -> __syncthreads -> one lane: agent-scope release,
-// drained, relaxed agent atomic; consumers: one lane polls relaxed, ONE agent-scope acquire, __syncthreads, plain loads.  Counters are
+// Hand-offs follow /opt/skills/guides/cdna_hip_programming.md guideline 16 in its fence-free form: every exchanged word is an 8-byte agent-scope
+// access on BOTH sides (stores write through, loads bypass L1), every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's one lane
+// bumps a relaxed agent-scope counter; consumers poll that counter relaxed, from one lane.  Counters are
 // monotonic over the steps of a launch (epoch = step + 1) and zeroed by the host before every launch.  Every poll is bounded: a timeout
 // sets the handle's fault word (DL_FAULT_GRID_TIMEOUT) and ends the workgroup.
 #define DL_FAULT_GRID_TIMEOUT 4
@@ -584,6 +589,7 @@ struct RolloutP {
     uint8_t *episode_starts, *next_done;
     double *partial, *xpart;      // [nblk][W][2], [2][8][W][2] (group sums, double-buffered by step parity: a group may not overwrite what another group's workgroups still read)
     unsigned* sync;               // group counters at [16 g], top counter at [128]
+    long long* prof;              // diagnostics (DL_EXP_ROLLOUT_PROF builds): [nblk][4] shader-clock cycles in P, E, R (sums + exchange), waiting in the exchange
     int32_t index_base, flags, T, per_rollout, spin_grid;
 };
 constexpr int RP_SYNC_WORDS = 160;
@@ -633,9 +639,16 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     const int grp = blk / vb.gsize, gb0 = grp * vb.gsize, gb1 = gb0 + vb.gsize < nblk ? gb0 + vb.gsize : nblk;
     const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !per_rollout;
     double acc_s = 0, acc_ss = 0;                           // per_rollout: this thread's column sums over the whole rollout
+#ifdef DL_EXP_ROLLOUT_PROF
+    long long prof_acc[4] = {0, 0, 0, 0}, prof_t = DL_CLOCK();
+#define DL_RP_TICK(k) do { const long long now_ = DL_CLOCK(); prof_acc[k] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define DL_RP_TICK(k) ((void)0)
+#endif
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < nT; t++) {
+        DL_RP_TICK(2);
         // ---- P: actions, values, log-probs of step t (and observations[t], rewards[t - 1] from the raw outputs of step t - 1)
         {
             const DL_CONST Args* p = args();
@@ -653,6 +666,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                                    a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t);
         }
         __syncthreads();          // the actions of the workgroup's rows are in memory (workgroup scope); the policy's LDS is free again
+        DL_RP_TICK(0);
         // ---- E: one control step of the sixteen walkers
         if (lane == 0) {
             volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
@@ -675,6 +689,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 g_constraint_server<T, TP>(lane_t, wblock, base, p->gm, st);
         }
         __syncthreads();          // raw observation / reward / done of the workgroup's rows are in memory
+        DL_RP_TICK(1);
         // ---- R: VecNormalize's moment update
         if (upd_obs || upd_ret) {
             const DL_CONST Args* p = args();
@@ -682,38 +697,44 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             if (mine) {
                 double s, ss;
                 vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, tid, row0, row1, vm[tid], p->a.gamma, s, ss);
-                if (exchange) { p->a.partial[((size_t)blk * W + tid) * 2] = s; p->a.partial[((size_t)blk * W + tid) * 2 + 1] = ss; }
+                if (exchange) {       // 8-byte agent-scope stores: write-through, so that the hand-over needs no release fence (guideline 16, R1)
+                    __hip_atomic_store(&p->a.partial[((size_t)blk * W + tid) * 2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&p->a.partial[((size_t)blk * W + tid) * 2 + 1], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the flag
+                }
                 else { acc_s += s; acc_ss += ss; }
             }
         }
         if (exchange) {
             const DL_CONST Args* p = args();
+            // every word of the exchange is an 8-byte agent-scope access on both sides (stores write through, loads bypass L1): the valid
+            // fence-free form of the guide -- an agent-scope release would write back the whole L2's dirty lines (the step's raw outputs) first
             unsigned* sync = p->a.sync;
-            const double* partial = p->a.partial;
+            double* partial = p->a.partial;
             double* xpart = p->a.xpart + (size_t)(t & 1) * 8 * W * 2;
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned old = __hip_atomic_fetch_add(sync + 16 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool last = old + 1u == (unsigned)(gb1 - gb0) * (unsigned)(t + 1);
-                if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                shf[0] = last ? 1 : 0;
+                shf[0] = (old + 1u == (unsigned)(gb1 - gb0) * (unsigned)(t + 1)) ? 1 : 0;
             }
             __syncthreads();
             if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order
                 if (tid < 2 * W) {
                     double x = 0;
-                    for (int b = gb0; b < gb1; b++) x += partial[(size_t)b * W * 2 + tid];
-                    xpart[(size_t)grp * W * 2 + tid] = x;
+                    for (int b0 = gb0; b0 < gb1; b0 += 8) {          // eight loads in flight, added in block order
+                        double v8[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) v8[i] = b0 + i < gb1 ? __hip_atomic_load(&partial[(size_t)(b0 + i) * W * 2 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) if (b0 + i < gb1) x += v8[i];
+                    }
+                    __hip_atomic_store(&xpart[(size_t)grp * W * 2 + tid], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (tid == 0) __hip_atomic_fetch_add(sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            DL_RP_TICK(2);
             if (tid == 0) {
                 const unsigned want = (unsigned)vb.ngrp * (unsigned)(t + 1);
                 const int budget = p->a.spin_grid;
@@ -722,15 +743,21 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                     if (__hip_atomic_load(sync + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
-                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                else if (p->st.fault) DL_FAULT_OR(p->st.fault, DL_FAULT_GRID_TIMEOUT);
+                if (!ok && p->st.fault) DL_FAULT_OR(p->st.fault, DL_FAULT_GRID_TIMEOUT);
                 shf[1] = ok ? 1 : 0;
             }
             __syncthreads();
+            DL_RP_TICK(3);
             if (!shf[1]) return;          // (uniform) the grid never completed this step: fault word set, nothing further is written
             if (tid < W && (tid < D ? upd_obs : upd_ret)) {
-                double S = 0, SS = 0;
-                for (int g = 0; g < vb.ngrp; g++) { S += xpart[((size_t)g * W + tid) * 2]; SS += xpart[((size_t)g * W + tid) * 2 + 1]; }
+                double S = 0, SS = 0, xs[8], xq[8];
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    xs[g] = g < vb.ngrp ? __hip_atomic_load(&xpart[((size_t)g * W + tid) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    xq[g] = g < vb.ngrp ? __hip_atomic_load(&xpart[((size_t)g * W + tid) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                }
+#pragma unroll
+                for (int g = 0; g < 8; g++) if (g < vb.ngrp) { S += xs[g]; SS += xq[g]; }
                 double m = vm[tid], v = vm[W + tid];
                 vn_chan_merge(m, v, tid < D ? vm[2 * W] : vm[2 * W + 1], S, SS, n);
                 vm[tid] = m; vm[W + tid] = v;
@@ -742,6 +769,9 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     }
     // ---- VecNormalize of the last step's outputs (k_vn_apply's work for the workgroup's rows): next_obs, rewards[T - 1], ret
     const DL_CONST Args* p = args();
+#ifdef DL_EXP_ROLLOUT_PROF
+    if (tid == 0 && p->a.prof) for (int k = 0; k < 4; k++) p->a.prof[(size_t)blk * 4 + k] = prof_acc[k];
+#endif
     const RolloutP a = p->a;
     for (int idx = tid; idx < (row1 - row0) * D; idx += 512) {
         const size_t e = (size_t)row0 * D + idx;
@@ -819,6 +849,7 @@ struct dl_env_s {
     virtual int capstate(float* out, hipStream_t) = 0;
     virtual int last_ctrl(float* out, hipStream_t) = 0;
     virtual int set_split(int on) = 0;
+    virtual int rollout_prof(long long* out, hipStream_t s) = 0;
     virtual int persistent_ok(int hidden, std::string* why) = 0;
     virtual int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t T, float* observations,
                                    float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
@@ -1132,7 +1163,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
 
     // ---- dl_collect_rollouts(DL_ROLLOUT_PERSISTENT): the whole rollout as one launch of k_rollout_persistent
-    double* rp_partial = nullptr; double* rp_xpart = nullptr; unsigned* rp_sync = nullptr;
+    double* rp_partial = nullptr; double* rp_xpart = nullptr; unsigned* rp_sync = nullptr; long long* rp_prof = nullptr;
     int n_cus = 0;
     int spin_grid = 1 << 22;      // polls of the grid exchange before a workgroup gives up (~2 s)
     int persistent_ok(int hidden, std::string* why) override {
@@ -1161,6 +1192,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 if ((rc = dalloc(&rp_partial, (size_t)nblk * W * 2))) return rc;
                 if ((rc = dalloc(&rp_xpart, (size_t)2 * 8 * W * 2))) return rc;
                 if ((rc = dalloc(&rp_sync, (size_t)RP_SYNC_WORDS))) return rc;
+                if ((rc = dalloc(&rp_prof, (size_t)nblk * 4))) return rc;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
             }
             RolloutP a{};
@@ -1169,7 +1201,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.gamma = vn.gamma; a.eps = vn.eps; a.clip_obs = vn.clip_obs; a.clip_rew = vn.clip_rew; a.flags = vn.flags;
             a.observations = observations; a.actions = actions; a.values = values; a.log_probs = log_probs; a.rewards = rewards; a.next_obs = next_obs; a.raw_obs = raw_obs; a.raw_rew = raw_rew;
             a.episode_starts = episode_starts; a.next_done = next_done;
-            a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync;
+            a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync; a.prof = rp_prof;
             a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
             st.push_step0 = push_step; push_step += nT;
@@ -1186,6 +1218,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
+    }
+    int rollout_prof(long long* out, hipStream_t s) override {
+        if (!rp_prof || !out) return fail(DL_E_INVAL, "dl_debug_rollout_prof: no persistent rollout has run on this handle");
+        HIPCHK(hipMemcpyAsync(out, rp_prof, (size_t)((n + 15) / 16) * 4 * sizeof(long long), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
     }
     int last_ctrl(float* out, hipStream_t s) override {
         if (!(variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_debug_last_ctrl: implemented by the 16-lane kernels");
@@ -1361,6 +1398,12 @@ int dl_debug_capstate(dl_handle h, float* out, void* stream) {
 int dl_set_split(dl_handle h, int32_t on) {
     NEED(h);
     return h->set_split(on);
+}
+/* diagnostics of the persistent rollout kernel (builds with -DDL_EXP_ROLLOUT_PROF; zeros otherwise): int64[ceil(N/16), 4] device = per workgroup
+ * the shader-clock cycles spent in the policy phase, the env phase, the moment sums + exchange, and waiting inside the exchange */
+int dl_debug_rollout_prof(dl_handle h, long long* out, void* stream) {
+    NEED(h);
+    return h->rollout_prof(out, (hipStream_t)stream);
 }
 int dl_debug_last_ctrl(dl_handle h, float* out, void* stream) {
     NEED(h);
