@@ -54,6 +54,36 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def _shr(x, k):
+    return (x >> k) & ((1 << (64 - k)) - 1)          # logical shift on int64 tensors
+
+
+def _mix64(x):
+    """splitmix64's finaliser on int64 tensors (torch integer arithmetic wraps)."""
+    x = x + (-7046029254386353131)                    # 0x9E3779B97F4A7C15
+    x = (x ^ _shr(x, 30)) * (-4658895280553007687)    # 0xBF58476D1CE4E5B9
+    x = (x ^ _shr(x, 27)) * (-7723592293110705685)    # 0x94D049BB133111EB
+    return x ^ _shr(x, 31)
+
+
+def tape_normal(seed, stream, T, idx0, n, width, device):
+    """Standard-normal tape [T, n, width] (or [T, n] for width 0) for the walkers idx0 .. idx0 + n - 1 from a counter-based generator keyed by
+    (seed, stream, step, GLOBAL walker index, component): a rank generates exactly its own columns, and a walker sees the same numbers
+    whatever the number of GPUs -- as it does for its RSI draws (the round-2 form drew the whole global tensor on every rank)."""
+    import math
+    import torch
+    w = max(width, 1)
+    t = torch.arange(T, dtype=torch.int64, device=device).view(T, 1, 1)
+    i = torch.arange(idx0, idx0 + n, dtype=torch.int64, device=device).view(1, n, 1)
+    a = torch.arange(w, dtype=torch.int64, device=device).view(1, 1, w)
+    key = _mix64(torch.tensor(int(seed) * 1000003 + int(stream), dtype=torch.int64, device=device))
+    r = _mix64(key ^ _mix64(((t << 32) | i) * 64 + a))
+    u1 = (_shr(r, 40) + 1).to(torch.float32) * (1.0 / 16777216.0)        # (0, 1]
+    u2 = (r & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)            # [0, 1)
+    z = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+    return z if width else z[..., 0]
+
+
 def cpu_baseline(n_envs, n_steps, seed=4321):
     """The oracle (a scalar float64 port of the same path) timed on one host core."""
     import numpy as np
@@ -186,6 +216,7 @@ def main():
     ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 16 walkers per CU)')
     ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="with --policy and the persistent form: 'per_rollout' is the opt-in relaxation (the rollout is normalised with its start-of-rollout moments, one exact merge at its end); not SB3's semantics")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump', type=str, default='', help='after the run every rank saves what its LAST rollout produced (episode starts, action tape, raw step outputs, moments) to <path>.rank<r>.npz (tests/test_gpu_distributed.py compares ranks with a single-process run)')
     args = ap.parse_args()
 
     import torch
@@ -251,14 +282,11 @@ def main():
     vn = HipVecNormalize(venv)
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
     # what the policy would have produced lives where it would have written it: in the rollout buffer.  The tapes are keyed by the GLOBAL
-    # walker index (every rank draws the same stream and keeps its walkers' columns), so a walker sees the same actions / values
-    # whatever the number of GPUs -- as it does for its RSI draws
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(4321)
-    sl = slice(rank * n, (rank + 1) * n)
-    buf.actions.copy_(torch.clamp(0.5 * torch.randn(T, n * world, venv.nu, device=dev, generator=gen)[:, sl], -1, 1))
-    buf.values.copy_(torch.randn(T, n * world, device=dev, generator=gen)[:, sl])
-    last_values = torch.randn(n * world, device=dev, generator=gen)[sl].contiguous()
+    # walker index (tape_normal: a counter-based generator, every rank draws exactly its own columns), so a walker sees the same actions /
+    # values whatever the number of GPUs -- as it does for its RSI draws
+    buf.actions.copy_(torch.clamp(0.5 * tape_normal(4321, 0, T, rank * n, n, venv.nu, dev), -1, 1))
+    buf.values.copy_(tape_normal(4321, 1, T, rank * n, n, 0, dev))
+    last_values = tape_normal(4321, 2, 1, rank * n, n, 0, dev)[0].contiguous()
     vn.reset()
     if not args.policy and not args.no_overlap:
         vn.enable_overlap(chunk=max(r for _, r in run_starts))      # pre-generated actions: VecNormalize of step t runs on a side stream under the simulation of step t + 1
@@ -365,8 +393,16 @@ def main():
         # MimicEnv.step: reward = 0 on done, else imitation (<= 1) + 0.2 alive bonus (mimic_env.py:142-168); VecNormalize clips at 10
         assert fin, f'bench self-check: non-finite values in the rollout buffer {checks}'
         assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'
-        assert 0 < n_done < n * T, f'bench self-check: implausible number of episode ends {checks}'
+        assert n_done < n * T and (n_done > 0 or T < 256), f'bench self-check: implausible number of episode ends {checks}'      # (random torques: walkers start falling after ~100 control steps)
         assert obs_absmax <= 10.0 + 1e-5, f'bench self-check: normalised observations beyond the clip {checks}'
+    if args.dump and group is None:
+        import numpy as np
+        ring = {}
+        if vn._ov is not None:
+            ring = dict(raw_obs=vn._ov['raw_obs'].cpu().numpy(), raw_rew=vn._ov['raw_rew'].cpu().numpy())
+        np.savez(f'{args.dump}.rank{rank}.npz', starts=buf._starts.cpu().numpy(), actions=buf.actions.cpu().numpy(), values=buf.values.cpu().numpy(), observations=buf.observations.cpu().numpy(),
+                 rewards=buf.rewards.cpu().numpy(), advantages=buf.advantages.cpu().numpy(), obs_mean=vn.obs_rms.mean, obs_var=vn.obs_rms.var, obs_count=vn.obs_rms.count,
+                 ret_mean=vn.ret_rms.mean, ret_var=vn.ret_rms.var, ret_count=vn.ret_rms.count, cursor=venv.get_state()['cursor'], qpos=venv.get_state()['qpos'], **ring)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

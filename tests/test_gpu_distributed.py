@@ -1,0 +1,70 @@
+"""bench.py's distributed branch on the one-GPU box: two fresh child ranks under torch.distributed.run (both on the one GPU, gloo as the
+process-group backend -- RCCL needs one GPU per rank; the code path, the sharding and the exchanges are the ones the 8-GPU run takes) against
+a single-process run of the same global walker count.  The reference's only parallelism is one process per environment
+(drloco/common/utils.py:121-125); sharding contiguous walker ranges over ranks must not change what any walker does:
+  * every rank's rollout -- episode boundaries, action tape, raw observations / rewards of every step, final cursors and positions -- equals
+    the matching columns of the single-process run bit for bit (RSI draws and tapes are keyed by the GLOBAL walker index);
+  * after the per-rollout exchange (collective C3) every rank holds the same VecNormalize moments, and they are the single process's to
+    1e-10 (the ranks' per-step batches are halves of the single process's: same samples, another grouping of the merges);
+  * the JSON line reports world_size 2 and a positive whole-job value."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert len(lines) == 1, p.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('extra', [[], ['--policy', '--rollout-form', 'launches']], ids=['fixed-actions', 'policy-in-the-loop'])
+def test_bench_two_ranks_match_one_process(tmp_path, extra):
+    import torch
+    assert torch.cuda.is_available()
+    n, T = 512, 192
+    common = ['--rollout-len', str(T), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'] + extra
+    env = dict(os.environ, DL_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = str(29600 + os.getpid() % 300)
+    two = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', port,
+                'bench.py', '--gpus', '2', '--envs-per-gpu', str(n), '--dump', str(tmp_path / 'two')] + common, env)
+    one = _run([sys.executable, 'bench.py', '--gpus', '1', '--envs-per-gpu', str(2 * n), '--dump', str(tmp_path / 'one')] + common, dict(os.environ))
+    assert two['distributed']['world_size'] == 2 and two['distributed']['backend'] == 'gloo' and two['n_gpus'] == 2
+    assert two['value'] > 0 and one['value'] > 0 and two['self_check']['finite']
+    ref = np.load(str(tmp_path / 'one') + '.rank0.npz')
+    ranks = [np.load(str(tmp_path / 'two') + f'.rank{r}.npz') for r in range(2)]
+    policy = bool(extra)
+    for r, d in enumerate(ranks):
+        cols = slice(r * n, (r + 1) * n)
+        if not policy:
+            # pre-generated actions: the simulation of a walker does not depend on the other walkers at all
+            for k in ('starts', 'actions', 'values'):
+                assert np.array_equal(d[k], ref[k][:, cols]), (r, k)
+            for k in ('raw_obs', 'raw_rew'):
+                assert np.array_equal(d[k], ref[k][:, cols]), (r, k)
+            assert np.array_equal(d['cursor'], ref['cursor'][:, cols]) and np.array_equal(d['qpos'], ref['qpos'][:, cols])
+            assert d['starts'][1:].sum() > 0
+        else:
+            # a policy in the loop sees observations normalised with its OWN rank's moments during a rollout (C3 merges between rollouts: the
+            # documented relaxation), so trajectories separate after the first steps: the first observation / action rows still agree
+            assert np.array_equal(d['observations'][0], ref['observations'][0][cols]) and np.array_equal(d['actions'][0], ref['actions'][0][cols])
+            assert np.array_equal(d['starts'][:2], ref['starts'][:2, cols])
+    # C3: after the exchange both ranks hold the same moments ...
+    for k in ('obs_mean', 'obs_var', 'obs_count', 'ret_mean', 'ret_var', 'ret_count'):
+        assert np.array_equal(ranks[0][k], ranks[1][k]), k
+    assert float(ranks[0]['obs_count']) == float(ref['obs_count'])
+    if not policy:
+        # ... and they are the single process's (same samples; halves merged in another grouping)
+        np.testing.assert_allclose(ranks[0]['obs_mean'], ref['obs_mean'], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ranks[0]['obs_var'], ref['obs_var'], rtol=1e-10)
+        np.testing.assert_allclose([float(ranks[0]['ret_mean']), float(ranks[0]['ret_var'])], [float(ref['ret_mean']), float(ref['ret_var'])], rtol=1e-10)

@@ -72,7 +72,7 @@ def test_row_primitives(torch_cuda):
 
 
 @LANES
-@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 5e-3)])
+@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 1e-3)])      # float32: measured max 9.2e-4 (16 lanes), 6.0e-4 (lane per walker); tools/diag_f32_outliers.py
 def test_forward_dynamics(torch_cuda, oracle, model, refs, precision, tol, lanes):
     n = 1024
     dev, orc = make_pair(oracle, model, refs, n, precision, lanes_per_walker=lanes)
@@ -664,7 +664,7 @@ def _loco3d_pair(oracle, n, precision, L=6000, seed=0, **cfg):
 
 
 @LANES
-@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 1e-2)])
+@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 2e-3)])      # float32: measured max 1.3e-3 -- one walker of 512, SAME active set as the oracle's solution
 def test_loco3d_forward_dynamics(torch_cuda, oracle, precision, tol, lanes):
     n = 512
     dev, orc = _loco3d_pair(oracle, n, precision, lanes_per_walker=lanes)
@@ -676,6 +676,15 @@ def test_loco3d_forward_dynamics(torch_cuda, oracle, precision, tol, lanes):
     qa, nc, ne, ni = orc.forward(u); qb, nc2, ne2, ni2 = dev.forward(u)
     assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2) and nc.max() >= 6
     err = np.abs(qa - qb) / (1 + np.abs(qa))
+    if precision == 32:
+        # walkers beyond 1e-3: do they sit on another active set than the oracle (a constraint row whose J a - aref changes sign between the
+        # two solutions)?  Reported either way; a walker beyond the bound with the SAME active set is a solver-tolerance finding.
+        werr = err.max(axis=0)
+        for i in np.nonzero(werr >= 1e-3)[0]:
+            r = oracle.probe_forward(dev.model, q[:, i], v[:, i], u[:, i], w[:, i])
+            ja, jb = r['efc_J'] @ qa[:, i] - r['efc_aref'], r['efc_J'] @ qb[:, i] - r['efc_aref']
+            print('walker %d: err %.2e ncon %d nefc %d niter oracle %d device %d, rows with another active state %d' % (i, werr[i], nc[i], ne[i], ni[i], ni2[i], int(((ja < 0) != (jb < 0)).sum())))
+        assert (werr >= 1e-3).mean() < 0.01
     assert err.max() < tol, err.max()
     if precision == 32:
         assert np.median(err.max(axis=0)) < 2e-4
