@@ -17,9 +17,13 @@ Neither SB3 nor gym is installed here, so both layouts are restated from SB3 1.0
 bag), the writer emits the SB3 class paths so that an SB3 installation unpickles real objects.
 
 What is interchangeable with the reference: `policy.pth` (the state dict, both directions) and the VecNormalize statistics
-(`obs_rms`, `ret_rms`, clip values, gamma, epsilon, the norm_* and training flags).  `write_policy_zip` does NOT produce a
-complete `PPO.load` archive: its `data` member lacks observation_space / action_space and the SB3-serialised policy class, and
-there is no `policy.optimizer.pth` -- SB3 users load the weights with `policy.load_state_dict(th.load(...))` instead.
+(`obs_rms`, `ret_rms`, clip values, gamma, epsilon, the norm_* and training flags).  `write_policy_zip` writes the weights only;
+`write_model_zip` writes the archive in the shape of SB3 1.0's `save_to_zip_file` (stable_baselines3/common/save_util.py): `data`
+as `data_to_json` leaves it (JSON values as they are, everything else as {":type:", ":serialized:" = base64(cloudpickle)} -- the
+observation / action spaces, the policy class, the schedules), `policy.pth`, `policy.optimizer.pth` (Adam's state dict over the nine
+parameters in `ActorCriticPolicy.parameters()` order), `pytorch_variables.pth`, `_stable_baselines3_version`.  Checked here by a round trip
+through a `load_from_zip_file`-shaped reader restated in tests/stubs (tests/test_interop.py); it stays UNPINNED until an archive written by a
+real SB3 1.0 exists to compare with.
 """
 import io
 import json
@@ -162,3 +166,112 @@ def write_policy_zip(policy, path, data=None):
         z.writestr('policy.pth', buf.getvalue())
         z.writestr('pytorch_variables.pth', empty.getvalue())
         z.writestr('_stable_baselines3_version', '1.0')
+
+
+# ---- the whole archive in SB3 1.0's save_to_zip_file layout -------------------------------------------
+_PARAM_ORDER = ('log_std', 'w1', 'b1', 'w2', 'b2', 'wa', 'ba', 'wv', 'bv')      # ActorCriticPolicy.parameters(): log_std, mlp_extractor (shared trunk once), action_net, value_net
+_POLICY_CLASS = ('drloco.custom.policies', 'CustomActorCriticPolicy')
+
+
+def _serialized(obj):
+    """One non-JSON entry of `data` as SB3 1.0's data_to_json writes it."""
+    import base64
+    import cloudpickle
+    d = {':type:': str(type(obj)), ':serialized:': base64.b64encode(cloudpickle.dumps(obj)).decode()}
+    if hasattr(obj, '__dict__'):
+        for k, v in obj.__dict__.items():
+            d[k] = str(v)
+    return d
+
+
+def _placeholder_class(module, name):
+    """The class `module.name` if importable, else a stand-in registered under that path so that the pickle stream names the real
+    class (by reference); returns (class, was_placeholder)."""
+    try:
+        __import__(module)
+        mod = sys.modules[module]
+        return getattr(mod, name), not hasattr(mod, '__file__')          # (a module without a file is one of our own placeholders)
+    except Exception:
+        parts = module.split('.')
+        for i in range(1, len(parts) + 1):
+            sys.modules.setdefault('.'.join(parts[:i]), types.ModuleType('.'.join(parts[:i])))
+        cls = type(name, (object,), {'__module__': module})
+        setattr(sys.modules[module], name, cls)
+        return cls, True
+
+
+def _drop_placeholder_modules(roots):
+    for m in [m for m in sys.modules if m.split('.')[0] in roots and not hasattr(sys.modules[m], '__file__')]:
+        del sys.modules[m]
+
+
+def _gym_box(low, high):
+    """gym.spaces.Box(low, high) -- the real class when gym imports, else an attribute-compatible object pickled under gym's class path."""
+    cls, fake = _placeholder_class('gym.spaces.box', 'Box')
+    low, high = np.asarray(low, np.float32), np.asarray(high, np.float32)
+    if not fake:
+        return cls(low=low, high=high, dtype=np.float32), fake
+    o = cls.__new__(cls)
+    o.__dict__.update(dtype=np.dtype(np.float32), shape=low.shape, low=low, high=high, bounded_below=-np.inf < low, bounded_above=np.inf > high, np_random=None)
+    return o, fake
+
+
+def adam_state_dict(policy, optimizer=None, lr=5e-4):
+    """`policy.optimizer.pth`: the state dict of torch.optim.Adam over the policy's nine parameters in SB3's order.  optimizer: a torch
+    optimiser whose single param group holds those tensors (in any order; matched by identity) or None = a fresh Adam (no moments yet)."""
+    params = [getattr(policy, k) for k in _PARAM_ORDER]
+    group = dict(lr=lr, betas=(0.9, 0.999), eps=1e-5, weight_decay=0, amsgrad=False)          # SB3 1.0 PPO: Adam(eps=1e-5)
+    state = {}
+    if optimizer is not None:
+        g0 = optimizer.param_groups[0]
+        group.update({k: g0[k] for k in ('lr', 'betas', 'eps', 'weight_decay', 'amsgrad') if k in g0})
+        for i, p in enumerate(params):
+            for q, st in optimizer.state.items():
+                if q is p:
+                    state[i] = {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    group['params'] = list(range(len(params)))
+    return {'state': state, 'param_groups': [group]}
+
+
+def write_model_zip(policy, path, observation_space=None, action_space=None, optimizer=None, data=None, hyper=None):
+    """The reference's `model.save(path)` (drloco/common/utils.py:175-192; callback.py:290) for a HipPolicy: SB3 1.0's save_to_zip_file
+    layout.  observation_space / action_space: (low, high) pairs or objects with .low / .high (HipVecEnv's spaces); default: the straight
+    walker's.  hyper: PPO's scalar constructor arguments for `data` (defaults: the reference's, drloco/config/hypers.py)."""
+    sd = {}
+    for k, name in _KEYS.items():
+        sd[name] = getattr(policy, k).detach().cpu()
+    for layer in ('0', '2'):
+        for q in ('weight', 'bias'):
+            sd[f'mlp_extractor.value_net.{layer}.{q}'] = sd[f'mlp_extractor.policy_net.{layer}.{q}']
+    lohi = lambda sp, d: (np.asarray(sp.low), np.asarray(sp.high)) if hasattr(sp, 'low') else (d if sp is None else sp)
+    obs_dim, act_dim = policy.w1.shape[1], policy.wa.shape[0]
+    olo, ohi = lohi(observation_space, (np.full(obs_dim, -np.inf), np.full(obs_dim, np.inf)))
+    alo, ahi = lohi(action_space, (np.full(act_dim, -300.0), np.full(act_dim, 300.0)))
+    fakes = []
+    try:
+        obs_box, f1 = _gym_box(olo, ohi)
+        act_box, f2 = _gym_box(alo, ahi)
+        pol_cls, f3 = _placeholder_class(*_POLICY_CLASS)
+        fakes = [f1 or f2, f3]
+        h = dict(learning_rate=5e-4, gamma=0.995, gae_lambda=0.95, n_steps=4096, batch_size=2048, n_epochs=4, ent_coef=-0.0075, vf_coef=0.5, max_grad_norm=0.5,
+                 clip_range=0.15, n_envs=8, num_timesteps=0, seed=None, verbose=1, sde_sample_freq=-1, use_sde=False, target_kl=None, tensorboard_log=None)
+        h.update(hyper or {})
+        meta = dict(h)
+        meta['policy_class'] = _serialized(pol_cls)
+        meta['policy_kwargs'] = dict(log_std_init=float(policy.log_std.detach().reshape(-1)[0]))
+        meta['observation_space'] = _serialized(obs_box)
+        meta['action_space'] = _serialized(act_box)
+        meta.update(data or {})
+        bufs = {}
+        for name, obj in (('policy.pth', sd), ('policy.optimizer.pth', adam_state_dict(policy, optimizer, lr=h['learning_rate'])), ('pytorch_variables.pth', {})):
+            b = io.BytesIO(); torch.save(obj, b); bufs[name] = b.getvalue()
+        with zipfile.ZipFile(path, 'w') as z:
+            z.writestr('data', json.dumps(meta, indent=4))
+            for name, raw in bufs.items():
+                z.writestr(name, raw)
+            z.writestr('_stable_baselines3_version', '1.0')
+    finally:
+        if fakes and fakes[0]:
+            _drop_placeholder_modules({'gym'})
+        if fakes and len(fakes) > 1 and fakes[1]:
+            _drop_placeholder_modules({'drloco'})
