@@ -589,6 +589,7 @@ struct RolloutP {
     uint8_t *episode_starts, *next_done;
     double *partial, *xpart;      // [nblk][W][2], [2][8][W][2] (group sums, double-buffered by step parity: a group may not overwrite what another group's workgroups still read)
     unsigned* sync;               // group counters at [16 g], top counter at [128]
+    const float* w2p;             // the hidden layer's weights in k-chunk-major order (k_pack_w2), packed by the host before the launch
     long long* prof;              // diagnostics (DL_EXP_ROLLOUT_PROF builds): [nblk][4] shader-clock cycles in P, E, R (sums + exchange), waiting in the exchange
     int32_t index_base, flags, T, per_rollout, spin_grid;
 };
@@ -616,7 +617,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     using Args = RolloutArgs<TP>;
     constexpr int D = TP::OBS, W = D + 1, NU = TP::NU;
     constexpr size_t ENV_LDS = (size_t)4 * GW * Sp::TOTAL * sizeof(T);
-    static_assert(pol_lds_bytes(8) <= ENV_LDS, "the policy's LDS aliases the walkers' regions between two env steps");
+    static_assert(pol_lds_bytes_whole(8, 512) <= ENV_LDS, "the policy's LDS aliases the walkers' regions between two env steps");
     // the first (only) explicit argument sits at offset 0 of the kernarg segment (HSA ABI)
     const DL_CONST Args* const ap0 = (const DL_CONST Args*)__builtin_amdgcn_kernarg_segment_ptr();
     auto args = [&]() { const DL_CONST Args* q = ap0; DL_SPIN(q); return q; };       // a fresh, opaque view: loads through it are not merged with earlier ones
@@ -662,8 +663,8 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 vf.obs_out = a.observations + (size_t)t * n * D; vf.rew_out = a.rewards + (size_t)(t - 1) * n;
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
-            pol_forward_rows<4, 8>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
-                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t);
+            pol_forward_rows<4, 8, true, true>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
+                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.w2p);
         }
         __syncthreads();          // the actions of the workgroup's rows are in memory (workgroup scope); the policy's LDS is free again
         DL_RP_TICK(0);
@@ -683,8 +684,13 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             int lane_t = lane;
             DL_VPIN(lane_t);          // per-step opaque (as above): lane topology, lane records and pinned constants are this phase's only
             if (role == 0)
+#ifdef DL_EXP_ROLLOUT_PROF        // per-section cycles of the LAST control step's env phase, per dynamics wave: prof[nblk * 4 + k * (nblk * 4) + wave block], k as in g_wave_env_step<TIMED>
+                g_wave_env_step<T, TP, true, true>(lane_t, wblock, wblock, nblk * 4, base, p->gm, c, st, p->a.actions + (size_t)t * n * NU, p->a.raw_obs, p->a.raw_rew, done, (float*)nullptr, (float*)nullptr,
+                                                   (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, p->eval_mode, 1, p->a.prof + (size_t)nblk * 4);
+#else
                 g_wave_env_step<T, TP, false, true>(lane_t, wblock, 0, 1, base, p->gm, c, st, p->a.actions + (size_t)t * n * NU, p->a.raw_obs, p->a.raw_rew, done, (float*)nullptr, (float*)nullptr,
                                                     (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, p->eval_mode, 1, nullptr);
+#endif
             else
                 g_constraint_server<T, TP>(lane_t, wblock, base, p->gm, st);
         }
@@ -851,6 +857,7 @@ struct dl_env_s {
     virtual int set_split(int on) = 0;
     virtual int rollout_prof(long long* out, hipStream_t s) = 0;
     virtual int persistent_ok(int hidden, std::string* why) = 0;
+    virtual int pack_w2(const dl_policy_params& pol, const float** out, hipStream_t s) = 0;
     virtual int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t T, float* observations,
                                    float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
                                    float* raw_rew, int per_rollout, hipStream_t s) = 0;
@@ -1164,8 +1171,19 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
 
     // ---- dl_collect_rollouts(DL_ROLLOUT_PERSISTENT): the whole rollout as one launch of k_rollout_persistent
     double* rp_partial = nullptr; double* rp_xpart = nullptr; unsigned* rp_sync = nullptr; long long* rp_prof = nullptr;
+    float* w2_packed = nullptr;       // [512 * 512]: k-chunk-major copy of the policy's hidden-layer weights, refreshed by every rollout call
     int n_cus = 0;
     int spin_grid = 1 << 22;      // polls of the grid exchange before a workgroup gives up (~2 s)
+    int pack_w2(const dl_policy_params& pol, const float** out, hipStream_t s) override {
+        *out = nullptr;
+        if (pol.hidden != 512) return DL_OK;                  // the packed form is built for the eight-wave kernel
+        int rc;
+        if (!w2_packed && (rc = dalloc(&w2_packed, (size_t)512 * 512))) return rc;
+        hipLaunchKernelGGL(k_pack_w2, dim3(512 * 128 / 256), dim3(256), 0, s, pol.w2, w2_packed, 512);
+        HIPCHK(hipGetLastError());
+        *out = w2_packed;
+        return DL_OK;
+    }
     int persistent_ok(int hidden, std::string* why) override {
         auto no = [&](const char* w) { if (why) *why = w; return 0; };
         if constexpr (!CAN_SPLIT) return no("the persistent rollout kernel exists for the 16-lane float32 kernels of the lane-only (straight) walker");
@@ -1192,7 +1210,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 if ((rc = dalloc(&rp_partial, (size_t)nblk * W * 2))) return rc;
                 if ((rc = dalloc(&rp_xpart, (size_t)2 * 8 * W * 2))) return rc;
                 if ((rc = dalloc(&rp_sync, (size_t)RP_SYNC_WORDS))) return rc;
-                if ((rc = dalloc(&rp_prof, (size_t)nblk * 4))) return rc;
+                if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11))) return rc;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
             }
             RolloutP a{};
@@ -1202,6 +1220,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.observations = observations; a.actions = actions; a.values = values; a.log_probs = log_probs; a.rewards = rewards; a.next_obs = next_obs; a.raw_obs = raw_obs; a.raw_rew = raw_rew;
             a.episode_starts = episode_starts; a.next_done = next_done;
             a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync; a.prof = rp_prof;
+            if ((rc = pack_w2(pol, &a.w2p, s))) return rc;
             a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
             st.push_step0 = push_step; push_step += nT;
@@ -1221,7 +1240,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int rollout_prof(long long* out, hipStream_t s) override {
         if (!rp_prof || !out) return fail(DL_E_INVAL, "dl_debug_rollout_prof: no persistent rollout has run on this handle");
-        HIPCHK(hipMemcpyAsync(out, rp_prof, (size_t)((n + 15) / 16) * 4 * sizeof(long long), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(out, rp_prof, (size_t)((n + 15) / 16) * 4 * 11 * sizeof(long long), hipMemcpyDeviceToDevice, s));
         return DL_OK;
     }
     int last_ctrl(float* out, hipStream_t s) override {
@@ -1400,7 +1419,8 @@ int dl_set_split(dl_handle h, int32_t on) {
     return h->set_split(on);
 }
 /* diagnostics of the persistent rollout kernel (builds with -DDL_EXP_ROLLOUT_PROF; zeros otherwise): int64[ceil(N/16), 4] device = per workgroup
- * the shader-clock cycles spent in the policy phase, the env phase, the moment sums + exchange, and waiting inside the exchange */
+ * the shader-clock cycles spent in the policy phase, the env phase, the moment sums + exchange, and waiting inside the exchange; followed by
+ * int64[10, 4 ceil(N/16)]: the sections of the last control step's env phase per dynamics wave (g_wave_env_step<TIMED>) */
 int dl_debug_rollout_prof(dl_handle h, long long* out, void* stream) {
     NEED(h);
     return h->rollout_prof(out, (hipStream_t)stream);
@@ -1645,7 +1665,7 @@ int dl_vecnormalize_steps(const dl_vecnorm_state* vn, int32_t K, const float* ob
     return DL_OK;
 }
 static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
-                         int32_t deterministic, float* actions, float* values, float* log_probs, const PolVnFuse& vf, void* stream) {
+                         int32_t deterministic, float* actions, float* values, float* log_probs, const PolVnFuse& vf, void* stream, const float* w2p = nullptr) {
     if (!p || !(obs || vf.raw_obs) || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward: bad arguments");
     if (!p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->wa || !p->ba || !p->wv || !p->bv || !p->log_std) return fail(DL_E_INVAL, "dl_policy_forward: NULL parameter array");
     if (p->hidden <= 0 || p->hidden % 64 || p->hidden > 64 * POL_MAXT || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15)
@@ -1654,12 +1674,18 @@ static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n,
     const size_t lds = pol_lds_bytes(nw);                       // 23 KB (8 waves): below the default limit, no attribute needed on any device
     const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(64 * nw);
 #define DL_POL_LAUNCH(NTW, NW) \
-    hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf);
+    hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, (const float*)nullptr);
     switch (p->hidden / 64) {
         case 1: DL_POL_LAUNCH(1, 4) break;
         case 2: DL_POL_LAUNCH(2, 4) break;
         case 4: DL_POL_LAUNCH(4, 4) break;
-        case 8: DL_POL_LAUNCH(4, 8) break;
+        case 8:
+            if (n <= POL_ROWS * 256 && w2p) {   // ... and with the hidden layer's weights packed by the caller of a whole rollout (same arithmetic: bit-identical)
+                hipLaunchKernelGGL((k_policy_forward<4, 8, true, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, w2p);
+            } else if (n <= POL_ROWS * 256) {   // at most one workgroup per CU on an MI355X: the barrier-free form with the whole h1 block in LDS (51 KB)
+                hipLaunchKernelGGL((k_policy_forward<4, 8, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, (const float*)nullptr);
+            } else DL_POL_LAUNCH(4, 8)
+            break;
         default: return fail(DL_E_INVAL, "dl_policy_forward: hidden must be 64, 128, 256 or 512");
     }
 #undef DL_POL_LAUNCH
@@ -1685,6 +1711,8 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
     // of this step's outputs folded into its input stage (PolVnFuse).  Step 0 reads observations[0] as given; the outputs of the
     // last step are normalised by the stand-alone k_vn_apply.
     const uint8_t* prev_done = nullptr;
+    const float* w2p = nullptr;           // the hidden layer's weights, packed once for the T forward passes of this rollout
+    { const int rc = h->pack_w2(*pol, &w2p, (hipStream_t)stream); if (rc) return rc; }
     for (int t = 0; t < T; t++) {
         const bool last = t + 1 == T;
         PolVnFuse vf{};
@@ -1695,7 +1723,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
             vf.eps = vn->eps; vf.clip_obs = vn->clip_obs; vf.clip_rew = vn->clip_rew; vf.flags = vn->flags;
         }
         int rc = policy_launch(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, 0,
-                               actions + t * n * ad, values + t * n, log_probs + t * n, vf, stream);
+                               actions + t * n * ad, values + t * n, log_probs + t * n, vf, stream, w2p);
         if (rc) return rc;
         uint8_t* done = last ? next_done : episode_starts + (t + 1) * n;
         if ((rc = h->step(actions + t * n * ad, raw_obs, raw_rew, done, nullptr, nullptr, (hipStream_t)stream))) return rc;

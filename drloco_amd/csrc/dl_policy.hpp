@@ -50,12 +50,20 @@ __device__ __forceinline__ float pol_gauss(uint64_t seed, uint64_t counter, uint
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
+#ifndef DL_POL_SKEW
+#define DL_POL_SKEW 2
+#endif
 constexpr int POL_ROWS = 16;       // walkers per workgroup
 constexpr int POL_MAXT = 8;        // accumulator tiles per wave in the hidden layer (hidden <= 512)
 constexpr int POL_SLD = 36;        // row stride of a staged 16 x 32 activation block (floats)
 constexpr int POL_PLD = 20;        // row stride of a wave's private 16 x 16 tile
 // dynamic LDS of k_policy_forward<NTW, NW>: two staged activation blocks + per wave a private tile and a partial head tile
 constexpr size_t pol_lds_bytes(int nw) { return ((size_t)2 * POL_ROWS * POL_SLD + (size_t)nw * POL_ROWS * POL_PLD + (size_t)nw * 256) * sizeof(float); }
+// WHOLE_H1 form: the whole 16 x hidden activation block of the first layer is staged once (row stride hidden + 4), the hidden layer's
+// reduction then runs WITHOUT workgroup barriers -- the two waves of a SIMD drift apart and one's weight-load latency falls under the other's
+// MFMAs.  51 KB for hidden 512: for callers with the CU's LDS to themselves (<= 4096 rows, one handle; the persistent rollout kernel, whose
+// env regions are idle during the policy phase).  Same accumulation order as the lean form: bit-identical results.
+constexpr size_t pol_lds_bytes_whole(int nw, int hidden) { return ((size_t)POL_ROWS * (hidden + 4) + (size_t)nw * POL_ROWS * POL_PLD + (size_t)nw * 256) * sizeof(float); }
 
 // VecNormalize.step_wait's second half (k_vn_apply) folded into the policy's input stage: with raw_obs != NULL the kernel reads the
 // raw observation / reward of the last env step, normalises them with the (already updated) moments exactly as k_vn_apply does,
@@ -96,17 +104,23 @@ __device__ __forceinline__ float vn_norm_rew(float r, double ret_var, double eps
 // own sixteen walkers).  sm: pol_lds_bytes(NW) bytes of LDS.  count_owner: this workgroup advances the moment counts of a folded
 // VecNormalize step (exactly one workgroup of a launch does).  tid: threadIdx.x (a parameter so that a caller looping over control steps can
 // pass it opaque per step: the lane's index arithmetic is then redone per step instead of being kept in registers across the other phases).
-template <int NTW, int NW>
+// PACKED: the hidden layer's weights are read from `w2p`, a copy of w2 in k-chunk-major order (k_pack_w2: w2p[(k / 4) * H + n][k % 4]).  In
+// torch's [out][in] layout the 16 lanes of a quarter-wave (one output column each) read 16 bytes from 16 DIFFERENT 2 KB-apart rows: 64 cache
+// lines per wave instruction, one tag lookup each -- the load path then delivers ~14 bytes per clock and CU and the kernel is bound by it
+// (measured: 13 of 37 us).  Packed, a quarter-wave's 16 x 16 bytes are one contiguous 256-byte run.  Same values, same order of arithmetic.
+template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
 __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                  uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                  float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse& vf,
-                                                 float* sm, int row0, bool count_owner, int tid) {
+                                                 float* sm, int row0, bool count_owner, int tid, const float* __restrict__ w2p = nullptr) {
     constexpr int H = 16 * NTW * NW, ntw = NTW;
     const int D = p.obs_dim, A = p.act_dim;
     const int wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
-    float* stage = sm;                                                     // [2][16][POL_SLD]
-    float* priv = sm + 2 * POL_ROWS * POL_SLD + wave * (POL_ROWS * POL_PLD);       // this wave's [16][POL_PLD]
-    float* part = sm + 2 * POL_ROWS * POL_SLD + NW * (POL_ROWS * POL_PLD);          // [NW][16][16] partial head tiles, then [16][16] log-prob terms
+    constexpr int HLD = H + 4;                                             // row stride of the whole-h1 block
+    constexpr int STAGE_WORDS = WHOLE_H1 ? POL_ROWS * HLD : 2 * POL_ROWS * POL_SLD;
+    float* stage = sm;                                                     // [2][16][POL_SLD], or [16][HLD]
+    float* priv = sm + STAGE_WORDS + wave * (POL_ROWS * POL_PLD);          // this wave's [16][POL_PLD]
+    float* part = sm + STAGE_WORDS + NW * (POL_ROWS * POL_PLD);            // [NW][16][16] partial head tiles, then [16][16] log-prob terms
     constexpr int ncw = H / NW;
     const int n0w = wave * ncw;
     auto wave_sync = [&]() {      // LDS operations of one wave execute in order: exchanging data inside the wave needs no s_barrier
@@ -190,7 +204,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         pf4 acc[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[t] = pf4{0.f, 0.f, 0.f, 0.f};
-        const float* wbase = p.w2 + (size_t)(n0w + lm) * H + lk * 4;
+        const float* wbase = PACKED ? w2p + ((size_t)lk * H + n0w + lm) * 4 : p.w2 + (size_t)(n0w + lm) * H + lk * 4;
         // two k blocks (32 k = one 128-byte line per weight row) per step: both halves of every line a wave touches are
         // consumed together.  Explicit ping-pong register sets: the loads of the next step are issued BEFORE the 64 MFMAs
         // of the current one (with one buffer the compiler reuses the registers and every step waits a full L2 latency).
@@ -202,9 +216,21 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         auto load_set = [&](pf4 (&b)[NTW][2], int kp) {
 #pragma unroll
             for (int t = 0; t < NTW; t++) {
+#ifndef DL_EXP_POL_NOLOAD
+                if constexpr (PACKED) {
+                    const float* q = wbase + (size_t)t * 64 + (size_t)kp * (8 * H * 4);
+                    const float* q1 = q + (size_t)4 * H * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[t][0]) : "v"(q) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[t][1]) : "v"(q1) : "memory");
+                } else {
                 const float* q = wbase + (size_t)t * 16 * H + kp * 32;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[t][0]) : "v"(q) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(b[t][1]) : "v"(q) : "memory");
+                }
+#else
+                const float* q = wbase;
+                asm volatile("" : "=v"(b[t][0]) : "v"(q)); asm volatile("" : "=v"(b[t][1]) : "v"(q));
+#endif
             }
         };
         // wait until the OLDEST set in flight has arrived while `newer` younger sets (2 * NTW loads each; loads return in order) stay
@@ -219,22 +245,53 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
             for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(b[t][0]), "+v"(b[t][1]));
         };
         auto compute = [&](const pf4 (&b4)[NTW][2], int kp) {
-            const float* buf = stage + (kp & 1) * (POL_ROWS * POL_SLD);
-            const pf4 a4a = *(const pf4*)&buf[lm * POL_SLD + lk * 4], a4b = *(const pf4*)&buf[lm * POL_SLD + 16 + lk * 4];
+            const float* buf = WHOLE_H1 ? stage + kp * 32 : stage + (kp & 1) * (POL_ROWS * POL_SLD);
+            constexpr int LD = WHOLE_H1 ? HLD : POL_SLD;
+            const pf4 a4a = *(const pf4*)&buf[lm * LD + lk * 4], a4b = *(const pf4*)&buf[lm * LD + 16 + lk * 4];
             // k step outermost: consecutive MFMAs go to different accumulator tiles (no back-to-back dependent issue)
+#ifndef DL_EXP_POL_NOMFMA
 #define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b4[t][H2].C, acc[t], 0, 0, 0);
+#else
+#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[t].x += AV * b4[t][H2].C;
+#endif
             DL_POL_KSTEP(a4a.x, 0, x) DL_POL_KSTEP(a4a.y, 0, y) DL_POL_KSTEP(a4a.z, 0, z) DL_POL_KSTEP(a4a.w, 0, w)
             DL_POL_KSTEP(a4b.x, 1, x) DL_POL_KSTEP(a4b.y, 1, y) DL_POL_KSTEP(a4b.z, 1, z) DL_POL_KSTEP(a4b.w, 1, w)
 #undef DL_POL_KSTEP
         };
         // DEPTH register sets, DEPTH - 1 of them in flight while one is consumed (4 sets were measured no faster than 2: the hidden
         // layer is bound by the matrix pipe plus the L2 -> CU stream of the weight matrix, not by the latency of a single load).
-        constexpr int DEPTH = 2;
+#ifndef DL_EXP_POL_DEPTH
+#define DL_EXP_POL_DEPTH 2
+#endif
+        constexpr int DEPTH = ((H / 32) % DL_EXP_POL_DEPTH == 0) ? DL_EXP_POL_DEPTH : 2;
         static_assert((H / 32) % DEPTH == 0, "steps come in groups of DEPTH");
         pf4 bs[DEPTH][NTW][2];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the compiler's own loads may be counted against the sets
+        // WHOLE_H1: the waves walk over the k blocks in ROTATED order (wave w starts at block 2 w).  A weight row is 2 KB long, so at a given k
+        // block the 512 rows' lines differ only in address bits >= 11: walked in step, all waves of a CU (and of every CU) would ask the same
+        // one or two of the L2's 16 channels at any moment (measured: the weight stream cost 13 of the kernel's 37 us); rotated, a
+        // workgroup's requests cover 8 k blocks = all channels.  Every wave keeps a fixed order: deterministic, own rounding order.
+        auto kp_at = [&](int i) { return WHOLE_H1 ? (i + DL_POL_SKEW * wave) % npair : i; };
 #pragma unroll
-        for (int d = 0; d < DEPTH - 1; d++) load_set(bs[d], d);
+        for (int d = 0; d < DEPTH - 1; d++) load_set(bs[d], kp_at(d));
+        if constexpr (WHOLE_H1) {
+            // every wave stages the 64 columns of h1 it owns, ONE barrier, then the reduction runs free
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) stage[(4 * lk + i) * HLD + n0w + t * 16 + lm] = h1r[t][i];
+            __syncthreads();
+            for (int i0 = 0; i0 < npair; i0 += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) {
+                    const int i = i0 + d, ahead = i + DEPTH - 1;
+                    if (ahead < npair) load_set(bs[(d + DEPTH - 1) % DEPTH], kp_at(ahead));
+                    const int left = npair - 1 - i;
+                    wait_set(bs[d], left < DEPTH - 1 ? left : DEPTH - 1);
+                    compute(bs[d], kp_at(i));
+                }
+            }
+        } else {
         publish(0);
         __syncthreads();
         for (int kp0 = 0; kp0 < npair; kp0 += DEPTH) {
@@ -248,6 +305,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
                 compute(bs[d], kp);
                 __syncthreads();
             }
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -306,12 +364,22 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
     }
 }
 
-template <int NTW, int NW>
+template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
 __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                         uint64_t seed, uint64_t counter, int index_base, int deterministic,
-                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf) {
+                                                        float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf,
+                                                        const float* __restrict__ w2p = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    pol_forward_rows<NTW, NW>(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, vf, sm, (int)blockIdx.x * POL_ROWS, blockIdx.x == 0, (int)threadIdx.x);
+    pol_forward_rows<NTW, NW, WHOLE_H1, PACKED>(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, vf, sm, (int)blockIdx.x * POL_ROWS, blockIdx.x == 0,
+                                                (int)threadIdx.x, w2p);
+}
+// w2 [H][H] (torch's [out][in]) -> w2p[(k / 4) * H + n][k % 4]: 16-byte k chunks, output-column-major inside a chunk row
+__global__ __launch_bounds__(256) void k_pack_w2(const float* __restrict__ w2, float* __restrict__ w2p, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread: (n, k4), reads coalesced along k
+    if (idx >= H * (H / 4)) return;
+    const int n = idx / (H / 4), k4 = idx % (H / 4);
+    const pf4 v = *(const pf4*)(w2 + (size_t)n * H + k4 * 4);
+    *(pf4*)(w2p + ((size_t)k4 * H + n) * 4) = v;
 }
 
 }  // namespace dl

@@ -122,7 +122,9 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
         from drloco_amd import checkpoint
         os.makedirs(os.path.join(save_path, 'models'), exist_ok=True); os.makedirs(os.path.join(save_path, 'envs'), exist_ok=True)
         ckpt = f'{int(total / 1e5)}'
-        checkpoint.write_policy_zip(pol, os.path.join(save_path, 'models', f'model_{ckpt}.zip'))
+        # SB3 1.0's save_to_zip_file layout: data (spaces, policy class, hyperparameters), policy.pth, policy.optimizer.pth (Adam's moments)
+        checkpoint.write_model_zip(pol, os.path.join(save_path, 'models', f'model_{ckpt}.zip'), observation_space=venv.observation_space, action_space=venv.action_space, optimizer=opt,
+                                   hyper=dict(n_envs=n_envs, num_timesteps=int(total), n_steps=batch // n_envs, batch_size=minibatch, n_epochs=epochs))
         vn.save(os.path.join(save_path, 'envs', f'env_{ckpt}'), sb3_format=True)
         if not quiet:
             print('saved', os.path.join(save_path, 'models', f'model_{ckpt}.zip'), 'and', os.path.join(save_path, 'envs', f'env_{ckpt}'))
