@@ -513,18 +513,27 @@ __device__ __forceinline__ void vn_chan_merge(double& mean, double& var, double 
 __device__ __forceinline__ void vn_block_sums(const float* __restrict__ x, const float* __restrict__ rew, double* ret, int D, int k, int r0, int r1, double K, double gamma,
                                               double& s_out, double& ss_out) {
     double s = 0, ss = 0;
+    // rows beyond the block are read from its last row and left out of the sums by a select: the loads stay unconditional, i.e. all sixteen
+    // are in flight at once (predicated, every load sits in its own branch and waits for its own round trip: measured 10 k cycles per step)
+    const int rl = r1 - 1;
     if (k < D) {
         float a[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) a[r] = r0 + r < r1 ? x[(size_t)(r0 + r) * D + k] : 0.0f;       // all loads in flight, then the sums in row order
+        for (int r = 0; r < 16; r++) { const int rr = r0 + r < r1 ? r0 + r : rl; a[r] = x[(size_t)rr * D + k]; }
 #pragma unroll
-        for (int r = 0; r < 16; r++) if (r0 + r < r1) { const double d = (double)a[r] - K; s += d; ss = fma(d, d, ss); }
+        for (int r = 0; r < 16; r++) { const double d = (double)a[r] - K; const bool ok = r0 + r < r1; s = ok ? s + d : s; ss = ok ? fma(d, d, ss) : ss; }
     } else {
         double o[16]; float w[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { o[r] = r0 + r < r1 ? ret[r0 + r] : 0.0; w[r] = r0 + r < r1 ? rew[r0 + r] : 0.0f; }
+        for (int r = 0; r < 16; r++) { const int rr = r0 + r < r1 ? r0 + r : rl; o[r] = ret[rr]; w[r] = rew[rr]; }
 #pragma unroll
-        for (int r = 0; r < 16; r++) if (r0 + r < r1) { const double rn = fma(o[r], gamma, (double)w[r]); ret[r0 + r] = rn; const double d = rn - K; s += d; ss = fma(d, d, ss); }
+        for (int r = 0; r < 16; r++) {
+            const bool ok = r0 + r < r1;
+            const double rn = fma(o[r], gamma, (double)w[r]);
+            if (ok) ret[r0 + r] = rn;
+            const double d = rn - K;
+            s = ok ? s + d : s; ss = ok ? fma(d, d, ss) : ss;
+        }
     }
     s_out = s; ss_out = ss;
 }
@@ -589,7 +598,7 @@ struct RolloutP {
     uint8_t *episode_starts, *next_done;
     double *partial, *xpart;      // [nblk][W][2], [2][8][W][2] (group sums, double-buffered by step parity: a group may not overwrite what another group's workgroups still read)
     unsigned* sync;               // group counters at [16 g], top counter at [128]
-    const float* w2p;             // the hidden layer's weights in k-chunk-major order (k_pack_w2), packed by the host before the launch
+    PolPacked pk;                 // the policy's weights in k-chunk-major order (k_pack_policy), packed by the host before the launch
     long long* prof;              // diagnostics (DL_EXP_ROLLOUT_PROF builds): [nblk][4] shader-clock cycles in P, E, R (sums + exchange), waiting in the exchange
     int32_t index_base, flags, T, per_rollout, spin_grid;
 };
@@ -664,7 +673,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
             pol_forward_rows<4, 8, true, true>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
-                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.w2p);
+                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.pk);
         }
         __syncthreads();          // the actions of the workgroup's rows are in memory (workgroup scope); the policy's LDS is free again
         DL_RP_TICK(0);
@@ -857,7 +866,7 @@ struct dl_env_s {
     virtual int set_split(int on) = 0;
     virtual int rollout_prof(long long* out, hipStream_t s) = 0;
     virtual int persistent_ok(int hidden, std::string* why) = 0;
-    virtual int pack_w2(const dl_policy_params& pol, const float** out, hipStream_t s) = 0;
+    virtual int pack_policy(const dl_policy_params& pol, PolPacked* out, hipStream_t s) = 0;
     virtual int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t T, float* observations,
                                    float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
                                    float* raw_rew, int per_rollout, hipStream_t s) = 0;
@@ -1171,17 +1180,18 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
 
     // ---- dl_collect_rollouts(DL_ROLLOUT_PERSISTENT): the whole rollout as one launch of k_rollout_persistent
     double* rp_partial = nullptr; double* rp_xpart = nullptr; unsigned* rp_sync = nullptr; long long* rp_prof = nullptr;
-    float* w2_packed = nullptr;       // [512 * 512]: k-chunk-major copy of the policy's hidden-layer weights, refreshed by every rollout call
+    float* pol_packed = nullptr;      // pol_packed_floats(512): k-chunk-major copies of the policy's weights, refreshed by every rollout call
     int n_cus = 0;
     int spin_grid = 1 << 22;      // polls of the grid exchange before a workgroup gives up (~2 s)
-    int pack_w2(const dl_policy_params& pol, const float** out, hipStream_t s) override {
-        *out = nullptr;
+    int pack_policy(const dl_policy_params& pol, PolPacked* out, hipStream_t s) override {
+        *out = PolPacked{nullptr, nullptr, nullptr};
         if (pol.hidden != 512) return DL_OK;                  // the packed form is built for the eight-wave kernel
         int rc;
-        if (!w2_packed && (rc = dalloc(&w2_packed, (size_t)512 * 512))) return rc;
-        hipLaunchKernelGGL(k_pack_w2, dim3(512 * 128 / 256), dim3(256), 0, s, pol.w2, w2_packed, 512);
+        if (!pol_packed && (rc = dalloc(&pol_packed, pol_packed_floats(512)))) return rc;
+        const int chunks = 512 * 128 + 12 * 512 + 128 * 16;
+        hipLaunchKernelGGL(k_pack_policy, dim3((chunks + 255) / 256), dim3(256), 0, s, pol, pol_packed);
         HIPCHK(hipGetLastError());
-        *out = w2_packed;
+        out->w2p = pol_packed; out->w1p = pol_packed + (size_t)512 * 512; out->whp = out->w1p + (size_t)48 * 512;
         return DL_OK;
     }
     int persistent_ok(int hidden, std::string* why) override {
@@ -1220,7 +1230,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.observations = observations; a.actions = actions; a.values = values; a.log_probs = log_probs; a.rewards = rewards; a.next_obs = next_obs; a.raw_obs = raw_obs; a.raw_rew = raw_rew;
             a.episode_starts = episode_starts; a.next_done = next_done;
             a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync; a.prof = rp_prof;
-            if ((rc = pack_w2(pol, &a.w2p, s))) return rc;
+            if ((rc = pack_policy(pol, &a.pk, s))) return rc;
             a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
             st.push_step0 = push_step; push_step += nT;
@@ -1665,7 +1675,7 @@ int dl_vecnormalize_steps(const dl_vecnorm_state* vn, int32_t K, const float* ob
     return DL_OK;
 }
 static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
-                         int32_t deterministic, float* actions, float* values, float* log_probs, const PolVnFuse& vf, void* stream, const float* w2p = nullptr) {
+                         int32_t deterministic, float* actions, float* values, float* log_probs, const PolVnFuse& vf, void* stream, const PolPacked pk = PolPacked{nullptr, nullptr, nullptr}) {
     if (!p || !(obs || vf.raw_obs) || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward: bad arguments");
     if (!p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->wa || !p->ba || !p->wv || !p->bv || !p->log_std) return fail(DL_E_INVAL, "dl_policy_forward: NULL parameter array");
     if (p->hidden <= 0 || p->hidden % 64 || p->hidden > 64 * POL_MAXT || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15)
@@ -1674,16 +1684,16 @@ static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n,
     const size_t lds = pol_lds_bytes(nw);                       // 23 KB (8 waves): below the default limit, no attribute needed on any device
     const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(64 * nw);
 #define DL_POL_LAUNCH(NTW, NW) \
-    hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, (const float*)nullptr);
+    hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, PolPacked{nullptr, nullptr, nullptr});
     switch (p->hidden / 64) {
         case 1: DL_POL_LAUNCH(1, 4) break;
         case 2: DL_POL_LAUNCH(2, 4) break;
         case 4: DL_POL_LAUNCH(4, 4) break;
         case 8:
-            if (n <= POL_ROWS * 256 && w2p) {   // ... and with the hidden layer's weights packed by the caller of a whole rollout (same arithmetic: bit-identical)
-                hipLaunchKernelGGL((k_policy_forward<4, 8, true, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, w2p);
+            if (n <= POL_ROWS * 256 && pk.w2p) {   // ... and with the hidden layer's weights packed by the caller of a whole rollout (same arithmetic: bit-identical)
+                hipLaunchKernelGGL((k_policy_forward<4, 8, true, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk);
             } else if (n <= POL_ROWS * 256) {   // at most one workgroup per CU on an MI355X: the barrier-free form with the whole h1 block in LDS (51 KB)
-                hipLaunchKernelGGL((k_policy_forward<4, 8, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, (const float*)nullptr);
+                hipLaunchKernelGGL((k_policy_forward<4, 8, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, PolPacked{nullptr, nullptr, nullptr});
             } else DL_POL_LAUNCH(4, 8)
             break;
         default: return fail(DL_E_INVAL, "dl_policy_forward: hidden must be 64, 128, 256 or 512");
@@ -1711,8 +1721,8 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
     // of this step's outputs folded into its input stage (PolVnFuse).  Step 0 reads observations[0] as given; the outputs of the
     // last step are normalised by the stand-alone k_vn_apply.
     const uint8_t* prev_done = nullptr;
-    const float* w2p = nullptr;           // the hidden layer's weights, packed once for the T forward passes of this rollout
-    { const int rc = h->pack_w2(*pol, &w2p, (hipStream_t)stream); if (rc) return rc; }
+    PolPacked pk{nullptr, nullptr, nullptr};          // the policy's weights, packed once for the T forward passes of this rollout
+    { const int rc = h->pack_policy(*pol, &pk, (hipStream_t)stream); if (rc) return rc; }
     for (int t = 0; t < T; t++) {
         const bool last = t + 1 == T;
         PolVnFuse vf{};
@@ -1723,7 +1733,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
             vf.eps = vn->eps; vf.clip_obs = vn->clip_obs; vf.clip_rew = vn->clip_rew; vf.flags = vn->flags;
         }
         int rc = policy_launch(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, 0,
-                               actions + t * n * ad, values + t * n, log_probs + t * n, vf, stream, w2p);
+                               actions + t * n * ad, values + t * n, log_probs + t * n, vf, stream, pk);
         if (rc) return rc;
         uint8_t* done = last ? next_done : episode_starts + (t + 1) * n;
         if ((rc = h->step(actions + t * n * ad, raw_obs, raw_rew, done, nullptr, nullptr, (hipStream_t)stream))) return rc;

@@ -91,6 +91,12 @@ __device__ __forceinline__ float vn_norm_rew(float r, double ret_var, double eps
     return (float)y;
 }
 
+// The policy's weights in k-chunk-major order (k_pack_policy), or all NULL = read torch's layout directly:
+//   w2p[(k / 4) * H + n][k % 4] = w2[n][k];   w1p[(k / 4) * H + n][k % 4] = w1[n][k] (k < obs_dim, else 0; 12 chunks = 48 inputs);
+//   whp[(k / 4) * 16 + j][k % 4] = wa[j][k] (j < act_dim), wv[0][k] (j == act_dim), 0 (else)
+struct PolPacked { const float* w2p; const float* w1p; const float* whp; };
+constexpr size_t pol_packed_floats(int hidden) { return (size_t)hidden * hidden + (size_t)48 * hidden + (size_t)hidden * 16; }
+
 // NTW = accumulator tiles per wave in the hidden layer, NW = waves per workgroup: hidden = 16 * NTW * NW (compile time, so
 // that the tile loops are straight-line code).  hidden = 512 runs as 8 waves x 4 tiles: two waves per SIMD, so that the LDS /
 // weight-load latency of one overlaps the MFMAs of the other.
@@ -112,7 +118,7 @@ template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
 __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                  uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                  float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse& vf,
-                                                 float* sm, int row0, bool count_owner, int tid, const float* __restrict__ w2p = nullptr) {
+                                                 float* sm, int row0, bool count_owner, int tid, const PolPacked pk = PolPacked{nullptr, nullptr, nullptr}) {
     constexpr int H = 16 * NTW * NW, ntw = NTW;
     const int D = p.obs_dim, A = p.act_dim;
     const int wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
@@ -142,33 +148,51 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
     // (one memory latency for the layer instead of one per tile).  h1 stays in registers (accumulator layout).
     float h1r[NTW][4];
     {
-        const int r = row0 + lm;
         constexpr int KB1 = 3;                                      // obs_dim <= 48 (checked by the host): 29 (straight walker), 47 (165 cm walker)
+        constexpr int OLD = 52;                                     // row stride of the staged observation block (conflict-free ds_read_b128)
         float a1[KB1 * 4], b1v[NTW][KB1 * 4];
-        const float* src = vf.raw_obs ? vf.raw_obs : obs;
-#pragma unroll
-        for (int q = 0; q < KB1 * 4; q++) {
-            const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
-            a1[q] = (k < D && r < n) ? src[(size_t)r * D + k] : 0.0f;
-        }
-        if (vf.raw_obs) {
-#pragma unroll
-            for (int q = 0; q < KB1 * 4; q++) {
-                const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
-                if (k < D && r < n) {
-                    if (vf.flags & 2) a1[q] = vn_norm_obs(a1[q], vf.mean[k], vf.var[k], vf.eps, vf.clip_obs);
-                    if (wave == 0) vf.obs_out[(size_t)r * D + k] = a1[q];
-                }
-            }
-        }
+        // the weights first (their latency covers the staging below) ...
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
             const int ncol = n0w + t * 16 + lm;
+            if constexpr (PACKED) {
 #pragma unroll
-            for (int q = 0; q < KB1 * 4; q++) {
-                const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
-                b1v[t][q] = (k < D) ? p.w1[(size_t)ncol * D + k] : 0.0f;
+                for (int kb = 0; kb < KB1; kb++) {
+                    const pf4 v = *(const pf4*)(pk.w1p + ((size_t)(kb * 4 + lk) * H + ncol) * 4);
+                    b1v[t][kb * 4] = v.x; b1v[t][kb * 4 + 1] = v.y; b1v[t][kb * 4 + 2] = v.z; b1v[t][kb * 4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KB1 * 4; q++) {
+                    const int k = (q >> 2) * 16 + lk * 4 + (q & 3);
+                    b1v[t][q] = (k < D) ? p.w1[(size_t)ncol * D + k] : 0.0f;
+                }
             }
+        }
+        // ... then the 16 observation rows, ONCE per workgroup: an element per lane (coalesced), normalised by the folded VecNormalize step
+        // where there is one (float64 divide and square root: eight waves used to repeat them for all twelve of a lane's values), staged in
+        // LDS (the space of the partial head tiles, unused until the heads), read back as the A fragments of every wave
+        float* ostage = part;
+        {
+            const float* src = vf.raw_obs ? vf.raw_obs : obs;
+            for (int e = tid; e < POL_ROWS * 48; e += 64 * NW) {
+                const int rr = e / 48, k = e % 48, r = row0 + rr;
+                float x = 0.0f;
+                if (k < D && r < n) {
+                    x = src[(size_t)r * D + k];
+                    if (vf.raw_obs) {
+                        if (vf.flags & 2) x = vn_norm_obs(x, vf.mean[k], vf.var[k], vf.eps, vf.clip_obs);
+                        vf.obs_out[(size_t)r * D + k] = x;
+                    }
+                }
+                ostage[rr * OLD + k] = x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++) {
+            const pf4 v = *(const pf4*)&ostage[lm * OLD + kb * 16 + lk * 4];
+            a1[kb * 4] = v.x; a1[kb * 4 + 1] = v.y; a1[kb * 4 + 2] = v.z; a1[kb * 4 + 3] = v.w;
         }
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -204,7 +228,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         pf4 acc[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[t] = pf4{0.f, 0.f, 0.f, 0.f};
-        const float* wbase = PACKED ? w2p + ((size_t)lk * H + n0w + lm) * 4 : p.w2 + (size_t)(n0w + lm) * H + lk * 4;
+        const float* wbase = PACKED ? pk.w2p + ((size_t)lk * H + n0w + lm) * 4 : p.w2 + (size_t)(n0w + lm) * H + lk * 4;
         // two k blocks (32 k = one 128-byte line per weight row) per step: both halves of every line a wave touches are
         // consumed together.  Explicit ping-pong register sets: the loads of the next step are issued BEFORE the 64 MFMAs
         // of the current one (with one buffer the compiler reuses the registers and every step waits a full L2 latency).
@@ -328,7 +352,9 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
             wave_sync();
             const int k0 = n0w + t * 16 + lk * 4;
             const pf4 a4 = *(const pf4*)&priv[lm * POL_PLD + lk * 4];
-            const pf4 b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
+            pf4 b4;
+            if constexpr (PACKED) b4 = *(const pf4*)(pk.whp + ((size_t)(k0 >> 2) * 16 + lm) * 4);
+            else b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
@@ -368,18 +394,30 @@ template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
 __global__ __launch_bounds__(64 * NW) void k_policy_forward(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                         uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                         float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse vf,
-                                                        const float* __restrict__ w2p = nullptr) {
+                                                        const PolPacked pk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     pol_forward_rows<NTW, NW, WHOLE_H1, PACKED>(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, vf, sm, (int)blockIdx.x * POL_ROWS, blockIdx.x == 0,
-                                                (int)threadIdx.x, w2p);
+                                                (int)threadIdx.x, pk);
 }
-// w2 [H][H] (torch's [out][in]) -> w2p[(k / 4) * H + n][k % 4]: 16-byte k chunks, output-column-major inside a chunk row
-__global__ __launch_bounds__(256) void k_pack_w2(const float* __restrict__ w2, float* __restrict__ w2p, int H) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread: (n, k4), reads coalesced along k
-    if (idx >= H * (H / 4)) return;
-    const int n = idx / (H / 4), k4 = idx % (H / 4);
-    const pf4 v = *(const pf4*)(w2 + (size_t)n * H + k4 * 4);
-    *(pf4*)(w2p + ((size_t)k4 * H + n) * 4) = v;
+// torch's [out][in] matrices -> the k-chunk-major copies of PolPacked (one 16-byte chunk per thread); buf: pol_packed_floats(H) floats
+__global__ __launch_bounds__(256) void k_pack_policy(const dl_policy_params p, float* __restrict__ buf) {
+    const int H = p.hidden, D = p.obs_dim, A = p.act_dim;
+    float* w2p = buf; float* w1p = buf + (size_t)H * H; float* whp = w1p + (size_t)48 * H;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n2 = H * (H / 4), n1 = 12 * H, nh = (H / 4) * 16;
+    if (idx < n2) {
+        const int n = idx / (H / 4), k4 = idx % (H / 4);          // reads coalesced along k
+        *(pf4*)(w2p + ((size_t)k4 * H + n) * 4) = *(const pf4*)(p.w2 + (size_t)n * H + k4 * 4);
+    } else if (idx < n2 + n1) {
+        const int e = idx - n2, n = e / 12, k4 = e % 12;
+        pf4 v;
+        for (int i = 0; i < 4; i++) { const int k = k4 * 4 + i; v[i] = k < D ? p.w1[(size_t)n * D + k] : 0.0f; }
+        *(pf4*)(w1p + ((size_t)k4 * H + n) * 4) = v;
+    } else if (idx < n2 + n1 + nh) {
+        const int e = idx - n2 - n1, j = e % 16, k4 = e / 16;
+        const float* row = j < A ? p.wa + (size_t)j * H : (j == A ? p.wv : nullptr);
+        *(pf4*)(whp + ((size_t)k4 * 16 + j) * 4) = row ? *(const pf4*)(row + k4 * 4) : pf4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 }  // namespace dl
