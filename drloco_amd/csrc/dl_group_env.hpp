@@ -224,6 +224,27 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         if (ctrl_out && valid) ctrl_out[(size_t)step * n * NU + (size_t)w * NU + a] = (float)ctrl;      // test hook: sim.data.ctrl as the reference sets it
     }
     const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
+    // ---- what the END of the step will look up does not depend on the physics: refs.next() is a function of the cursor alone.  The cursor
+    // is advanced on a copy here and the reference sample, the step length and the desired velocity behind it are requested BEFORE the
+    // physics (chains of dependent table reads: a lone wave per SIMD would wait out three or four memory round trips after the physics);
+    // a diverged step (exception path) discards them.  Lane-only walkers.  EXPERIMENT (DL_PREFETCH_REFS, off by default: measured no gain).
+    constexpr bool PRE = (NX == 0) && (TP::ENV_KIND == 0) && DL_PREFETCH_REFS;
+    int32_t cur_n[DL_CUR_WORDS];
+    T pre_qr = T(0), pre_vr = T(0), pre_dist = T(0), pre_desvel = T(0);
+    int pre_len = 1, pre_left = 0;
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < DL_CUR_WORDS; k++) cur_n[k] = cur[k];
+        cursor_next<T, TP>(c, cur_n);
+        const int rs = cur_n[DL_CUR_READ_STEP], off0 = c.step_off[rs];
+        const int base_n = off0 + cur_n[DL_CUR_POS];
+        pre_len = c.step_off[rs + 1] - off0;
+        if (isdof) { pre_qr = ref_at(c, jd, base_n); pre_vr = ref_at(c, NV + jd, base_n); }
+        if (cur_n[DL_CUR_HAS_DIST]) pre_dist = ref_at(c, 0, c.step_off[cur_n[DL_CUR_RSI_STEP] + 1] - 1);
+        const int iv = cur_n[DL_CUR_I_STEP] - cur_n[DL_CUR_COUNT] + 1;
+        pre_desvel = c.step_vel[iv > 0 ? iv : 0];
+        pre_left = c.step_is_left[cur_n[DL_CUR_I_STEP]];
+    }
     if constexpr (TIMED) tacc[8] = DL_CLOCK() - t_begin;
     // ---- physics
     bool exc = false;
@@ -307,15 +328,21 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         if (j == 0) static_for<NX>([&](auto ti) { constexpr int t = ti.value; wb[Ld::Q + t] = qx.x[t]; wb[Ld::V + t] = vx.x[t]; });
     };
     // observation from q, v staged in LDS: OBS outputs over 16 lanes
-    auto write_obs = [&](float* dst_base) {
+    auto write_obs = [&](float* dst_base, bool use_pre) {
         if (!(valid && dst_base)) return;
         if constexpr (TP::ENV_KIND == 0) {
             // mimic_env.py:403-437 + mirror_obs :440-480
-            const int rs = cur[DL_CUR_READ_STEP];
-            const T phase_var = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
-            const int iv = cur[DL_CUR_I_STEP] - cur[DL_CUR_COUNT] + 1;
-            const T desvel = c.step_vel[iv > 0 ? iv : 0];
-            const bool mirr_o = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+            T phase_var, desvel;
+            bool mirr_o;
+            if (PRE && use_pre) {           // looked up before the physics (same cursor, same table entries)
+                phase_var = T(cur[DL_CUR_POS]) / T(pre_len); desvel = pre_desvel; mirr_o = c.mirror_policy && pre_left;
+            } else {
+                const int rs = cur[DL_CUR_READ_STEP];
+                phase_var = T(cur[DL_CUR_POS]) / T(c.step_off[rs + 1] - c.step_off[rs]);
+                const int iv = cur[DL_CUR_I_STEP] - cur[DL_CUR_COUNT] + 1;
+                desvel = c.step_vel[iv > 0 ? iv : 0];
+                mirr_o = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
+            }
             auto raw_obs = [&](int k) -> T { return k == 0 ? phase_var : (k == 1 ? desvel : (k < 1 + NV ? wb[Ld::Q + (k - 1)] : wb[Ld::V + (k - 1 - NV)])); };
             for (int k = j; k < OBS; k += GL) {
                 const T plain = raw_obs(k);
@@ -348,7 +375,10 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         r = 0.0f; dn = true; walked = 0;
         terms[0] = terms[1] = terms[2] = 1.0;
     } else {
-        cursor_next<T, TP>(c, cur);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = cur_n[k];
+        } else cursor_next<T, TP>(c, cur);
         g_sync<T>();
         stage_qv();
         g_sync<T>();
@@ -370,7 +400,13 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             };
             T dp = T(0), dvv = T(0), dc = T(0);
             if (isdof) {
-                const T d1 = q - ref_q(jd), d2 = v - ref_at(c, NV + jd, base);
+                T d1, d2;
+                if constexpr (PRE) {
+                    T qr = pre_qr;
+                    if (cur[DL_CUR_HAS_DIST]) { if (jd == 0) qr += pre_dist; }
+                    else if (jd == 2) qr -= comz;
+                    d1 = q - qr; d2 = v - pre_vr;
+                } else { d1 = q - ref_q(jd); d2 = v - ref_at(c, NV + jd, base); }
                 if (jd < 3) dc = d1 * d1; else { dp = d1 * d1; dvv = d2 * d2; }
             }
             T s3[3] = {dp, dvv, dc};
@@ -380,7 +416,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             terms[0] = (double)tp; terms[1] = (double)tv; terms[2] = (double)tc;
             r = (float)((c.rew_w[0] * tp + c.rew_w[1] * tv + c.rew_w[2] * tc) * c.rew_scale + c.alive_bonus);
         }
-        write_obs(dn ? term_obs : obs);
+        write_obs(dn ? term_obs : obs, true);
     }
     if (valid && j == 0 && st.dbg) {
         st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
@@ -427,7 +463,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             static_for<NX>([&](auto ti) { warmx.x[ti.value] = T(0); });
             cursor_next<T, TP>(c, cur);
             g_sync<T>();
-            write_obs((nrep == 2 && rep == 0) ? term_obs : obs);
+            write_obs((nrep == 2 && rep == 0) ? term_obs : obs, false);
             g_sync<T>();
         }
         walked = 0;
