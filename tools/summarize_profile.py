@@ -16,12 +16,13 @@ stats = glob.glob(os.path.join(src, 'bench_trace', '*', '*kernel_stats.csv'))
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    flags = {'straight': '', 'policy': ' --policy', 'policy_32768_h2': ' --policy --envs-per-gpu 32768 --handles 2 --steps 2'}.get(walker, f' --walker {walker}')
+    flags = {'straight': '', 'policy': ' --policy', 'policy_per_rollout': ' --policy --moments per_rollout', 'policy_launches': ' --policy --rollout-form launches',
+             'policy_32768_h2': ' --policy --envs-per-gpu 32768 --handles 2 --steps 2'}.get(walker, f' --walker {walker}')
     lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' + flags + '   (kernel_stats.csv, top rows)')
     lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
     for r in rows[:14]:
         lines.append(f'{r["Name"][:70]:70s} {r["Calls"]:>7s} {float(r["AverageNs"]) / 1e3:12.2f} {float(r["MinNs"]) / 1e3:10.2f} {float(r["MaxNs"]) / 1e3:10.2f} {float(r["Percentage"]):7.2f}')
-        if 'k_env_step' in r['Name']:
+        if 'k_env_step' in r['Name'] or 'k_rollout_persistent' in r['Name']:
             out['k_env_step_avg_us'] = float(r['AverageNs']) / 1e3
             out['k_env_step_calls'] = int(r['Calls'])
 pmc = {}
@@ -29,7 +30,7 @@ for p in sorted(glob.glob(os.path.join(src, 'pmc*', '*', '*counter_collection.cs
     acc = collections.defaultdict(list)
     meta = None
     for r in csv.DictReader(open(p)):
-        if 'k_env_step' in r['Kernel_Name']:
+        if 'k_env_step' in r['Kernel_Name'] or 'k_rollout_persistent' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
             meta = r
     for k, v in acc.items():
@@ -45,7 +46,7 @@ if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
     out['hbm_bytes_per_launch_raw'] = (pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024
     out['hbm_bytes_per_launch'] = (2 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024
 lines.append('')
-lines.append('PMC counters of the env-step kernel (k_env_step*; average per launch over the schedule of the benchmark (dl_rollout_fixed: one launch of 448 control steps, one of 64 = 256 per launch), whole grid; separate rocprofv3 --pmc passes on tools/prof_step.py):')
+lines.append('PMC counters of the dominant kernel (k_env_step* / k_rollout_persistent; average per launch over the schedule of the benchmark (dl_rollout_fixed: one launch of 448 control steps, one of 64 = 256 per launch), whole grid; separate rocprofv3 --pmc passes on tools/prof_step.py):')
 for k in sorted(pmc):
     lines.append(f'  {k:24s} {pmc[k]:16.1f}')
 lines.append('')
