@@ -845,6 +845,7 @@ struct dl_env_s {
     }
     int fault_code() const { return fault_host ? __atomic_load_n(fault_host, __ATOMIC_RELAXED) : 0; }
     virtual void set_spin_limits(int dyn, int srv) = 0;
+    virtual void set_grid_spin(int polls) = 0;
     int n = 0, device = 0, real_size = 4, eval_mode = 0, obs_dim = 0, act_dim = 0, variant = 0;
     virtual int init(const dl_model_desc&, const dl_refs_desc&, const dl_config&, int n, int device) = 0;
     virtual int reset(const uint8_t*, const int32_t*, const int32_t*, float*, hipStream_t) = 0;
@@ -1171,6 +1172,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         }
         return fail(DL_E_INVAL, "dl_debug_step_timed: float32 only");
     }
+    void set_grid_spin(int polls) override { spin_grid = polls >= 0 ? polls : (1 << 22); }
     void set_spin_limits(int dyn, int srv) override { st.spin_dyn = dyn >= 0 ? dyn : GSplit<TP>::SPIN_LIMIT; st.spin_srv = srv >= 0 ? srv : GSplit<TP>::SPIN_LIMIT; }
     int set_split(int on) override {
         if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels of the lane-only (straight) walker");
@@ -1325,6 +1327,7 @@ static int fault_error(dl_handle h) {
     std::string why = "device fault " + std::to_string(code) + ":";
     if (code & DL_FAULT_DYN_TIMEOUT) why += " a dynamics wave of a split workgroup gave up waiting for its constraint wave;";
     if (code & DL_FAULT_SRV_TIMEOUT) why += " a constraint wave of a split workgroup gave up waiting for a request;";
+    if (code & DL_FAULT_GRID_TIMEOUT) why += " a workgroup of the persistent rollout kernel gave up waiting for the grid-wide moment exchange (the rollout buffer is incomplete);";
     return fail(DL_E_FAULT, why + " the walkers of the affected waves took the exception path (reward 0, episode ended, reset) -- results since the fault are "
                 "not a valid rollout; dl_fault_clear + dl_reset to continue");
 }
@@ -1346,6 +1349,12 @@ int dl_fault_clear(dl_handle h) {
 int dl_debug_set_spin_limit(dl_handle h, int32_t dyn, int32_t srv) {
     NEED(h);
     h->set_spin_limits(dyn, srv);
+    return DL_OK;
+}
+/* test hook: poll budget of the persistent rollout kernel's grid exchange (negative = default); 0 makes every workgroup give up at its first exchange */
+int dl_debug_set_grid_spin(dl_handle h, int32_t polls) {
+    NEED(h);
+    h->set_grid_spin(polls);
     return DL_OK;
 }
 

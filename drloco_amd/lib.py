@@ -93,6 +93,7 @@ _EXTRA = {
     'dl_debug_counters': (C.c_int, [_V, _P, _I, _P]),
     'dl_debug_set_spin_limit': (C.c_int, [_V, _I, _I]),
     'dl_debug_rollout_prof': (C.c_int, [_V, _P, _P]),
+    'dl_debug_set_grid_spin': (C.c_int, [_V, _I]),
     'dl_debug_capstate': (C.c_int, [_V, _P, _P]),
     'dl_debug_last_ctrl': (C.c_int, [_V, _P, _P]),
     'dl_debug_selftest': (C.c_int, [_P, _P, _P]),

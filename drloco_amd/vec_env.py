@@ -188,7 +188,11 @@ class HipVecEnv(_VecEnvBase):
     def env_is_wrapped(self, wrapper_class, indices=None):
         """SB3 VecEnv protocol: the walkers are not gym.Wrapper chains; Monitor's statistics are kept by the step kernel."""
         idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
-        return [getattr(wrapper_class, '__name__', '') == 'Monitor' for _ in idx]
+        # only the Monitor classes the reference wraps its envs in (drloco/common/utils.py:109: drloco.mujoco.monitor_wrapper.Monitor; SB3's own
+        # Monitor is what evaluate_policy asks about) -- not any class that happens to be called Monitor
+        mod = getattr(wrapper_class, '__module__', '') or ''
+        is_monitor = getattr(wrapper_class, '__name__', '') == 'Monitor' and (mod.startswith('stable_baselines3.') or mod.startswith('drloco.') or mod.endswith('monitor_wrapper') or mod.endswith('.monitor'))
+        return [is_monitor for _ in idx]
 
     def get_images(self):
         raise NotImplementedError('rendering is outside the device path (SURVEY.md 8: out of scope)')

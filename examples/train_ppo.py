@@ -33,7 +33,7 @@ from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 
-def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False, save_path=None):
+def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False, save_path=None, moments='per_step'):
     # one process per GPU under torch.distributed.run (backend nccl = RCCL); a single process otherwise
     import torch.distributed as dist
     world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -78,7 +78,7 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
             gp['lr'] = lr
         # ---- collect_rollouts
         with torch.no_grad():
-            buf.collect_rollouts(vn, pol, obs, start)        # dl_rollout_policy: T x (policy -> step -> normalise) in one call
+            buf.collect_rollouts(vn, pol, obs, start, moments=moments)        # dl_collect_rollouts: T x (policy -> step -> normalise) in one call -- one persistent launch where that form exists
             last_done.copy_(start)
             _, last_values, _ = pol.forward(obs, deterministic=True)
             buf.compute_returns_and_advantage(last_values, last_done)
@@ -140,5 +140,6 @@ if __name__ == '__main__':
     ap.add_argument('--seed', type=int, default=1, help='seeds 1, 2, 3 learn to walk within 8 M steps with the current kernels, seed 0 plateaus (DESIGN.md 5.1)')
     ap.add_argument('--save', default=None, help='directory for models/model_<ckpt>.zip (policy.pth with SB3 1.0 key names) and envs/env_<ckpt> (VecNormalize statistics), drloco_amd/checkpoint.py')
     ap.add_argument('--no-norm-reward', action='store_true', help='VecNormalize(norm_reward=False)')
+    ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="VecNormalize moments inside a rollout: SB3's per-step update (default) or the opt-in per-rollout relaxation of the persistent rollout kernel")
     args = ap.parse_args()
-    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward, evaluate=True, save_path=args.save)
+    train(args.mio, args.envs, batch=args.batch, minibatch=args.minibatch, seed=args.seed, norm_reward=not args.no_norm_reward, evaluate=True, save_path=args.save, moments=args.moments)

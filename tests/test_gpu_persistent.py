@@ -171,3 +171,76 @@ def test_persistent_form_refusals(torch_cuda, model, refs):
     venv = HipVecEnv(num_envs=64, model=model, refs=refs)
     assert attempt(venv, HipPolicy(hidden=512)) == 'persistent'          # (dl_set_split need not be on: the persistent kernel IS the split form)
     venv.close()
+
+
+def test_blocked_reduction_order_against_numpy(torch_cuda):
+    """dl_vecnormalize_step with the blocked summation order (flag 32: blocks of 16 rows -> <= 8 groups -> total; the order the persistent
+    rollout kernel follows) against numpy's RunningMeanStd.update for several consecutive steps, ragged batch sizes included: moments to
+    1e-12, float32 outputs to one rounding."""
+    torch = torch_cuda
+    import ctypes as C
+    from drloco_amd import abi, lib as L
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for B, D in ((4096, 29), (1000, 29), (5, 29), (130, 47)):
+        om, ov, oc, rm, rv, rc = np.zeros(D), np.ones(D), 1e-4, 0.0, 1.0, 1e-4
+        ret = np.zeros(B)
+        dev = 'cuda'
+        mean, var, cnt = torch.zeros(D, dtype=torch.float64, device=dev), torch.ones(D, dtype=torch.float64, device=dev), torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
+        rmean, rvar, rcnt = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev), torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
+        dret = torch.zeros(B, dtype=torch.float64, device=dev)
+        work = torch.zeros(abi.vn_workspace_bytes(D) // 8, dtype=torch.float64, device=dev)
+        p = lambda x: C.c_void_p(x.data_ptr())
+
+        def upd(m, v, c, x):
+            bm, bv, bc = x.mean(0), x.var(0), x.shape[0]
+            d, tot = bm - m, c + bc
+            return m + d * bc / tot, (v * c + bv * bc + d * d * c * bc / tot) / tot, tot
+        for t in range(6):
+            obs = (3.0 + rng.standard_normal((B, D)) * np.linspace(0.5, 2, D)).astype(np.float32)
+            rew = (0.2 + rng.random(B)).astype(np.float32)
+            done = (rng.random(B) < 0.05).astype(np.uint8)
+            om, ov, oc = upd(om, ov, oc, obs.astype(np.float64))
+            ret = ret * 0.99 + rew
+            rm, rv, rc = upd(rm, rv, rc, ret)
+            exp_o = np.clip((obs.astype(np.float64) - om) / np.sqrt(ov + 1e-8), -10, 10)
+            exp_r = np.clip(rew / np.sqrt(rv + 1e-8), -10, 10)
+            ret[done != 0] = 0
+            d_obs, d_rew, d_done = torch.as_tensor(obs, device=dev), torch.as_tensor(rew, device=dev), torch.as_tensor(done, device=dev)
+            out_o, out_r = torch.zeros(B, D, device=dev), torch.zeros(B, device=dev)
+            L.check(lib.dl_vecnormalize_step(p(d_obs), p(d_rew), p(d_done), p(mean), p(var), p(cnt), p(dret), p(rmean), p(rvar), p(rcnt), B, D, 0.99, 1e-8, 10.0, 10.0,
+                                             1 | 2 | 4 | 8 | 32, p(out_o), p(out_r), p(work), None))
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(mean.cpu().numpy(), om, rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(var.cpu().numpy(), ov, rtol=1e-11)
+            assert float(cnt) == oc and float(rcnt) == rc
+            np.testing.assert_allclose([float(rmean), float(rvar)], [rm, rv], rtol=1e-11)
+            np.testing.assert_allclose(dret.cpu().numpy(), ret, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(out_o.cpu().numpy(), exp_o, rtol=0, atol=2e-6)
+            np.testing.assert_allclose(out_r.cpu().numpy(), exp_r, rtol=0, atol=2e-6)
+
+
+def test_grid_exchange_timeout_raises(torch_cuda, model, refs):
+    """A workgroup of the persistent rollout kernel that gives up on the grid-wide exchange (forced: poll budget 0) sets the handle's fault
+    word and stops writing; the next C-ABI call raises, dl_fault_clear + reset bring the handle back."""
+    torch = torch_cuda
+    import ctypes as C
+    from drloco_amd import abi, lib as L
+    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, 200, 6)
+    L.check(venv._lib.dl_debug_set_grid_spin(venv._h, 0))
+    buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+    torch.cuda.synchronize()
+    code = C.c_int32(0)
+    assert venv._lib.dl_fault_check(venv._h, C.byref(code)) == abi.DL_E_FAULT and (code.value & 4)
+    assert b'grid-wide' in venv._lib.dl_last_error()
+    with pytest.raises(L.DrlocoFault):
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+    L.check(venv._lib.dl_fault_clear(venv._h))
+    L.check(venv._lib.dl_debug_set_grid_spin(venv._h, -1))
+    vn.reset()
+    last_obs = vn.norm_obs_t.clone(); last_done.fill_(1)
+    buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+    torch.cuda.synchronize()
+    L.check(venv._lib.dl_fault_check(venv._h, None))
+    assert torch.isfinite(buf.observations).all() and (buf.rewards >= 0).all()
+    venv.close()

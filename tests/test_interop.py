@@ -121,7 +121,8 @@ def test_sb3_wrap_env_takes_the_device_env_as_it_is():
         obs, rew, done, infos = env.step(np.zeros((64, 8), np.float32))
         assert obs.shape == (64, 29) and rew.shape == (64,) and done.dtype == bool and len(infos) == 64
         assert len(env.get_attr('ep_len_smoothed')) == 64 and len(env.get_attr('moved_distance', indices=[3, 5])) == 2
-        assert env.env_is_wrapped(type('Monitor', (), {})) == [True] * 64
+        assert env.env_is_wrapped(type('Monitor', (), {'__module__': 'drloco.mujoco.monitor_wrapper'})) == [True] * 64
+        assert env.env_is_wrapped(type('Monitor', (), {})) == [False] * 64          # a class that is merely CALLED Monitor is not one
         assert env.unwrapped is env.venv
         env.close()
         print('ok')
