@@ -31,10 +31,19 @@ EP_DUR_MAX = 3000            # drloco/config/hypers.py:58
 ALIVE_BONUS, REW_SCALE = 0.2, 1.0   # drloco/config/hypers.py:51-55
 
 
-def make_eval_env(train_env, n_episodes=EVAL_N_TIMES, **kw):
+def make_eval_env(train_env, n_episodes=EVAL_N_TIMES, history='fresh', **kw):
     """utils.load_env (drloco/common/utils.py:234-240) without the trip through the file system: a fresh handle of
     `n_episodes` walkers in evaluation mode that normalises with a copy of `train_env`'s moments (norm_rew=False as
-    in load_env).  Walker i starts its first episode from deterministic init state k = i."""
+    in load_env).  Walker i starts its first episode from deterministic init state k = i.
+    history: 'fresh' (the reference: load_env builds a NEW environment, whose count_steps_same_vel starts at 1) or 'training' (the counter
+    of the training walkers is carried over).  It matters more than it looks: the counter only ever grows and survives resets (quirk Q2,
+    straight_walk_trajecs.py:124,336), so after the first few thousand steps of training the desired-velocity observation
+    step_velocities[max(0, i_step - count + 1)] is the CONSTANT step_velocities[0]; VecNormalize's variance of that column collapses, and a
+    fresh environment -- whose observation walks through the per-step velocities again -- presents the policy with inputs clipped at +-10.
+    Measured (tools/diag_eval.py, 6 M steps, seed 1): training episodes 2600 steps / 21 m; 'fresh' evaluation 400-500 steps / 3-4 m;
+    'training' history: the training env's behaviour.  The reference's own evaluation has the same mismatch."""
+    if history not in ('fresh', 'training'):
+        raise ValueError("history must be 'fresh' or 'training'")
     src = train_env.venv
     venv = HipVecEnv(src.env_id, num_envs=n_episodes, device=src.device.index, seed=src.cfg.seed, precision=src.precision,
                      model=src.model, refs=src.refs, **kw)
@@ -45,6 +54,8 @@ def make_eval_env(train_env, n_episodes=EVAL_N_TIMES, **kw):
     venv.activate_evaluation()
     st = venv.get_state()
     st['cursor'][abi.DL_CUR_EVAL_K] = np.arange(n_episodes) % 20
+    if history == 'training':
+        st['cursor'][abi.DL_CUR_COUNT] = int(np.median(src.get_state()['cursor'][abi.DL_CUR_COUNT]))
     venv.set_state(cursor=st['cursor'])
     return vn
 

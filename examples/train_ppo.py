@@ -33,7 +33,7 @@ from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 
-def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False, save_path=None, moments='per_step'):
+def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, log_every=25, quiet=False, norm_reward=True, evaluate=False, save_path=None, moments='per_step', return_objects=False):
     # one process per GPU under torch.distributed.run (backend nccl = RCCL); a single process otherwise
     import torch.distributed as dist
     world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -111,10 +111,15 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
     if evaluate:
         # TrainingMonitor.eval_walking (drloco/common/callback.py:272-390): 20 deterministic episodes, here as one batch
         from drloco_amd.evaluation import evaluate_walking, make_eval_env
-        res = evaluate_walking(make_eval_env(vn), pol)
+        # history='training': the walkers' step counter is carried into the evaluation env (the reference's load_env starts a fresh one, whose
+        # desired-velocity observation the policy has not seen since its first thousand steps: drloco_amd/evaluation.py).  Episodes with an odd
+        # evaluation counter k start mirrored against the reference data they read (quirk Q3 of _get_deterministic_init_state) and fall.
+        res = evaluate_walking(make_eval_env(vn, history='training'), pol)
         hist[-1]['evaluation'] = res
         if not quiet:
-            print(f"evaluation (20 deterministic episodes): mean distance {res['mean_walked_distance']:.1f} m, min {res['min_walked_distance']:.1f} m, "
+            import numpy as np
+            dist_k = np.array(res['moved_distances'])
+            print(f"evaluation (20 deterministic episodes, training step counter): mean distance {res['mean_walked_distance']:.1f} m (even k {dist_k[0::2].mean():.1f} m, odd k {dist_k[1::2].mean():.1f} m), "
                   f"mean episode length {res['mean_episode_duration'] * 3000:.0f}, stable walks {res['count_stable_walks']}/20, "
                   f"mean step reward (normalised) {res['mean_reward_means']:.2f}")
     if save_path:
@@ -128,6 +133,8 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
         vn.save(os.path.join(save_path, 'envs', f'env_{ckpt}'), sb3_format=True)
         if not quiet:
             print('saved', os.path.join(save_path, 'models', f'model_{ckpt}.zip'), 'and', os.path.join(save_path, 'envs', f'env_{ckpt}'))
+    if return_objects:          # (tools/diag_eval.py)
+        return hist, pol, vn
     return hist
 
 
