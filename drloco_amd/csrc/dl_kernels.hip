@@ -733,15 +733,30 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 shf[0] = (old + 1u == (unsigned)(gb1 - gb0) * (unsigned)(t + 1)) ? 1 : 0;
             }
             __syncthreads();
-            if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order
+            if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order: every load in flight at once (eight lanes per
+                                  // column pair fetch four blocks each into LDS -- the idle env regions --, then the column's lane adds them in order)
+                double* gs = (double*)smem;                         // [32][2 W]
+                const int gn = gb1 - gb0;
+                if (gn <= 32 && tid < 8 * 2 * W) {
+                    const int col = tid % (2 * W), part = tid / (2 * W);
+                    double v4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const int b = part * 4 + i; v4[i] = b < gn ? __hip_atomic_load(&partial[(size_t)(gb0 + b) * W * 2 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) gs[(part * 4 + i) * (2 * W) + col] = v4[i];
+                }
+                __syncthreads();
                 if (tid < 2 * W) {
                     double x = 0;
-                    for (int b0 = gb0; b0 < gb1; b0 += 8) {          // eight loads in flight, added in block order
-                        double v8[8];
+                    if (gn <= 32) { for (int b = 0; b < gn; b++) x += gs[b * (2 * W) + tid]; }
+                    else {
+                        for (int b0 = gb0; b0 < gb1; b0 += 8) {          // (more than 32 blocks per group: not reachable at one workgroup per CU on 256 CUs; kept general)
+                            double v8[8];
 #pragma unroll
-                        for (int i = 0; i < 8; i++) v8[i] = b0 + i < gb1 ? __hip_atomic_load(&partial[(size_t)(b0 + i) * W * 2 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                            for (int i = 0; i < 8; i++) v8[i] = b0 + i < gb1 ? __hip_atomic_load(&partial[(size_t)(b0 + i) * W * 2 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
-                        for (int i = 0; i < 8; i++) if (b0 + i < gb1) x += v8[i];
+                            for (int i = 0; i < 8; i++) if (b0 + i < gb1) x += v8[i];
+                        }
                     }
                     __hip_atomic_store(&xpart[(size_t)grp * W * 2 + tid], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1703,6 +1718,8 @@ static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n,
                 hipLaunchKernelGGL((k_policy_forward<4, 8, true, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk);
             } else if (n <= POL_ROWS * 256) {   // at most one workgroup per CU on an MI355X: the barrier-free form with the whole h1 block in LDS (51 KB)
                 hipLaunchKernelGGL((k_policy_forward<4, 8, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, PolPacked{nullptr, nullptr, nullptr});
+            } else if (pk.w2p) {                // more rows than one workgroup per CU: the lean (23 KB) form, packed weights
+                hipLaunchKernelGGL((k_policy_forward<4, 8, false, true>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk);
             } else DL_POL_LAUNCH(4, 8)
             break;
         default: return fail(DL_E_INVAL, "dl_policy_forward: hidden must be 64, 128, 256 or 512");
