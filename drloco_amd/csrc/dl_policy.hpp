@@ -51,7 +51,7 @@ __device__ __forceinline__ float pol_gauss(uint64_t seed, uint64_t counter, uint
 }
 
 #ifndef DL_POL_SKEW
-#define DL_POL_SKEW 2
+#define DL_POL_SKEW 0      // experiment switch: k > 0 lets wave w of the barrier-free form start its walk over the k blocks at block k w (measured: no gain; 0 keeps the forms bit-identical)
 #endif
 constexpr int POL_ROWS = 16;       // walkers per workgroup
 constexpr int POL_MAXT = 8;        // accumulator tiles per wave in the hidden layer (hidden <= 512)
@@ -291,10 +291,9 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         static_assert((H / 32) % DEPTH == 0, "steps come in groups of DEPTH");
         pf4 bs[DEPTH][NTW][2];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the compiler's own loads may be counted against the sets
-        // WHOLE_H1: the waves walk over the k blocks in ROTATED order (wave w starts at block 2 w).  A weight row is 2 KB long, so at a given k
-        // block the 512 rows' lines differ only in address bits >= 11: walked in step, all waves of a CU (and of every CU) would ask the same
-        // one or two of the L2's 16 channels at any moment (measured: the weight stream cost 13 of the kernel's 37 us); rotated, a
-        // workgroup's requests cover 8 k blocks = all channels.  Every wave keeps a fixed order: deterministic, own rounding order.
+        // (experiment, DL_POL_SKEW > 0: the waves of the barrier-free form walk over the k blocks in rotated order -- a weight row is 2 KB long, so at
+        // a given k block the rows' lines differ only in address bits >= 11 and all waves might ask the same L2 channels; measured: no effect,
+        // what bound the weight stream was the number of cache lines per wave instruction, see PACKED)
         auto kp_at = [&](int i) { return WHOLE_H1 ? (i + DL_POL_SKEW * wave) % npair : i; };
 #pragma unroll
         for (int d = 0; d < DEPTH - 1; d++) load_set(bs[d], kp_at(d));

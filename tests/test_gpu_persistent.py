@@ -244,3 +244,19 @@ def test_grid_exchange_timeout_raises(torch_cuda, model, refs):
     L.check(venv._lib.dl_fault_check(venv._h, None))
     assert torch.isfinite(buf.observations).all() and (buf.rewards >= 0).all()
     venv.close()
+
+
+def test_policy_forms_agree_bit_for_bit(torch_cuda):
+    """dl_policy_forward picks its form by batch size (<= 4096 rows: the whole first-layer block staged in LDS, barrier-free hidden layer;
+    above: the lean 23 KB form that fits next to env-step workgroups); rollouts add the packed weight layout.  Same order of arithmetic in
+    all of them: the first 4096 rows of an 8192-row call (lean) equal a 4096-row call (whole) bit for bit."""
+    torch = torch_cuda
+    from drloco_amd.policy import HipPolicy
+    pol = HipPolicy(hidden=512, seed=11)
+    g = torch.Generator(device='cuda'); g.manual_seed(2)
+    obs = torch.randn(8192, 29, device='cuda', generator=g)
+    eps = torch.randn(8192, 8, device='cuda', generator=g)
+    a8, v8, l8 = pol.forward(obs, eps=eps)
+    a4, v4, l4 = pol.forward(obs[:4096].contiguous(), eps=eps[:4096].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(a8[:4096], a4) and torch.equal(v8[:4096], v4) and torch.equal(l8[:4096], l4)
