@@ -18,10 +18,12 @@ The actions are pre-generated, so nothing waits for an observation: the env step
 wave with the largest SUM over its steps, not the sum of every step's slowest wave) -- one run of 448 steps, one of 64 --
 and the two dl_vecnormalize_step launches of every step run on a side HIP stream under the following run (raw
 outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
-the fused policy into the loop (dl_rollout_policy: 4 launches per control step).  Same results in all forms
-(tests/test_gpu_parity.py::test_steps_fixed_runs_match_the_step_by_step_path).
-Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) and values synthetic, both keyed by the global walker index
-(one stream, every rank keeps its columns), RSI comes from the counter-based stream keyed by the global walker index.  Inputs are resident in
+the fused policy into the loop (dl_collect_rollouts: the whole rollout as ONE persistent launch -- policy forward, env step and VecNormalize's
+moment exchange per control step inside the kernel -- or, --rollout-form launches, three launches per control step; --moments per_rollout is
+the opt-in relaxation of the persistent form).  Same results in all forms (tests/test_gpu_bench_shapes.py, tests/test_gpu_persistent.py).
+After the timed region the run checks its own output (fault word, finite buffers, reward range, episode ends: `self_check` in the JSON line).
+Actions are pre-generated a_t = clip(0.5*N(0,1), -1, 1) and values synthetic, both from a counter-based generator keyed by the global walker
+index (tape_normal: every rank draws exactly its own columns), RSI comes from the counter-based stream keyed by the global walker index.  Inputs are resident in
 HBM before the timed region.  value = walkers * 512 * K * N / time  [env-steps/s, whole job].
 """
 import argparse

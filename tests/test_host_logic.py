@@ -330,3 +330,22 @@ def test_bench_cpu_baselines_run(oracle):
         assert d['unit'] == 'env-steps/s' and d['value'] > 0 and d['cores'] == cores and isinstance(d['sample'], str)
     assert one['kind'] == 'port'
     assert len(bench.kernel_sources_sha16()) == 16
+
+
+def test_bench_tapes_are_keyed_by_the_global_walker_index():
+    """bench.py's action / value tapes (tape_normal): a counter-based generator keyed by (seed, stream, step, GLOBAL walker index, component) --
+    a rank that draws only its own columns gets exactly the columns of the global tape, whatever the number of ranks; standard normal."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    full = bench.tape_normal(4321, 0, 32, 0, 96, 8, 'cpu')
+    for world in (2, 3, 4):
+        n = 96 // world
+        for rank in range(world):
+            assert torch.equal(bench.tape_normal(4321, 0, 32, rank * n, n, 8, 'cpu'), full[:, rank * n:(rank + 1) * n])
+    assert not torch.equal(bench.tape_normal(4321, 1, 32, 0, 96, 8, 'cpu'), full) and not torch.equal(bench.tape_normal(4322, 0, 32, 0, 96, 8, 'cpu'), full)
+    assert bench.tape_normal(4321, 2, 4, 5, 7, 0, 'cpu').shape == (4, 7)
+    big = bench.tape_normal(7, 0, 64, 0, 4096, 8, 'cpu')
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1) < 5e-3 and float(big.abs().max()) < 6.5
+    k = float(((big - big.mean()) ** 4).mean() / big.var() ** 2)
+    assert abs(k - 3) < 0.05          # kurtosis of a normal
