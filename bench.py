@@ -210,7 +210,7 @@ def main():
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
-    ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: rollout length - 64, 64 -- one long launch, then a 64-step launch under which the normalisations of the long one execute on the side stream (tools/prof_step.py issues the same schedule for the PMC passes)')
+    ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: with split workgroups ONE launch for the rollout (nothing overlaps with them), otherwise rollout length - 64, 64 -- one long launch, then a 64-step launch under which the normalisations of the long one execute on the side stream (tools/prof_step.py issues the same schedule for the PMC passes)')
     ap.add_argument('--handles', type=int, default=1, help='with --policy: split the walkers of a rank over this many env handles, each driving its policy -> step -> normalise chain on its own stream (drloco_amd/group.py); balanced single-step launches need >= 8192 walkers per GPU')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--vn-single-steps', action='store_true', help='normalise the steps of a fixed-action run one dl_vecnormalize_step at a time instead of with dl_vecnormalize_steps (five launches per run)')
@@ -260,9 +260,19 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     n, T = args.envs_per_gpu, args.rollout_len
-    runs = [int(x) for x in args.runs.split(',')] if args.runs else ([T - 64, 64] if T >= 128 else [T])
-    if sum(runs) < T:
-        runs += [runs[-1]] * ((T - sum(runs) + runs[-1] - 1) // runs[-1])
+    # the split workgroups fill the GPU: good for the policy-free rollout at any size and for a policy in the loop at the benchmark size;
+    # with a policy and more walkers the one-wave form leaves room for the policy kernel next to the env steps (measured: 18.7 vs 20.0 M at 32 768)
+    split = (not args.no_split) and args.walker == 'straight' and args.lanes in (0, 16) and not (args.policy and (args.handles > 1 or n > 4096))
+    # launch schedule of the policy-free rollout.  One-wave step kernels leave registers for other kernels: a long launch, then a 64-step
+    # launch under which the normalisations of the long one execute on the side stream.  Split workgroups hold every SIMD's whole register
+    # file (two waves x 256): nothing runs next to them, the side stream's launches only wait -- so ONE launch covers the rollout (<= 512
+    # steps) and its normalisations follow as one dl_vecnormalize_steps call (measured: 71.1 + 0.5 ms against 62.5 + 10.0 + 0.6 ms)
+    if args.runs:
+        runs = [int(x) for x in args.runs.split(',')]
+    elif split:
+        runs = [min(T, 512)]
+    else:
+        runs = [T - 64, 64] if T >= 128 else [T]
     run_starts, t0 = [], 0
     for r in runs:
         r = min(r, 512, T - t0)
@@ -276,9 +286,6 @@ def main():
         venv = HipVecEnv(models.WALKER_165CM, num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, refs=mocap.loco3d_table(ang, vel), lanes_per_walker=args.lanes)
     else:
         venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
-    # the split workgroups fill the GPU: good for the policy-free rollout at any size and for a policy in the loop at the benchmark size;
-    # with a policy and more walkers the one-wave form leaves room for the policy kernel next to the env steps (measured: 18.7 vs 20.0 M at 32 768)
-    split = (not args.no_split) and args.walker == 'straight' and args.lanes in (0, 16) and not (args.policy and (args.handles > 1 or n > 4096))
     if split:
         venv.set_split(True)          # dynamics waves + constraint waves (include/drloco_hip.h: dl_set_split)
     vn = HipVecNormalize(venv)

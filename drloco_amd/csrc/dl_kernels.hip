@@ -1558,7 +1558,21 @@ __global__ __launch_bounds__(256) void k_vns_returns(const float* __restrict__ r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     double r = ret[i];
-    for (int t = 0; t < K; t++) {
+    // sixteen steps per trip: their loads are independent of the recurrence and go out together (one memory round trip per sixteen steps
+    // instead of one per step -- the kernel is a chain of K dependent steps per walker and nothing else hides the latency)
+    int t = 0;
+    for (; t + 16 <= K; t += 16) {
+        float w[16]; uint8_t d[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { w[u] = rew[(size_t)(t + u) * B + i]; d[u] = done[(size_t)(t + u) * B + i]; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            r = r * gamma + (double)w[u];
+            rets[(size_t)(t + u) * B + i] = r;
+            if (d[u]) r = 0;
+        }
+    }
+    for (; t < K; t++) {
         r = r * gamma + (double)rew[(size_t)t * B + i];
         rets[(size_t)t * B + i] = r;
         if (done[(size_t)t * B + i]) r = 0;
@@ -1604,9 +1618,21 @@ __global__ __launch_bounds__(256) void k_vns_partial(const float* __restrict__ x
         if (t == 0) { wk[D * 2] = s; wk[D * 2 + 1] = ss; }
     }
 }
-__global__ __launch_bounds__(128) void k_vns_merge(const double* __restrict__ work, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
-                                                int K, int B, int D, int flags, double* stats) {
-    const int d = threadIdx.x, W = D + 1;
+// Two phases in one workgroup: (A) every step's 32 block partials are added up, in block order, by all lanes in parallel (K x (D + 1) sums, left
+// in `stats`); (B) the lanes of the D + 1 columns run the K Chan merges in step order -- the only sequential part, ~10 float64 operations per
+// step with the sums of sixteen steps requested ahead.
+__global__ __launch_bounds__(1024) void k_vns_merge(const double* __restrict__ work, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
+                                                 int K, int B, int D, int flags, double* stats) {
+    const int W = D + 1;
+    for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
+        const int t = e / W, d = e % W;
+        const double* wk = work + (size_t)t * VN_BLOCKS * W * 2;
+        double S = 0, SS = 0;
+        for (int b = 0; b < VN_BLOCKS; b++) { S += wk[((size_t)b * W + d) * 2]; SS += wk[((size_t)b * W + d) * 2 + 1]; }
+        stats[(size_t)e * 2] = S; stats[(size_t)e * 2 + 1] = SS;
+    }
+    __syncthreads();
+    const int d = threadIdx.x;
     const bool active = d < W, is_obs = d < D, upd = is_obs ? (flags & 1) != 0 : (flags & 4) != 0;
     double* mp = is_obs ? mean + d : ret_mean;
     double* vp = is_obs ? var + d : ret_var;
@@ -1615,17 +1641,24 @@ __global__ __launch_bounds__(128) void k_vns_merge(const double* __restrict__ wo
     __syncthreads();                           // every column has read the counts before one of them writes them back
     if (!active) return;
     const double K0 = m;                       // the shift of every step's sums
-    for (int t = 0; t < K; t++) {
-        if (upd) {
-            const double* wk = work + (size_t)t * VN_BLOCKS * W * 2;
-            double S = 0, SS = 0;
-            for (int b = 0; b < VN_BLOCKS; b++) { S += wk[((size_t)b * W + d) * 2]; SS += wk[((size_t)b * W + d) * 2 + 1]; }
-            const double bm = K0 + S / B, bv = SS / B - (S / B) * (S / B);
-            const double tot = cnt + B, delta = bm - m;
-            const double M2 = v * cnt + bv * B + delta * delta * cnt * B / tot;
-            m = m + delta * B / tot; v = M2 / tot; cnt = tot;
+    for (int t0 = 0; t0 < K; t0 += 16) {
+        double Sb[16], SSb[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int t = t0 + u < K ? t0 + u : K - 1; Sb[u] = stats[((size_t)t * W + d) * 2]; SSb[u] = stats[((size_t)t * W + d) * 2 + 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int t = t0 + u;
+            if (t < K) {
+                if (upd) {
+                    const double S = Sb[u], SS = SSb[u];
+                    const double bm = K0 + S / B, bv = SS / B - (S / B) * (S / B);
+                    const double tot = cnt + B, delta = bm - m;
+                    const double M2 = v * cnt + bv * B + delta * delta * cnt * B / tot;
+                    m = m + delta * B / tot; v = M2 / tot; cnt = tot;
+                }
+                stats[((size_t)t * W + d) * 2] = m; stats[((size_t)t * W + d) * 2 + 1] = v;
+            }
         }
-        stats[((size_t)t * W + d) * 2] = m; stats[((size_t)t * W + d) * 2 + 1] = v;
     }
     *mp = m; *vp = v;
     if (upd && (d == 0 || d == D)) { if (is_obs) *count = cnt; else *ret_count = cnt; }
@@ -1692,7 +1725,7 @@ int dl_vecnormalize_steps(const dl_vecnorm_state* vn, int32_t K, const float* ob
     hipStream_t s = (hipStream_t)stream;
     if (flags & 4) hipLaunchKernelGGL(k_vns_returns, dim3((B + 255) / 256), dim3(256), 0, s, rew, done, vn->ret, rets, K, B, vn->gamma);
     if (flags & 5) hipLaunchKernelGGL(k_vns_partial, dim3(VN_BLOCKS, K), dim3(256), 0, s, obs, (const double*)rets, (const double*)vn->obs_mean, (const double*)vn->ret_mean, B, D, flags, work);
-    hipLaunchKernelGGL(k_vns_merge, dim3(1), dim3(128), 0, s, (const double*)work, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret_mean, vn->ret_var, vn->ret_count, K, B, D, flags, stats);
+    hipLaunchKernelGGL(k_vns_merge, dim3(1), dim3(1024), 0, s, (const double*)work, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret_mean, vn->ret_var, vn->ret_count, K, B, D, flags, stats);
     const size_t ne = (size_t)K * B * D;
     hipLaunchKernelGGL(k_vns_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, obs, rew, (const double*)stats, K, B, D, vn->eps, vn->clip_obs, vn->clip_rew, flags, obs_out, rew_out);
     HIPCHK(hipGetLastError());

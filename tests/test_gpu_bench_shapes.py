@@ -59,14 +59,15 @@ def _bench_rollout(torch, model, refs, n, T, runs, acts, form):
     return out
 
 
-def test_benchmark_launch_shapes_match_the_step_by_step_path(torch_cuda, model, refs):
-    """bench.py's headline configuration at its full size -- 4096 walkers x 512 control steps, split workgroups, launches of 448 + 64
-    steps, batched VecNormalize on the side stream -- against the same rollout taken one dl_step + dl_vecnormalize_step at a time:
+@pytest.mark.parametrize('runs', [(512,), (448, 64)], ids=['one-launch-of-512', 'launches-of-448+64'])
+def test_benchmark_launch_shapes_match_the_step_by_step_path(torch_cuda, model, refs, runs):
+    """bench.py's headline configuration at its full size -- 4096 walkers x 512 control steps, split workgroups, ONE launch of 512 steps
+    (the default schedule; round 2's 448 + 64 as well), the rollout's normalisations as one dl_vecnormalize_steps call -- against the same rollout taken one dl_step + dl_vecnormalize_step at a time:
     everything the simulation produces (episode boundaries, final walker state, cursors, walked distance, Monitor words, the raw
     observation / reward of the last step) is bit-identical; the normalised rollout-buffer contents agree to one float32 rounding of the
     normalisation and the moments to 1e-12 (the batched form sums with the start-of-run mean as its shift)."""
     torch = torch_cuda
-    n, T, runs = 4096, 512, (448, 64)
+    n, T = 4096, 512
     g = torch.Generator(device='cuda'); g.manual_seed(4321)
     acts = torch.clamp(0.5 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
     a = _bench_rollout(torch, model, refs, n, T, runs, acts, 'bench')
