@@ -398,7 +398,10 @@ def main():
             raw_rew, raw_obs = vn.old_rew, vn.old_obs
         rmin, rmax = float(raw_rew.min().item()), float(raw_rew.max().item())
         fin = fin and bool(torch.isfinite(raw_obs).all().item() and torch.isfinite(raw_rew).all().item())
-        checks = {'finite': fin, 'raw_reward_min': rmin, 'raw_reward_max': rmax, 'episodes_ended_last_rollout': n_done, 'normalised_obs_absmax': obs_absmax}
+        # (random torques of +-300 N m make a walker's trunk spin up to 1e3 .. 1e7 rad/s now and then before it falls -- the float64 oracle shows the same
+        #  events --, and one such observation stays in VecNormalize's never-forgetting variance: DESIGN.md 7.  Reported, not asserted.)
+        checks = {'finite': fin, 'raw_reward_min': rmin, 'raw_reward_max': rmax, 'episodes_ended_last_rollout': n_done, 'normalised_obs_absmax': obs_absmax,
+                  'obs_rms_var_max': float(vn.obs_rms.var.max())}
         # MimicEnv.step: reward = 0 on done, else imitation (<= 1) + 0.2 alive bonus (mimic_env.py:142-168); VecNormalize clips at 10
         assert fin, f'bench self-check: non-finite values in the rollout buffer {checks}'
         assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'

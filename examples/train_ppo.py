@@ -104,10 +104,10 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
             mean_rew = torch.tensor(venv.get_attr('mean_reward_smoothed')).mean().item()
             dist_ = torch.tensor(venv.get_attr('moved_distance')).mean().item()
             el = time.perf_counter() - t0
-            hist.append(dict(update=upd, env_steps=(upd + 1) * batch, ep_len=ep_len, mean_step_reward=mean_rew, moved_distance=dist_, seconds=el))
+            hist.append(dict(update=upd, env_steps=(upd + 1) * batch, ep_len=ep_len, mean_step_reward=mean_rew, moved_distance=dist_, seconds=el, obs_var_max=float(vn.obs_rms.var.max())))
             if not quiet:
                 print(f'update {upd:5d}  env-steps {(upd + 1) * batch / 1e6:6.2f} M  ep_len {ep_len:7.1f}  step reward {mean_rew:.3f}  '
-                      f'walked {dist_:5.2f} m  lr {lr:.2e}  {el:6.1f} s  ({(upd + 1) * batch / el / 1e3:.0f} k env-steps/s incl. learning)', flush=True)
+                      f'walked {dist_:5.2f} m  max obs var {float(vn.obs_rms.var.max()):9.3g}  lr {lr:.2e}  {el:6.1f} s  ({(upd + 1) * batch / el / 1e3:.0f} k env-steps/s incl. learning)', flush=True)
     if evaluate:
         # TrainingMonitor.eval_walking (drloco/common/callback.py:272-390): 20 deterministic episodes, here as one batch
         from drloco_amd.evaluation import evaluate_walking, make_eval_env
