@@ -15,9 +15,8 @@ One "step" of this benchmark = ONE 512-step rollout of all walkers of a rank:
                      (RCCL all-reduce of 3 doubles when N > 1 -- the only collective), VecNormalize moment merge across ranks.
 The actions are pre-generated, so nothing waits for an observation: the env steps go through dl_rollout_fixed, whose
 16-lane kernel takes a whole run of control steps per launch (walker state in registers; a launch lasts as long as the
-wave with the largest SUM over its steps, not the sum of every step's slowest wave) -- one run of 448 steps, one of 64 --
-and the two dl_vecnormalize_step launches of every step run on a side HIP stream under the following run (raw
-outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
+wave with the largest SUM over its steps, not the sum of every step's slowest wave) -- ONE launch of 512 steps per rollout --
+and the rollout's normalisations follow as one dl_vecnormalize_steps call (five launches; raw outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
 the fused policy into the loop (dl_collect_rollouts: the whole rollout as ONE persistent launch -- policy forward, env step and VecNormalize's
 moment exchange per control step inside the kernel -- or, --rollout-form launches, three launches per control step; --moments per_rollout is
 the opt-in relaxation of the persistent form).  Same results in all forms (tests/test_gpu_bench_shapes.py, tests/test_gpu_persistent.py).
@@ -210,7 +209,7 @@ def main():
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
-    ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: with split workgroups ONE launch for the rollout (nothing overlaps with them), otherwise rollout length - 64, 64 -- one long launch, then a 64-step launch under which the normalisations of the long one execute on the side stream (tools/prof_step.py issues the same schedule for the PMC passes)')
+    ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: ONE launch for the rollout (the 16-lane kernels; tools/prof_step.py issues the same schedule for the PMC passes)')
     ap.add_argument('--handles', type=int, default=1, help='with --policy: split the walkers of a rank over this many env handles, each driving its policy -> step -> normalise chain on its own stream (drloco_amd/group.py); balanced single-step launches need >= 8192 walkers per GPU')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--vn-single-steps', action='store_true', help='normalise the steps of a fixed-action run one dl_vecnormalize_step at a time instead of with dl_vecnormalize_steps (five launches per run)')
@@ -263,13 +262,14 @@ def main():
     # the split workgroups fill the GPU: good for the policy-free rollout at any size and for a policy in the loop at the benchmark size;
     # with a policy and more walkers the one-wave form leaves room for the policy kernel next to the env steps (measured: 18.7 vs 20.0 M at 32 768)
     split = (not args.no_split) and args.walker == 'straight' and args.lanes in (0, 16) and not (args.policy and (args.handles > 1 or n > 4096))
-    # launch schedule of the policy-free rollout.  One-wave step kernels leave registers for other kernels: a long launch, then a 64-step
-    # launch under which the normalisations of the long one execute on the side stream.  Split workgroups hold every SIMD's whole register
-    # file (two waves x 256): nothing runs next to them, the side stream's launches only wait -- so ONE launch covers the rollout (<= 512
-    # steps) and its normalisations follow as one dl_vecnormalize_steps call (measured: 71.1 + 0.5 ms against 62.5 + 10.0 + 0.6 ms)
+    # launch schedule of the policy-free rollout: ONE launch covers the rollout (<= 512 steps) and its normalisations follow as one
+    # dl_vecnormalize_steps call.  (Round 2 ran 448 + 64 steps with the normalisations of the long launch "on the side stream under the short
+    # one": the split workgroups -- two waves x 256 registers -- and the 19-dof kernel -- 508 registers -- hold every SIMD's whole register
+    # file, so nothing ever ran next to them and the side stream's kernels only trickled in as workgroups retired; measured, one launch
+    # against 448 + 64: 29.06 vs 28.77 M split, 27.44 vs 27.28 M one-wave straight walker, 12.82 vs 12.78 M 19-dof walker.)
     if args.runs:
         runs = [int(x) for x in args.runs.split(',')]
-    elif split:
+    elif args.lanes in (0, 16):
         runs = [min(T, 512)]
     else:
         runs = [T - 64, 64] if T >= 128 else [T]

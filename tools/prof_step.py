@@ -31,12 +31,8 @@ acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, env.nu, 
 if args.single:
     for t in range(args.warm + args.steps):
         env.step_tensors(acts[t])
-else:       # the benchmark's form: dl_rollout_fixed in the benchmark's launch schedule (split workgroups: one launch of T control steps; else T - 64, then 64)
+else:       # the benchmark's form: dl_rollout_fixed in the benchmark's launch schedule (one launch of T control steps)
     T = args.warm + args.steps
-    if getattr(env, 'split', False):      # split workgroups: ONE launch per rollout (bench.py's default schedule for them)
-        env.rollout_fixed(acts[:T])
-    else:
-        env.rollout_fixed(acts[:T - 64])
-        env.rollout_fixed(acts[T - 64:T])
+    env.rollout_fixed(acts[:T])             # ONE launch per rollout: bench.py's default schedule (T <= 512)
 torch.cuda.synchronize()
 print('done')

@@ -46,7 +46,7 @@ if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
     out['hbm_bytes_per_launch_raw'] = (pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024
     out['hbm_bytes_per_launch'] = (2 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024
 lines.append('')
-lines.append('PMC counters of the dominant kernel (k_env_step* / k_rollout_persistent; average per launch over the launch schedule of the benchmark (dl_rollout_fixed: split workgroups one launch of 512 control steps; one-wave kernels 448 + 64 = 256 per launch), whole grid; separate rocprofv3 --pmc passes on tools/prof_step.py):')
+lines.append('PMC counters of the dominant kernel (k_env_step* / k_rollout_persistent; average per launch over the launch schedule of the benchmark (dl_rollout_fixed: one launch of 512 control steps), whole grid; separate rocprofv3 --pmc passes on tools/prof_step.py):')
 for k in sorted(pmc):
     lines.append(f'  {k:24s} {pmc[k]:16.1f}')
 lines.append('')
