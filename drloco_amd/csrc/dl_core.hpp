@@ -276,6 +276,10 @@ template <typename T> DL_HD T dl_max(T a, T b) { return a > b ? a : b; }
 template <typename T> DL_HD T dl_min(T a, T b) { return a < b ? a : b; }
 template <typename T> DL_HD T dl_clamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
 template <typename T> DL_HD bool dl_bad(T x) { return !(x == x) || x > T(1e10) || x < T(-1e10); }
+// A float32 output of a step whose state left float32's range in its LAST substep (the state is caught by the next mj_checkPos / mj_checkVel, one
+// control step later, exactly as in the reference -- but there, in float64, the value that becomes an observation is still a finite number):
+// saturate at the largest finite float instead of handing inf / NaN to VecNormalize, whose moments would turn NaN for good
+DL_HD float dl_sat_out(float x) { return x == x ? (x > 3.0e38f ? 3.0e38f : (x < -3.0e38f ? -3.0e38f : x)) : 3.0e38f; }
 
 // symmetric 3x3
 template <typename T> struct S3 { T xx, xy, xz, yy, yz, zz; };

@@ -244,13 +244,13 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
             terms[0] = (double)tt[0]; terms[1] = (double)tt[1]; terms[2] = (double)tt[2];
         }
         float* dst = dn ? term_obs : obs;
-        if (dst) static_for<TP::OBS>([&](auto ki) { dst[(size_t)i * TP::OBS + ki.value] = o[ki.value]; });
+        if (dst) static_for<TP::OBS>([&](auto ki) { dst[(size_t)i * TP::OBS + ki.value] = dl_sat_out(o[ki.value]); });
         if (dn) st.need_reset[i] = 1;
     }
     monitor_step(st.mon, n, i, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
     st.mon[(size_t)MON_POSREW * n + i] = terms[0]; st.mon[(size_t)MON_VELREW * n + i] = terms[1]; st.mon[(size_t)MON_COMREW * n + i] = terms[2];
     if (rew_terms) { rew_terms[3 * (size_t)i] = (float)terms[0]; rew_terms[3 * (size_t)i + 1] = (float)terms[1]; rew_terms[3 * (size_t)i + 2] = (float)terms[2]; }
-    rew[i] = r;
+    rew[i] = r == r ? r : 0.0f;
     done[i] = dn ? 1 : 0;
     static_for<TP::NV>([&](auto ji) { constexpr int j = ji.value; st.qpos[(size_t)j * n + i] = q[j]; st.qvel[(size_t)j * n + i] = v[j]; st.warm[(size_t)j * n + i] = warm[j]; });
     static_for<DL_CUR_WORDS>([&](auto ki) { st.cur[(size_t)ki.value * n + i] = cur[ki.value]; });

@@ -347,7 +347,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             for (int k = j; k < OBS; k += GL) {
                 const T plain = raw_obs(k);
                 const T mir = TP::obs_neg(k) ? -raw_obs(TP::obs_perm(k)) : raw_obs(TP::obs_perm(k));
-                dst_base[(size_t)w * OBS + k] = (float)(mirr_o ? mir : plain);
+                dst_base[(size_t)w * OBS + k] = dl_sat_out((float)(mirr_o ? mir : plain));
             }
         } else {
             // MimicWalker165cm65kg: 4 x (phase angle, phase radius) from joint phase plots (mimic_env.py:330-401), 2 desired
@@ -367,7 +367,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 else if (k == 9) o = (float)((c.pref[(size_t)c.total_len + 1 + end] - c.pref[(size_t)c.total_len + 1 + pos]) / cnt);
                 else if (k < 9 + NV) o = (float)wb[Ld::Q + (k - 9)];
                 else o = (float)wb[Ld::V + (k - 9 - NV)];
-                dst_base[(size_t)w * OBS + k] = o;
+                dst_base[(size_t)w * OBS + k] = dl_sat_out(o);
             }
         }
     };
@@ -427,7 +427,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     if (valid && j == 0) {
         monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
         if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
-        rew[w] = r;
+        rew[w] = r == r ? r : 0.0f;          // (a NaN can only come out of a state beyond float32's range: see dl_sat_out)
         done[w] = dn ? 1 : 0;
     }
     // ---- vec-env auto reset inside the same launch (SubprocVecEnv worker: obs = env.reset() after done; a

@@ -282,3 +282,32 @@ def test_split_handover_timeout_raises(torch_cuda, model, refs):
     L.check(env._lib.dl_fault_check(env._h, C.byref(code)))
     assert code.value == 0 and (env.rew > 0.2).all() and not env.done.any()
     env.close()
+
+
+@pytest.mark.parametrize('lanes', [1, 16, 'split'], ids=['lane-per-walker', '16-lanes-per-walker', '16-lanes-split-workgroups'])
+def test_outputs_beyond_float32_range_saturate(torch_cuda, model, refs, lanes):
+    """A state that leaves float32's range in the LAST substep of a control step becomes an observation before any check sees it (MuJoCo checks
+    at the start of an mj_step: the reference emits the value -- a finite float64 there -- and raises one control step later).  The float32
+    kernels hand out +-3e38 instead of inf / NaN, so that VecNormalize's moments stay finite; the next step takes the exception path."""
+    torch = torch_cuda
+    from drloco_amd.vec_env import HipVecEnv
+    n = 8
+    env = HipVecEnv(num_envs=n, seed=4, model=model, refs=refs, lanes_per_walker=lanes)
+    env.reset_tensors()
+    st = env.get_state()
+    q, v = st['qpos'].copy(), st['qvel'].copy()
+    v[5, 0] = np.inf; v[7, 1] = -np.inf; v[9, 2] = np.nan; q[4, 3] = 1e30
+    flags = np.zeros(n, np.int32); flags[:4] = 1                      # walkers 0..3: the step ends in the injected state
+    env.debug_inject(qpos=q, qvel=v, flags=flags)
+    a = torch.zeros(n, 8, device='cuda')
+    obs, rew, done, _ = env.step_tensors(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    o = obs.cpu().numpy()
+    big = np.float32(3.0e38)                                          # (which column: the policy mirrors observations on left steps)
+    assert all((np.abs(o[i]) == big).sum() == 1 for i in range(3)) and (np.abs(o[3]) > 1e29).sum() == 1 and (np.abs(o[4:]) < 1e3).all()
+    assert not done[:4].any()                                        # nothing is flagged in the step that produced the values ...
+    obs, rew, done, _ = env.step_tensors(a)
+    torch.cuda.synchronize()
+    assert done[:4].all() and (rew[:4] == 0).all() and not done[4:].any() and torch.isfinite(obs).all()      # ... the next one takes the exception path
+    env.close()
