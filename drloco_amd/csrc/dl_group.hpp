@@ -68,6 +68,9 @@
 #ifndef DL_PREFETCH_REFS
 #define DL_PREFETCH_REFS 0     // experiment switch: 1 advances a copy of the cursor and requests the step's reference sample BEFORE the physics (measured: no gain -- the values wait in scratch, 68 instead of 44 spilled registers)
 #endif
+#ifndef DL_PREFETCH_ACTIONS
+#define DL_PREFETCH_ACTIONS 1   // the constraint wave of a split workgroup touches the next control step's action row (0: off, experiment switch)
+#endif
 #ifndef DL_UNROLL_JTF
 #define DL_UNROLL_JTF 1
 #endif

@@ -90,7 +90,8 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
 // next request then runs out too, its walkers take the exception path and the host raises DL_E_FAULT (dl_fault_check).
 #if !defined(DL_GROUP_EMU)
 template <typename T, typename TP>
-__device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevState<T>& st) {
+__device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevState<T>& st,
+                                                    const float* __restrict__ actions_all = nullptr, int nsteps = 0) {
     using D = GD<TP>;
     using Ld = GLds<TP>;
     using Sp = GSplit<TP>;
@@ -110,6 +111,13 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     g_lane_topo<T, TP>(j, lt);
     volatile DL_LDS int* flags = (volatile DL_LDS int*)g.mbox0;
     int seq = 0;
+    // multi-step launches: the action row of the NEXT control step is a cold line of a tape that streams through (67 MB per rollout at 4096
+    // walkers) -- the dynamics wave would wait out an HBM round trip at every step start with nothing to switch to.  This wave is idle most of
+    // the time: after the first evaluation of a step it touches the next step's row of its four walkers (the value is thrown away; the line
+    // then sits in this CU's L1 / the XCD's L2).  The step index is counted from the requests (4 per mj_step); steps without evaluations
+    // (exception path) make it lag -- it is a prefetch, it only has to stay inside the tape.
+    const int evals_per_step = 4 * m->frame_skip;
+    float pf_sink = 0.0f;
     for (;;) {
         int cur = seq, it = 0;
         while ((cur = flags[Sp::MB_CMDSEQ]) == seq && it < g.spin_limit) { DL_SLEEP(); it++; }
@@ -133,7 +141,12 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         DL_WG_RELEASE();
         if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
         DL_WAKE();
+        if (DL_PREFETCH_ACTIONS && actions_all && (seq - 1) % evals_per_step == 0) {
+            const int next = (seq - 1) / evals_per_step + 1;
+            if (next < nsteps && j < TP::NU) pf_sink += actions_all[((size_t)next * n + w) * TP::NU + j];
+        }
     }
+    if (DL_PREFETCH_ACTIONS && actions_all && pf_sink == 12345.678f) g.mbox[Sp::MB_SIZE - 1] = pf_sink;      // (keeps the prefetch loads alive)
 }
 #endif
 

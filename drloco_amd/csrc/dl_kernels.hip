@@ -123,7 +123,7 @@ void k_env_step_g16_split(const GModel<T, TP>* __restrict__ gm, const DevCfg<T> 
         g_wave_env_step<T, TP, false, true>(lane, wblock, vwg, nvwg, base, gm, c, st, actions_all, obs_all, rew_all, done_all, term_obs_all, rew_terms_all,
                                             inj_q, inj_v, inj_flags, ctrl_out, eval_mode, nsteps, nullptr);
     else
-        g_constraint_server<T, TP>(lane, wblock, base, gm, st);
+        g_constraint_server<T, TP>(lane, wblock, base, gm, st, nsteps > 1 ? actions_all : nullptr, nsteps);
 }
 
 // row primitives of dl_group.hpp on known data (tests/test_gpu_parity.py::test_row_primitives)
