@@ -66,3 +66,16 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(('.py', '.hip', '.hpp', '.h')):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.replace('the oracle', '').replace("oracle's", '').replace('CPU oracle', '').lower() or f in ('dl_core.hpp',), (dirpath, f)
+
+
+def test_the_boundary_is_usable_from_plain_c(L, tmp_path):
+    """examples/c_abi_smoke.c: the header compiles as C99, the library loads with dlopen, versions and struct sizes agree, and dl_create refuses
+    to run without a device (DL_E_NODEVICE) or with an empty model descriptor (DL_E_INVAL)."""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    exe = str(tmp_path / 'c_abi_smoke')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'c_abi_smoke.c'), '-o', exe, '-ldl'])
+    p = subprocess.run([exe, lib.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.startswith('ok: ABI %d' % abi.DL_ABI_VERSION), p.stdout + p.stderr
