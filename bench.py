@@ -16,7 +16,7 @@ One "step" of this benchmark = ONE 512-step rollout of all walkers of a rank:
 The actions are pre-generated, so nothing waits for an observation: the env steps go through dl_rollout_fixed, whose
 16-lane kernel takes a whole run of control steps per launch (walker state in registers; a launch lasts as long as the
 wave with the largest SUM over its steps, not the sum of every step's slowest wave) -- ONE launch of 512 steps per rollout --
-and the rollout's normalisations follow as one dl_vecnormalize_steps call (five launches; raw outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
+and the rollout's normalisations follow as one dl_vecnormalize_steps call (six small launches; raw outputs in a ring, one event pair per run).  --no-overlap keeps one launch per control step on one stream; --policy puts
 the fused policy into the loop (dl_collect_rollouts: the whole rollout as ONE persistent launch -- policy forward, env step and VecNormalize's
 moment exchange per control step inside the kernel -- or, --rollout-form launches, three launches per control step; --moments per_rollout is
 the opt-in relaxation of the persistent form).  Same results in all forms (tests/test_gpu_bench_shapes.py, tests/test_gpu_persistent.py).
@@ -212,7 +212,7 @@ def main():
     ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: ONE launch for the rollout (the 16-lane kernels; tools/prof_step.py issues the same schedule for the PMC passes)')
     ap.add_argument('--handles', type=int, default=1, help='with --policy: split the walkers of a rank over this many env handles, each driving its policy -> step -> normalise chain on its own stream (drloco_amd/group.py); balanced single-step launches need >= 8192 walkers per GPU')
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
-    ap.add_argument('--vn-single-steps', action='store_true', help='normalise the steps of a fixed-action run one dl_vecnormalize_step at a time instead of with dl_vecnormalize_steps (five launches per run)')
+    ap.add_argument('--vn-single-steps', action='store_true', help='normalise the steps of a fixed-action run one dl_vecnormalize_step at a time instead of with dl_vecnormalize_steps (six small launches per run)')
     ap.add_argument('--no-split', action='store_true', help='keep the one-wave-per-four-walkers launch form of the step kernel (dl_set_split 0); the default switches the split workgroup on where it exists (straight walker, float32, 16 lanes, one handle)')
     ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 16 walkers per CU)')
     ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="with --policy and the persistent form: 'per_rollout' is the opt-in relaxation (the rollout is normalised with its start-of-rollout moments, one exact merge at its end); not SB3's semantics")

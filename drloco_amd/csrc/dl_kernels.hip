@@ -1618,20 +1618,27 @@ __global__ __launch_bounds__(256) void k_vns_partial(const float* __restrict__ x
         if (t == 0) { wk[D * 2] = s; wk[D * 2 + 1] = ss; }
     }
 }
-// Two phases in one workgroup: (A) every step's 32 block partials are added up, in block order, by all lanes in parallel (K x (D + 1) sums, left
-// in `stats`); (B) the lanes of the D + 1 columns run the K Chan merges in step order -- the only sequential part, ~10 float64 operations per
-// step with the sums of sixteen steps requested ahead.
-__global__ __launch_bounds__(1024) void k_vns_merge(const double* __restrict__ work, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
-                                                 int K, int B, int D, int flags, double* stats) {
+// Three kernels: k_vns_sum adds every step's 32 block partials up, in block order (K x (D + 1) independent sums, spread over the chip, left in
+// `stats`); k_vns_merge -- one small workgroup -- runs the K Chan merges of the D + 1 columns in step order, the only sequential part (~10 float64
+// operations per step, the sums of eight steps requested ahead); k_vns_rstd turns every step's variances into 1 / sqrt(var + eps) for
+// k_vns_apply: the float64 square root and division happen once per step and column, not once per element.
+__global__ __launch_bounds__(256) void k_vns_sum(const double* __restrict__ work, int K, int W, double* stats) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= K * W) return;
+    const int t = e / W, d = e % W;
+    const double* wk = work + (size_t)t * VN_BLOCKS * W * 2;
+    double S = 0, SS = 0;
+    for (int b = 0; b < VN_BLOCKS; b++) { S += wk[((size_t)b * W + d) * 2]; SS += wk[((size_t)b * W + d) * 2 + 1]; }
+    stats[(size_t)e * 2] = S; stats[(size_t)e * 2 + 1] = SS;
+}
+// var -> 1 / sqrt(var + eps) for every step and column (after the merges)
+__global__ __launch_bounds__(256) void k_vns_rstd(double* stats, int KW, double eps) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < KW) stats[(size_t)e * 2 + 1] = 1.0 / sqrt(stats[(size_t)e * 2 + 1] + eps);
+}
+__global__ __launch_bounds__(128) void k_vns_merge(double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
+                                                int K, int B, int D, int flags, double* stats) {
     const int W = D + 1;
-    for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
-        const int t = e / W, d = e % W;
-        const double* wk = work + (size_t)t * VN_BLOCKS * W * 2;
-        double S = 0, SS = 0;
-        for (int b = 0; b < VN_BLOCKS; b++) { S += wk[((size_t)b * W + d) * 2]; SS += wk[((size_t)b * W + d) * 2 + 1]; }
-        stats[(size_t)e * 2] = S; stats[(size_t)e * 2 + 1] = SS;
-    }
-    __syncthreads();
     const int d = threadIdx.x;
     const bool active = d < W, is_obs = d < D, upd = is_obs ? (flags & 1) != 0 : (flags & 4) != 0;
     double* mp = is_obs ? mean + d : ret_mean;
@@ -1641,12 +1648,12 @@ __global__ __launch_bounds__(1024) void k_vns_merge(const double* __restrict__ w
     __syncthreads();                           // every column has read the counts before one of them writes them back
     if (!active) return;
     const double K0 = m;                       // the shift of every step's sums
-    for (int t0 = 0; t0 < K; t0 += 16) {
-        double Sb[16], SSb[16];
+    for (int t0 = 0; t0 < K; t0 += 8) {
+        double Sb[8], SSb[8];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int t = t0 + u < K ? t0 + u : K - 1; Sb[u] = stats[((size_t)t * W + d) * 2]; SSb[u] = stats[((size_t)t * W + d) * 2 + 1]; }
+        for (int u = 0; u < 8; u++) { const int t = t0 + u < K ? t0 + u : K - 1; Sb[u] = stats[((size_t)t * W + d) * 2]; SSb[u] = stats[((size_t)t * W + d) * 2 + 1]; }
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
+        for (int u = 0; u < 8; u++) {
             const int t = t0 + u;
             if (t < K) {
                 if (upd) {
@@ -1664,23 +1671,26 @@ __global__ __launch_bounds__(1024) void k_vns_merge(const double* __restrict__ w
     if (upd && (d == 0 || d == D)) { if (is_obs) *count = cnt; else *ret_count = cnt; }
 }
 __global__ __launch_bounds__(256) void k_vns_apply(const float* __restrict__ x, const float* __restrict__ rew, const double* __restrict__ stats, int K, int B, int D,
-                                                double eps, double clip_obs, double clip_rew, int flags, float* const* obs_out, float* const* rew_out) {
+                                                double clip_obs, double clip_rew, int flags, float* const* obs_out, float* const* rew_out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = (size_t)B * D;
     const int W = D + 1;
     if (idx < (size_t)K * per) {
         const int t = (int)(idx / per);
         const size_t e = idx - (size_t)t * per;
         const int k = (int)(e % D);
-        const double* st = stats + ((size_t)t * W + k) * 2;
-        obs_out[t][e] = (flags & 2) ? vn_norm_obs(x[idx], st[0], st[1], eps, clip_obs) : x[idx];
+        const double* st = stats + ((size_t)t * W + k) * 2;          // (mean, 1 / sqrt(var + eps)) after step t
+        float o = x[idx];
+        if (flags & 2) { double y = ((double)o - st[0]) * st[1]; y = y < -clip_obs ? -clip_obs : (y > clip_obs ? clip_obs : y); o = (float)y; }
+        obs_out[t][e] = o;
     }
     if (idx < (size_t)K * B) {
         const int t = (int)(idx / B);
         const size_t e = idx - (size_t)t * B;
-        rew_out[t][e] = (flags & 8) ? vn_norm_rew(rew[idx], stats[((size_t)t * W + D) * 2 + 1], eps, clip_rew) : rew[idx];
+        float o = rew[idx];
+        if (flags & 8) { double y = (double)o * stats[((size_t)t * W + D) * 2 + 1]; y = y < -clip_rew ? -clip_rew : (y > clip_rew ? clip_rew : y); o = (float)y; }
+        rew_out[t][e] = o;
     }
 }
-
 static int vn_reduce_launch(const float* obs, const float* rew, double* obs_mean, double* obs_var, double* obs_count, double* ret, double* ret_mean, double* ret_var,
                             double* ret_count, int32_t B, int32_t D, double gamma, int32_t flags, void* workspace, void* stream) {
     if ((flags & 5) && (flags & 32)) {
@@ -1725,9 +1735,11 @@ int dl_vecnormalize_steps(const dl_vecnorm_state* vn, int32_t K, const float* ob
     hipStream_t s = (hipStream_t)stream;
     if (flags & 4) hipLaunchKernelGGL(k_vns_returns, dim3((B + 255) / 256), dim3(256), 0, s, rew, done, vn->ret, rets, K, B, vn->gamma);
     if (flags & 5) hipLaunchKernelGGL(k_vns_partial, dim3(VN_BLOCKS, K), dim3(256), 0, s, obs, (const double*)rets, (const double*)vn->obs_mean, (const double*)vn->ret_mean, B, D, flags, work);
-    hipLaunchKernelGGL(k_vns_merge, dim3(1), dim3(1024), 0, s, (const double*)work, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret_mean, vn->ret_var, vn->ret_count, K, B, D, flags, stats);
+    hipLaunchKernelGGL(k_vns_sum, dim3((K * W + 255) / 256), dim3(256), 0, s, (const double*)work, K, W, stats);
+    hipLaunchKernelGGL(k_vns_merge, dim3(1), dim3(128), 0, s, vn->obs_mean, vn->obs_var, vn->obs_count, vn->ret_mean, vn->ret_var, vn->ret_count, K, B, D, flags, stats);
+    hipLaunchKernelGGL(k_vns_rstd, dim3((K * W + 255) / 256), dim3(256), 0, s, stats, K * W, vn->eps);
     const size_t ne = (size_t)K * B * D;
-    hipLaunchKernelGGL(k_vns_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, obs, rew, (const double*)stats, K, B, D, vn->eps, vn->clip_obs, vn->clip_rew, flags, obs_out, rew_out);
+    hipLaunchKernelGGL(k_vns_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, obs, rew, (const double*)stats, K, B, D, vn->clip_obs, vn->clip_rew, flags, obs_out, rew_out);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

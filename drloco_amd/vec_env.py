@@ -450,7 +450,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         # flags bit 32: the "blocked" summation order (blocks of 16 rows -> <= 8 groups -> total), which the persistent rollout kernel of
         # dl_collect_rollouts follows by construction: with it a launch-per-step rollout and a persistent one agree bit for bit
         self.blocked_reduce = False
-        # fixed-action runs (steps_fixed): normalise the K steps of a run with dl_vecnormalize_steps (five launches) instead of K x
+        # fixed-action runs (steps_fixed): normalise the K steps of a run with dl_vecnormalize_steps (six small launches) instead of K x
         # dl_vecnormalize_step; the moments then agree with the step-by-step form to rounding (the shift of the sums differs), not bit for bit
         self.batched_steps = False
 
@@ -537,7 +537,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         side.wait_event(ov['stepped'][half])
         pending, ov['pending'] = ov['pending'], []         # cleared whatever happens below: a failed hand-over must not be re-issued
         with torch.cuda.stream(side):
-            # the five-launch form needs consecutive ring slots and one contiguous block of done rows (steps_fixed produces exactly that;
+            # the batched form needs consecutive ring slots and one contiguous block of done rows (steps_fixed produces exactly that;
             # step_tensors callers that pass their own done_out slots may not): otherwise one dl_vecnormalize_step per step
             if self.batched_steps and len(pending) > 1 and self._run_is_contiguous(pending):
                 self._vn_launch_steps(pending)
@@ -552,7 +552,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         return all(p[0] == k0 + i and p[1].is_contiguous() and p[1].data_ptr() == pending[0][1].data_ptr() + i * n for i, p in enumerate(pending))
 
     def _vn_launch_steps(self, pending):
-        """dl_vecnormalize_steps for a run of consecutive ring slots: five launches instead of two per control step (the moments agree
+        """dl_vecnormalize_steps for a run of consecutive ring slots: six small launches instead of two per control step (the moments agree
         with the step-by-step form to rounding, include/drloco_hip.h).  pending: [(ring slot, done row, obs_out, rew_out)], slots consecutive."""
         ov = self._ov
         K, k0 = len(pending), pending[0][0]
@@ -582,7 +582,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         dev = self.venv.device
         self.multi_block_reduce = True
         if getattr(self.venv, 'split', False):
-            # nothing hides under split workgroups (they fill the GPU): the normalisations of a run go through dl_vecnormalize_steps (five
+            # nothing hides under split workgroups (they fill the GPU): the normalisations of a run go through dl_vecnormalize_steps (six small
             # launches per run; moments agree with the step-by-step form to rounding, not bit for bit).  Set batched_steps = False to opt out.
             self.batched_steps = True
         ev = lambda: torch.cuda.Event()

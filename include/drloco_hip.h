@@ -348,7 +348,7 @@ typedef struct dl_vecnorm_state {
     int32_t flags;                                            /* as dl_vecnormalize_step */
 } dl_vecnorm_state;
 
-/* K consecutive dl_vecnormalize_step calls (SB3 1.0 VecNormalize.step_wait, K control steps of a fixed-action rollout) in five launches
+/* K consecutive dl_vecnormalize_step calls (SB3 1.0 VecNormalize.step_wait, K control steps of a fixed-action rollout) in six small launches
  * instead of 2 K: obs float[K, B, D], rew float[K, B], done uint8[K, B] (time-major, contiguous, DEVICE); obs_out / rew_out: DEVICE arrays of K
  * pointers, the destination of every step (rollout-buffer slots).  The moments advance exactly as K single steps would advance them, up
  * to rounding: the shifted sums of all K batches use the moments at the start of the run as their shift (the single steps use the moments
