@@ -1779,6 +1779,25 @@ int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, co
     PolVnFuse none{};
     return policy_launch(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, none, stream);
 }
+int dl_policy_pack(const dl_policy_params* p, float* packed, void* stream) {
+    if (!p || !packed || !p->w1 || !p->w2 || !p->wa || !p->wv) return fail(DL_E_INVAL, "dl_policy_pack: bad arguments");
+    if (p->hidden != 512 || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15) return fail(DL_E_INVAL, "dl_policy_pack: the packed layout exists for hidden = 512 (obs_dim <= 48, act_dim <= 15)");
+    const int chunks = 512 * 128 + 12 * 512 + 128 * 16;
+    hipLaunchKernelGGL(k_pack_policy, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_policy_forward_packed(const dl_policy_params* p, const float* packed, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                             int32_t deterministic, float* actions, float* values, float* log_probs, void* stream) {
+    if (!obs) return fail(DL_E_INVAL, "dl_policy_forward_packed: bad arguments");
+    PolVnFuse none{};
+    PolPacked pk{nullptr, nullptr, nullptr};
+    if (packed) {
+        if (!p || p->hidden != 512) return fail(DL_E_INVAL, "dl_policy_forward_packed: the packed layout exists for hidden = 512");
+        pk.w2p = packed; pk.w1p = packed + (size_t)512 * 512; pk.whp = pk.w1p + (size_t)48 * 512;
+    }
+    return policy_launch(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, none, stream, pk);
+}
 int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
                       float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
                       float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, void* stream) {

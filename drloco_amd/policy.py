@@ -31,6 +31,26 @@ class HipPolicy:
         self.wv, self.bv = linear(1, hidden)
         self.log_std = torch.full((act_dim,), float(log_std_init), device=device)
         self.seed, self.counter, self.index_base = int(seed), 0, int(index_base)
+        self._packed, self._packed_key = None, None
+
+    def _packed_weights(self):
+        """k-chunk-major copy of the weights for the stand-alone forward pass (hidden = 512), refreshed whenever a weight tensor was replaced
+        or written to (torch bumps `tensor._version` on every in-place update, e.g. an optimiser step)."""
+        if self.hidden != 512:
+            return None
+        ws = (self.w1, self.w2, self.wa, self.wv)
+        key = tuple((t.data_ptr(), t._version) for t in ws)
+        if key != self._packed_key:
+            if self._packed is None:
+                self._packed = torch.empty(512 * 512 + 48 * 512 + 16 * 512, device=self.w1.device)
+            p = self._params()
+            lib.check(self._lib.dl_policy_pack(C.byref(p), _ptr(self._packed), _stream()))
+            self._packed_key = key
+        return self._packed
+
+    def invalidate_packed(self):
+        """Call after changing the weights in a way torch's version counter does not see (writes through `.data` or raw pointers)."""
+        self._packed_key = None
 
     def load_state(self, w1, b1, w2, b2, wa, ba, wv, bv, log_std):
         """Take the tensors of a trained torch policy: mlp_extractor.policy_net[0], [2] (shared with value_net),
@@ -57,8 +77,8 @@ class HipPolicy:
         v = torch.empty(n, device=dev) if values_out is None else values_out
         lp = torch.empty(n, device=dev) if log_probs_out is None else log_probs_out
         p = self._params()
-        lib.check(self._lib.dl_policy_forward(C.byref(p), _ptr(obs), n, _ptr(eps), self.seed, self.counter, self.index_base,
-                                              int(deterministic), _ptr(a), _ptr(v), _ptr(lp), _stream()))
+        lib.check(self._lib.dl_policy_forward_packed(C.byref(p), _ptr(self._packed_weights()), _ptr(obs), n, _ptr(eps), self.seed, self.counter, self.index_base,
+                                                     int(deterministic), _ptr(a), _ptr(v), _ptr(lp), _stream()))
         self.counter += 1
         return a, v, lp
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32 */
+#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -338,6 +338,16 @@ typedef struct dl_policy_params {
 int dl_policy_forward(const dl_policy_params* params, const float* obs, int32_t n, const float* eps,
                       uint64_t seed, uint64_t counter, int32_t index_base, int32_t deterministic,
                       float* actions, float* values, float* log_probs, void* stream);
+
+/* The same forward pass reading the weights from a k-chunk-major copy (hidden = 512): in torch's [out][in] layout the 16 lanes of a quarter-wave
+ * read 16 bytes from 16 different rows (64 cache lines per wave instruction), packed they read one contiguous 256-byte run -- 29 instead of 40 us for
+ * 4096 rows, bit-identical results.  dl_policy_pack writes the copy (DL_POLICY_PACKED_FLOATS(512) floats, device memory; call it again whenever
+ * the weights change -- dl_collect_rollouts / dl_rollout_policy do so themselves, once per call); packed == NULL = dl_policy_forward. */
+#define DL_POLICY_PACKED_FLOATS(hidden) ((size_t)(hidden) * (hidden) + (size_t)48 * (hidden) + (size_t)16 * (hidden))
+int dl_policy_pack(const dl_policy_params* params, float* packed, void* stream);
+int dl_policy_forward_packed(const dl_policy_params* params, const float* packed, const float* obs, int32_t n,
+                             const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                             int32_t deterministic, float* actions, float* values, float* log_probs, void* stream);
 
 /* VecNormalize state as dl_vecnormalize_step takes it, bundled for dl_rollout_policy (all DEVICE pointers). */
 typedef struct dl_vecnorm_state {

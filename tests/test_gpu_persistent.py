@@ -260,3 +260,20 @@ def test_policy_forms_agree_bit_for_bit(torch_cuda):
     a4, v4, l4 = pol.forward(obs[:4096].contiguous(), eps=eps[:4096].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(a8[:4096], a4) and torch.equal(v8[:4096], v4) and torch.equal(l8[:4096], l4)
+    # HipPolicy.forward reads the packed copy of the weights (refreshed when torch's version counter of a weight tensor moves); the C-ABI's
+    # dl_policy_forward reads torch's layout: same bits
+    import ctypes as C
+    from drloco_amd import lib as L
+    from drloco_amd.vec_env import _ptr, _stream
+    for n in (4096, 8192):
+        a, v, lp = torch.empty(n, 8, device='cuda'), torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+        p = pol._params()
+        L.check(pol._lib.dl_policy_forward(C.byref(p), _ptr(obs[:n].contiguous()), n, _ptr(eps[:n].contiguous()), pol.seed, 0, 0, 0, _ptr(a), _ptr(v), _ptr(lp), _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(a, a8[:n]) and torch.equal(v, v8[:n]) and torch.equal(lp, l8[:n]), n
+    # an in-place update of a weight (what an optimiser step is) is seen by the next forward
+    pol.w2.mul_(1.5)
+    a9, _, _ = pol.forward(obs[:64].contiguous(), eps=eps[:64].contiguous())
+    ref, _, _ = pol.torch_reference(obs[:64], eps[:64])
+    torch.cuda.synchronize()
+    assert not torch.equal(a9, a4[:64]) and torch.allclose(a9, ref, atol=2e-5)

@@ -9,10 +9,11 @@ import ctypes as C
 from drloco_amd import lib
 from drloco_amd.vec_env import _ptr, _stream
 for n in (16, 1024, 4096, 16384):
-  for mode in (0,):
+  for mode in (0, 1):          # 0: torch's weight layout, 1: the packed copy
     obs = torch.randn(n, 29, device='cuda')
     a = torch.empty(n, 8, device='cuda'); v = torch.empty(n, device='cuda'); lp = torch.empty(n, device='cuda'); p = pol._params()
-    call = lambda: lib.check(pol._lib.dl_policy_forward(C.byref(p), _ptr(obs), n, None, 1, 1, 0, mode, _ptr(a), _ptr(v), _ptr(lp), _stream()))
+    pk = pol._packed_weights() if mode else None
+    call = lambda: lib.check(pol._lib.dl_policy_forward_packed(C.byref(p), _ptr(pk), _ptr(obs), n, None, 1, 1, 0, 0, _ptr(a), _ptr(v), _ptr(lp), _stream()))
     for _ in range(20): call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
