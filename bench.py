@@ -217,6 +217,7 @@ def main():
     ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 16 walkers per CU)')
     ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="with --policy and the persistent form: 'per_rollout' is the opt-in relaxation (the rollout is normalised with its start-of-rollout moments, one exact merge at its end); not SB3's semantics")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--vn-sync', choices=['per_rollout', 'per_step'], default='per_rollout', help="with --policy on several ranks: 'per_step' = VecNormalize's moments advance with the batch of ALL ranks every control step (SB3's semantics across ranks: one all-reduce of 2 (obs_dim + 1) doubles per control step, host loop); default: per rank, merged exactly between rollouts")
     ap.add_argument('--dump', type=str, default='', help='after the run every rank saves what its LAST rollout produced (episode starts, action tape, raw step outputs, moments) to <path>.rank<r>.npz (tests/test_gpu_distributed.py compares ranks with a single-process run)')
     args = ap.parse_args()
 
@@ -288,7 +289,9 @@ def main():
         venv = HipVecEnv(num_envs=n, device=local_rank, seed=1234, env_index_base=rank * n, lanes_per_walker=args.lanes)
     if split:
         venv.set_split(True)          # dynamics waves + constraint waves (include/drloco_hip.h: dl_set_split)
-    vn = HipVecNormalize(venv)
+    vn = HipVecNormalize(venv, sync=args.vn_sync if args.policy else 'per_rollout')
+    if vn.sync == 'per_step':
+        vn.blocked_reduce = True
     buf = HipRolloutBuffer(T, n, venv.obs_dim, venv.nu, dev, gamma=0.995, gae_lambda=0.95)
     # what the policy would have produced lives where it would have written it: in the rollout buffer.  The tapes are keyed by the GLOBAL
     # walker index (tape_normal: a counter-based generator, every rank draws exactly its own columns), so a walker sees the same actions /
@@ -463,7 +466,8 @@ def main():
                          'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
-        out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'backend': dist.get_backend() if use_dist else None,
+        out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'backend': dist.get_backend() if use_dist else None, 'vn_sync': vn.sync,
+                              'collectives_per_control_step': 'all-reduce of 2 x (obs_dim + 1) doubles (VecNormalize batch sums: exact per-step moments over all ranks)' if (use_dist and vn.sync == 'per_step') else None,
                               'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None}
         out['self_check'] = checks
         if world == 1 and not args.no_cpu_baseline:

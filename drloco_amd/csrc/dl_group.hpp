@@ -62,6 +62,9 @@
 #define DL_PIN_STRAIGHT 1       // experiment switch: 0 builds the straight walker with the fetch-at-use policy of the 19-dof walker
 #endif
 // experiment switches: unroll factor of the contact-pair loops (J^T f / Hessian, J dir); 1 = as written
+#ifndef DL_CHOL_SHORT_CHAIN
+#define DL_CHOL_SHORT_CHAIN 1   // 0: round-2 form of the leaf-first factorisation / substitutions (experiment switch)
+#endif
 #ifndef DL_CHOL_LEAF_FIRST
 #define DL_CHOL_LEAF_FIRST 1    // 0: the root-first dense row-per-lane Cholesky for every model (experiment switch)
 #endif
@@ -328,6 +331,17 @@ template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float
     asm("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
 __device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
+// max(bcast_K(x), lo): the row broadcast folded into the v_max.  The two wait states between the VALU write of x and its DPP read are
+// part of the statement: the register allocator may place a copy of x right before an asm statement, behind a separate g_dpp_ready.
+template <int K> __device__ __forceinline__ float max_bcast(float x, float lo) {
+    float d;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x), "v"(lo), "n"(K));
+    return d;
+}
+// x += bcast_K(x) * b for a chain of such steps on one register (each reads what the previous one wrote: wait states included, see max_bcast)
+template <int K> __device__ __forceinline__ void fmac_bcast_chain(float& x, float b) {
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
+}
 // one wait for a whole group of values that are about to be read through DPP
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) {
     if constexpr (NV == 2) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]));
@@ -344,6 +358,8 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp(float& d, float a, 
 template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, float b) { x += dpp_f<CTRL>(x) * b; }
 template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) { x += rbcast<K>(x) * b; }
 __device__ __forceinline__ void g_dpp_ready(float&) {}
+template <int K> __device__ __forceinline__ float max_bcast(float x, float lo) { const float b = rbcast<K>(x); return b > lo ? b : lo; }
+template <int K> __device__ __forceinline__ void fmac_bcast_chain(float& x, float b) { x += rbcast<K>(x) * b; }
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&)[NV]) {}
 #endif
 template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
@@ -354,6 +370,8 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(double& x, dou
 template <int K> __device__ __forceinline__ void fmac_bcast_self(double& x, double b) { x += rbcast<K>(x) * b; }
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(double (&)[NV]) {}
 __device__ __forceinline__ void g_dpp_ready(double&) {}
+template <int K> __device__ __forceinline__ double max_bcast(double x, double lo) { const double b = rbcast<K>(x); return b > lo ? b : lo; }
+template <int K> __device__ __forceinline__ void fmac_bcast_chain(double& x, double b) { x += rbcast<K>(x) * b; }
 
 // ------------------------------------------------------------------------------------------
 // Uniform model scalars of the hot path, read ONCE per kernel and pinned in VGPRs (the empty asm makes the values
@@ -915,6 +933,27 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
 template <typename T, typename TP> __device__ __forceinline__ void g_chol_rev(T (&h)[GL], T (&lo)[GL], T hd, T& invd, int j, T floor_) {
     using TPL = GTopo<TP>;
     constexpr int N = GD<TP>::NL;
+#if DL_CHOL_SHORT_CHAIN
+    // The pivots are one dependent chain through the whole factorisation (a dependent VALU instruction issues ~7 cycles after its producer
+    // where independent ones issue every ~2.6): per step it is  max(bcast(hd), floor) [one DPP instruction] -> v_rsq -> multiply -> hd update;
+    // the lane mask is applied to h[k] (ready long before the pivot) instead of to the pivot's reciprocal root.
+    // Out (this form): lo[k] = -U[j][k] / U[k][k] -- the forward substitution's multiplier, scaled and negated here, off the chain.
+    static_for<N>([&](auto ss) {
+        constexpr int k = TPL::order.at[ss.value];
+        if constexpr (k > 0) {
+            const T inv = dl_rsqrt_pivot(max_bcast<k>(hd, floor_));
+            const T hk = (j < k) ? h[k] : T(0);               // ancestors of k (unrelated lanes hold an exact zero; descendants their frozen column)
+            T lik = hk * inv;
+            lo[k] = -lik * inv;
+            hd -= lik * lik;
+            g_dpp_ready(lik);
+            static_for<k>([&](auto aa) {
+                constexpr int a = aa.value;
+                if constexpr (TPL::proper_anc(k, a)) fmac_bcast<a, -1>(h[a], lik, lik);
+            });
+        }
+    });
+#else
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[ss.value];
         if constexpr (k > 0) {
@@ -930,12 +969,36 @@ template <typename T, typename TP> __device__ __forceinline__ void g_chol_rev(T 
             });
         }
     });
+#endif
     invd = dl_rsqrt_pivot(dl_max(hd, floor_));
 }
 // solve (U U^T) x = b with the factor as g_chol_rev leaves it; b_j in, x_j out
 template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev(const T (&lo)[GL], const T (&up)[GL], T invd, T b, int j) {
     using TPL = GTopo<TP>;
     constexpr int N = GD<TP>::NL;
+#if DL_CHOL_SHORT_CHAIN
+    // Both substitutions as ONE self-referencing DPP multiply-add per step (destination = broadcast source = the running vector):
+    //   U y = b, children first:  acc_j -= (U[j][k] / U[k][k]) acc_k  for the ancestors j of k; acc_k is final by then; y = acc / U[j][j] at the end;
+    //   U^T x = y, parents first, on u_j = (y_j - sum over the proper ancestors a of U[a][j] x_a) / U[j][j], which IS x_j once j's ancestors are done:
+    //   u_j -= x_k U[k][j] / U[j][j] = x_k * up_j[k] / U[j][j]^2 for the lanes j below k.  Lane k's own value is taken before its step (its
+    //   up[k] slot is not a matrix entry, and the slots of the lanes above k are stale rows).
+    T acc = b;
+    static_for<N>([&](auto ss) {
+        constexpr int k = TPL::order.at[ss.value];
+        if constexpr (k > 0) fmac_bcast_chain<k>(acc, lo[k]);
+    });
+    const T s2 = -invd * invd;
+    T u = acc * invd * invd;
+    T up2[GL];
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = s2 * up[k]; });
+    T x = T(0);
+    static_for<N>([&](auto ss) {
+        constexpr int k = TPL::order.at[N - 1 - ss.value];
+        if (j == k) x = u;
+        if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
+    });
+    return x;
+#else
     // U y = b, children first: y_k = (b_k - sum over the descendants d of k of U[k][d] y_d) / U[k][k]; lo[k] is zero in the lanes that are
     // not ancestors of k, so a lane's accumulator is final once its descendants are done
     T acc = b;
@@ -960,6 +1023,7 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
         }
     });
     return x;
+#endif
 }
 
 // The replicated dofs are eliminated FIRST: with the Hessian ordered [replicated | lanes], L = [[Lxx, 0], [Lxl, Lll]].

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_vn_apply(const float* __restrict__ x, c
                                                   double* ret, const double* __restrict__ ret_var, double* ret_count,
                                                   int B, int D, double eps, double clip_obs, double clip_rew, int flags, float* obs_out, float* rew_out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0) { if (flags & 1) *count += (double)B; if (flags & 4) *ret_count += (double)B; }
+    if (idx == 0 && !(flags & 64)) { if (flags & 1) *count += (double)B; if (flags & 4) *ret_count += (double)B; }
     if (idx < (size_t)B * D) {
         const int k = (int)(idx % D);
         obs_out[idx] = (flags & 2) ? vn_norm_obs(x[idx], mean[k], var[k], eps, clip_obs) : x[idx];
@@ -567,6 +567,53 @@ __global__ __launch_bounds__(1024) void k_vn_reduce_blk(const float* __restrict_
             if (k < D) { mean[k] = m; var[k] = v; } else { *ret_mean = m; *ret_var = v; }
         }
     }
+}
+
+
+// ---- exact per-step moments across ranks (collective C3 in its exact form): the local half of the reduction and the merge are separate calls,
+// the caller all-reduces the 2 (D + 1) sums in between.  k_vn_sums_blk: this rank's shifted sums in the blocked order (one workgroup; advances the
+// discounted returns); k_vn_merge_sums: RunningMeanStd.update_from_moments with the GLOBAL batch size, counts advanced here.
+__global__ __launch_bounds__(1024) void k_vn_sums_blk(const float* __restrict__ x, const float* __restrict__ rew, const double* mean, double* ret, const double* ret_mean,
+                                                      int B, int D, double gamma, int flags, double* sums) {
+    constexpr int CH = 32;
+    __shared__ double sh[CH][2][32];
+    const int t = threadIdx.x, W = D + 1;
+    const VnBlk vb = vn_blk(B);
+    for (int k0 = 0; k0 < W; k0 += 32) {
+        const int kl = t & 31, bl = t >> 5, k = k0 + kl;
+        const bool colok = k < W && ((k < D) ? (flags & 1) != 0 : (flags & 4) != 0);
+        const double K = colok ? (k < D ? mean[k] : *ret_mean) : 0.0;
+        double tot_s = 0, tot_ss = 0;
+        for (int g = 0; g < vb.ngrp; g++) {
+            const int b0 = g * vb.gsize, b1 = b0 + vb.gsize < vb.nblk ? b0 + vb.gsize : vb.nblk;
+            double xs = 0, xss = 0;
+            for (int c0 = b0; c0 < b1; c0 += CH) {
+                const int b = c0 + bl;
+                if (colok && b < b1) vn_block_sums(x, rew, ret, D, k, 16 * b, 16 * b + 16 < B ? 16 * b + 16 : B, K, gamma, sh[bl][0][kl], sh[bl][1][kl]);
+                __syncthreads();
+                if (bl == 0 && colok) { const int nb = b1 - c0 < CH ? b1 - c0 : CH; for (int i = 0; i < nb; i++) { xs += sh[i][0][kl]; xss += sh[i][1][kl]; } }
+                __syncthreads();
+            }
+            tot_s += xs; tot_ss += xss;
+        }
+        if (bl == 0 && k < W) { sums[2 * k] = colok ? tot_s : 0.0; sums[2 * k + 1] = colok ? tot_ss : 0.0; }
+    }
+}
+__global__ __launch_bounds__(128) void k_vn_merge_sums(const double* __restrict__ sums, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
+                                                       long long B, int D, int flags) {
+    const int k = threadIdx.x, W = D + 1;
+    const bool mine = k < W && (k < D ? (flags & 1) != 0 : (flags & 4) != 0);
+    double cnt = 0;
+    if (mine) cnt = k < D ? *count : *ret_count;
+    __syncthreads();
+    if (!mine) return;
+    double* mp = k < D ? mean + k : ret_mean;
+    double* vp = k < D ? var + k : ret_var;
+    double m = *mp, v = *vp;
+    vn_chan_merge_d(m, v, cnt, sums[2 * k], sums[2 * k + 1], (double)B);
+    *mp = m; *vp = v;
+    if (k == 0) *count = cnt + (double)B;
+    if (k == D) *ret_count = cnt + (double)B;
 }
 
 // ---- SB3 collect_rollouts as ONE launch (dl_collect_rollouts, DL_ROLLOUT_PERSISTENT) ---------------------------------------------
@@ -1713,13 +1760,27 @@ int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done
                          double clip_obs, double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace, void* stream) {
     if (!obs || !rew || !done || !obs_mean || !obs_var || !obs_count || !ret || !ret_mean || !ret_var || !ret_count || !obs_out || !rew_out || B <= 0 || D <= 0 || D > 128)
         return fail(DL_E_INVAL, "dl_vecnormalize_step: bad arguments");
-    {
+    if (!(flags & 64)) {         // 64: the moments were advanced by dl_vn_local_sums + the caller's all-reduce + dl_vn_merge_sums
         const int rc = vn_reduce_launch(obs, rew, obs_mean, obs_var, obs_count, ret, ret_mean, ret_var, ret_count, B, D, gamma, flags, workspace, stream);
         if (rc) return rc;
     }
     const size_t ne = (size_t)B * D;
     hipLaunchKernelGGL(k_vn_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, rew, done, (const double*)obs_mean, (const double*)obs_var, obs_count,
                        ret, (const double*)ret_var, ret_count, B, D, eps, clip_obs, clip_rew, flags, obs_out, rew_out);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_vn_local_sums(const float* obs, const float* rew, const double* obs_mean, double* ret, const double* ret_mean, int32_t B, int32_t D, double gamma, int32_t flags,
+                     double* sums, void* stream) {
+    if (!obs || !rew || !obs_mean || !ret || !ret_mean || !sums || B <= 0 || D <= 0 || D > 63) return fail(DL_E_INVAL, "dl_vn_local_sums: bad arguments");
+    hipLaunchKernelGGL(k_vn_sums_blk, dim3(1), dim3(1024), 0, (hipStream_t)stream, obs, rew, obs_mean, ret, ret_mean, B, D, gamma, flags, sums);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
+}
+int dl_vn_merge_sums(const double* sums, int64_t B_global, double* obs_mean, double* obs_var, double* obs_count, double* ret_mean, double* ret_var, double* ret_count,
+                     int32_t D, int32_t flags, void* stream) {
+    if (!sums || !obs_mean || !obs_var || !obs_count || !ret_mean || !ret_var || !ret_count || B_global <= 0 || D <= 0 || D > 127) return fail(DL_E_INVAL, "dl_vn_merge_sums: bad arguments");
+    hipLaunchKernelGGL(k_vn_merge_sums, dim3(1), dim3(128), 0, (hipStream_t)stream, sums, obs_mean, obs_var, obs_count, ret_mean, ret_var, ret_count, (long long)B_global, D, flags);
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

@@ -78,6 +78,8 @@ _SIGNATURES = {
     'dl_normalize_obs': (C.c_int, [_P, _P, _P, _I, _I, C.c_double, C.c_double, _P]),
     'dl_normalize_reward': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, _P]),
     'dl_vecnormalize_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P, _P, _P, _P]),
+    'dl_vn_local_sums': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_double, _I, _P, _P]),
+    'dl_vn_merge_sums': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'dl_vecnormalize_steps': (C.c_int, [C.POINTER(abi.VecNormState), _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'dl_policy_forward': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _I, _P, C.c_uint64, C.c_uint64, _I, _I, _P, _P, _P, _P]),
     'dl_policy_pack': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _P]),

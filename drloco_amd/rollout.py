@@ -47,6 +47,25 @@ class HipRolloutBuffer:
         normalised with the moments at its start, which are advanced once, by all T x N samples, at its end -- include/drloco_hip.h)."""
         if moments not in ('per_step', 'per_rollout'):
             raise ValueError("moments must be 'per_step' or 'per_rollout'")
+        if getattr(vn, 'sync', 'per_rollout') == 'per_step':
+            # exact per-step moments ACROSS RANKS (HipVecNormalize(sync='per_step')): every control step's update needs the other ranks' sums, so
+            # the loop runs on the host -- policy forward, env step, local sums, all-reduce, merge, normalise: six launches + one collective per
+            # control step.  With one rank and blocked_reduce it is the launch form of dl_collect_rollouts bit for bit (tests/test_gpu_persistent.py).
+            if persistent or moments == 'per_rollout':
+                raise lib.DrlocoError("HipVecNormalize(sync='per_step') exchanges moments between ranks every control step: the persistent / per-rollout forms do not apply")
+            if vn._ov is not None:
+                raise lib.DrlocoError("HipVecNormalize(sync='per_step') and enable_overlap() do not combine (a policy in the loop needs each step's normalised observation)")
+            self.reset()
+            self.observations[0].copy_(last_obs)
+            self.episode_starts[0].copy_(last_done)
+            for t in range(self.T):
+                policy.forward(self.observations[t], actions_out=self.actions[t], values_out=self.values[t], log_probs_out=self.log_probs[t])
+                last = t + 1 == self.T
+                vn.step_tensors(self.actions[t], obs_out=last_obs if last else self.observations[t + 1], rew_out=self.rewards[t],
+                                done_out=last_done if last else self.episode_starts[t + 1])
+            self.pos = self.T
+            self.last_form = 'host loop'
+            return
         self.reset()
         self.observations[0].copy_(last_obs)
         self.episode_starts[0].copy_(last_done)

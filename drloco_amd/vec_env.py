@@ -426,9 +426,15 @@ class HipVecNormalize(_VecEnvWrapperBase):
       norm_terminal_obs      whether infos['terminal_observation'] is normalised (later releases) or raw (1.0, default)."""
 
     def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
-                 gamma=0.99, epsilon=1e-8, reset_moments='none', norm_terminal_obs=False):
+                 gamma=0.99, epsilon=1e-8, reset_moments='none', norm_terminal_obs=False, sync='per_rollout', process_group=None):
         if reset_moments not in ('none', 'ret', 'obs'):
             raise ValueError("reset_moments must be 'none', 'ret' or 'obs'")
+        if sync not in ('per_rollout', 'per_step'):
+            raise ValueError("sync must be 'per_rollout' or 'per_step'")
+        # data-parallel runs (one process per GPU): 'per_rollout' advances the moments per rank and merges them exactly between rollouts
+        # (sync_moments(): no collective inside a rollout); 'per_step' is SB3's semantics across ranks -- every control step's update uses the
+        # batch of ALL ranks: one all-reduce of 2 (obs_dim + 1) doubles per control step (step_tensors / step; not the long fixed-action launches)
+        self.sync, self.process_group = sync, process_group
         _VecEnvWrapperBase.__init__(self, venv)          # venv, num_envs, observation_space, action_space
         self.reset_moments, self.norm_terminal_obs = reset_moments, norm_terminal_obs
         self._lib = venv._lib
@@ -492,6 +498,23 @@ class HipVecNormalize(_VecEnvWrapperBase):
     def _vn_launch(self, obs, rew, done, obs_out, rew_out):
         n, d = obs.shape
         flags = self._flags()
+        if self.sync == 'per_step' and self.training:
+            import torch.distributed as dist
+            world = dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
+            if getattr(self, '_sums', None) is None:
+                self._sums = torch.zeros(2 * (d + 1), dtype=torch.float64, device=obs.device)
+            lib.check(self._lib.dl_vn_local_sums(_ptr(obs), _ptr(rew), _ptr(self.obs_rms._mean), _ptr(self.ret), _ptr(self.ret_rms._mean), n, d, self.gamma, flags,
+                                                 _ptr(self._sums), _stream()))
+            if world > 1:
+                if dist.get_backend(self.process_group) == 'gloo':          # (CPU collectives: the one-GPU test rig)
+                    h = self._sums.cpu()
+                    dist.all_reduce(h, group=self.process_group)
+                    self._sums.copy_(h)
+                else:
+                    dist.all_reduce(self._sums, group=self.process_group)
+            lib.check(self._lib.dl_vn_merge_sums(_ptr(self._sums), n * world, _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
+                                                 _ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), d, flags, _stream()))
+            flags |= 64
         lib.check(self._lib.dl_vecnormalize_step(
             _ptr(obs), _ptr(rew), _ptr(done), _ptr(self.obs_rms._mean), _ptr(self.obs_rms._var), _ptr(self.obs_rms._count),
             _ptr(self.ret), _ptr(self.ret_rms._mean), _ptr(self.ret_rms._var), _ptr(self.ret_rms._count), n, d,
@@ -633,6 +656,10 @@ class HipVecNormalize(_VecEnvWrapperBase):
     def sync_moments(self, process_group=None):
         """Data-parallel runs: make the observation / return moments of all ranks those of the union of their batches
         (call between rollouts; every rank then normalises identically, as the single-process reference does)."""
+        if self.sync == 'per_step':
+            for r in (self.obs_rms, self.ret_rms):          # nothing to merge: every step's update already used all ranks' batches
+                r._sync = (r._mean.clone(), r._var.clone(), r._count.clone())
+            return
         self.obs_rms.sync(process_group)
         self.ret_rms.sync(process_group)
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed */
+#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed, dl_vn_local_sums / dl_vn_merge_sums (flag 64) */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -295,7 +295,8 @@ int dl_normalize_reward(float* rew, double* ret, const uint8_t* done, double* re
  * flags: 1 update the observation moments (training), 2 normalise observations, 4 advance ret and update its
  * moments (training), 8 normalise rewards, 16 reduce with 32 blocks instead of one workgroup (for launches on a side stream
  * under other kernels), 32 reduce in the "blocked" order -- sums over blocks of 16 rows, blocks over <= 8 groups, groups in order: the order
- * dl_collect_rollouts' persistent kernel follows, so that the two agree bit for bit (all forms are deterministic, their summation orders differ).  obs/rew are not modified (get_original_obs / get_original_reward);
+ * dl_collect_rollouts' persistent kernel follows, so that the two agree bit for bit (all forms are deterministic, their summation orders differ), 64 the
+ * moments were already advanced for this batch (dl_vn_local_sums / dl_vn_merge_sums below): only normalise and reset ret[done].  obs/rew are not modified (get_original_obs / get_original_reward);
  * obs_out/rew_out may be rollout-buffer slots.  workspace: device memory, DL_VN_WORKSPACE_BYTES(D) bytes,
  * zero-initialised once by the caller and owned by this call sequence. */
 #define DL_VN_WORKSPACE_BYTES(D) (8 * (2 * 32 * ((D) + 1) + 2))   /* used by the multi-block reduction (flags bit 16) only */
@@ -304,6 +305,20 @@ int dl_vecnormalize_step(const float* obs, const float* rew, const uint8_t* done
                          double* ret_count, int32_t B, int32_t D, double gamma, double eps, double clip_obs,
                          double clip_rew, int32_t flags, float* obs_out, float* rew_out, void* workspace,
                          void* stream);
+
+/* VecNormalize.step_wait's moment update with the batch spread over several ranks (one process per GPU), EXACT per control step -- what SB3's single
+ * process computes from all N walkers, here from N / world walkers per rank and one all-reduce of 2 (D + 1) doubles per control step:
+ *   dl_vn_local_sums     this rank's shifted sums [2 (D + 1)] (column k: sum of (x - mean_k), sum of squares; column D: the discounted returns, which
+ *                        are advanced here) in the blocked summation order; the running moments are only read -- they are equal on all ranks;
+ *   (caller)             all-reduce (sum) of `sums` over the ranks (RCCL / gloo);
+ *   dl_vn_merge_sums     RunningMeanStd.update_from_moments with the GLOBAL batch size; advances the counts;
+ *   dl_vecnormalize_step with flags | 64 ("moments already merged") normalises observations / rewards and resets ret[done].
+ * HipVecNormalize(sync='per_step') does this; the default (sync='per_rollout') advances the moments per rank and merges them exactly between
+ * rollouts (HipVecNormalize.sync_moments), which needs no collective inside a rollout. */
+int dl_vn_local_sums(const float* obs, const float* rew, const double* obs_mean, double* ret, const double* ret_mean,
+                     int32_t B, int32_t D, double gamma, int32_t flags, double* sums, void* stream);
+int dl_vn_merge_sums(const double* sums, int64_t B_global, double* obs_mean, double* obs_var, double* obs_count,
+                     double* ret_mean, double* ret_var, double* ret_count, int32_t D, int32_t flags, void* stream);
 
 /* RolloutBuffer.compute_returns_and_advantage: arrays are [T, N] time-major float;
  * ep_start[t] = "obs_t starts an episode"; last_val float[N]; last_done uint8[N]. */

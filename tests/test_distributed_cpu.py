@@ -18,6 +18,13 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:          # (a pid-derived port can still be held by an earlier run's lingering socket)
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -50,7 +57,7 @@ def _worker(rank, world, port, tmp):
 
 @pytest.mark.timeout(300)
 def test_sharded_rollout_and_advnorm_allreduce(tmp_path):
-    world, port = 2, 29541 + os.getpid() % 500
+    world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from drloco_amd import abi, mocap, models
@@ -105,7 +112,7 @@ def _moments_worker(rank, world, port, tmp):
 @pytest.mark.timeout(300)
 def test_moment_merge_across_ranks(tmp_path):
     """C3: after a merge every rank holds the moments one process would have computed from all ranks' batches."""
-    world, port = 2, 30041 + os.getpid() % 500
+    world, port = 2, _free_port()
     mp.spawn(_moments_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     D = 5
     rng = np.random.default_rng(100)
@@ -181,7 +188,7 @@ def test_gradient_allreduce_matches_single_process(tmp_path):
     walkers end at the parameters of one rank x 16 walkers -- same minibatch indices, per-minibatch advantage statistics
     of the global minibatch, gradients summed through one flat bucket, then identical clipping and Adam steps."""
     sys.path.insert(0, ROOT)
-    world, port = 2, 30541 + os.getpid() % 500
+    world, port = 2, _free_port()
     mp.spawn(_grad_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     data, w = _ppo_problem()
     want = _ppo_updates(data, w, 0, 1)

@@ -6,6 +6,8 @@ a single-process run of the same global walker count.  The reference's only para
     the matching columns of the single-process run bit for bit (RSI draws and tapes are keyed by the GLOBAL walker index);
   * after the per-rollout exchange (collective C3) every rank holds the same VecNormalize moments, and they are the single process's to
     1e-10 (the ranks' per-step batches are halves of the single process's: same samples, another grouping of the merges);
+  * with --vn-sync per_step (HipVecNormalize(sync='per_step'): the batch sums are all-reduced every control step) the ranks hold bitwise equal
+    moments and follow the single process's rollout;
   * the JSON line reports world_size 2 and a positive whole-job value."""
 import json
 import os
@@ -28,14 +30,18 @@ def _run(cmd, env):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize('extra', [[], ['--policy', '--rollout-form', 'launches']], ids=['fixed-actions', 'policy-in-the-loop'])
+@pytest.mark.parametrize('extra', [[], ['--policy', '--rollout-form', 'launches'], ['--policy', '--rollout-form', 'launches', '--vn-sync', 'per_step']],
+                         ids=['fixed-actions', 'policy-in-the-loop', 'policy-per-step-moments'])
 def test_bench_two_ranks_match_one_process(tmp_path, extra):
     import torch
     assert torch.cuda.is_available()
     n, T = 512, 192
     common = ['--rollout-len', str(T), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'] + extra
     env = dict(os.environ, DL_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    port = str(29600 + os.getpid() % 300)
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = str(so.getsockname()[1])
     two = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', port,
                 'bench.py', '--gpus', '2', '--envs-per-gpu', str(n), '--dump', str(tmp_path / 'two')] + common, env)
     one = _run([sys.executable, 'bench.py', '--gpus', '1', '--envs-per-gpu', str(2 * n), '--dump', str(tmp_path / 'one')] + common, dict(os.environ))
@@ -44,6 +50,25 @@ def test_bench_two_ranks_match_one_process(tmp_path, extra):
     ref = np.load(str(tmp_path / 'one') + '.rank0.npz')
     ranks = [np.load(str(tmp_path / 'two') + f'.rank{r}.npz') for r in range(2)]
     policy = bool(extra)
+    per_step = '--vn-sync' in extra
+    if per_step:
+        # SB3's semantics across ranks: every control step's moment update uses the batch of BOTH ranks (one all-reduce of the batch sums per
+        # control step), so each rank normalises -- and acts -- as the single process does.  The ranks hold bitwise equal moments at every step;
+        # against the single process the sums are grouped differently (rounding of float64 sums), which a chaotic contact simulation amplifies
+        # slowly: the first steps agree to float32 rounding, the moments after T steps to 1e-6.
+        assert two['distributed']['vn_sync'] == 'per_step' and one['distributed']['vn_sync'] == 'per_step'
+        for k in ('obs_mean', 'obs_var', 'obs_count', 'ret_mean', 'ret_var', 'ret_count'):
+            assert np.array_equal(ranks[0][k], ranks[1][k]), k
+        assert float(ranks[0]['obs_count']) == float(ref['obs_count']) and float(ranks[0]['ret_count']) == float(ref['ret_count'])
+        for r, d in enumerate(ranks):
+            cols = slice(r * n, (r + 1) * n)
+            for t in range(8):
+                np.testing.assert_allclose(d['observations'][t], ref['observations'][t][cols], rtol=0, atol=2e-5, err_msg=f'rank {r} step {t}')
+                np.testing.assert_allclose(d['actions'][t], ref['actions'][t][cols], rtol=0, atol=2e-5)
+            assert np.array_equal(d['starts'][:8], ref['starts'][:8, cols])
+        np.testing.assert_allclose(ranks[0]['obs_mean'], ref['obs_mean'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ranks[0]['obs_var'], ref['obs_var'], rtol=1e-3)
+        return
     for r, d in enumerate(ranks):
         cols = slice(r * n, (r + 1) * n)
         if not policy:

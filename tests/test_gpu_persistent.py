@@ -142,6 +142,47 @@ def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs):
     venv.close(); rep.close()
 
 
+@pytest.mark.parametrize('n,T,kw', [(1000, 33, {}), (5, 9, {}), (300, 12, dict(training=False)), (300, 12, dict(norm_reward=False))], ids=['ragged', 'tiny', 'frozen', 'raw-rewards'])
+def test_per_step_sync_host_loop_is_the_launch_path_bit_for_bit(torch_cuda, model, refs, n, T, kw):
+    """HipVecNormalize(sync='per_step') -- dl_vn_local_sums, (all-reduce), dl_vn_merge_sums, dl_vecnormalize_step | 64 in a host loop -- with ONE rank
+    is dl_collect_rollouts' launch form with the blocked reduction order, bit for bit: the split of VecNormalize.step_wait into 'local sums' and
+    'merge' changes nothing but where the collective goes (tests/test_gpu_distributed.py runs it with two ranks)."""
+    torch = torch_cuda
+    res = []
+    for sync in ('per_rollout', 'per_step'):
+        venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T, sync=sync, **kw)
+        for rollout in range(2):
+            buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=None if sync == 'per_step' else False)
+            assert buf.last_form == ('host loop' if sync == 'per_step' else 'launches')
+        torch.cuda.synchronize()
+        res.append(dict(observations=buf.observations.cpu().clone(), actions=buf.actions.cpu().clone(), values=buf.values.cpu().clone(), log_probs=buf.log_probs.cpu().clone(),
+                        rewards=buf.rewards.cpu().clone(), episode_starts=buf.episode_starts.cpu().clone(), last_obs=last_obs.cpu().clone(), last_done=last_done.cpu().clone(),
+                        om=torch.as_tensor(vn.obs_rms.mean), ov=torch.as_tensor(vn.obs_rms.var), oc=torch.tensor(vn.obs_rms.count), rm=torch.as_tensor(vn.ret_rms.mean),
+                        rv=torch.as_tensor(vn.ret_rms.var), rc=torch.tensor(vn.ret_rms.count), ret=vn.ret.cpu().clone(), counter=torch.tensor(pol.counter)))
+        venv.close()
+    a, b = res
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].double() - b[k].double()).abs().max()))
+    assert a['counter'] == 2 * T and abs(float(a['oc']) - (1e-4 + 2 * T * n if kw.get('training', True) else 1e-4)) < 0.5
+
+
+def test_per_step_sync_refusals(torch_cuda, model, refs):
+    torch = torch_cuda
+    from drloco_amd import lib as L
+    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, 64, 4, sync='per_step')
+    for kw in (dict(persistent=True), dict(moments='per_rollout', persistent=True)):
+        with pytest.raises(L.DrlocoError):
+            buf.collect_rollouts(vn, pol, last_obs, last_done, **kw)
+    with pytest.raises(ValueError):
+        from drloco_amd.vec_env import HipVecNormalize
+        HipVecNormalize(venv, sync='sometimes')
+    # the C entry points check their arguments
+    from drloco_amd import abi
+    assert venv._lib.dl_vn_local_sums(None, None, None, None, None, 4, 29, 0.99, 5, None, None) == abi.DL_E_INVAL
+    assert venv._lib.dl_vn_merge_sums(None, 8, None, None, None, None, None, None, 29, 5, None) == abi.DL_E_INVAL
+    venv.close()
+
+
 def test_persistent_form_refusals(torch_cuda, model, refs):
     torch = torch_cuda
     from drloco_amd import lib as L, mocap, models
