@@ -62,6 +62,16 @@
 #define DL_PIN_STRAIGHT 1       // experiment switch: 0 builds the straight walker with the fetch-at-use policy of the 19-dof walker
 #endif
 // experiment switches: unroll factor of the contact-pair loops (J^T f / Hessian, J dir); 1 = as written
+// experiment switches of the round-3 dependent-chain work in the Newton loop (1 = product)
+#ifndef DL_OPT_GRADSQ
+#define DL_OPT_GRADSQ 1
+#endif
+#ifndef DL_OPT_MX2
+#define DL_OPT_MX2 1
+#endif
+#ifndef DL_OPT_FSQRT
+#define DL_OPT_FSQRT 1
+#endif
 #ifndef DL_CHOL_SHORT_CHAIN
 #define DL_CHOL_SHORT_CHAIN 1   // 0: round-2 form of the leaf-first factorisation / substitutions (experiment switch)
 #endif
@@ -744,8 +754,13 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
     const bool isdof = j < NL;
     // motion subspace of dof j and its joint velocity contribution
     SV<T> S;
-    if (ln.type == 0) { S.w = mk<T>(0, 0, 0); S.v = k.axis; } else { S.w = k.axis; S.v = cross(k.pos, k.axis); }
-    if (!isdof) { S.w = mk<T>(0, 0, 0); S.v = mk<T>(0, 0, 0); }
+    {
+        // (selects, not branches: an exec-masked region costs more scalar instructions than these six moves)
+        const bool hinge = isdof && ln.type != 0, slide = isdof && ln.type == 0;
+        const V3<T> pa = cross(k.pos, k.axis);
+        S.w = mk<T>(hinge ? k.axis.x : T(0), hinge ? k.axis.y : T(0), hinge ? k.axis.z : T(0));
+        S.v = mk<T>(hinge ? pa.x : (slide ? k.axis.x : T(0)), hinge ? pa.y : (slide ? k.axis.y : T(0)), hinge ? pa.z : (slide ? k.axis.z : T(0)));
+    }
     const T qd = isdof ? v : T(0);
     const SV<T> vJ = {qd * S.w, qd * S.v};
     T sv[6] = {vJ.w.x, vJ.w.y, vJ.w.z, vJ.v.x, vJ.v.y, vJ.v.z};
@@ -859,6 +874,14 @@ template <typename C, typename T> __device__ __forceinline__ T g_impedance(const
     return x >= T(1) ? m.solimp[1] : (x <= T(0) ? m.solimp[0] : imp);
 }
 
+__device__ __forceinline__ float dl_sqrt_fast(float x) {
+#if defined(DL_GROUP_EMU)
+    return sqrtf(x);
+#else
+    return __builtin_amdgcn_sqrtf(x);
+#endif
+}
+__device__ __forceinline__ double dl_sqrt_fast(double x) { return sqrt(x); }
 // 1/sqrt(x): float = v_rsq_f32 + one Newton step (<= 1 ulp-ish, no denormal fix-ups); double = exact path
 __device__ __forceinline__ float dl_rsqrt(float x) {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -980,8 +1003,7 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
     // Both substitutions as ONE self-referencing DPP multiply-add per step (destination = broadcast source = the running vector):
     //   U y = b, children first:  acc_j -= (U[j][k] / U[k][k]) acc_k  for the ancestors j of k; acc_k is final by then; y = acc / U[j][j] at the end;
     //   U^T x = y, parents first, on u_j = (y_j - sum over the proper ancestors a of U[a][j] x_a) / U[j][j], which IS x_j once j's ancestors are done:
-    //   u_j -= x_k U[k][j] / U[j][j] = x_k * up_j[k] / U[j][j]^2 for the lanes j below k.  Lane k's own value is taken before its step (its
-    //   up[k] slot is not a matrix entry, and the slots of the lanes above k are stale rows).
+    //   u_j -= x_k U[k][j] / U[j][j] = x_k * up_j[k] / U[j][j]^2 for the lanes j below k.
     T acc = b;
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[ss.value];
@@ -989,15 +1011,15 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
     });
     const T s2 = -invd * invd;
     T u = acc * invd * invd;
+    // only the lanes below k take part in step k: the slot up[k] of lane k itself is not a matrix entry and those of the lanes above k are
+    // stale rows (lanes of the other branch hold an exact zero) -- masked here, off the chain, so that u is x when the loop ends
     T up2[GL];
-    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = s2 * up[k]; });
-    T x = T(0);
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = (j > k) ? s2 * up[k] : T(0); });
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[N - 1 - ss.value];
-        if (j == k) x = u;
         if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
     });
-    return x;
+    return u;
 #else
     // U y = b, children first: y_k = (b_k - sum over the descendants d of k of U[k][d] y_d) / U[k][k]; lo[k] is zero in the lanes that are
     // not ancestors of k, so a lane's accumulator is final once its descendants are done
@@ -1279,9 +1301,11 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
     constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, MAXROW = Ld::MAXROW;
     DL_LDS T* wb = g.wb;
     const int j = g.j;
-    T mx = sm.mcorr * x, xb = x;
+    T mx = sm.mcorr * x, mx1 = T(0), xb = x;
     g_dpp_ready(xb);
-    static_for<N>([&](auto ai) { constexpr int a = ai.value; fmac_bcast<a, 1>(mx, xb, sm.mrow[a]); });
+    // two accumulators: fourteen dependent multiply-adds are ~100 cycles of latency for a wave that has its SIMD to itself
+    static_for<N>([&](auto ai) { constexpr int a = ai.value; if constexpr (a % 2 == 0 || !DL_OPT_MX2) fmac_bcast<a, 1>(mx, xb, sm.mrow[a]); else fmac_bcast<a, 1>(mx1, xb, sm.mrow[a]); });
+    mx += mx1;
     if constexpr (NX > 0) {
         T s[NX];
         static_for<NX>([&](auto ti) { constexpr int t = ti.value; mx += sm.mxl[t] * xx[t]; s[t] = sm.mxl[t] * x; });
@@ -1447,17 +1471,18 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             if constexpr (NX > 0) { const Q4<T> B = ld4(wb + Ld::CON + Ld::CON_W * cc + 4); ctx = B.a; cty = B.b; mu = B.c; }
             else mu = wb[Ld::CON + Ld::CON_W * cc + Ld::C_MU];
             const T jar[4] = {ja.a, ja.b, ja.c, ja.d}, was[4] = {tm.a, tm.b, tm.c, tm.d};
-            T f4[4], dD[4], onf[4];
+            T f4[4], dD[4], onf[4], c4[4];
             bool anyflip = false;
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 const bool on = jar[s4] < T(0), w = was[s4] != T(0);
                 f4[s4] = on ? -D * jar[s4] : T(0);
-                if (on) c += T(0.5) * D * jar[s4] * jar[s4];
+                c4[s4] = on ? T(0.5) * D * jar[s4] * jar[s4] : T(0);
                 dD[s4] = (on == w) ? T(0) : (on ? D : -D);
                 anyflip = anyflip || (on != w);
                 onf[s4] = on ? T(1) : T(0);
             }
+            c += (c4[0] + c4[1]) + (c4[2] + c4[3]);
             // dW = sum_s dD_s d_s d_s^T with d = (1, +-mu, 0) or (1, 0, +-mu)
             DL_LDS T* fc = wb + Ld::FC + Ld::FC_W * cc;
             const T Fn = f4[0] + f4[1] + f4[2] + f4[3], F1 = mu * (f4[0] - f4[1]), F2 = mu * (f4[2] - f4[3]);
@@ -1476,7 +1501,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         for (int c2 = 0; c2 < ncon; c2 += 2) {
             const DL_LDS T* fca = wb + Ld::FC + Ld::FC_W * c2;
             const Q4<T> Fa = ld4(fca), Fb = ld4(fca + Ld::FC_W), ja = ld4(wb + Ld::JC + (c2 * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c2 + 1) * GL + j) * 4);
-            fcon += ja.a * Fa.a + ja.b * Fa.b + ja.c * Fa.c + jb.a * Fb.a + jb.b * Fb.b + jb.c * Fb.c;
+            fcon += (ja.a * Fa.a + ja.b * Fa.b + ja.c * Fa.c) + (jb.a * Fb.a + jb.b * Fb.b + jb.c * Fb.c);
             if constexpr (NX > 0) {
                 const Q4<T> Ga = ld4(fca + 8), Gb = ld4(fca + Ld::FC_W + 8);      // (w22, Fx, Fy, Fz)
                 const V3<T> Fw = mk<T>(Ga.b + Gb.b, Ga.c + Gb.c, Ga.d + Gb.d);
@@ -1526,8 +1551,14 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         const T pc0 = r3[0];
         {
             const T gn = r3[1], gmag = r3[2];
-            // float32: the gradient carries rounding noise proportional to the magnitude of its terms
-            if (!(scale * dl_sqrt(gn) >= cs.tolerance + cs.tol_rel * scale * gmag) || iter >= cs.iterations) alive = false;   // also stops on NaN
+            // float32: the gradient carries rounding noise proportional to the magnitude of its terms.  scale |g| >= bound, compared as squares
+            // (both sides are >= 0): the correctly rounded square root was a dozen dependent instructions in front of the loop's exit branch
+            const T bound = cs.tolerance + cs.tol_rel * scale * gmag;
+#if DL_OPT_GRADSQ
+            if (!(scale * scale * gn >= bound * bound) || iter >= cs.iterations) alive = false;   // also stops on NaN
+#else
+            if (!(scale * dl_sqrt(gn) >= bound) || iter >= cs.iterations) alive = false;
+#endif
         }
         tick(2);
         if (!__any(alive)) break;
@@ -1591,7 +1622,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             constexpr int t = ti.value;
             r4[0] += dirx[t] * (Max[t] - sm.smoothx[t]); r4[1] += T(0.5) * dirx[t] * Mdx[t]; r4[2] += dirx[t] * gradx[t]; r4[3] += dirx[t] * dirx[t];
         });
-        const T g1s = r4[0], g2 = r4[1], d0 = r4[2], snorm = dl_sqrt(r4[3]);
+        const T g1s = r4[0], g2 = r4[1], d0 = r4[2], snorm = DL_OPT_FSQRT ? dl_sqrt_fast(r4[3]) : dl_sqrt(r4[3]);     // (scales a tolerance: 1 ulp is plenty)
         const T gtol = cs.tolerance * cs.ls_tolerance * snorm * cs.meaninertia * nvf + cs.ls_reltol * dl_abs(d0);
         T alpha = T(1), lo = T(0), hi = T(1e30), best_a = T(0), best_dc = T(0), best_mag = T(0), res_a = T(0), res_dc = T(0), res_mag = T(0);
         bool done = !alive || !(snorm >= T(1e-15));
