@@ -63,6 +63,12 @@
 #endif
 // experiment switches: unroll factor of the contact-pair loops (J^T f / Hessian, J dir); 1 = as written
 // experiment switches of the round-3 dependent-chain work in the Newton loop (1 = product)
+#ifndef DL_OPT_ARMIJO
+#define DL_OPT_ARMIJO 1     // 0: always the exact line search (round-2 behaviour)
+#endif
+#ifndef DL_OPT_ARMIJO_C
+#define DL_OPT_ARMIJO_C 0.1
+#endif
 #ifndef DL_OPT_GRADSQ
 #define DL_OPT_GRADSQ 1
 #endif
@@ -1645,6 +1651,11 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             const T dc = alpha * g1s + alpha * alpha * g2 + (pc - pc0);
             const T mag = dl_abs(alpha * g1s) + alpha * alpha * g2 + pc + pc0;
             it++;
+#if DL_OPT_ARMIJO
+            // the full Newton step is taken as it is when it already brings a fair part of the decrease the quadratic model promises (d0 / 2 on
+            // an unchanged active set): the exact minimiser along dir is worth two or three more trials only when it does not
+            if (!done && it == 1 && dc <= T(DL_OPT_ARMIJO_C) * d0) { res_a = alpha; res_dc = dc; res_mag = mag; done = true; }
+#endif
             if (!done) {
                 if (d1 < T(0)) lo = alpha; else hi = alpha;
                 const T cand = alpha - d1 * dl_rcp(d2);
@@ -1658,6 +1669,9 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
                 alpha = next;
             }
         }
+#ifdef DL_EXP_LS_COUNT            // diagnostics: trials and line searches of the wave (tools/diag_sections.py --ls)
+        if constexpr (TIMED) tacc[7] += (long long)it * 65536 + 1;
+#endif
         // ---- step
         if (alive) {
             if (res_a == T(0)) alive = false;                      // no improvement along a descent direction: converged to working precision

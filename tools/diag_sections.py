@@ -40,6 +40,9 @@ tot = t[:6].sum(0)
 print(f'kernel {e0.elapsed_time(e1) * 1e3:.1f} us; per wave: total cycles mean {tot.mean():.0f} median {np.median(tot):.0f} max {tot.max():.0f}; wave iterations mean {t[6].mean():.2f} max {t[6].max():.0f}')
 for k in range(6):
     print(f'  {names[k]:22s} mean {t[k].mean():9.0f}  ({100 * t[k].mean() / tot.mean():5.1f} %)  max {t[k].max():9.0f}   per iteration {t[k].mean() / t[6].mean():8.0f}')
+if t[7].sum() > 0:      # a -DDL_EXP_LS_COUNT build: trials * 65536 + line searches per wave
+    ls, tr = np.mod(t[7], 65536), np.floor(t[7] / 65536)
+    print(f'line searches per wave and evaluation: mean {ls.mean():.2f}; trials per line search: {tr.sum() / max(1, ls.sum()):.2f}; trials per wave mean {tr.mean():.2f} max {tr.max():.0f}')
 qa, nc, ne, ni = env.forward(ctrl.cpu().numpy().astype(np.float64))
 print('iters: mean %.2f  hist %s' % (ni.mean(), np.bincount(ni)[:12]))
 print('nefc: mean %.1f  hist(0,1-8,9-16,17-32,33+) %s' % (ne.mean(), [int((ne == 0).sum()), int(((ne > 0) & (ne <= 8)).sum()), int(((ne > 8) & (ne <= 16)).sum()), int(((ne > 16) & (ne <= 32)).sum()), int((ne > 32).sum())]))
