@@ -911,6 +911,23 @@ __device__ __forceinline__ double dl_rsqrt_pivot(double x) { return 1.0 / sqrt(x
 // h[a] for a > j = L[a][j] * L[j][j]; invd.  A lane's pivot is final once the steps k < j are done (l_jk = 0 for k >= j),
 // so invd is taken once at the end from the lane's own hd -- the same bits every lane used at step j.
 template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], T (&lo)[GL], T hd, T& invd, int j, T floor_) {
+#if DL_CHOL_SHORT_CHAIN
+    // (see g_chol_rev: one-instruction pivot broadcast + floor, lane mask on h[k] instead of on the pivot's reciprocal root; lo[k] leaves
+    // as the forward substitution's multiplier -L[j][k] / L[k][k])
+    static_for<N>([&](auto kk) {
+        constexpr int k = kk.value;
+        const T inv = dl_rsqrt_pivot(max_bcast<k>(hd, floor_));
+        const T hk = (j > k) ? h[k] : T(0);
+        T lik = hk * inv;                                     // lanes j > k: L[j][k]
+        lo[k] = -lik * inv;
+        hd -= lik * lik;
+        g_dpp_ready(lik);
+        static_for<N - 1 - k>([&](auto aa) {
+            constexpr int a = k + 1 + aa.value;
+            fmac_bcast<a, -1>(h[a], lik, lik);                // lanes j > k, all columns a > k: h[a] -= L[a][k] L[j][k]
+        });
+    });
+#else
     static_for<N>([&](auto kk) {
         constexpr int k = kk.value;
         const T inv = dl_rsqrt_pivot(dl_max(rbcast<k>(hd), floor_));
@@ -923,10 +940,22 @@ template <typename T, int N> __device__ __forceinline__ void g_chol(T (&h)[GL], 
             fmac_bcast<a, -1>(h[a], lik, lik);                // lanes j > k, all columns a > k: h[a] -= L[a][k] L[j][k]
         });
     });
+#endif
     invd = dl_rsqrt_pivot(dl_max(hd, floor_));
 }
 // solve (L L^T) x = b with the factor as g_chol leaves it; b_j in, x_j out
 template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (&lo)[GL], const T (&up)[GL], T invd, T b, int j) {
+#if DL_CHOL_SHORT_CHAIN
+    // both substitutions as one self-referencing DPP multiply-add per step (see g_chol_solve_rev)
+    T acc = b;
+    static_for<N - 1>([&](auto kk) { constexpr int k = kk.value; fmac_bcast_chain<k>(acc, lo[k]); });
+    const T s2 = -invd * invd;
+    T u = acc * invd * invd;
+    T up2[GL];
+    static_for<N - 1>([&](auto kk) { constexpr int k = 1 + kk.value; up2[k] = (j < k) ? s2 * up[k] : T(0); });     // the lanes above row k hold column entries
+    static_for<N - 1>([&](auto kk) { constexpr int k = N - 1 - kk.value; fmac_bcast_chain<k>(u, up2[k]); });
+    return u;
+#else
     // forward: y_k = (b_k - sum_{a<k} L[k][a] y_a) / L[k][k].  lo[k] is zero in the lanes j <= k, so a lane's accumulator
     // is final after step j - 1 and y_j is read off after the loop
     T acc = b;
@@ -950,6 +979,7 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
         }
     });
     return x;
+#endif
 }
 
 // Leaf-first variant for tree-sparse matrices (H = M + J^T D J couples two dofs only if one is an ancestor of the other): eliminating
