@@ -118,6 +118,9 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     // (exception path) make it lag -- it is a prefetch, it only has to stay inside the tape.
     const int evals_per_step = 4 * m->frame_skip;
     float pf_sink = 0.0f;
+#ifdef DL_EXP_SPLIT_PROF
+    long long srv_busy = 0;
+#endif
     for (;;) {
         int cur = seq, it = 0;
         while ((cur = flags[Sp::MB_CMDSEQ]) == seq && it < g.spin_limit) { DL_SLEEP(); it++; }
@@ -126,6 +129,9 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
             break;
         }
         if (flags[Sp::MB_CMD] == 0) break;          // released
+#ifdef DL_EXP_SPLIT_PROF
+        const long long tsrv0 = DL_CLOCK();
+#endif
         DL_WG_ACQUIRE();
         seq = cur;
         g_sync<T>();
@@ -141,11 +147,17 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         DL_WG_RELEASE();
         if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
         DL_WAKE();
+#ifdef DL_EXP_SPLIT_PROF          // busy cycles of this wave (request seen -> answer posted), summed over the launch: dbg slot 0 (tools/diag_split.py)
+        srv_busy += DL_CLOCK() - tsrv0;
+#endif
         if (DL_PREFETCH_ACTIONS && actions_all && (seq - 1) % evals_per_step == 0) {
             const int next = (seq - 1) / evals_per_step + 1;
             if (next < nsteps && j < TP::NU) pf_sink += actions_all[((size_t)next * n + w) * TP::NU + j];
         }
     }
+#ifdef DL_EXP_SPLIT_PROF
+    if (j == 0 && w0 < n && st.dbg) st.dbg[w] = (int)(srv_busy >> 4);
+#endif
     if (DL_PREFETCH_ACTIONS && actions_all && pf_sink == 12345.678f) g.mbox[Sp::MB_SIZE - 1] = pf_sink;      // (keeps the prefetch loads alive)
 }
 #endif
@@ -432,7 +444,10 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         write_obs(dn ? term_obs : obs, true);
     }
     if (valid && j == 0 && st.dbg) {
-        st.dbg[w] += dbg_it; st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
+#ifndef DL_EXP_SPLIT_PROF
+        st.dbg[w] += dbg_it;
+#endif
+        st.dbg[(size_t)n + w] = dbg_max; st.dbg[(size_t)2 * n + w] += dbg_rows; st.dbg[(size_t)3 * n + w] += exc ? 1 : 0;
 #ifdef DL_EXP_SPLIT_PROF
         if constexpr (SPLIT) { st.dbg[(size_t)n + w] = split_seq[1]; st.dbg[(size_t)2 * n + w] = split_seq[2]; st.dbg[(size_t)3 * n + w] = (int)((DL_CLOCK() - t_begin0) >> 4); }
 #endif

@@ -15,4 +15,5 @@ env.debug_counters()
 env.rollout_fixed(acts)
 c = env.debug_counters().astype(np.float64) * 16
 wait, smooth, total = c[1][::4] / T, c[2][::4] / T, c[3][::4] / T
-print(f'per control step and dynamics wave (cycles): whole {total.mean():.0f} (max {total.max():.0f}), smooth dynamics {smooth.mean():.0f}, waiting for the constraint wave {wait.mean():.0f} (max {wait.max():.0f})')
+srv = c[0][::4] / T          # the constraint wave's busy cycles (request seen -> answer posted)
+print(f'per control step and dynamics wave (cycles): whole {total.mean():.0f} (max {total.max():.0f}), smooth dynamics {smooth.mean():.0f}, waiting for the constraint wave {wait.mean():.0f} (max {wait.max():.0f}); constraint wave busy {srv.mean():.0f} per step = {srv.mean() / 20:.0f} per evaluation')
