@@ -63,6 +63,9 @@
 #endif
 // experiment switches: unroll factor of the contact-pair loops (J^T f / Hessian, J dir); 1 = as written
 // experiment switches of the round-3 dependent-chain work in the Newton loop (1 = product)
+#ifndef DL_OPT_JAC_PIPE
+#define DL_OPT_JAC_PIPE 0
+#endif
 #ifndef DL_OPT_ARMIJO
 #define DL_OPT_ARMIJO 1     // 0: always the exact line search (round-2 behaviour)
 #endif
@@ -442,7 +445,7 @@ template <typename TP> struct GSplit {
     using Ld = GLds<TP>;
     static constexpr int MMX = Ld::TOTAL;                        // M mirror [16][MS]
     static constexpr int MB = MMX + GL * Ld::MS;                 // mailbox
-    static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_DONESEQ = 67, MB_CMD = 68, MB_SIZE = 96;
+    static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_CMD = 67, MB_DONESEQ = 68, MB_SIZE = 96;      // (CMDSEQ, CMD): one aligned 8-byte word
     static constexpr int TOTAL = MB + MB_SIZE;                   // per walker; 16 (mod 32) like GLds::TOTAL
     static_assert(TOTAL % 32 == 16 && MB % 4 == 0, "walker regions keep their bank offset");
     // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
@@ -873,9 +876,10 @@ __device__ __forceinline__ double dl_rcp(double x) { return 1.0 / x; }
 // [3P] solimp sigmoid (getimpedance) with the three reciprocals of the constants taken once (GModel::solimp_inv)
 template <typename C, typename T> __device__ __forceinline__ T g_impedance(const C& m, T pos) {
     const T x = dl_abs(pos) * m.solimp_inv[0];
-    T y;
-    if (m.solimp[4] == T(1)) y = x;
-    else y = (x <= m.solimp[3]) ? x * x * m.solimp_inv[1] : T(1) - (T(1) - x) * (T(1) - x) * m.solimp_inv[2];
+    // (both branches of the power-2 sigmoid and a select: lanes of one wave sit on either side of the midpoint, and an exec-masked
+    //  region per side costs more than the three extra multiplies)
+    const T ya = x * x * m.solimp_inv[1], yb = T(1) - (T(1) - x) * (T(1) - x) * m.solimp_inv[2];
+    const T y = (m.solimp[4] == T(1)) ? x : ((x <= m.solimp[3]) ? ya : yb);
     const T imp = m.solimp[0] + y * (m.solimp[1] - m.solimp[0]);
     return x >= T(1) ? m.solimp[1] : (x <= T(0) ? m.solimp[0] : imp);
 }
@@ -1177,27 +1181,43 @@ __device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const 
     // every contact from its joint axis / anchor in registers (dofs that do not move the contact's body write zeros),
     // two contacts per trip; the same trip adds J x0 to the contacts' rows (six interleaved row sums, expanded to the
     // pyramid rows by lanes 0..7), so the Jacobian is not read back for the start point
+#if DL_OPT_JAC_PIPE
+    // the records of a pair are requested one trip ahead -- those of the first pair before the contact count is looked at (the slots exist
+    // whatever they hold): a trip is one LDS round trip + six row sums of dependent instructions, with nothing else to issue meanwhile
+    Q4<T> A0 = ld4(wb + Ld::CON), B0 = ld4(wb + Ld::CON + 4), A1 = ld4(wb + Ld::CON + Ld::CON_W), B1 = ld4(wb + Ld::CON + Ld::CON_W + 4);
+    T base = wb[Ld::ROW + Ld::R_JAREF * MAXROW + (j < 8 ? j : 0)];
+#endif
     for (int c = 0; c < ncon; c += 2) {
-        const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * c;
-        const Q4<T> A0 = ld4(cn), B0 = ld4(cn + 4), A1 = ld4(cn + Ld::CON_W), B1 = ld4(cn + Ld::CON_W + 4);
         DL_LDS T* rja = wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * c + j;
         const bool writer = j < 4 || (j < 8 && c + 1 < ncon);
-        const T base = writer ? *rja : T(0);
-        V3<T> w0 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A0.a, A0.b, A0.c) - kin.pos);
-        V3<T> w1 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A1.a, A1.b, A1.c) - kin.pos);
-        if (!((lt.bodies >> (int)A0.d) & 1u)) w0 = mk<T>(0, 0, 0);
-        if (!((lt.bodies >> (int)A1.d) & 1u)) w1 = mk<T>(0, 0, 0);
-        const T j0n = w0.z, j0a = B0.a * w0.x + B0.b * w0.y, j0b = -B0.b * w0.x + B0.a * w0.y;
-        const T j1n = w1.z, j1a = B1.a * w1.x + B1.b * w1.y, j1b = -B1.b * w1.x + B1.a * w1.y;
+#if DL_OPT_JAC_PIPE
+        const Q4<T> A0n = A0, B0n = B0, A1n = A1, B1n = B1;
+        const T basen = base;
+        if (c + 2 < ncon) {
+            const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * (c + 2);
+            A0 = ld4(cn); B0 = ld4(cn + 4); A1 = ld4(cn + Ld::CON_W); B1 = ld4(cn + Ld::CON_W + 4);
+            base = wb[Ld::ROW + Ld::R_JAREF * MAXROW + 4 * (c + 2) + (j < 8 ? j : 0)];
+        }
+#else
+        const DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * c;
+        const Q4<T> A0n = ld4(cn), B0n = ld4(cn + 4), A1n = ld4(cn + Ld::CON_W), B1n = ld4(cn + Ld::CON_W + 4);
+        const T basen = writer ? *rja : T(0);
+#endif
+        V3<T> w0 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A0n.a, A0n.b, A0n.c) - kin.pos);
+        V3<T> w1 = ln.type == 0 ? kin.axis : cross(kin.axis, mk<T>(A1n.a, A1n.b, A1n.c) - kin.pos);
+        if (!((lt.bodies >> (int)A0n.d) & 1u)) w0 = mk<T>(0, 0, 0);
+        if (!((lt.bodies >> (int)A1n.d) & 1u)) w1 = mk<T>(0, 0, 0);
+        const T j0n = w0.z, j0a = B0n.a * w0.x + B0n.b * w0.y, j0b = -B0n.b * w0.x + B0n.a * w0.y;
+        const T j1n = w1.z, j1a = B1n.a * w1.x + B1n.b * w1.y, j1b = -B1n.b * w1.x + B1n.a * w1.y;
         st4(wb + Ld::JC + (c * GL + j) * 4, j0n, j0a, j0b, T(0));
         st4(wb + Ld::JC + ((c + 1) * GL + j) * 4, j1n, j1a, j1b, T(0));
         T r[6] = {j0n * x0, j0a * x0, j0b * x0, j1n * x0, j1a * x0, j1b * x0};
         gsum_n<6>(r);
-        if constexpr (NX > 0) { g_slide_jx<T, TP>(B0.a, B0.b, x0x, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1.a, B1.b, x0x, r[3], r[4], r[5]); }
+        if constexpr (NX > 0) { g_slide_jx<T, TP>(B0n.a, B0n.b, x0x, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1n.a, B1n.b, x0x, r[3], r[4], r[5]); }
         if (writer) {
             const bool second = j >= 4;
-            const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? B1.c : B0.c;
-            *rja = base + vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
+            const T vn = second ? r[3] : r[0], v1 = second ? r[4] : r[1], v2 = second ? r[5] : r[2], mu = second ? B1n.c : B0n.c;
+            *rja = basen + vn + ((j & 1) ? -mu : mu) * ((j & 2) ? v2 : v1);
         }
     }
     g_sync<T>();
@@ -1225,11 +1245,12 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
     // ---- joint limits (dof lanes), ranked by dof order through a ballot
     bool lim = false, lim_lo = false;
     T lim_dist = T(0);
-    if (j < NL && ln.limited) {
+    {
+        const bool has = j < NL && ln.limited;
         const T dlo = q - ln.range_lo, dhi = ln.range_hi - q;
-        lim_lo = dlo < T(0);
-        lim = lim_lo || dhi < T(0);
-        lim_dist = lim_lo ? dlo : dhi;
+        lim_lo = has && dlo < T(0);
+        lim = has && (dlo < T(0) || dhi < T(0));
+        lim_dist = lim ? (lim_lo ? dlo : dhi) : T(0);
     }
     const uint32_t lmask = (uint32_t)((__ballot(lim) >> (GL * grp)) & 0xFFFFull);
     const int nlim = __popc(lmask);
@@ -1284,19 +1305,35 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
     //  the rows written below overwrite the mirror block of the mass matrix, whose reads precede them in program order)
     // ---- the lane of a candidate writes the contact record AND the contact's rows (rows 4c..4c+3: D, K imp r, cleared
     // active flags): nothing about a contact waits for another lane
+    // (the impedance / regulariser chains -- two reciprocals each -- of all passes and of the limit row are computed side by side, for every lane,
+    //  and pinned: behind their lanes' predicates they ran one after the other, ~300 cycles of dependent instructions each)
+    T r_mu[NPASS], r_D[NPASS], r_kd[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
+        const T mu = dl_max(cd.cmu[pass], g.wk->floor_mu), dist = cdist[pass];
+        const T imp = g_impedance(simp, dist);
+        const T diag = cd.cinvw[pass] * (T(1) + mu * mu);
+        const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
+        r_mu[pass] = mu; r_D[pass] = dl_rcp(R); r_kd[pass] = g.c->solK * imp * dist;
+    }
+    T l_D, l_k;
+    {
+        const T imp = g_impedance(simp, lim_dist);
+        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
+        l_D = dl_rcp(R); l_k = g.c->solK * imp * lim_dist + lim_sign * x0;
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) { g_pin(r_D[pass]); g_pin(r_kd[pass]); g_pin(ctx[pass]); g_pin(cty[pass]); }
+    g_pin(l_D); g_pin(l_k);
 #pragma unroll
     for (int pass = 0; pass < NPASS; pass++) {
         const int c = j + GL * pass;
         if (act[pass]) {
             const int slot = g_popc((CM)(cm & (((CM)1 << c) - (CM)1)));
-            const T mu = dl_max(cd.cmu[pass], g.wk->floor_mu), dist = cdist[pass];
+            const T mu = r_mu[pass], dist = cdist[pass], D = r_D[pass], kd = r_kd[pass];
             DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * slot;
             st4(cn, cp[pass].x, cp[pass].y, cp[pass].z, T((cinf[pass] >> 5) & 15));
             st4(cn + 4, ctx[pass], cty[pass], mu, dist);
-            const T imp = g_impedance(simp, dist);
-            const T diag = cd.cinvw[pass] * (T(1) + mu * mu);
-            const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
-            const T D = dl_rcp(R), kd = g.c->solK * imp * dist;
             st4(wb + Ld::ROW + Ld::R_D * MAXROW + 4 * slot, D, D, D, D);
             st4(wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * slot, kd, kd, kd, kd);
             st4(wb + Ld::ROW + Ld::R_TMP * MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
@@ -1313,10 +1350,8 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
     if (lim) {
         const int r = 4 * ncon + __popc(lmask & ((1u << j) - 1u));
         my_lim = r;
-        const T imp = g_impedance(simp, lim_dist);
-        const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
-        wb[Ld::ROW + Ld::R_D * MAXROW + r] = dl_rcp(R);
-        wb[Ld::ROW + Ld::R_JAREF * MAXROW + r] = g.c->solK * imp * lim_dist + lim_sign * x0;
+        wb[Ld::ROW + Ld::R_D * MAXROW + r] = l_D;
+        wb[Ld::ROW + Ld::R_JAREF * MAXROW + r] = l_k;
         wb[Ld::ROW + Ld::R_TMP * MAXROW + r] = T(0);
     }
     g_sync<T>();

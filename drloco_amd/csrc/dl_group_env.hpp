@@ -122,20 +122,28 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     long long srv_busy = 0;
 #endif
     for (;;) {
-        int cur = seq, it = 0;
-        while ((cur = flags[Sp::MB_CMDSEQ]) == seq && it < g.spin_limit) { DL_SLEEP(); it++; }
+        // (sequence number, command) in one 8-byte read: the partner stores the command first, LDS operations of a wave complete in order
+        static_assert(Sp::MB_CMD == Sp::MB_CMDSEQ + 1 && Sp::MB_CMDSEQ % 2 == 0, "the command word pair is one aligned 8-byte word");
+        int cur = seq, cmd = 0, it = 0;
+        for (;;) {
+            const long long wd = *(volatile DL_LDS long long*)(flags + Sp::MB_CMDSEQ);
+            cur = (int)(wd & 0xffffffffll); cmd = (int)(wd >> 32);
+            if (cur != seq || it >= g.spin_limit) break;
+            DL_SLEEP(); it++;
+        }
         if (cur == seq) {         // timeout: the partner never asked and never released -- say so (the partner's next request then times out as well)
             if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
             break;
         }
-        if (flags[Sp::MB_CMD] == 0) break;          // released
+        if (cmd == 0) break;          // released
 #ifdef DL_EXP_SPLIT_PROF
         const long long tsrv0 = DL_CLOCK();
 #endif
         DL_WG_ACQUIRE();
         seq = cur;
         g_sync<T>();
-        const T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j];
+        T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j];
+        g_pin(q); g_pin(x0);         // requested here, with the body frames -- not behind the predicates of their first uses
         GKin<T> kin{};                 // the first half of the constraint stage reads the body frames its partner left in LDS, not the lane's kinematics
         int nlim, ncon, my_lim;
         T lim_sign;
