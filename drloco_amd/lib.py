@@ -31,18 +31,41 @@ class DrlocoFault(DrlocoError):
     """DL_E_FAULT: a kernel of the handle reported a fault (include/drloco_hip.h: dl_fault_check)."""
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 of the kernels + C-ABI into an in-tree shared library."""
-    srcs = [os.path.join(CSRC, s) for s in _SOURCES] + [os.path.join(INCLUDE, 'drloco_hip.h')]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+LISTING_DIR = os.path.join(os.path.dirname(_HERE), 'build_dbg', 'listing')
+LISTING = os.path.join(LISTING_DIR, 'dl_kernels-hip-amdgcn-amd-amdhsa-gfx950.s')
+
+
+def _sources():
+    return [os.path.join(CSRC, s) for s in _SOURCES] + [os.path.join(INCLUDE, 'drloco_hip.h')]
+
+
+def build(force=False, verbose=False, listing=False):
+    """hipcc --offload-arch=gfx950 of the kernels + C-ABI into an in-tree shared library.  listing=True keeps the device assembly of the
+    same compilation (-save-temps, build_dbg/listing/) for tools/check_dpp_hazards.py -- the hand-written DPP statements carry their own
+    wait states, which the compiler's hazard recogniser does not check."""
+    srcs = _sources()
+    fresh = lambda path: os.path.exists(path) and all(os.path.getmtime(s) <= os.path.getmtime(path) for s in srcs)
+    if not force and fresh(LIB_PATH) and (not listing or fresh(LISTING)):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I' + INCLUDE, '-I' + CSRC] + EXTRA_FLAGS + \
-          os.environ.get('DL_EXTRA_FLAGS', '').split() + [os.path.join(CSRC, 'dl_kernels.hip'), '-o', LIB_PATH]
+          os.environ.get('DL_EXTRA_FLAGS', '').split() + (['-save-temps'] if listing else []) + [os.path.join(CSRC, 'dl_kernels.hip'), '-o', LIB_PATH]
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    if listing:
+        os.makedirs(LISTING_DIR, exist_ok=True)
+    subprocess.check_call(cmd, cwd=LISTING_DIR if listing else None)
     return LIB_PATH
+
+
+def check_dpp_hazards():
+    """Run tools/check_dpp_hazards.py over the listing of the product build (building it if needed); raises on a violation."""
+    build(listing=True)
+    tool = os.path.join(os.path.dirname(_HERE), 'tools', 'check_dpp_hazards.py')
+    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, LISTING], capture_output=True, text=True)
+    if p.returncode != 0:
+        raise DrlocoError('DPP read-after-write hazard in the device code:\n' + p.stdout[-4000:] + p.stderr[-2000:])
+    return p.stdout.strip().splitlines()[-1]
 
 
 _V, _I, _P = C.c_void_p, C.c_int32, C.c_void_p
