@@ -45,3 +45,24 @@ def test_product_listing_has_no_dpp_hazard():
     text = open(lib.LISTING).read()
     # the listing is the product's: the step kernels and their hand-written DPP forms are in it
     assert 'k_env_step_g16_split' in text and 'k_rollout_persistent' in text and text.count('v_fmac_f32_dpp') > 1000 and 'v_max_f32_dpp' in text
+
+
+ACROSS_BRANCH = """_Z3kerPf: ; @_Z3kerPf
+\tv_mul_f32_e32 v3, v1, v2
+\tv_mov_b32_e32 v5, v3
+\ts_cbranch_vccz .LBB0_2
+\tv_add_f32_e32 v7, v1, v2
+\tv_add_f32_e32 v8, v1, v2
+\tv_add_f32_e32 v9, v1, v2
+.LBB0_2:
+\tv_fmac_f32_dpp v6, v5, v4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+\ts_endpgm
+"""
+
+
+def test_checker_follows_branches(tmp_path):
+    # the write is two instructions (one wait state: the branch) in front of the read on the TAKEN path, four on the fall-through path
+    p = _run(ACROSS_BRANCH, tmp_path, 'branch.s')
+    assert p.returncode == 1 and 'v_mov_b32_e32 v5, v3' in p.stdout, p.stdout
+    ok = ACROSS_BRANCH.replace("\ts_cbranch_vccz", "\ts_nop 0\n\ts_cbranch_vccz")
+    assert _run(ok, tmp_path, 'branch_ok.s').returncode == 0

@@ -2,15 +2,17 @@
 """Static check of a `hipcc -S` listing for the gfx9 hazard the hand-written DPP statements have to respect themselves: a VGPR written by a VALU
 instruction may be read through DPP (src0 of a *_dpp instruction) only two wait states later.  Inline asm is opaque to the compiler's hazard
 recogniser, and the register allocator may put a copy right in front of an asm statement -- behind the s_nop that was meant to cover it.
-usage: tools/check_dpp_hazards.py build_dbg/dl_kernels.s [substring of a kernel name]      (exit code 1 if a violation is found)
-Straight-line check per basic block (a label resets the window: a branch target's predecessors are not followed, so this can miss a
-hazard across a branch but reports no false ones)."""
+usage: tools/check_dpp_hazards.py <listing.s> [substring of a kernel name]      (exit code 1 if a violation is found)
+Paths: the straight-line window inside a basic block, carried over a label on the fall-through path and -- two passes -- from the tail of every
+block that branches to the label (s_branch / s_cbranch_* with a label operand).  Only the last instructions of a predecessor block are looked at
+(a predecessor shorter than the hazard window does not inherit from its own predecessors)."""
 import re
 import sys
 
 path = sys.argv[1]
 key = sys.argv[2] if len(sys.argv) > 2 else ''
 REG = re.compile(r'^v(\d+)$|^v\[(\d+):(\d+)\]$')
+NEED = 2            # wait states between the VALU write and the DPP read
 
 
 def regs(tok):
@@ -22,47 +24,98 @@ def regs(tok):
     return set(range(int(m.group(2)), int(m.group(3)) + 1))
 
 
-bad = 0
-kernel = None
-window = []          # [(wait states this instruction occupies, set of VGPRs it writes, text)]
-for ln, raw in enumerate(open(path), 1):
-    l = raw.split(';')[0].strip()
-    if raw.startswith('_Z') and raw.rstrip().endswith(':') or (raw.startswith('_Z') and ': ' in raw):
-        kernel = raw.split(':')[0]
-        window = []
-        continue
-    if not l or l.startswith('.') or l.startswith(';'):
-        if l.endswith(':') or l.startswith('.LBB'):
-            window = []
-        continue
-    if l.endswith(':'):
-        window = []
-        continue
-    if kernel is None or key not in kernel:
-        continue
+def parse(lines):
+    """-> {kernel: [(line number, kind, payload)]}, kind in 'label' / 'ins'"""
+    kernels, cur, name = {}, None, None
+    for ln, raw in enumerate(lines, 1):
+        if raw.startswith('_Z') and ':' in raw and not raw.startswith('\t'):
+            name = raw.split(':')[0]
+            cur = kernels.setdefault(name, [])
+            continue
+        if cur is None:
+            continue
+        if raw.startswith('.Lfunc_end'):
+            cur = None
+            continue
+        l = raw.split(';')[0].strip()
+        if not l:
+            continue
+        if l.endswith(':'):
+            cur.append((ln, 'label', l[:-1]))
+            continue
+        if l.startswith('.'):
+            continue
+        cur.append((ln, 'ins', l))
+    return kernels
+
+
+def effect(l):
+    """(wait states, VGPRs written by a VALU instruction) of one instruction"""
     op, _, rest = l.partition(' ')
     ops = [o.strip() for o in rest.split(',')] if rest else []
-    if '_dpp' in op or re.search(r'\b(row_|quad_perm|wave_)', l):
-        # src0 is operand 1 (dst, src0[, src1]); modifiers trail the last operand separated by spaces
-        if len(ops) >= 2:
-            src = regs(ops[1].split(' ')[0])
-            need = 2
-            for ws, w, text in reversed(window):
-                if need <= 0:
-                    break
-                if src & w:
-                    print(f'{path}:{ln}: {kernel[:60]}: `{l}` reads v{sorted(src & w)} through DPP {2 - need} wait state(s) after `{text}`')
-                    bad += 1
-                    break
-                need -= ws
     if op == 's_nop':
-        window.append((int(ops[0], 0) + 1, set(), l))
-    elif op.startswith('v_') and ops and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
-        window.append((1, regs(ops[0].split(' ')[0]), l))
-    elif op.startswith(('s_cbranch', 's_branch', 's_setpc', 's_endpgm')):
-        window = []
-    else:
-        window.append((1, set(), l))
-    window = window[-4:]
-print(f'{bad} DPP read-after-write hazard(s)')
-sys.exit(1 if bad else 0)
+        return int(ops[0], 0) + 1, set()
+    if op.startswith('v_') and ops and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
+        return 1, regs(ops[0].split(' ')[0])
+    return 1, set()
+
+
+def dpp_src(l):
+    op, _, rest = l.partition(' ')
+    if '_dpp' not in op and not re.search(r'\b(row_|quad_perm|wave_)', l):
+        return None
+    ops = [o.strip() for o in rest.split(',')]
+    return regs(ops[1].split(' ')[0]) if len(ops) >= 2 else None
+
+
+def check(name, items, report):
+    bad = 0
+    tails = {}                      # label -> [window at a branch to it]
+    for final in (False, True):
+        window, fall = [], True     # window: [(wait states, written VGPRs, text)] most recent last
+        entry = [[]]                # the windows a block may start with
+        for ln, kind, l in items:
+            if kind == 'label':
+                entry = ([list(window)] if fall else []) + [list(w) for w in tails.get(l, [])]
+                if not entry:
+                    entry = [[]]
+                window, fall = [], True
+                continue
+            src = dpp_src(l)
+            if final and src:
+                for pre in entry:
+                    need = NEED
+                    for ws, w, text in reversed(pre + window):
+                        if need <= 0:
+                            break
+                        if src & w:
+                            report(f'{path}:{ln}: {name[:60]}: `{l}` reads v{sorted(src & w)} through DPP {NEED - need} wait state(s) after `{text}`')
+                            bad += 1
+                            need = -1
+                            break
+                        need -= ws
+                    if need == -1:
+                        break
+            ws, w = effect(l)
+            window = (window + [(ws, w, l)])[-(NEED + 1):]
+            op = l.split(' ')[0]
+            if op.startswith(('s_cbranch', 's_branch')):
+                tgt = l.split(' ')[-1].strip()
+                if not final:
+                    tails.setdefault(tgt, []).append(list(window))
+                if op == 's_branch':
+                    fall = False
+            elif op.startswith(('s_setpc', 's_endpgm')):
+                fall = False
+            if sum(x[0] for x in window) >= NEED and len(window) >= NEED:
+                entry = [[]]        # the block is long enough: its predecessors no longer matter
+    return bad
+
+
+kernels = parse(open(path).read().split('\n'))
+total = 0
+for name, items in kernels.items():
+    if key in name:
+        total += check(name, items, print)
+print(f'{total} DPP read-after-write hazard(s)')
+sys.exit(1 if total else 0)
