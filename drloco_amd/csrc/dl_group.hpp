@@ -1434,9 +1434,15 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
     constexpr int MAXROW = Ld::MAXROW;
     long long t_last = 0;
     if constexpr (TIMED) t_last = DL_CLOCK();
+#ifdef DL_EXP_FINE        // diagnostics: the first phase of the Newton loop in three parts (2 row phase, 3 J^T f + Hessian, 4 reductions + exit test), the rest lumped into 5
     auto tick = [&](int k) {
-        if constexpr (TIMED) { const long long t = DL_CLOCK(); tacc[k] += t - t_last; t_last = t; }
+        if constexpr (TIMED) { const long long t = DL_CLOCK(); const int kk = k < 2 ? k : (k == 2 ? 4 : (k >= 10 ? k - 8 : 5)); tacc[kk] += t - t_last; t_last = t; }
     };
+#else
+    auto tick = [&](int k) {
+        if constexpr (TIMED) { if (k < 10) { const long long t = DL_CLOCK(); tacc[k] += t - t_last; t_last = t; } }
+    };
+#endif
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     GKin<T> kin;
@@ -1565,6 +1571,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             st4(rTM + 4 * cc, onf[0], onf[1], onf[2], onf[3]);
         }
         g_sync<T>();
+        tick(10);
         // ---- J^T f and the Hessian rows (dof lanes; the lane's Jacobian column of contact cc is one 16-byte read)
         T fcx[NXA];
         static_for<NX>([&](auto ti) { fcx[ti.value] = T(0); });
@@ -1609,6 +1616,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
                 }
             }
         }
+        tick(11);
         const T grad = Ma - smooth - fcon;
         T gradx[NXA];
         T r3[3] = {c, grad * grad, dl_abs(Ma) + dl_abs(smooth) + dl_abs(fcon)};
