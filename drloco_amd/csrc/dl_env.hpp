@@ -26,6 +26,7 @@ enum {
     MON_INIT_POS, MON_ET_POS, MON_TOR_LAST, MON_DIFFICULT, MON_WORDS
 };
 
+constexpr int DL_DBG_EVALS = 40;      // evaluations per control step the diagnostics record (4 x frame_skip: 20 / 40)
 template <typename T> struct DevState {
     T *qpos, *qvel, *warm;   // [NV][N]
     T* comz_off;             // [N]
@@ -41,7 +42,7 @@ template <typename T> struct DevState {
     // (k + push_phase[w]) % push_period < push_dur, k = push_step0 + step inside the launch (counted by the handle)
     const int32_t* push_phase;
     int32_t push_period, push_dur, push_step0;
-    float* dbgf;             // [3*16][N] or NULL: stage input (q, v, solver start) of the last evaluation with >= dbg_cap iterations
+    float* dbgf;             // [3*16 + DL_DBG_EVALS][N] or NULL: stage input (q, v, solver start) of the last evaluation with >= dbg_cap iterations; Newton iterations per evaluation of the last control step
     int dbg_cap;             // default: the iteration cap of the model (env DL_DEBUG_CAP_ITERS overrides; diagnostics)
     int32_t* dbg;            // [4][N] or NULL: solver diagnostics of the 16-lane step kernel (sum iters, max iters, sum rows, diverged)
     // fault word of the handle (host-pinned, written by the device with system scope; NULL = none): a wave of a split workgroup that leaves a

@@ -323,8 +323,10 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
                 if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
-                if (st.dbgf && valid && ni >= st.dbg_cap) {
-                    st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)start;
+                if (st.dbgf && valid) {
+                    if (ni >= st.dbg_cap) { st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)start; }
+                    // Newton iterations of this walker in evaluation (kf, stage) of the launch's last control step (tools/diag_lockstep.py)
+                    if (j == 0 && 4 * kf + stage < DL_DBG_EVALS) st.dbgf[(size_t)(48 + 4 * kf + stage) * n + w] = (float)ni;
                 }
                 if (simulate && !exc) { warm = acc; warmx = accx; }
                 if (stage == 0 && simulate && !exc) {     // mj_checkAcc

@@ -925,6 +925,7 @@ struct dl_env_s {
     virtual int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t) = 0;
     virtual int counters(int32_t* out, int clear, hipStream_t) = 0;
     virtual int capstate(float* out, hipStream_t) = 0;
+    virtual int eval_iters(float* out, hipStream_t) = 0;
     virtual int last_ctrl(float* out, hipStream_t) = 0;
     virtual int set_split(int on) = 0;
     virtual int rollout_prof(long long* out, hipStream_t s) = 0;
@@ -1205,7 +1206,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int counters(int32_t* out, int clear, hipStream_t s) override {
         if (!st.dbg) {
-            int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; if ((rc = dalloc(&st.dbgf, (size_t)48 * n))) return rc;
+            int rc; if ((rc = dalloc(&st.dbg, (size_t)4 * n))) return rc; if ((rc = dalloc(&st.dbgf, (size_t)(48 + DL_DBG_EVALS) * n))) return rc;
             const char* e = getenv("DL_DEBUG_CAP_ITERS");
             st.dbg_cap = e ? atoi(e) : (int)m.iterations;
         }
@@ -1326,6 +1327,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int capstate(float* out, hipStream_t s) override {
         if (!st.dbgf || !out) return fail(DL_E_INVAL, "dl_debug_capstate: enable the counters first");
         HIPCHK(hipMemcpyAsync(out, st.dbgf, (size_t)48 * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
+    }
+    int eval_iters(float* out, hipStream_t s) override {
+        if (!st.dbgf || !out) return fail(DL_E_INVAL, "dl_debug_eval_iters: enable the counters first");
+        HIPCHK(hipMemcpyAsync(out, st.dbgf + (size_t)48 * n, (size_t)DL_DBG_EVALS * n * sizeof(float), hipMemcpyDeviceToDevice, s));
         return DL_OK;
     }
     int inject(const void* q, const void* v, const int32_t* flags, const int32_t* rsi, hipStream_t s) override {
@@ -1492,6 +1498,12 @@ int dl_debug_selftest(const float* in, float* out, void* stream) {
 int dl_debug_capstate(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->capstate(out, (hipStream_t)stream);
+}
+/* float[DL_DBG_EVALS = 40, N] device: Newton iterations of every walker in the forward evaluations (4 per mj_step) of the last control step
+ * (16-lane step kernels, after dl_debug_counters has enabled the diagnostics) */
+int dl_debug_eval_iters(dl_handle h, float* out, void* stream) {
+    NEED(h);
+    return h->eval_iters(out, (hipStream_t)stream);
 }
 /* sim.data.ctrl as the last dl_step set it (after _rescale_actions and mirror_action): float[N, nu] device; the first call
  * (out may be NULL) enables the record */

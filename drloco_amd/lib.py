@@ -122,6 +122,7 @@ _EXTRA = {
     'dl_debug_rollout_prof': (C.c_int, [_V, _P, _P]),
     'dl_debug_set_grid_spin': (C.c_int, [_V, _I]),
     'dl_debug_capstate': (C.c_int, [_V, _P, _P]),
+    'dl_debug_eval_iters': (C.c_int, [_V, _P, _P]),
     'dl_debug_last_ctrl': (C.c_int, [_V, _P, _P]),
     'dl_debug_selftest': (C.c_int, [_P, _P, _P]),
     'dl_debug_forward_timed': (C.c_int, [_V, _P, _P, _P, _P]),

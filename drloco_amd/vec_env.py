@@ -317,6 +317,13 @@ class HipVecEnv(_VecEnvBase):
         lib.check(self._lib.dl_debug_capstate(self._h, _ptr(out), _stream()))
         return out.cpu().numpy()
 
+    def debug_eval_iters(self):
+        """Newton iterations of every walker in the 4 x frame_skip forward evaluations of the last control step: int [evals, N]
+        (16-lane kernels, after debug_counters() has enabled the diagnostics; tools/diag_lockstep.py)."""
+        out = torch.zeros(40, self.num_envs, device=self.device)
+        lib.check(self._lib.dl_debug_eval_iters(self._h, _ptr(out), _stream()))
+        return out[:4 * self.model.frame_skip].cpu().numpy().astype(np.int32)
+
     def debug_last_ctrl(self):
         """sim.data.ctrl of the last step() (after _rescale_actions / mirror_action), float32 [N, nu]; the first call enables
         the record (and returns zeros)."""
