@@ -28,6 +28,7 @@ DL_CUR_WORDS = 9
 EVAL_N_TIMES = 20        # drloco/config/config.py:23
 DL_ROLLOUT_PERSISTENT, DL_ROLLOUT_MOMENTS_PER_ROLLOUT = 1, 2
 DL_OK, DL_E_INVAL, DL_E_NODEVICE, DL_E_HIP, DL_E_NOMEM, DL_E_FAULT = 0, -1, -2, -3, -4, -5
+DL_FAULT_DYN_TIMEOUT, DL_FAULT_SRV_TIMEOUT, DL_FAULT_GRID_TIMEOUT = 1, 2, 4          # bits of the fault word (dl_fault_check)
 
 _d, _i = C.c_double, C.c_int32
 

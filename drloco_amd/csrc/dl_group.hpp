@@ -50,9 +50,7 @@
 #endif
 #define DL_FAULT_OR(p, code) __hip_atomic_fetch_or((p), (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #endif
-// reasons in a handle's fault word (include/drloco_hip.h: dl_fault_check)
-#define DL_FAULT_DYN_TIMEOUT 1      // a dynamics wave gave up waiting for its constraint wave
-#define DL_FAULT_SRV_TIMEOUT 2      // a constraint wave gave up waiting for a request
+// (the reasons in a handle's fault word, DL_FAULT_*: include/drloco_hip.h)
 
 #include <type_traits>
 

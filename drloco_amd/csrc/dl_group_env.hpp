@@ -325,8 +325,8 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
                 if (st.dbgf && valid) {
                     if (ni >= st.dbg_cap) { st.dbgf[(size_t)j * n + w] = (float)qs; st.dbgf[(size_t)(16 + j) * n + w] = (float)vs; st.dbgf[(size_t)(32 + j) * n + w] = (float)start; }
-                    // Newton iterations of this walker in evaluation (kf, stage) of the launch's last control step (tools/diag_lockstep.py)
-                    if (j == 0 && 4 * kf + stage < DL_DBG_EVALS) st.dbgf[(size_t)(48 + 4 * kf + stage) * n + w] = (float)ni;
+                    // Newton iterations and constraint rows of this walker in evaluation (kf, stage) of the launch's last control step: iterations + 128 rows
+                    if (j == 0 && 4 * kf + stage < DL_DBG_EVALS) st.dbgf[(size_t)(48 + 4 * kf + stage) * n + w] = (float)(ni + 128 * ne);
                 }
                 if (simulate && !exc) { warm = acc; warmx = accx; }
                 if (stage == 0 && simulate && !exc) {     // mj_checkAcc

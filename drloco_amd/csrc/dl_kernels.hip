@@ -635,7 +635,6 @@ __global__ __launch_bounds__(128) void k_vn_merge_sums(const double* __restrict_
 // bumps a relaxed agent-scope counter; consumers poll that counter relaxed, from one lane.  Counters are
 // monotonic over the steps of a launch (epoch = step + 1) and zeroed by the host before every launch.  Every poll is bounded: a timeout
 // sets the handle's fault word (DL_FAULT_GRID_TIMEOUT) and ends the workgroup.
-#define DL_FAULT_GRID_TIMEOUT 4
 struct RolloutP {
     dl_policy_params pol;
     uint64_t seed, counter0;
@@ -1499,8 +1498,8 @@ int dl_debug_capstate(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->capstate(out, (hipStream_t)stream);
 }
-/* float[DL_DBG_EVALS = 40, N] device: Newton iterations of every walker in the forward evaluations (4 per mj_step) of the last control step
- * (16-lane step kernels, after dl_debug_counters has enabled the diagnostics) */
+/* float[DL_DBG_EVALS = 40, N] device: Newton iterations + 128 x constraint rows of every walker in the forward evaluations (4 per mj_step) of the
+ * last control step (16-lane step kernels, after dl_debug_counters has enabled the diagnostics) */
 int dl_debug_eval_iters(dl_handle h, float* out, void* stream) {
     NEED(h);
     return h->eval_iters(out, (hipStream_t)stream);

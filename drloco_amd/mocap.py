@@ -14,10 +14,17 @@ import numpy as np
 
 from . import abi
 
-# row indices of the constant-speed file (38 rows): straight_walk_trajecs.py:59-91
-_QPOS_ROWS = [0, 1, 2, 35, 36, 37, 8, 7, 9, 10, 12, 11, 13, 14]
+# row indices of the two file layouts (straight_walk_trajecs.py:59-91): the trunk's Euler angles are rows 35-37 of the 38-row
+# constant-speed file and rows 37-39 of the 40-row speed-ramp file (the reference's default PATH_REF_TRAJECS, :22-27), where the two
+# ground-reaction-force rows sit at 35-36; everything else is shared
+_TRUNK_EULER_ROW0 = {38: 35, 40: 37}
 _QVEL_ROWS = [15, 16, 17, 18, 19, 20, 22, 21, 23, 24, 26, 25, 27, 28]
 _KNEE_VEL_R, _KNEE_VEL_L, _COM_VEL_X = 23, 27, 15
+
+
+def _qpos_rows(n_rows):
+    e = _TRUNK_EULER_ROW0[n_rows]
+    return [0, 1, 2, e, e + 1, e + 2, 8, 7, 9, 10, 12, 11, 13, 14]
 
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 DEFAULT_TABLE = os.path.join(DATA_DIR, 'straight_walk_const400.npz')
@@ -108,23 +115,26 @@ def _sequential_mean(row):
 
 
 def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200, mirror_refs=False):
-    """Trajecs_Constant_Speed_400Hz.mat -> RefTable.  mirror_refs: StraightWalkingTrajectories(mirror_refs=True)
-    (straight_walk_trajecs.py:98-116): applied after the step velocities and the left-step indices were computed from
-    the recorded data, exactly as the reference orders it."""
+    """Trajecs_Constant_Speed_400Hz.mat (38 rows per step) or Trajecs_Ramp_Slow_400Hz_EulerTrunkAdded.mat (40 rows per step: the
+    reference's default file, straight_walk_trajecs.py:22-27; any number of steps) -> RefTable.  mirror_refs:
+    StraightWalkingTrajectories(mirror_refs=True) (straight_walk_trajecs.py:98-116): applied after the step velocities and the
+    left-step indices were computed from the recorded data, exactly as the reference orders it."""
     import scipy.io as spio
-    steps = spio.loadmat(mat_path, squeeze_me=True)['Data'].flatten()
-    if steps[0].shape[0] != 38:
-        raise ValueError('only the 38-row constant-speed layout is supported')
+    raw = spio.loadmat(mat_path, squeeze_me=True)['Data'].flatten()
+    n_rows = raw[0].shape[0]
+    if n_rows not in _TRUNK_EULER_ROW0 or any(s.shape[0] != n_rows for s in raw):
+        raise ValueError(f'{mat_path}: {n_rows} rows per step; the reference defines the 38-row (constant speed) and the 40-row (speed ramp, GRF rows 35-36) layouts')
     stride = sample_freq / control_freq
     if stride != int(stride):
         raise ValueError('sample frequency must be an integer multiple of the control frequency')
-    steps = [np.asarray(s, dtype=np.float64) for s in steps]
+    steps = [np.asarray(s, dtype=np.float64) for s in raw]
     lens = [s.shape[1] for s in steps]
     off = np.concatenate([[0], np.cumsum(lens)])
-    table = np.concatenate([s[_QPOS_ROWS + _QVEL_ROWS, :] for s in steps], axis=1)
+    table = np.concatenate([s[_qpos_rows(n_rows) + _QVEL_ROWS, :] for s in steps], axis=1)
     is_left = [int(np.max(s[_KNEE_VEL_L]) > np.max(s[_KNEE_VEL_R])) for s in steps]
-    # the reference's arrays are dtype=object, so its np.mean adds left to right: do the same
-    vel = np.array([_sequential_mean(s[_COM_VEL_X]) for s in steps])
+    # _calculate_walking_speed (:393-415) calls np.mean on the rows as loadmat returns them: the reference's files hold every sample as a 1 x 1
+    # cell, i.e. dtype=object arrays, whose mean adds left to right; a file with plain float matrices gets numpy's pairwise sum
+    vel = np.array([_sequential_mean(s[_COM_VEL_X]) if r.dtype == object else float(np.mean(s[_COM_VEL_X])) for r, s in zip(raw, steps)])
     for t in range(1, len(vel)):
         vel[t] = 0.2 * vel[t] + 0.8 * vel[t - 1]
     for s in steps:
@@ -132,6 +142,58 @@ def convert_straight_walk_mat(mat_path, sample_freq=400, control_freq=200, mirro
             raise ValueError('COM-x of every step must start at 0 (straight_walk_trajecs.py:343)')
     ref = RefTable(table, off, is_left, vel, int(stride))
     return ref.mirrored() if mirror_refs else ref
+
+
+def synthetic_straight_walk(n_steps=250, seed=0, n_rows=40, len_lo=56, len_hi=84, sample_freq=400.0):
+    """Synthetic stand-in for the missing Trajecs_Ramp_Slow_400Hz_EulerTrunkAdded.mat (.MISSING_LARGE_BLOBS:2) in the reference's
+    step-segmented schema: a list of n_steps float64 arrays (n_rows, len_i) with the row meaning of straight_walk_trajecs.py:29-91 --
+    COM-x starting at 0 in every step, a walking speed that ramps over the steps (0.7 -> 1.3 m/s with noise), alternating swing legs
+    (the swing knee is the faster one), distinct values in the GRF rows (35-36) and the trunk's Euler rows (37-39) so that a wrong row
+    map shows.  Steps are shorter than real ones (56-84 samples instead of ~260) to keep the fixture small."""
+    rng = np.random.default_rng(seed)
+    steps = []
+    for i in range(n_steps):
+        L = int(rng.integers(len_lo, len_hi + 1))
+        t = np.arange(L) / sample_freq
+        u = np.arange(L) / L
+        s = np.zeros((n_rows, L))
+        speed = 0.7 + 0.6 * i / max(1, n_steps - 1) + 0.05 * rng.standard_normal()
+        left = (i % 2 == 1) != (i % 17 == 16)       # mostly alternating; now and then a side repeats (the list is data, not parity); step 0 is a right step
+        vx = speed * (1 + 0.1 * np.sin(2 * np.pi * u + rng.uniform(0, 6.28)))
+        s[15] = vx; s[0] = np.concatenate([[0.0], np.cumsum(vx[:-1]) / sample_freq])
+        s[1] = 0.03 * np.sin(2 * np.pi * u) * (1 if left else -1); s[16] = 0.03 * 2 * np.pi / (L / sample_freq) * np.cos(2 * np.pi * u) * (1 if left else -1)
+        s[2] = 1.05 + 0.02 * np.cos(4 * np.pi * u); s[17] = -0.02 * 4 * np.pi / (L / sample_freq) * np.sin(4 * np.pi * u)
+        q = rng.standard_normal(4) * 0.02 + np.array([1, 0, 0, 0]); s[3:7] = (q / np.linalg.norm(q))[:, None]
+        for r in range(7, 15):
+            a, ph = rng.uniform(0.05, 0.4), rng.uniform(0, 6.28)
+            s[r] = a * np.sin(2 * np.pi * u + ph); s[r + 14] = a * 2 * np.pi / (L / sample_freq) * np.cos(2 * np.pi * u + ph)
+        s[18:21] = 0.2 * rng.standard_normal((3, 1)) * np.cos(2 * np.pi * u)[None, :]
+        # the swing knee moves faster: the left-step list is computed from these two rows (:221-230)
+        s[_KNEE_VEL_R] *= 0.5; s[_KNEE_VEL_L] *= 0.5
+        s[_KNEE_VEL_L if left else _KNEE_VEL_R] += 3.0 * np.sin(np.pi * u)
+        s[29:35] = 0.1 * rng.standard_normal((6, 1)) + 0.01 * np.sin(2 * np.pi * u)[None, :]
+        e = _TRUNK_EULER_ROW0[n_rows]
+        if n_rows == 40:
+            s[35] = 800.0 * np.sin(np.pi * u) * (0 if left else 1); s[36] = 800.0 * np.sin(np.pi * u) * (1 if left else 0)
+        s[e:e + 3] = 0.05 * rng.standard_normal((3, 1)) + 0.03 * np.sin(2 * np.pi * u + 1.0)[None, :] * np.array([[1.0], [0.5], [-0.7]])
+        steps.append(s)
+    return steps
+
+
+def write_straight_walk_mat(path, steps, nested=True):
+    """Write step arrays in the reference's file schema: 'Data' = a 1 x n MATLAB cell array of steps.  nested=True stores every sample as
+    a 1 x 1 cell, as the reference's own files do (loadmat then returns dtype=object arrays and numpy reductions on them add left to
+    right); nested=False stores plain double matrices."""
+    import scipy.io as spio
+    data = np.empty((1, len(steps)), dtype=object)
+    for i, s in enumerate(steps):
+        if nested:
+            o = np.empty(s.shape, dtype=object)
+            o[...] = s
+            data[0, i] = o
+        else:
+            data[0, i] = np.asarray(s, np.float64)
+    spio.savemat(path, {'Data': data}, do_compression=True)
 
 
 # loco3d: rows of angJoi / angDJoi used by MimicWalker165cm65kg (mimic_walker_165cm_65kg.py:6-15,

@@ -42,7 +42,9 @@ class HipRolloutBuffer:
         policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]: the normalised observation and episode-start flags that
         open this rollout -- overwritten with the ones that open the next (SB3's _last_obs / _last_episode_starts).
         persistent: True = ONE launch for the whole rollout (a persistent workgroup per sixteen walkers, one grid-wide exchange per control
-        step; straight walker, float32, <= 16 walkers per CU), False = three launches per control step, None = persistent where it exists.
+        step; straight walker, float32, <= 16 walkers per CU; needs the GPU to itself -- the call waits for the launch and raises DrlocoFault if
+        the exchange timed out), False = three launches per control step, None = persistent where it exists, falling back to the launch form
+        (walkers reset, moments restored, a warning) if the exchange times out.
         moments: 'per_step' (SB3's semantics, default) or 'per_rollout' (opt-in relaxation, persistent form only: the whole rollout is
         normalised with the moments at its start, which are advanced once, by all T x N samples, at its end -- include/drloco_hip.h)."""
         if moments not in ('per_step', 'per_rollout'):
@@ -71,14 +73,45 @@ class HipRolloutBuffer:
         self.episode_starts[0].copy_(last_done)
         p, st = policy._params(), vn.state_struct()
         ok = bool(self._lib.dl_rollout_persistent_ok(vn.venv._h, C.byref(p)))
-        if persistent is None:
-            persistent = ok
+        auto = persistent is None
+        if auto:
+            persistent = ok and not getattr(self, '_persistent_off', False)
         if moments == 'per_rollout' and not persistent:
             raise lib.DrlocoError("moments='per_rollout' exists in the persistent form of collect_rollouts only")
-        mode = (abi.DL_ROLLOUT_PERSISTENT if persistent else 0) | (abi.DL_ROLLOUT_MOMENTS_PER_ROLLOUT if moments == 'per_rollout' else 0)
-        lib.check(self._lib.dl_collect_rollouts(vn.venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), self.T,
-                                                _ptr(self.observations), _ptr(self.actions), _ptr(self.values), _ptr(self.log_probs), _ptr(self.rewards),
-                                                _ptr(self.episode_starts), _ptr(last_obs), _ptr(last_done), _ptr(vn.venv.obs), _ptr(vn.venv.rew), mode, _stream()))
+
+        def launch(mode):
+            lib.check(self._lib.dl_collect_rollouts(vn.venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), self.T,
+                                                    _ptr(self.observations), _ptr(self.actions), _ptr(self.values), _ptr(self.log_probs), _ptr(self.rewards),
+                                                    _ptr(self.episode_starts), _ptr(last_obs), _ptr(last_done), _ptr(vn.venv.obs), _ptr(vn.venv.rew), mode, _stream()))
+        if persistent:
+            # The persistent kernel's grid-wide exchange needs every workgroup co-resident: the GPU has to be this launch's alone (include/drloco_hip.h).
+            # Another process or stream holding CUs makes the exchange time out; the kernel then sets the handle's fault word and stops writing -- the call
+            # itself has returned DL_OK long before.  So the rollout is complete only once the launch has finished with a clear fault word: wait and look
+            # (a rollout lasts tens of milliseconds; the learner needs it finished anyway) instead of handing a half-written buffer to the PPO update.
+            snap = [t.clone() for t in (vn.obs_rms._mean, vn.obs_rms._var, vn.obs_rms._count, vn.ret_rms._mean, vn.ret_rms._var, vn.ret_rms._count)] if auto else None
+            launch(abi.DL_ROLLOUT_PERSISTENT | (abi.DL_ROLLOUT_MOMENTS_PER_ROLLOUT if moments == 'per_rollout' else 0))
+            torch.cuda.current_stream().synchronize()
+            code = C.c_int32(0)
+            rc = self._lib.dl_fault_check(vn.venv._h, C.byref(code))
+            if rc == abi.DL_E_FAULT and auto and (code.value & abi.DL_FAULT_GRID_TIMEOUT) and moments == 'per_step':
+                # auto mode: the launch form needs no co-residency.  The half-advanced walkers are re-initialised, the moments restored to their state
+                # before the launch, and the rollout is redone in this process with three launches per control step; later rollouts stay on that form.
+                import warnings
+                warnings.warn('drloco_amd: the persistent rollout kernel timed out in its grid-wide exchange (is another process or stream using this GPU?); '
+                              'walkers reset, rollout redone with the launch form, which this buffer keeps using from now on')
+                lib.check(self._lib.dl_fault_clear(vn.venv._h))
+                for t, s0 in zip((vn.obs_rms._mean, vn.obs_rms._var, vn.obs_rms._count, vn.ret_rms._mean, vn.ret_rms._var, vn.ret_rms._count), snap):
+                    t.copy_(s0)
+                vn.reset()
+                last_obs.copy_(vn.norm_obs_t); last_done.fill_(1)
+                self.observations[0].copy_(last_obs); self.episode_starts[0].copy_(last_done)
+                self._persistent_off = True
+                persistent = False
+                launch(0)
+            else:
+                lib.check(rc)
+        else:
+            launch(0)
         policy.counter += self.T
         self.pos = self.T
         self.last_form = 'persistent' if persistent else 'launches'

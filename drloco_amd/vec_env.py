@@ -317,12 +317,13 @@ class HipVecEnv(_VecEnvBase):
         lib.check(self._lib.dl_debug_capstate(self._h, _ptr(out), _stream()))
         return out.cpu().numpy()
 
-    def debug_eval_iters(self):
+    def debug_eval_iters(self, rows=False):
         """Newton iterations of every walker in the 4 x frame_skip forward evaluations of the last control step: int [evals, N]
-        (16-lane kernels, after debug_counters() has enabled the diagnostics; tools/diag_lockstep.py)."""
+        (16-lane kernels, after debug_counters() has enabled the diagnostics; tools/diag_lockstep.py).  rows=True: (iterations, constraint rows)."""
         out = torch.zeros(40, self.num_envs, device=self.device)
         lib.check(self._lib.dl_debug_eval_iters(self._h, _ptr(out), _stream()))
-        return out[:4 * self.model.frame_skip].cpu().numpy().astype(np.int32)
+        v = out[:4 * self.model.frame_skip].cpu().numpy().astype(np.int32)
+        return (v % 128, v // 128) if rows else v % 128
 
     def debug_last_ctrl(self):
         """sim.data.ctrl of the last step() (after _rescale_actions / mirror_action), float32 [N, nu]; the first call enables

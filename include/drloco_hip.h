@@ -46,6 +46,10 @@ extern "C" {
 #define DL_E_HIP (-3)       /* a HIP runtime call failed */
 #define DL_E_NOMEM (-4)
 #define DL_E_FAULT (-5)     /* a kernel of this handle reported a fault (dl_fault_check): results since then are not a valid rollout */
+/* bits of the fault word (dl_fault_check) */
+#define DL_FAULT_DYN_TIMEOUT 1      /* a dynamics wave of a split workgroup gave up waiting for its constraint wave */
+#define DL_FAULT_SRV_TIMEOUT 2      /* a constraint wave of a split workgroup gave up waiting for a request */
+#define DL_FAULT_GRID_TIMEOUT 4     /* a workgroup of the persistent rollout kernel gave up waiting for the grid-wide exchange */
 
 /* environment kinds (the reference's env_map, drloco/mujoco/config.py:9-10) */
 #define DL_ENV_STRAIGHT 0
@@ -410,8 +414,12 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
  *       and VecNormalize's moment update through one grid-wide exchange.  Exact SB3 semantics (every step normalises with the moments of all
  *       walkers up to that step); bit-identical to mode 0 when `vn->flags` selects the blocked reduction order (bit 32) and dl_set_split is on.
  *       Needs: straight walker, float32, 16 lanes per walker, hidden = 512, at most 16 walkers per CU (4096 on an MI355X) -- query with
- *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  A grid exchange that does not complete within its (bounded, ~2 s) poll budget
- *       raises the handle's fault word (bit 4, dl_fault_check).
+ *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  EXCLUSIVE GPU: the grid-wide exchange needs every workgroup of the launch resident at
+ *       the same time (one per CU), so no other process, stream or handle may hold CUs while it runs -- dl_rollout_persistent_ok only checks the
+ *       walker count, it cannot see other users of the device.  A grid exchange that does not complete within its (bounded, ~2 s) poll budget raises
+ *       the handle's fault word (DL_FAULT_GRID_TIMEOUT = 4) and the workgroup stops: the call has returned DL_OK by then, so the caller must
+ *       synchronise with the stream and call dl_fault_check BEFORE it reads the buffers (drloco_amd.rollout.HipRolloutBuffer.collect_rollouts does,
+ *       and in its automatic mode clears the fault, resets the walkers and redoes the rollout with mode 0).
  *   DL_ROLLOUT_PERSISTENT | DL_ROLLOUT_MOMENTS_PER_ROLLOUT   opt-in relaxation: observations and rewards of the whole rollout are normalised
  *       with the moments at its START, workgroups exchange nothing during the rollout (they run free; a rollout lasts as long as its slowest
  *       workgroup's sum of steps), and ONE exact Chan merge of all T x N samples follows -- RunningMeanStd.update fed the rollout as one batch.

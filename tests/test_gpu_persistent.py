@@ -269,8 +269,8 @@ def test_grid_exchange_timeout_raises(torch_cuda, model, refs):
     from drloco_amd import abi, lib as L
     venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, 200, 6)
     L.check(venv._lib.dl_debug_set_grid_spin(venv._h, 0))
-    buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
-    torch.cuda.synchronize()
+    with pytest.raises(L.DrlocoFault):          # collect_rollouts waits for the persistent launch and looks at the fault word before anything reads the buffer
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
     code = C.c_int32(0)
     assert venv._lib.dl_fault_check(venv._h, C.byref(code)) == abi.DL_E_FAULT and (code.value & 4)
     assert b'grid-wide' in venv._lib.dl_last_error()
@@ -284,6 +284,34 @@ def test_grid_exchange_timeout_raises(torch_cuda, model, refs):
     torch.cuda.synchronize()
     L.check(venv._lib.dl_fault_check(venv._h, None))
     assert torch.isfinite(buf.observations).all() and (buf.rewards >= 0).all()
+    venv.close()
+
+
+def test_grid_exchange_timeout_falls_back_in_auto_mode(torch_cuda, model, refs):
+    """persistent=None (what examples/train_ppo.py uses): when the persistent kernel's grid-wide exchange times out (forced here; in the field: another
+    process or stream holding CUs) the SAME call clears the fault, restores the moments, resets the walkers and redoes the rollout with the launch
+    form -- the learner never sees a half-written buffer -- and the buffer stays on the launch form afterwards."""
+    torch = torch_cuda
+    import warnings
+    from drloco_amd import lib as L
+    n, T = 200, 6
+    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
+    count0, counter0 = vn.obs_rms.count, pol.counter
+    buf.observations.fill_(float('nan')); buf.rewards.fill_(float('nan'))
+    L.check(venv._lib.dl_debug_set_grid_spin(venv._h, 0))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        buf.collect_rollouts(vn, pol, last_obs, last_done)
+    torch.cuda.synchronize()
+    assert any('launch form' in str(x.message) for x in w) and buf.last_form == 'launches'
+    L.check(venv._lib.dl_fault_check(venv._h, None))                                   # the fault word is clear again
+    assert torch.isfinite(buf.observations).all() and torch.isfinite(buf.rewards).all() and (buf.episode_starts[0] == 1).all()     # every slot was written by the redo
+    assert vn.obs_rms.count == pytest.approx(count0 + n * T, abs=1e-9) and vn.ret_rms.count == pytest.approx(count0 + n * T, abs=1e-9)   # moments: restored, then T batches
+    assert pol.counter == counter0 + T
+    # the redone rollout is a regular launch-form rollout: replaying its recorded actions from the state the redo started from gives its rewards
+    L.check(venv._lib.dl_debug_set_grid_spin(venv._h, -1))
+    buf.collect_rollouts(vn, pol, last_obs, last_done)          # stays on the launch form
+    assert buf.last_form == 'launches' and vn.obs_rms.count == pytest.approx(count0 + 2 * n * T, abs=1e-9)
     venv.close()
 
 

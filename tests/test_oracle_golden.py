@@ -342,6 +342,61 @@ def test_G11_adapt_trajectories():
     assert not np.array_equal(plain.table, t.table)
 
 
+def test_G14_ramp_layout_table(ramp_refs):
+    """convert_straight_walk_mat on the 40-row layout == what the UNPATCHED reference module holds after loading the same file: table rows
+    (trunk Euler angles from rows 37-39, not the GRF rows), step lengths, left-step list, smoothed step velocities -- bit for bit."""
+    table, g = ramp_refs
+    assert table.n_steps == 250 and table.table.shape[0] == 28
+    assert np.array_equal(table.step_len, g['step_len'])
+    assert np.array_equal(np.nonzero(table.step_is_left)[0], g['left_step_indices'])
+    assert np.array_equal(table.step_vel, g['step_velocities'])
+    assert list(g['qpos_rows'][3:6]) == [37, 38, 39]
+    o = table.step_off
+    assert np.array_equal(table.table[:, :o[3]], g['table_head']) and np.array_equal(table.table[:, o[-3]:], g['table_tail'])
+    for i in range(table.n_steps):
+        blk = table.table[:, o[i]:o[i + 1]]
+        assert np.array_equal(blk.sum(axis=1), g['rowsum'][i]) and np.array_equal(np.abs(blk).sum(axis=1), g['rowabs'][i]), i
+    # the 38-row layout keeps working and a foreign layout is refused
+    from drloco_amd import mocap
+    import scipy.io as spio
+    with pytest.raises(ValueError, match='rows per step'):
+        p = os.path.join(os.path.dirname(GOLDEN), '_bad.mat')
+        try:
+            d = np.empty((1, 2), dtype=object); d[0, 0] = np.zeros((39, 10)); d[0, 1] = np.zeros((39, 10))
+            spio.savemat(p, {'Data': d})
+            mocap.convert_straight_walk_mat(p)
+        finally:
+            if os.path.exists(p):
+                os.remove(p)
+
+
+def test_G14_ramp_layout_cursor(oracle, model, ramp_refs):
+    """The oracle's cursor on the 250-step ramp table against the reference's own next() traces: step index, position, counter (quirk Q2),
+    phase, desired velocity (moving through changing step speeds and across the wrap after the last step), reference sample."""
+    table, g = ramp_refs
+    starts = g['starts']
+    K, T = g['i_step'].shape
+    env = make_env(oracle, model, table, n=K, ep_dur_max=10 ** 9)
+    env.set_state(cursor=cursor(starts[:, 0], starts[:, 1], starts[:, 2], n=K))
+    q_up = np.array(model.jnt_qpos0[:14])
+    for t in range(T):
+        for k in range(K):
+            env.inject_state(k, q_up, np.zeros(14))
+        obs, rew, done, _, _ = env.step(np.zeros((K, 8)))
+        assert not done.any()
+        st = env.get_state()['cursor']
+        assert np.array_equal(st[abi.DL_CUR_I_STEP], g['i_step'][:, t].astype(int)), t
+        assert np.array_equal(st[abi.DL_CUR_POS], g['pos'][:, t].astype(int)), t
+        assert np.array_equal(st[abi.DL_CUR_COUNT], g['count_same_vel'][:, t].astype(int)), t
+        assert np.array_equal(obs[:, 0], g['phase'][:, t]) and np.array_equal(obs[:, 1], g['desvel'][:, t]), t
+        assert np.array_equal(table.step_len[st[abi.DL_CUR_READ_STEP]], g['len'][:, t].astype(int))
+        assert np.array_equal(table.step_is_left[st[abi.DL_CUR_I_STEP]], g['is_left'][:, t].astype(int))
+        for k in range(K):
+            qr, vr = env.ref_lookup(k)
+            assert np.array_equal(qr, g['ref_qpos'][k, t]) and np.array_equal(vr, g['ref_qvel'][k, t]), (k, t)
+    assert len(set(g['desvel'].reshape(-1).tolist())) >= 5 and (g['i_step'][2] == 0).any() | (g['i_step'][2] == 1).any()
+
+
 def test_G13_hip3d_rows(oracle, model, refs):
     """StraightWalking3dHipTrajectories (straight_walk_hip3d_trajecs.py:8-19): the 16-value rows the class returns at a few cursors,
     from the oracle's reference lookup on the packaged table + mocap.hip3d_qpos / hip3d_qvel."""
