@@ -236,7 +236,8 @@ def adam_state_dict(policy, optimizer=None, lr=5e-4):
 def write_model_zip(policy, path, observation_space=None, action_space=None, optimizer=None, data=None, hyper=None):
     """The reference's `model.save(path)` (drloco/common/utils.py:175-192; callback.py:290) for a HipPolicy: SB3 1.0's save_to_zip_file
     layout.  observation_space / action_space: (low, high) pairs or objects with .low / .high (HipVecEnv's spaces); default: the straight
-    walker's.  hyper: PPO's scalar constructor arguments for `data` (defaults: the reference's, drloco/config/hypers.py)."""
+    walker's.  hyper: PPO's scalar constructor arguments for `data` (defaults: the reference's, drloco/config/hypers.py + train.py:110-118; `log_std_init`
+    is the policy's constructor value, `lr_start` / `lr_final` the end points of the reference's linear decay)."""
     sd = {}
     for k, name in _KEYS.items():
         sd[name] = getattr(policy, k).detach().cpu()
@@ -253,12 +254,19 @@ def write_model_zip(policy, path, observation_space=None, action_space=None, opt
         act_box, f2 = _gym_box(alo, ahi)
         pol_cls, f3 = _placeholder_class(*_POLICY_CLASS)
         fakes = [f1 or f2, f3]
-        h = dict(learning_rate=5e-4, gamma=0.995, gae_lambda=0.95, n_steps=4096, batch_size=2048, n_epochs=4, ent_coef=-0.0075, vf_coef=0.5, max_grad_norm=0.5,
-                 clip_range=0.15, n_envs=8, num_timesteps=0, seed=None, verbose=1, sde_sample_freq=-1, use_sde=False, target_kl=None, tensorboard_log=None)
+        # the reference's PPO(...) call (drloco/train.py:110-118 with drloco/config/hypers.py:68-116): n_steps = batch_size // n_envs = 16384 // 8,
+        # minibatch 2048, clip_range_vf = clip_range, learning rate = LinearDecay(lr_start = 5e-4 -> lr_final = 1e-6) of the remaining progress
+        # (drloco/common/schedules.py:16-27).  SB3 stores the schedule as a pickled callable; here its two end points travel as plain values
+        # (`lr_start`, `lr_final`) next to `learning_rate` = the value at the current progress, so that a resumed run can rebuild the decay.
+        h = dict(learning_rate=5e-4, lr_start=5e-4, lr_final=1e-6, gamma=0.995, gae_lambda=0.95, n_steps=2048, batch_size=2048, n_epochs=4, ent_coef=-0.0075, vf_coef=0.5,
+                 max_grad_norm=0.5, clip_range=0.15, clip_range_vf=0.15, n_envs=8, num_timesteps=0, seed=None, verbose=1, sde_sample_freq=-1, use_sde=False, target_kl=None,
+                 tensorboard_log=None, log_std_init=-0.75)
         h.update(hyper or {})
+        if (h['n_steps'] * h['n_envs']) % h['batch_size']:
+            raise ValueError(f"n_steps * n_envs = {h['n_steps'] * h['n_envs']} is not a multiple of the minibatch size {h['batch_size']} (SB3's PPO warns about a truncated last minibatch; the reference uses 2048 x 8 / 2048)")
         meta = dict(h)
         meta['policy_class'] = _serialized(pol_cls)
-        meta['policy_kwargs'] = dict(log_std_init=float(policy.log_std.detach().reshape(-1)[0]))
+        meta['policy_kwargs'] = dict(log_std_init=float(meta.pop('log_std_init')))          # the CONSTRUCTOR value (hypers.init_logstd), not the trained log_std (that is in policy.pth)
         meta['observation_space'] = _serialized(obs_box)
         meta['action_space'] = _serialized(act_box)
         meta.update(data or {})

@@ -31,21 +31,28 @@ class HipPolicy:
         self.wv, self.bv = linear(1, hidden)
         self.log_std = torch.full((act_dim,), float(log_std_init), device=device)
         self.seed, self.counter, self.index_base = int(seed), 0, int(index_base)
-        self._packed, self._packed_key = None, None
+        self._packed, self._packed_key, self._packed_stream = None, None, None
 
     def _packed_weights(self):
         """k-chunk-major copy of the weights for the stand-alone forward pass (hidden = 512), refreshed whenever a weight tensor was replaced
-        or written to (torch bumps `tensor._version` on every in-place update, e.g. an optimiser step)."""
+        (load_state) or written to (torch bumps `tensor._version` on every in-place update, e.g. an optimiser step) or the caller moved to
+        another stream (the copy is written and read in stream order: the key carries the stream, a repack waits for the last read)."""
         if self.hidden != 512:
             return None
         ws = (self.w1, self.w2, self.wa, self.wv)
-        key = tuple((t.data_ptr(), t._version) for t in ws)
-        if key != self._packed_key:
+        stream = torch.cuda.current_stream()
+        try:
+            key = tuple((t.data_ptr(), t._version) for t in ws) + (stream.cuda_stream,)
+        except RuntimeError:          # inference-mode tensors have no version counter: repack every time
+            key = None
+        if key is None or key != self._packed_key:
             if self._packed is None:
                 self._packed = torch.empty(512 * 512 + 48 * 512 + 16 * 512, device=self.w1.device)
+            if self._packed_stream is not None and self._packed_stream != stream:
+                stream.wait_stream(self._packed_stream)          # a forward pass on the other stream may still be reading the old copy
             p = self._params()
             lib.check(self._lib.dl_policy_pack(C.byref(p), _ptr(self._packed), _stream()))
-            self._packed_key = key
+            self._packed_key, self._packed_stream = key, stream
         return self._packed
 
     def invalidate_packed(self):
@@ -59,6 +66,7 @@ class HipPolicy:
         self.w1, self.b1, self.w2, self.b2, self.wa, self.ba, self.wv, self.bv, self.log_std = map(f, (w1, b1, w2, b2, wa, ba, wv, bv, log_std))
         self.hidden, self.obs_dim = self.w1.shape
         self.act_dim = self.wa.shape[0]
+        self._packed_key = None          # new tensors: the allocator may hand out an old address with a fresh version counter
 
     def _params(self):
         p = abi.PolicyParams()

@@ -111,17 +111,23 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
     if evaluate:
         # TrainingMonitor.eval_walking (drloco/common/callback.py:272-390): 20 deterministic episodes, here as one batch
         from drloco_amd.evaluation import evaluate_walking, make_eval_env
-        # history='training': the walkers' step counter is carried into the evaluation env (the reference's load_env starts a fresh one, whose
-        # desired-velocity observation the policy has not seen since its first thousand steps: drloco_amd/evaluation.py).  Episodes with an odd
-        # evaluation counter k start mirrored against the reference data they read (quirk Q3 of _get_deterministic_init_state) and fall.
-        res = evaluate_walking(make_eval_env(vn, history='training'), pol)
-        hist[-1]['evaluation'] = res
+        # Two protocols, both recorded: 'fresh' is the reference's (load_env builds a NEW environment, count_steps_same_vel = 1) and the
+        # reference-comparable headline; 'training' carries the training walkers' step counter into the evaluation env -- a fresh env's
+        # desired-velocity observation is one the policy has not seen since its first thousand steps (drloco_amd/evaluation.py).  Episodes with an
+        # odd evaluation counter k start mirrored against the reference data they read (quirk Q3 of _get_deterministic_init_state) and fall.
+        res = evaluate_walking(make_eval_env(vn, history='fresh'), pol)
+        res['history'] = 'fresh'
+        res_t = evaluate_walking(make_eval_env(vn, history='training'), pol)
+        res_t['history'] = 'training'
+        hist[-1]['evaluation'] = res                               # the reference's protocol
+        hist[-1]['evaluation_training_history'] = res_t            # NOT comparable with the reference's eval numbers
         if not quiet:
             import numpy as np
-            dist_k = np.array(res['moved_distances'])
-            print(f"evaluation (20 deterministic episodes, training step counter): mean distance {res['mean_walked_distance']:.1f} m (even k {dist_k[0::2].mean():.1f} m, odd k {dist_k[1::2].mean():.1f} m), "
-                  f"mean episode length {res['mean_episode_duration'] * 3000:.0f}, stable walks {res['count_stable_walks']}/20, "
-                  f"mean step reward (normalised) {res['mean_reward_means']:.2f}")
+            for r, label in ((res, "reference protocol: fresh env"), (res_t, "training step counter carried over -- not the reference's protocol")):
+                dist_k = np.array(r['moved_distances'])
+                print(f"evaluation (20 deterministic episodes, {label}): mean distance {r['mean_walked_distance']:.1f} m (even k {dist_k[0::2].mean():.1f} m, odd k {dist_k[1::2].mean():.1f} m), "
+                      f"mean episode length {r['mean_episode_duration'] * 3000:.0f}, stable walks {r['count_stable_walks']}/20, "
+                      f"mean step reward (normalised) {r['mean_reward_means']:.2f}")
     if save_path:
         # utils.save_model (drloco/common/utils.py:175-192): models/model_<ckpt>.zip (policy.pth under SB3 1.0's key names) + envs/env_<ckpt> (VecNormalize statistics)
         from drloco_amd import checkpoint

@@ -83,6 +83,7 @@ def test_model_zip_round_trips_through_sb3s_reader(tmp_path):
         from drloco.custom.policies import CustomActorCriticPolicy
         assert data['policy_class'] is CustomActorCriticPolicy and abs(data['policy_kwargs']['log_std_init'] + 0.75) < 1e-3
         assert data['gamma'] == 0.995 and data['n_envs'] == 128 and data['num_timesteps'] == 81920 and data['clip_range'] == 0.15
+        assert data['clip_range_vf'] == 0.15 and data['n_steps'] == 2048 and data['batch_size'] == 2048 and (data['lr_start'], data['lr_final']) == (5e-4, 1e-6)      # train.py:110-118
         sd = params['policy']
         order = ['log_std', 'mlp_extractor.policy_net.0.weight', 'mlp_extractor.policy_net.0.bias', 'mlp_extractor.policy_net.2.weight', 'mlp_extractor.policy_net.2.bias',
                  'action_net.weight', 'action_net.bias', 'value_net.weight', 'value_net.bias']
