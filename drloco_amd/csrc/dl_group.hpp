@@ -444,6 +444,11 @@ template <typename TP> struct GSplit {
     static constexpr int MMX = Ld::TOTAL;                        // M mirror [16][MS]
     static constexpr int MB = MMX + GL * Ld::MS;                 // mailbox
     static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_CMD = 67, MB_DONESEQ = 68, MB_SIZE = 96;      // (CMDSEQ, CMD): one aligned 8-byte word
+    // look-ahead of the mass matrix: MB_QN = the configuration of the NEXT evaluation (known when this one is requested); MB_MOK = sequence number of
+    // the request whose mass matrix is in the mirror block (posted by the partner once it has checked that what it precomputed is for this request's
+    // configuration); MB_MFREE = sequence number of the last request whose mass matrix the dynamics wave has taken into registers
+    static constexpr int MB_MOK = 69, MB_MFREE = 70, MB_QN = 72;
+    static_assert(MB_QN % 4 == 0 && MB_QN + GL <= MB_SIZE, "mailbox layout");
     static constexpr int TOTAL = MB + MB_SIZE;                   // per walker; 16 (mod 32) like GLds::TOTAL
     static_assert(TOTAL % 32 == 16 && MB % 4 == 0, "walker regions keep their bank offset");
     // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
@@ -749,7 +754,10 @@ template <typename T, typename TP> struct GSmooth {
 // The replicated root translations are ancestors of every lane: their velocity enters every twist, their composite
 // inertia / wrench is the whole walker's (the subtree of lane 0), M[j][t] = S_t . (Ic_j S_j) is one entry per lane.
 // Out: sm; kinematics in k; body frames (BFR) and rootz (MISC[0]) in LDS.
-template <typename T, typename TP, bool PUBLISH = true, bool HAVE_KIN = false>      // HAVE_KIN: the caller has run g_fk already (k is an input)
+// WITH_M = false (the dynamics wave of a split workgroup): the velocity-dependent half only -- bias, passive and applied forces (sm.smooth).  The
+// configuration-dependent half, the mass matrix, is the partner wave's (g_mass_rows), computed one evaluation AHEAD: inside RK4 the configuration of the
+// next stage depends on this stage's velocity only, which is known before this stage's constraint solve starts.
+template <typename T, typename TP, bool PUBLISH = true, bool HAVE_KIN = false, bool WITH_M = true>      // HAVE_KIN: the caller has run g_fk already (k is an input)
 __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, T v, T ctrl_force, const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx,
                                                   GKin<T>& k, GSmooth<T, TP>& sm) {
     using Ld = GLds<TP>;
@@ -804,13 +812,22 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
         F = {Ia.w + cross(vel.w, Iv.w) + cross(vel.v, Iv.v), Ia.v + cross(vel.w, Iv.v)};
     }
     // composite inertia and wrench of the subtree of dof j
-    T cs16[16] = {I.m, I.h.x, I.h.y, I.h.z, I.I.xx, I.I.xy, I.I.xz, I.I.yy, I.I.yz, I.I.zz, F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
-    g_subtree_sum_n<T, TP, 16>(cs16, j, lt);
     SI<T> Ic;
-    Ic.m = cs16[0]; Ic.h = mk<T>(cs16[1], cs16[2], cs16[3]);
-    Ic.I.xx = cs16[4]; Ic.I.xy = cs16[5]; Ic.I.xz = cs16[6]; Ic.I.yy = cs16[7]; Ic.I.yz = cs16[8]; Ic.I.zz = cs16[9];
-    const SV<T> W = {mk<T>(cs16[10], cs16[11], cs16[12]), mk<T>(cs16[13], cs16[14], cs16[15])};
+    SV<T> W;
+    if constexpr (WITH_M) {
+        T cs16[16] = {I.m, I.h.x, I.h.y, I.h.z, I.I.xx, I.I.xy, I.I.xz, I.I.yy, I.I.yz, I.I.zz, F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
+        g_subtree_sum_n<T, TP, 16>(cs16, j, lt);
+        Ic.m = cs16[0]; Ic.h = mk<T>(cs16[1], cs16[2], cs16[3]);
+        Ic.I.xx = cs16[4]; Ic.I.xy = cs16[5]; Ic.I.xz = cs16[6]; Ic.I.yy = cs16[7]; Ic.I.yz = cs16[8]; Ic.I.zz = cs16[9];
+        W = {mk<T>(cs16[10], cs16[11], cs16[12]), mk<T>(cs16[13], cs16[14], cs16[15])};
+    } else {
+        static_assert(WITH_M || NX == 0, "the velocity-only half is built for the lane-only walker");
+        T cs6[6] = {F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
+        g_subtree_sum_n<T, TP, 6>(cs6, j, lt);
+        W = {mk<T>(cs6[0], cs6[1], cs6[2]), mk<T>(cs6[3], cs6[4], cs6[5])};
+    }
     const T bias = sdot(S, W);
+    if constexpr (WITH_M) {
     const SV<T> f = si_mul(Ic, S);
     // M[j][a] = S_a . (Ic_j S_j) for the dofs a on the chain of j (incl. j) -- zero elsewhere by the chain mask -- is what the
     // lane can compute.  The lane writes this part of its row as four 16-byte groups, no per-entry predicates; after the
@@ -840,6 +857,16 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
     g_sync<T>();
 #pragma unroll
     for (int a = 0; a < GL; a++) sm.mrow[a] = (a < NL) ? ml[a] + g.mm[a * Ld::MS + j] : T(0);
+    if constexpr (NX > 0) {
+        static_assert(GTopo<TP>::rooted(), "lane 0 must be the root of the lane tree");
+        const T mtot = rbcast<0>(Ic.m);
+        static_for<NX>([&](auto ti) {
+            constexpr int t = ti.value, ax = TP::dof_axis(t);
+            sm.mxl[t] = isdof ? T(TP::dof_sign(t)) * vcomp<ax>(f.v) : T(0);
+            sm.mxx[t] = mtot + g.c->xs_armature[t];
+        });
+    }
+    }   // WITH_M
     // [3P] xfrc_applied on the torso (body 1): J^T of a world-frame force at its centre of mass
     T push_q = T(0);
     if (g.wk->pushed) {
@@ -849,20 +876,82 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
     }
     sm.smooth = isdof ? -ln.damping * v - bias + ctrl_force + push_q : T(0);
     if constexpr (NX > 0) {
-        static_assert(GTopo<TP>::rooted(), "lane 0 must be the root of the lane tree");
-        // total mass and wrench of the walker = composite quantities of lane 0
-        const T mtot = rbcast<0>(Ic.m);
+        // total wrench of the walker = composite wrench of lane 0 (the total mass: above, with M)
         const V3<T> Wv = mk<T>(rbcast<0>(W.v.x), rbcast<0>(W.v.y), rbcast<0>(W.v.z));
         static_for<NX>([&](auto ti) {
             constexpr int t = ti.value, ax = TP::dof_axis(t);
             const T sg = T(TP::dof_sign(t));
-            sm.mxl[t] = isdof ? sg * vcomp<ax>(f.v) : T(0);
-            sm.mxx[t] = mtot + g.c->xs_armature[t];
             T fs = -g.c->xs_damping[t] * vx.x[t] - sg * vcomp<ax>(Wv);
             if (g.wk->pushed) fs += sg * vcomp<ax>(g.wk->push);
             sm.smoothx[t] = fs;
         });
     }
+}
+
+// The configuration-dependent half of the smooth dynamics for the lane-only walker: [3P] mj_crb -- composite inertias (subtree sums) and
+// M[j][a] = S_a . (Ic_j S_j) -- from the kinematics `k` of the configuration.  Leaves the COMPLETE row j of M in g.mm (16-byte groups: M[j][0..15],
+// then mdiag, mcorr as g_smooth_dynamics defines them), i.e. performs the mirror exchange itself.  Run by the partner wave of a split workgroup.
+template <typename T, typename TP>
+__device__ __forceinline__ void g_mass_rows(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& k) {
+    using Ld = GLds<TP>;
+    constexpr int NL = GD<TP>::NL;
+    static_assert(GD<TP>::NX == 0 && Ld::MS >= GL + 2, "lane-only walker; two spare words per row of the mirror block");
+    const int j = g.j;
+    const auto& ln = *g.ln;
+    const bool isdof = j < NL;
+    SV<T> S;
+    {
+        const bool hinge = isdof && ln.type != 0, slide = isdof && ln.type == 0;
+        const V3<T> pa = cross(k.pos, k.axis);
+        S.w = mk<T>(hinge ? k.axis.x : T(0), hinge ? k.axis.y : T(0), hinge ? k.axis.z : T(0));
+        S.v = mk<T>(hinge ? pa.x : (slide ? k.axis.x : T(0)), hinge ? pa.y : (slide ? k.axis.y : T(0)), hinge ? pa.z : (slide ? k.axis.z : T(0)));
+    }
+    SI<T> I;
+    {
+        const T ms = (isdof && lt.last) ? g.wk->mscale : T(0);
+        const T mass = ms * ln.mass, i0 = ms * ln.inertia[0], i1 = ms * ln.inertia[1], i2 = ms * ln.inertia[2];
+        const V3<T>&X = k.X, &Y = k.Y, &Z = k.Z;
+        const V3<T> c = k.pos + ln.ipos[0] * X + ln.ipos[1] * Y + ln.ipos[2] * Z;
+        const T cc = dot(c, c);
+        I.m = mass; I.h = mass * c;
+        I.I.xx = i0 * X.x * X.x + i1 * Y.x * Y.x + i2 * Z.x * Z.x + mass * (cc - c.x * c.x);
+        I.I.yy = i0 * X.y * X.y + i1 * Y.y * Y.y + i2 * Z.y * Z.y + mass * (cc - c.y * c.y);
+        I.I.zz = i0 * X.z * X.z + i1 * Y.z * Y.z + i2 * Z.z * Z.z + mass * (cc - c.z * c.z);
+        I.I.xy = i0 * X.x * X.y + i1 * Y.x * Y.y + i2 * Z.x * Z.y - mass * c.x * c.y;
+        I.I.xz = i0 * X.x * X.z + i1 * Y.x * Y.z + i2 * Z.x * Z.z - mass * c.x * c.z;
+        I.I.yz = i0 * X.y * X.z + i1 * Y.y * Y.z + i2 * Z.y * Z.z - mass * c.y * c.z;
+    }
+    T cs10[10] = {I.m, I.h.x, I.h.y, I.h.z, I.I.xx, I.I.xy, I.I.xz, I.I.yy, I.I.yz, I.I.zz};
+    g_subtree_sum_n<T, TP, 10>(cs10, j, lt);
+    SI<T> Ic;
+    Ic.m = cs10[0]; Ic.h = mk<T>(cs10[1], cs10[2], cs10[3]);
+    Ic.I.xx = cs10[4]; Ic.I.xy = cs10[5]; Ic.I.xz = cs10[6]; Ic.I.yy = cs10[7]; Ic.I.yz = cs10[8]; Ic.I.zz = cs10[9];
+    const SV<T> f = si_mul(Ic, S);
+    T Sr[6] = {S.w.x, S.w.y, S.w.z, S.v.x, S.v.y, S.v.z};
+    g_dpp_ready_n<6>(Sr);
+    T ml[GL];
+#pragma unroll
+    for (int a = NL; a < GL; a++) ml[a] = T(0);
+    static_for<NL>([&](auto ai) {
+        constexpr int a = ai.value;
+        T mij = T(0);
+        if constexpr (GTopo<TP>::l_type(a) == 1) { fmac_bcast<a, 1>(mij, Sr[0], f.w.x); fmac_bcast<a, 1>(mij, Sr[1], f.w.y); fmac_bcast<a, 1>(mij, Sr[2], f.w.z); }
+        fmac_bcast<a, 1>(mij, Sr[3], f.v.x); fmac_bcast<a, 1>(mij, Sr[4], f.v.y); fmac_bcast<a, 1>(mij, Sr[5], f.v.z);
+        ml[a] = mij * lt.ancf[a];
+    });
+    const T mjj = sdot(S, f);
+    DL_LDS T* row = g.mm + j * Ld::MS;
+    st4(row, ml[0], ml[1], ml[2], ml[3]); st4(row + 4, ml[4], ml[5], ml[6], ml[7]);
+    st4(row + 8, ml[8], ml[9], ml[10], ml[11]); st4(row + 12, ml[12], ml[13], ml[14], ml[15]);
+    g_sync<T>();
+    T mr[GL];
+#pragma unroll
+    for (int a = 0; a < GL; a++) mr[a] = (a < NL) ? ml[a] + g.mm[a * Ld::MS + j] : T(0);
+    g_sync<T>();          // every lane has read its column before the rows are overwritten with the completed ones
+    st4(row, mr[0], mr[1], mr[2], mr[3]); st4(row + 4, mr[4], mr[5], mr[6], mr[7]);
+    st4(row + 8, mr[8], mr[9], mr[10], mr[11]); st4(row + 12, mr[12], mr[13], mr[14], mr[15]);
+    st4(row + 16, isdof ? mjj + ln.armature : T(1), isdof ? ln.armature - mjj : T(0), T(0), T(0));
+    g_sync<T>();
 }
 
 // 1/x: float = v_rcp_f32 + one Newton step; double = exact division
@@ -1426,7 +1515,7 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
 template <typename T, typename TP, bool TIMED = false, bool SPLIT = false>
 __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm,
                                        const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx, const GX<T, GD<TP>::NX>& warmx, GX<T, GD<TP>::NX>& qaccx,
-                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr) {
+                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr, T q_next = T(0)) {
     constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, NXA = GD<TP>::NXA;
     using Ld = GLds<TP>;
     constexpr int MAXROW = Ld::MAXROW;
@@ -1455,23 +1544,48 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         if (split_seq[3]) { ncon_o = 0; nefc_o = 0; niter_o = 0; return warm; }
         // the kinematics first: body frames and root height go to LDS for the constraint wave, which then needs no kinematics of its own;
         // with them the configuration and the solver's start point; then the rest of the smooth dynamics while the partner works
+        // the request: this evaluation's configuration and solver start point, and the NEXT evaluation's configuration.  The partner publishes body
+        // frames / root height (from the kinematics it precomputed for this configuration one evaluation ago -- or computes them now if what it holds is
+        // for another configuration: first request, reset, injected state), builds contacts and rows, and then goes on to the mass matrix of q_next while
+        // this wave solves.  This wave keeps its own kinematics in registers (motion subspace, contact Jacobians) and publishes nothing.
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
-        g_fk<T, TP, true>(g, lt, q, qx, kin);
+        g.mbox[Sp::MB_QN + j] = q_next;
         const int seq = ++*split_seq;
+        g_sync<T>();
         DL_WG_RELEASE();
         if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
         DL_WAKE();
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp0 = DL_CLOCK();
 #endif
-        g_smooth_dynamics<T, TP, false, true>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
-        tick(0);
+        g_fk<T, TP, false>(g, lt, q, qx, kin);
+        g_smooth_dynamics<T, TP, false, true, false>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp1 = DL_CLOCK();
 #endif
+        volatile DL_LDS int* fl = (volatile DL_LDS int*)g.mbox0;
         bool answered = false;
-        for (int it = 0; !(answered = ((volatile DL_LDS int*)g.mbox0)[Sp::MB_DONESEQ] == seq) && it < g.spin_limit; it++) DL_SLEEP();
+        for (int it = 0; !(answered = fl[Sp::MB_MOK] == seq) && it < g.spin_limit; it++) DL_SLEEP();
+        if (answered) {
+            // the complete row of M (the partner performed the mirror exchange): four 16-byte reads + (mdiag, mcorr)
+            DL_WG_ACQUIRE();
+            g_sync<T>();
+            const DL_LDS T* row = g.mm + j * Ld::MS;
+            const Q4<T> m0 = ld4(row), m1 = ld4(row + 4), m2 = ld4(row + 8), m3 = ld4(row + 12), m4 = ld4(row + 16);
+            sm.mrow[0] = m0.a; sm.mrow[1] = m0.b; sm.mrow[2] = m0.c; sm.mrow[3] = m0.d; sm.mrow[4] = m1.a; sm.mrow[5] = m1.b; sm.mrow[6] = m1.c; sm.mrow[7] = m1.d;
+            sm.mrow[8] = m2.a; sm.mrow[9] = m2.b; sm.mrow[10] = m2.c; sm.mrow[11] = m2.d; sm.mrow[12] = m3.a; sm.mrow[13] = m3.b; sm.mrow[14] = m3.c; sm.mrow[15] = m3.d;
+            sm.mdiag = m4.a; sm.mcorr = m4.b;
+#pragma unroll
+            for (int a = 0; a < GL; a++) g_pin(sm.mrow[a]);          // the loads are complete before the block is handed back
+            g_pin(sm.mdiag); g_pin(sm.mcorr);
+            g_sync<T>();
+            if (grp == 0 && j == 0) fl[Sp::MB_MFREE] = seq;       // the partner may overwrite the mirror block with the next evaluation's matrix
+            DL_WAKE();
+            tick(0);
+            answered = false;
+            for (int it = 0; !(answered = fl[Sp::MB_DONESEQ] == seq) && it < g.spin_limit; it++) DL_SLEEP();
+        }
 #ifdef DL_EXP_SPLIT_PROF
         split_seq[1] += (int)((DL_CLOCK() - tp1) >> 4); split_seq[2] += (int)((tp1 - tp0) >> 4);
 #endif

@@ -121,6 +121,11 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
 #ifdef DL_EXP_SPLIT_PROF
     long long srv_busy = 0;
 #endif
+    // what this wave holds in advance: the kinematics (registers) and the mass matrix (mirror block in LDS) of configuration q_pre
+    GKin<T> kin_pre{};
+    T q_pre = T(0);
+    bool have_pre = false;
+    const GX<T, 0> noqx{};
     for (;;) {
         // (sequence number, command) in one 8-byte read: the partner stores the command first, LDS operations of a wave complete in order
         static_assert(Sp::MB_CMD == Sp::MB_CMDSEQ + 1 && Sp::MB_CMDSEQ % 2 == 0, "the command word pair is one aligned 8-byte word");
@@ -142,9 +147,28 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         DL_WG_ACQUIRE();
         seq = cur;
         g_sync<T>();
-        T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j];
-        g_pin(q); g_pin(x0);         // requested here, with the body frames -- not behind the predicates of their first uses
-        GKin<T> kin{};                 // the first half of the constraint stage reads the body frames its partner left in LDS, not the lane's kinematics
+        T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j], qn = g.mbox[Sp::MB_QN + j];
+        g_pin(q); g_pin(x0); g_pin(qn);
+        // ---- is what was computed in advance for THIS configuration?  (It is, except for the first request of a launch and after a reset / an
+        // injected state: the dynamics wave announced this q as q_next one evaluation ago.)  Compared as bits; decided for the whole wave.
+        const bool match = have_pre && (__builtin_bit_cast(uint32_t, (float)q) == __builtin_bit_cast(uint32_t, (float)q_pre) || j >= D::NL);
+        if (!__all(match)) {
+            g_fk<T, TP, false>(g, lt, q, noqx, kin_pre);
+            g_mass_rows<T, TP>(g, lt, kin_pre);          // (the dynamics wave has taken the previous matrix long ago: it asks only after an evaluation is complete)
+        }
+        g_sync<T>();
+        DL_WG_RELEASE();
+        if (lane == 0) flags[Sp::MB_MOK] = seq;          // the mirror block holds this request's mass matrix
+        // ---- body frames / root height of this configuration for the collision stage, then contacts and rows
+        {
+            if (j < D::NL && lt.last) {
+                DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
+                st4(f, kin_pre.X.x, kin_pre.X.y, kin_pre.X.z, kin_pre.Y.x); st4(f + 4, kin_pre.Y.y, kin_pre.Y.z, kin_pre.Z.x, kin_pre.Z.y); st4(f + 8, kin_pre.Z.z, kin_pre.pos.x, kin_pre.pos.y, kin_pre.pos.z);
+            }
+            if (j == 0) wb[Ld::MISC + 0] = kin_pre.rootz;
+            g_sync<T>();
+        }
+        GKin<T> kin{};                 // the first half of the constraint stage reads the body frames from LDS, not the lane's kinematics
         int nlim, ncon, my_lim;
         T lim_sign;
         const T x0x[1] = {T(0)};
@@ -155,13 +179,27 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         DL_WG_RELEASE();
         if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
         DL_WAKE();
-#ifdef DL_EXP_SPLIT_PROF          // busy cycles of this wave (request seen -> answer posted), summed over the launch: dbg slot 0 (tools/diag_split.py)
-        srv_busy += DL_CLOCK() - tsrv0;
-#endif
         if (DL_PREFETCH_ACTIONS && actions_all && (seq - 1) % evals_per_step == 0) {
             const int next = (seq - 1) / evals_per_step + 1;
             if (next < nsteps && j < TP::NU) pf_sink += actions_all[((size_t)next * n + w) * TP::NU + j];
         }
+        // ---- in advance, while the dynamics wave solves: kinematics and mass matrix of the NEXT evaluation's configuration.  The mirror block is
+        // free once the dynamics wave has taken this request's matrix into registers (MB_MFREE; it does so before it waits for the rows above).
+        g_fk<T, TP, false>(g, lt, qn, noqx, kin_pre);
+        q_pre = qn; have_pre = true;
+        {
+            bool freed = false;
+            for (int k2 = 0; !(freed = flags[Sp::MB_MFREE] == seq) && k2 < g.spin_limit; k2++) DL_SLEEP();
+            if (!freed) {         // (cannot happen while the dynamics wave lives: it posts MB_MFREE before it waits for the rows)
+                if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
+                break;
+            }
+        }
+        DL_WG_ACQUIRE();
+        g_mass_rows<T, TP>(g, lt, kin_pre);
+#ifdef DL_EXP_SPLIT_PROF          // busy cycles of this wave (request seen -> look-ahead finished), summed over the launch: dbg slot 0 (tools/diag_split.py)
+        srv_busy += DL_CLOCK() - tsrv0;
+#endif
     }
 #ifdef DL_EXP_SPLIT_PROF
     if (j == 0 && w0 < n && st.dbg) st.dbg[w] = (int)(srv_busy >> 4);
@@ -304,7 +342,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 if (simulate && !exc && gany(bad)) exc = true;
             }
             const T q0 = q, v0 = v;
-            T dq = T(0), dv = T(0), qs = q, vs = v;
+            T dq = T(0), dv = T(0), qs = q, vs = v, q_end = q;
             T acc_s0 = warm;
             GX<T, NX> qx0 = qx, vx0 = vx, dqx, dvx, qsx = qx, vsx = vx, accx_s0 = warmx;
             static_for<NX>([&](auto ti) { dqx.x[ti.value] = T(0); dvx.x[ti.value] = T(0); });
@@ -318,7 +356,13 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 GX<T, NX> startx = warmx, accx;
                 if (stage == 1 && kf > 0) { start = warm + (warm - acc_s2_prev); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s2_prev.x[t]); }); }
                 else if (stage == 3) { start = warm + (warm - acc_s0); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s0.x[t]); }); }
-                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq);
+                // RK4: the configuration of the NEXT evaluation depends on this stage's velocity only -- known before this stage's solve.  A split
+                // workgroup hands it to the partner wave, which computes that configuration's mass matrix while this wave solves (g_forward<SPLIT>).
+                const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
+                const T al = stage == 2 ? T(1) : T(0.5);
+                const T dq_new = dq + wgt * vs;
+                const T q_ahead = stage == 3 ? q0 + h * dq_new : q0 + h * al * vs;          // stage 3: the state after this mj_step = stage 0 of the next
+                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq, q_ahead);
                 if constexpr (SPLIT) { if (split_seq[3] && simulate) exc = true; }      // the hand-over with the constraint wave failed: MujocoException path
                 if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
                 if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
@@ -334,11 +378,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                     static_for<NX>([&](auto ti) { bad = bad || dl_bad(accx.x[ti.value]); });
                     if (gany(bad)) exc = true;
                 }
-                const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
-                const T al = stage == 2 ? T(1) : T(0.5);
-                dq += wgt * vs; dv += wgt * acc;
-                const T vstage = vs;
-                qs = q0 + h * al * vstage; vs = v0 + h * al * acc;
+                dq = dq_new; dv += wgt * acc;
+                q_end = q_ahead;
+                qs = q_ahead; vs = v0 + h * al * acc;
                 static_for<NX>([&](auto ti) {
                     constexpr int t = ti.value;
                     dqx.x[t] += wgt * vsx.x[t]; dvx.x[t] += wgt * accx.x[t];
@@ -347,7 +389,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 });
             }
             if (simulate && !exc) {
-                q = q0 + h * dq; v = v0 + h * dv;
+                q = q_end; v = v0 + h * dv;          // q_end = q0 + h * dq, formed before the last stage's solve
                 static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = qx0.x[t] + h * dqx.x[t]; vx.x[t] = vx0.x[t] + h * dvx.x[t]; });
             }
         }
