@@ -436,6 +436,8 @@ template <typename T, typename TP> struct GCtx {
     DL_LDS T* mbox0;                             //                  the mailbox of the wave's first walker (sequence numbers of the wave pair)
     int32_t* fault;                              //                  the handle's fault word (or null) and the poll budget of this wave's waits
     int spin_limit;
+    DL_LDS T* bfr;                               // body frames [MAXB][BFR_W] and root height as g_fk publishes them / the collision stage reads them: GLds::BFR and
+    DL_LDS T* rz;                                //   GLds::MISC inside the walker's region, or (partner wave of a split workgroup) GSplit::BFRX / RZX, its own space
 };
 // Split workgroup: a second wave builds the constraints of the same four walkers while the first runs the smooth dynamics.
 // Per walker, behind the regular region: the mirror block of M (which may no longer share the rows' space) and the mailbox.
@@ -447,9 +449,14 @@ template <typename TP> struct GSplit {
     // look-ahead of the mass matrix: MB_QN = the configuration of the NEXT evaluation (known when this one is requested); MB_MOK = sequence number of
     // the request whose mass matrix is in the mirror block (posted by the partner once it has checked that what it precomputed is for this request's
     // configuration); MB_MFREE = sequence number of the last request whose mass matrix the dynamics wave has taken into registers
-    static constexpr int MB_MOK = 69, MB_MFREE = 70, MB_QN = 72;
+    static constexpr int MB_MOK = 69, MB_MFREE = 70, MB_QN = 72, MB_PRE = 71;          // MB_PRE: sequence number of the last request whose look-ahead is complete
     static_assert(MB_QN % 4 == 0 && MB_QN + GL <= MB_SIZE, "mailbox layout");
-    static constexpr int TOTAL = MB + MB_SIZE;                   // per walker; 16 (mod 32) like GLds::TOTAL
+    // what the partner wave computes one evaluation ahead and hands over through LDS: the body frames (its own copy: GLds::BFR shares the space of the contact
+    // Jacobians, which are live while it works) and, per dof lane, (joint axis x y z, root height)
+    static constexpr int BFRX = MB + MB_SIZE;                    // body frames [MAXB][BFR_W]
+    static constexpr int AXX = BFRX + ((GD<TP>::MAXB * Ld::BFR_W + 31) / 32) * 32;      // [16 lanes][4]: axis, root height
+    static constexpr int RZX = AXX + 3;                          // the root height of lane 0's record
+    static constexpr int TOTAL = AXX + GL * 4;                   // per walker; 16 (mod 32) like GLds::TOTAL
     static_assert(TOTAL % 32 == 16 && MB % 4 == 0, "walker regions keep their bank offset");
     // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
     // wave sets the handle's fault word, its walkers take the reference's exception path (mimic_env.py:86-91) and the host raises DL_E_FAULT
@@ -705,10 +712,10 @@ __device__ __forceinline__ void g_fk(const GCtx<T, TP>& g, const GLaneTopo<T>& l
     k.X = X; k.Y = Y; k.Z = Z; k.pos = pos; k.axis = ln.sign * col; k.rootz = rootz;
     if constexpr (PUBLISH) {
         if (j < NL && lt.last) {
-            DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
+            DL_LDS T* f = g.bfr + Ld::BFR_W * ln.body;
             st4(f, X.x, X.y, X.z, Y.x); st4(f + 4, Y.y, Y.z, Z.x, Z.y); st4(f + 8, Z.z, pos.x, pos.y, pos.z);
         }
-        if (j == 0) wb[Ld::MISC + 0] = rootz;
+        if (j == 0) *g.rz = rootz;
         g_sync<T>();
     }
 }
@@ -724,9 +731,9 @@ __device__ __forceinline__ T g_lowest_site(const GCtx<T, TP>& g) {
     T low = T(1e30);
     if (j < m.nsite) {
         const int b = m.site_body[j];
-        DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * b;
+        DL_LDS T* f = g.bfr + Ld::BFR_W * b;
         const T pz = f[11] + m.site_pos[j][0] * f[2] + m.site_pos[j][1] * f[5] + m.site_pos[j][2] * f[8];
-        low = wb[Ld::MISC + 0] + pz;
+        low = *g.rz + pz;
     }
     low = dl_min(low, dpp_f<0x128>(low));
     low = dl_min(low, dpp_f<0x124>(low));
@@ -1310,14 +1317,21 @@ __device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const 
     g_sync<T>();
 }
 
-// WITH_J = false: stop after the contact records and rows (the caller -- the dynamics wave of a split workgroup -- runs g_contact_jacobians itself)
-template <typename T, typename TP, bool WITH_J = true>
-__device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, T x0, const T (&x0x)[GD<TP>::NXA],
-                                                   int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
+// ---- first half of the constraint stage in two parts: DETECT (a function of the configuration alone: which limits and candidates are active, where, with
+// which impedance / regulariser; results in the lane's registers) and COMMIT (records and rows into LDS; the limit rows take the solver's start point).
+// The partner wave of a split workgroup detects one evaluation ahead and commits when the evaluation is requested.
+template <typename T, typename TP> struct GDet {
+    static constexpr int NPASS = GD<TP>::NPASS;
+    bool act[NPASS], lim;
+    int cinf[NPASS], slot[NPASS], nlim, ncon, my_lim;
+    V3<T> cp[NPASS];
+    T cdist[NPASS], ctx[NPASS], cty[NPASS], r_mu[NPASS], r_D[NPASS], r_kd[NPASS], lim_sign, l_D, l_k0;
+};
+template <typename T, typename TP>
+__device__ __forceinline__ void g_detect_constraints(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, GDet<T, TP>& d) {
     using Ld = GLds<TP>;
     using CM = GCandMask<TP>;
-    constexpr int NL = GD<TP>::NL, NX = GD<TP>::NX, NPASS = GD<TP>::NPASS, MAXROW = Ld::MAXROW, MAXCON = Ld::MAXCON;
-    DL_LDS T* wb = g.wb;
+    constexpr int NL = GD<TP>::NL, NPASS = GD<TP>::NPASS;
     const int j = g.j;
     const auto& ln = *g.ln;
     // collision candidates and solimp: pinned registers, or (19-dof walker) loads of this evaluation from the model block
@@ -1328,7 +1342,7 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
     struct { T solimp[5], solimp_inv[3]; } simp;
     for (int k = 0; k < 5; k++) simp.solimp[k] = GD<TP>::PIN_ALL ? g.c->solimp[k] : mc->solimp[k];
     for (int k = 0; k < 3; k++) simp.solimp_inv[k] = GD<TP>::PIN_ALL ? g.c->solimp_inv[k] : mc->solimp_inv[k];
-    const T rootz = wb[Ld::MISC + 0];
+    const T rootz = *g.rz;
     // ---- joint limits (dof lanes), ranked by dof order through a ballot
     bool lim = false, lim_lo = false;
     T lim_dist = T(0);
@@ -1340,20 +1354,16 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
         lim_dist = lim ? (lim_lo ? dlo : dhi) : T(0);
     }
     const uint32_t lmask = (uint32_t)((__ballot(lim) >> (GL * grp)) & 0xFFFFull);
-    const int nlim = __popc(lmask);
-    my_lim = -1; lim_sign = lim_lo ? T(1) : T(-1);
+    d.nlim = __popc(lmask);
+    d.lim = lim; d.lim_sign = lim_lo ? T(1) : T(-1);
     // ---- contact candidates: NPASS passes of 16 (capsule ends and box corners in geom order); a candidate is a
     // constant body-local point (GLane), so the test is one frame transform + the floor distance
-    bool act[NPASS];
-    V3<T> cp[NPASS];
-    T cdist[NPASS], ctx[NPASS], cty[NPASS];
-    int cinf[NPASS];
 #pragma unroll
     for (int pass = 0; pass < NPASS; pass++) {
         const int cinfo = cd.cinfo[pass];
-        cinf[pass] = cinfo;
+        d.cinf[pass] = cinfo;
         const int b = (cinfo >> 5) & 15;
-        DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * b;
+        DL_LDS T* f = g.bfr + Ld::BFR_W * b;
         const Q4<T> f0 = ld4(f), f1 = ld4(f + 4), f2 = ld4(f + 8);
         const V3<T> X = mk<T>(f0.a, f0.b, f0.c), Y = mk<T>(f0.d, f1.a, f1.b), Z = mk<T>(f1.c, f1.d, f2.a), pos = mk<T>(f2.b, f2.c, f2.d);
         const V3<T> pt = pos + cd.cpl[pass][0] * X + cd.cpl[pass][1] * Y + cd.cpl[pass][2] * Z;
@@ -1365,85 +1375,101 @@ __device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const G
         if (n2 < T(1e-30)) { tx = box ? T(0) : T(1); ty = box ? T(1) : T(0); } else { const T inv = dl_rsqrt(n2); tx *= inv; ty *= inv; }
         const T rad = cd.crad[pass];
         const T dist = rootz + pt.z - rad;
-        act[pass] = (cinfo & 1) && dist < T(0) && !(relz > T(0));
-        cp[pass] = mk<T>(pt.x, pt.y, pt.z - (rad + T(0.5) * dist));
-        cdist[pass] = dist; ctx[pass] = tx; cty[pass] = ty;
+        d.act[pass] = (cinfo & 1) && dist < T(0) && !(relz > T(0));
+        d.cp[pass] = mk<T>(pt.x, pt.y, pt.z - (rad + T(0.5) * dist));
+        d.cdist[pass] = dist; d.ctx[pass] = tx; d.cty[pass] = ty;
     }
     // box rule: only the first four qualifying corners of a box make contacts (mjc_PlaneBox)
     auto cand_mask = [&]() {
         CM m = 0;
 #pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) m |= (CM)((__ballot(act[pass]) >> (GL * grp)) & 0xFFFFull) << (GL * pass);
+        for (int pass = 0; pass < NPASS; pass++) m |= (CM)((__ballot(d.act[pass]) >> (GL * grp)) & 0xFFFFull) << (GL * pass);
         return m;
     };
     CM cm = cand_mask();
 #pragma unroll
     for (int pass = 0; pass < NPASS; pass++) {
         const int c = j + GL * pass;
-        if (act[pass] && ((cinf[pass] >> 1) & 1)) {
-            const int first = c - ((cinf[pass] >> 2) & 7);                             // first corner of this box in the candidate list
+        if (d.act[pass] && ((d.cinf[pass] >> 1) & 1)) {
+            const int first = c - ((d.cinf[pass] >> 2) & 7);                             // first corner of this box in the candidate list
             const CM before = cm & (((CM)1 << c) - (CM)1) & ~(((CM)1 << first) - (CM)1);
-            if (g_popc(before) >= 4) act[pass] = false;
+            if (g_popc(before) >= 4) d.act[pass] = false;
         }
     }
     cm = cand_mask();
-    const int ncon = g_popc(cm);
-    // (BFR is aliased with JC, which is first written after the next g_sync: the frame reads above are complete by then;
-    //  the rows written below overwrite the mirror block of the mass matrix, whose reads precede them in program order)
-    // ---- the lane of a candidate writes the contact record AND the contact's rows (rows 4c..4c+3: D, K imp r, cleared
-    // active flags): nothing about a contact waits for another lane
+    d.ncon = g_popc(cm);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) d.slot[pass] = g_popc((CM)(cm & (((CM)1 << (j + GL * pass)) - (CM)1)));
+    d.my_lim = lim ? 4 * d.ncon + __popc(lmask & ((1u << j) - 1u)) : -1;
     // (the impedance / regulariser chains -- two reciprocals each -- of all passes and of the limit row are computed side by side, for every lane,
     //  and pinned: behind their lanes' predicates they ran one after the other, ~300 cycles of dependent instructions each)
-    T r_mu[NPASS], r_D[NPASS], r_kd[NPASS];
 #pragma unroll
     for (int pass = 0; pass < NPASS; pass++) {
-        const T mu = dl_max(cd.cmu[pass], g.wk->floor_mu), dist = cdist[pass];
+        const T mu = dl_max(cd.cmu[pass], g.wk->floor_mu), dist = d.cdist[pass];
         const T imp = g_impedance(simp, dist);
         const T diag = cd.cinvw[pass] * (T(1) + mu * mu);
         const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
-        r_mu[pass] = mu; r_D[pass] = dl_rcp(R); r_kd[pass] = g.c->solK * imp * dist;
+        d.r_mu[pass] = mu; d.r_D[pass] = dl_rcp(R); d.r_kd[pass] = g.c->solK * imp * dist;
     }
-    T l_D, l_k;
     {
         const T imp = g_impedance(simp, lim_dist);
         const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
-        l_D = dl_rcp(R); l_k = g.c->solK * imp * lim_dist + lim_sign * x0;
+        d.l_D = dl_rcp(R); d.l_k0 = g.c->solK * imp * lim_dist;
     }
 #pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) { g_pin(r_D[pass]); g_pin(r_kd[pass]); g_pin(ctx[pass]); g_pin(cty[pass]); }
-    g_pin(l_D); g_pin(l_k);
+    for (int pass = 0; pass < NPASS; pass++) { g_pin(d.r_D[pass]); g_pin(d.r_kd[pass]); g_pin(d.ctx[pass]); g_pin(d.cty[pass]); }
+    g_pin(d.l_D); g_pin(d.l_k0);
+}
+// x0: the solver's start point B v + a of the lane's dof, folded into the limit rows' J a - aref
+template <typename T, typename TP>
+__device__ __forceinline__ void g_commit_constraints(const GCtx<T, TP>& g, const GDet<T, TP>& d, T x0) {
+    using Ld = GLds<TP>;
+    constexpr int NX = GD<TP>::NX, NPASS = GD<TP>::NPASS, MAXROW = Ld::MAXROW, MAXCON = Ld::MAXCON;
+    DL_LDS T* wb = g.wb;
+    const int j = g.j;
+    // (BFR is aliased with JC, which is first written after the next g_sync: the frame reads of the detection are complete by then;
+    //  the rows written below overwrite the mirror block of the mass matrix, whose reads precede them in program order)
+    // ---- the lane of a candidate writes the contact record AND the contact's rows (rows 4c..4c+3: D, K imp r, cleared
+    // active flags): nothing about a contact waits for another lane
 #pragma unroll
     for (int pass = 0; pass < NPASS; pass++) {
-        const int c = j + GL * pass;
-        if (act[pass]) {
-            const int slot = g_popc((CM)(cm & (((CM)1 << c) - (CM)1)));
-            const T mu = r_mu[pass], dist = cdist[pass], D = r_D[pass], kd = r_kd[pass];
+        if (d.act[pass]) {
+            const int slot = d.slot[pass];
+            const T mu = d.r_mu[pass], dist = d.cdist[pass], D = d.r_D[pass], kd = d.r_kd[pass];
             DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * slot;
-            st4(cn, cp[pass].x, cp[pass].y, cp[pass].z, T((cinf[pass] >> 5) & 15));
-            st4(cn + 4, ctx[pass], cty[pass], mu, dist);
+            st4(cn, d.cp[pass].x, d.cp[pass].y, d.cp[pass].z, T((d.cinf[pass] >> 5) & 15));
+            st4(cn + 4, d.ctx[pass], d.cty[pass], mu, dist);
             st4(wb + Ld::ROW + Ld::R_D * MAXROW + 4 * slot, D, D, D, D);
             st4(wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * slot, kd, kd, kd, kd);
             st4(wb + Ld::ROW + Ld::R_TMP * MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
         }
     }
     // contacts are processed in pairs: a neutral record (world body: no dof moves it; mu = 0) closes an odd count
-    if (j == 0 && ncon < MAXCON) {
-        DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * ncon;
+    if (j == 0 && d.ncon < MAXCON) {
+        DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * d.ncon;
         st4(cn, T(0), T(0), T(0), T(0)); st4(cn + 4, T(1), T(0), T(0), T(0));
-        st4(wb + Ld::FC + Ld::FC_W * ncon, T(0), T(0), T(0), T(0));
-        if constexpr (NX > 0) st4(wb + Ld::FC + Ld::FC_W * ncon + 8, T(0), T(0), T(0), T(0));
+        st4(wb + Ld::FC + Ld::FC_W * d.ncon, T(0), T(0), T(0), T(0));
+        if constexpr (NX > 0) st4(wb + Ld::FC + Ld::FC_W * d.ncon + 8, T(0), T(0), T(0), T(0));
     }
     // limit rows follow in dof order; jar = J a - aref at the start point x0 = B v + a:  K imp r + (+-x0_j)
-    if (lim) {
-        const int r = 4 * ncon + __popc(lmask & ((1u << j) - 1u));
-        my_lim = r;
-        wb[Ld::ROW + Ld::R_D * MAXROW + r] = l_D;
-        wb[Ld::ROW + Ld::R_JAREF * MAXROW + r] = l_k;
+    if (d.lim) {
+        const int r = d.my_lim;
+        wb[Ld::ROW + Ld::R_D * MAXROW + r] = d.l_D;
+        wb[Ld::ROW + Ld::R_JAREF * MAXROW + r] = d.l_k0 + d.lim_sign * x0;
         wb[Ld::ROW + Ld::R_TMP * MAXROW + r] = T(0);
     }
     g_sync<T>();
-    if constexpr (WITH_J) g_contact_jacobians<T, TP>(g, lt, kin, ncon, x0, x0x);
-    nlim_out = nlim; ncon_out = ncon;
+}
+
+// [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes): detection, commit, contact Jacobians (one-wave form)
+template <typename T, typename TP>
+__device__ __forceinline__ void g_make_constraints(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& kin, int grp, T q, T x0, const T (&x0x)[GD<TP>::NXA],
+                                                   int& nlim_out, int& ncon_out, int& my_lim, T& lim_sign) {
+    GDet<T, TP> d;
+    g_detect_constraints<T, TP>(g, lt, grp, q, d);
+    g_commit_constraints<T, TP>(g, d, x0);
+    g_contact_jacobians<T, TP>(g, lt, kin, d.ncon, x0, x0x);
+    nlim_out = d.nlim; ncon_out = d.ncon; my_lim = d.my_lim; lim_sign = d.lim_sign;
 }
 
 template <typename T> struct GEps;
@@ -1515,7 +1541,7 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
 template <typename T, typename TP, bool TIMED = false, bool SPLIT = false>
 __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm,
                                        const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx, const GX<T, GD<TP>::NX>& warmx, GX<T, GD<TP>::NX>& qaccx,
-                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr, T q_next = T(0)) {
+                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr, T q_next = T(0), T* q_ann = nullptr) {
     constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, NXA = GD<TP>::NXA;
     using Ld = GLds<TP>;
     constexpr int MAXROW = Ld::MAXROW;
@@ -1544,51 +1570,69 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         if (split_seq[3]) { ncon_o = 0; nefc_o = 0; niter_o = 0; return warm; }
         // the kinematics first: body frames and root height go to LDS for the constraint wave, which then needs no kinematics of its own;
         // with them the configuration and the solver's start point; then the rest of the smooth dynamics while the partner works
-        // the request: this evaluation's configuration and solver start point, and the NEXT evaluation's configuration.  The partner publishes body
-        // frames / root height (from the kinematics it precomputed for this configuration one evaluation ago -- or computes them now if what it holds is
-        // for another configuration: first request, reset, injected state), builds contacts and rows, and then goes on to the mass matrix of q_next while
-        // this wave solves.  This wave keeps its own kinematics in registers (motion subspace, contact Jacobians) and publishes nothing.
+        // The partner wave works one evaluation AHEAD: with the previous request this wave announced the configuration of this evaluation (inside RK4 it
+        // depends on the previous stage's velocity only), and while this wave solved, the partner computed its kinematics, its mass matrix and the
+        // configuration half of its constraints.  So an evaluation starts by taking the lane's kinematics (body frame, joint axis) and its row of M from
+        // LDS, then sends the request (solver start point, NEXT configuration): the partner commits contacts and rows -- a few stores -- and goes on to
+        // the next configuration.  If this evaluation's configuration is not the announced one (first request of a launch, reset, injected state), the
+        // request says so and waits for the partner to compute everything now.
+        volatile DL_LDS int* fl = (volatile DL_LDS int*)g.mbox0;
+        const int seq = ++*split_seq;
+        const bool fast = __all(j >= N || __builtin_bit_cast(uint32_t, (float)q) == __builtin_bit_cast(uint32_t, (float)*q_ann));
+        *q_ann = q_next;
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
         g.mbox[Sp::MB_QN + j] = q_next;
-        const int seq = ++*split_seq;
-        g_sync<T>();
-        DL_WG_RELEASE();
-        if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
-        DL_WAKE();
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp0 = DL_CLOCK();
 #endif
-        g_fk<T, TP, false>(g, lt, q, qx, kin);
-        g_smooth_dynamics<T, TP, false, true, false>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
-#ifdef DL_EXP_SPLIT_PROF
-        const long long tp1 = DL_CLOCK();
-#endif
-        volatile DL_LDS int* fl = (volatile DL_LDS int*)g.mbox0;
         bool answered = false;
-        for (int it = 0; !(answered = fl[Sp::MB_MOK] == seq) && it < g.spin_limit; it++) DL_SLEEP();
+        if (fast) {
+            for (int it = 0; !(answered = fl[Sp::MB_PRE] == seq - 1) && it < g.spin_limit; it++) DL_SLEEP();      // (complete long ago: the partner had a whole solve for it)
+        } else {
+            g_sync<T>();
+            DL_WG_RELEASE();
+            if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 2; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
+            DL_WAKE();
+            for (int it = 0; !(answered = fl[Sp::MB_MOK] == seq) && it < g.spin_limit; it++) DL_SLEEP();
+        }
         if (answered) {
-            // the complete row of M (the partner performed the mirror exchange): four 16-byte reads + (mdiag, mcorr)
             DL_WG_ACQUIRE();
             g_sync<T>();
-            const DL_LDS T* row = g.mm + j * Ld::MS;
-            const Q4<T> m0 = ld4(row), m1 = ld4(row + 4), m2 = ld4(row + 8), m3 = ld4(row + 12), m4 = ld4(row + 16);
-            sm.mrow[0] = m0.a; sm.mrow[1] = m0.b; sm.mrow[2] = m0.c; sm.mrow[3] = m0.d; sm.mrow[4] = m1.a; sm.mrow[5] = m1.b; sm.mrow[6] = m1.c; sm.mrow[7] = m1.d;
-            sm.mrow[8] = m2.a; sm.mrow[9] = m2.b; sm.mrow[10] = m2.c; sm.mrow[11] = m2.d; sm.mrow[12] = m3.a; sm.mrow[13] = m3.b; sm.mrow[14] = m3.c; sm.mrow[15] = m3.d;
-            sm.mdiag = m4.a; sm.mcorr = m4.b;
+            {   // kinematics of the lane: the frame of its body, its joint axis; the complete row of M (the partner performed the mirror exchange)
+                const DL_LDS T* f = wb + Sp::BFRX + Ld::BFR_W * g.ln->body;
+                const Q4<T> f0 = ld4(f), f1 = ld4(f + 4), f2 = ld4(f + 8), ax = ld4(wb + Sp::AXX + 4 * j);
+                const DL_LDS T* row = g.mm + j * Ld::MS;
+                const Q4<T> m0 = ld4(row), m1 = ld4(row + 4), m2 = ld4(row + 8), m3 = ld4(row + 12), m4 = ld4(row + 16);
+                kin.X = mk<T>(f0.a, f0.b, f0.c); kin.Y = mk<T>(f0.d, f1.a, f1.b); kin.Z = mk<T>(f1.c, f1.d, f2.a); kin.pos = mk<T>(f2.b, f2.c, f2.d);
+                kin.axis = mk<T>(ax.a, ax.b, ax.c); kin.rootz = ax.d;
+                sm.mrow[0] = m0.a; sm.mrow[1] = m0.b; sm.mrow[2] = m0.c; sm.mrow[3] = m0.d; sm.mrow[4] = m1.a; sm.mrow[5] = m1.b; sm.mrow[6] = m1.c; sm.mrow[7] = m1.d;
+                sm.mrow[8] = m2.a; sm.mrow[9] = m2.b; sm.mrow[10] = m2.c; sm.mrow[11] = m2.d; sm.mrow[12] = m3.a; sm.mrow[13] = m3.b; sm.mrow[14] = m3.c; sm.mrow[15] = m3.d;
+                sm.mdiag = m4.a; sm.mcorr = m4.b;
+                // the loads are complete before the regions are handed back to the partner
 #pragma unroll
-            for (int a = 0; a < GL; a++) g_pin(sm.mrow[a]);          // the loads are complete before the block is handed back
-            g_pin(sm.mdiag); g_pin(sm.mcorr);
+                for (int a = 0; a < GL; a++) g_pin(sm.mrow[a]);
+                g_pin(sm.mdiag); g_pin(sm.mcorr); g_pin(kin.X.x); g_pin(kin.Y.y); g_pin(kin.Z.z); g_pin(kin.pos.x); g_pin(kin.axis.x);
+            }
             g_sync<T>();
-            if (grp == 0 && j == 0) fl[Sp::MB_MFREE] = seq;       // the partner may overwrite the mirror block with the next evaluation's matrix
+            DL_WG_RELEASE();
+            if (fast) { if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; } }
+            else if (grp == 0 && j == 0) fl[Sp::MB_MFREE] = seq;
             DL_WAKE();
+#ifdef DL_EXP_SPLIT_PROF
+            const long long tp1 = DL_CLOCK();
+#endif
+            g_smooth_dynamics<T, TP, false, true, false>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
             tick(0);
+#ifdef DL_EXP_SPLIT_PROF
+            const long long tp2 = DL_CLOCK();
+#endif
             answered = false;
             for (int it = 0; !(answered = fl[Sp::MB_DONESEQ] == seq) && it < g.spin_limit; it++) DL_SLEEP();
-        }
-#ifdef DL_EXP_SPLIT_PROF
-        split_seq[1] += (int)((DL_CLOCK() - tp1) >> 4); split_seq[2] += (int)((tp1 - tp0) >> 4);
+#ifdef DL_EXP_SPLIT_PROF          // [1]: waiting for the rows (DL_EXP_SPLIT_PROF = 1) or taking kinematics + mass matrix incl. any wait (= 2); [2]: the velocity half
+            split_seq[1] += (int)(((DL_EXP_SPLIT_PROF == 2) ? (tp1 - tp0) : (DL_CLOCK() - tp2)) >> 4); split_seq[2] += (int)((tp2 - tp1) >> 4);
 #endif
+        }
         if (!answered) {      // timeout (wave-uniform): never carry on with stale rows -- fault word, exception path for the four walkers
             split_seq[3] = 1;
             if (grp == 0 && j == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_DYN_TIMEOUT);

@@ -56,7 +56,8 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
     g_load_const<T, TP>(*m, cst);
     GWalk<T> wk;
     g_load_walk<T, TP>(m, st, wi, wk);
-    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MM, nullptr, nullptr, nullptr, 0};
+    GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MM, nullptr, nullptr, nullptr, 0,
+                  smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::BFR, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MISC};
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < NL) {
         const size_t o = (size_t)(j + NX) * n + wi;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     GWalk<T> wk;
     g_load_walk<T, TP>(m, st, w, wk);
     DL_LDS T* wb = smem + (size_t)grp * Sp::TOTAL;
-    GCtx<T, TP> g{wb, m, j, &ln, &cst, &wk, wb + Sp::MMX, wb + Sp::MB, smem + Sp::MB, st.fault, st.spin_srv};
+    GCtx<T, TP> g{wb, m, j, &ln, &cst, &wk, wb + Sp::MMX, wb + Sp::MB, smem + Sp::MB, st.fault, st.spin_srv, wb + Sp::BFRX, wb + Sp::RZX};
     GLaneTopo<T> lt;
     g_lane_topo<T, TP>(j, lt);
     volatile DL_LDS int* flags = (volatile DL_LDS int*)g.mbox0;
@@ -121,11 +122,27 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
 #ifdef DL_EXP_SPLIT_PROF
     long long srv_busy = 0;
 #endif
-    // what this wave holds in advance: the kinematics (registers) and the mass matrix (mirror block in LDS) of configuration q_pre
-    GKin<T> kin_pre{};
-    T q_pre = T(0);
-    bool have_pre = false;
+    // what this wave holds in advance, for the configuration its partner announced with the last request: body frames, joint axes and mass matrix in LDS
+    // (GSplit::BFRX / AXX, the mirror block) and the configuration half of the constraints in registers (det)
+    GDet<T, TP> det;
+    GKin<T> kin{};
     const GX<T, 0> noqx{};
+    auto geometry = [&](T qc, bool with_m_first) {
+        // kinematics -> body frames + root height (g_fk publishes into this wave's own region) and the lanes' joint axes; mass matrix; detection
+        g_fk<T, TP, true>(g, lt, qc, noqx, kin);
+        st4(wb + Sp::AXX + 4 * j, kin.axis.x, kin.axis.y, kin.axis.z, kin.rootz);
+        if (with_m_first) {
+            g_mass_rows<T, TP>(g, lt, kin);
+            g_sync<T>();
+            DL_WG_RELEASE();
+            if (lane == 0) flags[Sp::MB_MOK] = seq;
+            DL_WAKE();
+            g_detect_constraints<T, TP>(g, lt, grp, qc, det);
+        } else {
+            g_detect_constraints<T, TP>(g, lt, grp, qc, det);
+            g_mass_rows<T, TP>(g, lt, kin);
+        }
+    };
     for (;;) {
         // (sequence number, command) in one 8-byte read: the partner stores the command first, LDS operations of a wave complete in order
         static_assert(Sp::MB_CMD == Sp::MB_CMDSEQ + 1 && Sp::MB_CMDSEQ % 2 == 0, "the command word pair is one aligned 8-byte word");
@@ -149,32 +166,13 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         g_sync<T>();
         T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j], qn = g.mbox[Sp::MB_QN + j];
         g_pin(q); g_pin(x0); g_pin(qn);
-        // ---- is what was computed in advance for THIS configuration?  (It is, except for the first request of a launch and after a reset / an
-        // injected state: the dynamics wave announced this q as q_next one evaluation ago.)  Compared as bits; decided for the whole wave.
-        const bool match = have_pre && (__builtin_bit_cast(uint32_t, (float)q) == __builtin_bit_cast(uint32_t, (float)q_pre) || j >= D::NL);
-        if (!__all(match)) {
-            g_fk<T, TP, false>(g, lt, q, noqx, kin_pre);
-            g_mass_rows<T, TP>(g, lt, kin_pre);          // (the dynamics wave has taken the previous matrix long ago: it asks only after an evaluation is complete)
-        }
-        g_sync<T>();
-        DL_WG_RELEASE();
-        if (lane == 0) flags[Sp::MB_MOK] = seq;          // the mirror block holds this request's mass matrix
-        // ---- body frames / root height of this configuration for the collision stage, then contacts and rows
-        {
-            if (j < D::NL && lt.last) {
-                DL_LDS T* f = wb + Ld::BFR + Ld::BFR_W * ln.body;
-                st4(f, kin_pre.X.x, kin_pre.X.y, kin_pre.X.z, kin_pre.Y.x); st4(f + 4, kin_pre.Y.y, kin_pre.Y.z, kin_pre.Z.x, kin_pre.Z.y); st4(f + 8, kin_pre.Z.z, kin_pre.pos.x, kin_pre.pos.y, kin_pre.pos.z);
-            }
-            if (j == 0) wb[Ld::MISC + 0] = kin_pre.rootz;
-            g_sync<T>();
-        }
-        GKin<T> kin{};                 // the first half of the constraint stage reads the body frames from LDS, not the lane's kinematics
-        int nlim, ncon, my_lim;
-        T lim_sign;
-        const T x0x[1] = {T(0)};
-        g_make_constraints<T, TP, false>(g, lt, kin, grp, q, x0, x0x, nlim, ncon, my_lim, lim_sign);
-        g.mbox[Sp::MB_LIM + j] = (T)my_lim; g.mbox[Sp::MB_SGN + j] = lim_sign;
-        if (j == 0) { g.mbox[Sp::MB_NCON] = (T)ncon; g.mbox[Sp::MB_NLIM] = (T)nlim; }
+        // command 2: this evaluation's configuration is not the one announced (first request of a launch, reset, injected state) -- everything now,
+        // the mass matrix first (the dynamics wave waits for it and the kinematics)
+        if (cmd == 2) geometry(q, true);
+        // ---- commit: contact records and rows of this evaluation (the limit rows take the solver's start point), report
+        g_commit_constraints<T, TP>(g, det, x0);
+        g.mbox[Sp::MB_LIM + j] = (T)det.my_lim; g.mbox[Sp::MB_SGN + j] = det.lim_sign;
+        if (j == 0) { g.mbox[Sp::MB_NCON] = (T)det.ncon; g.mbox[Sp::MB_NLIM] = (T)det.nlim; }
         g_sync<T>();
         DL_WG_RELEASE();
         if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
@@ -183,20 +181,22 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
             const int next = (seq - 1) / evals_per_step + 1;
             if (next < nsteps && j < TP::NU) pf_sink += actions_all[((size_t)next * n + w) * TP::NU + j];
         }
-        // ---- in advance, while the dynamics wave solves: kinematics and mass matrix of the NEXT evaluation's configuration.  The mirror block is
-        // free once the dynamics wave has taken this request's matrix into registers (MB_MFREE; it does so before it waits for the rows above).
-        g_fk<T, TP, false>(g, lt, qn, noqx, kin_pre);
-        q_pre = qn; have_pre = true;
-        {
+        // ---- in advance, while the dynamics wave solves: the NEXT evaluation's configuration.  (After command 2 the dynamics wave may still be reading
+        // what was computed above: it says when it has it, MB_MFREE.  After command 1 it had taken everything before it sent the request.)
+        if (cmd == 2) {
             bool freed = false;
             for (int k2 = 0; !(freed = flags[Sp::MB_MFREE] == seq) && k2 < g.spin_limit; k2++) DL_SLEEP();
-            if (!freed) {         // (cannot happen while the dynamics wave lives: it posts MB_MFREE before it waits for the rows)
+            if (!freed) {
                 if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
                 break;
             }
+            DL_WG_ACQUIRE();
         }
-        DL_WG_ACQUIRE();
-        g_mass_rows<T, TP>(g, lt, kin_pre);
+        geometry(qn, false);
+        g_sync<T>();
+        DL_WG_RELEASE();
+        if (lane == 0) flags[Sp::MB_PRE] = seq;
+        DL_WAKE();
 #ifdef DL_EXP_SPLIT_PROF          // busy cycles of this wave (request seen -> look-ahead finished), summed over the launch: dbg slot 0 (tools/diag_split.py)
         srv_busy += DL_CLOCK() - tsrv0;
 #endif
@@ -240,8 +240,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     constexpr int WSTRIDE = SPLIT ? GSplit<TP>::TOTAL : Ld::TOTAL;         // LDS words per walker
     GCtx<T, TP> g{smem + (size_t)grp * WSTRIDE, m, j, &ln, &cst, &wk,
                   smem + (size_t)grp * WSTRIDE + (SPLIT ? GSplit<TP>::MMX : Ld::MM), SPLIT ? smem + (size_t)grp * WSTRIDE + GSplit<TP>::MB : nullptr, SPLIT ? smem + GSplit<TP>::MB : nullptr,
-                  st.fault, st.spin_dyn};
+                  st.fault, st.spin_dyn, smem + (size_t)grp * WSTRIDE + Ld::BFR, smem + (size_t)grp * WSTRIDE + Ld::MISC};
     int split_seq[4] = {0, 0, 0, 0};         // [0] command counter of the wave pair, [1], [2] cycle counters of the profiling build, [3] the hand-over has failed
+    T q_ann = __builtin_bit_cast(T, (std::conditional_t<sizeof(T) == 4, uint32_t, uint64_t>)(~0ull));      // split workgroup: the configuration announced to the partner wave with the last request (none yet: a NaN pattern no state carries)
     DL_LDS T* wb = g.wb;
     const bool isdof = j < NL;
     const int jd = j + NX;                         // dof of this lane
@@ -362,7 +363,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 const T al = stage == 2 ? T(1) : T(0.5);
                 const T dq_new = dq + wgt * vs;
                 const T q_ahead = stage == 3 ? q0 + h * dq_new : q0 + h * al * vs;          // stage 3: the state after this mj_step = stage 0 of the next
-                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq, q_ahead);
+                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq, q_ahead, &q_ann);
                 if constexpr (SPLIT) { if (split_seq[3] && simulate) exc = true; }      // the hand-over with the constraint wave failed: MujocoException path
                 if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
                 if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
