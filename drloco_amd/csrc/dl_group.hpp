@@ -32,12 +32,16 @@
 #define DL_WG_RELEASE() ((void)0)
 #define DL_WG_ACQUIRE() ((void)0)
 #define DL_FAULT_OR(p, code) ((void)0)
+#define DL_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define DL_VPIN(x) asm volatile("" : "+v"(x))
 #define DL_SPIN(x) asm volatile("" : "+s"(x))
 #define DL_CLOCK() ((long long)__builtin_readcyclecounter())
-#define DL_SLEEP() __builtin_amdgcn_s_sleep(16)        // a waiting wave of a split workgroup: ~1000 cycles, cut short by the partner's s_wakeup
+#ifndef DL_SLEEP_N
+#define DL_SLEEP_N 16
+#endif
+#define DL_SLEEP() __builtin_amdgcn_s_sleep(DL_SLEEP_N)        // a waiting wave of a split workgroup: 64 x N cycles, cut short by the partner's s_wakeup
 #define DL_WAKE() asm volatile("s_wakeup")
 // the hand-over between the two waves of a split pair is the one place where DIFFERENT waves exchange data through LDS: workgroup-scope
 // release before the flag store, acquire after the successful poll (g_sync's wavefront scope orders a wave against itself only)
@@ -49,6 +53,7 @@
 #define DL_WG_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
 #endif
 #define DL_FAULT_OR(p, code) __hip_atomic_fetch_or((p), (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define DL_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)      // a wave-uniform int as a scalar (SGPR): scalar branches instead of exec-mask regions
 #endif
 // (the reasons in a handle's fault word, DL_FAULT_*: include/drloco_hip.h)
 
@@ -400,13 +405,16 @@ template <typename T, typename TP> struct GConst {
     T xs_qpos0[D::NXA], xs_damping[D::NXA], xs_armature[D::NXA];
     int iterations, ls_iterations;
 };
-template <typename T, typename TP>
+// PIN: the register policy of the caller -- everything a lane touches pinned in VGPRs (the straight walker's dynamics wave), or body offsets / solimp / collision
+// candidates fetched where they are used (the 19-dof walker; the partner wave of a split workgroup, which has time but needs its registers for what it holds
+// from one evaluation to the next)
+template <typename T, typename TP, bool PIN = GD<TP>::PIN_ALL>
 __device__ __forceinline__ void g_load_const(const DL_CONST GModel<T, TP>& m, GConst<T, TP>& c) {
-    if constexpr (GD<TP>::PIN_ALL) for (int b = 0; b < GD<TP>::MAXB; b++) for (int k = 0; k < 3; k++) { c.body_pos[b][k] = b < m.nb ? m.body_pos[b][k] : T(0); g_pin(c.body_pos[b][k]); }
+    if constexpr (PIN) for (int b = 0; b < GD<TP>::MAXB; b++) for (int k = 0; k < 3; k++) { c.body_pos[b][k] = b < m.nb ? m.body_pos[b][k] : T(0); g_pin(c.body_pos[b][k]); }
     c.root_z0 = m.root_z0; c.gravity_z = m.gravity_z; c.solK = m.solK; c.solB = m.solB; c.meaninertia = m.meaninertia;
     c.tolerance = m.tolerance; c.ls_tolerance = m.ls_tolerance; c.ls_reltol = m.ls_reltol; c.tol_rel = m.tol_rel;
     c.nvf = T(m.nv); c.scale = T(1) / (m.meaninertia * c.nvf);
-    if constexpr (GD<TP>::PIN_ALL) {
+    if constexpr (PIN) {
         for (int k = 0; k < 5; k++) { c.solimp[k] = m.solimp[k]; g_pin(c.solimp[k]); }
         for (int k = 0; k < 3; k++) { c.solimp_inv[k] = m.solimp_inv[k]; g_pin(c.solimp_inv[k]); }
     }
@@ -660,7 +668,7 @@ template <typename T> struct GKin { V3<T> X, Y, Z, pos, axis; T rootz; };
 // (s, c) = (0, 1), so no lane waits for another one and nothing goes through LDS except the body frames that the
 // collision stage reads (BFR) and rootz (MISC[0]).  qx: the replicated root translations (only the vertical one
 // matters: positions are relative to the root origin).
-template <typename T, typename TP, bool PUBLISH = true>      // PUBLISH = false: registers only (the dynamics wave of a split workgroup; its partner publishes)
+template <typename T, typename TP, bool PUBLISH = true, bool PIN = GD<TP>::PIN_ALL>      // PUBLISH = false: registers only
 __device__ __forceinline__ void g_fk(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, T q, const GX<T, GD<TP>::NX>& qx, GKin<T>& k) {
     static_assert(GTopo<TP>::slides_first(), "slide joints must be world-aligned root joints");
     using Ld = GLds<TP>;
@@ -678,8 +686,8 @@ __device__ __forceinline__ void g_fk(const GCtx<T, TP>& g, const GLaneTopo<T>& l
     // body offsets: pinned registers, or (19-dof walker) scalar loads of this evaluation -- the opaque pointer keeps them from
     // being hoisted out of the RK4 loops into registers the kernel does not have
     const DL_CONST GModel<T, TP>* mc = g.m;
-    if constexpr (!GD<TP>::PIN_ALL) DL_SPIN(mc);
-    auto body_pos = [&](int b, int kk) -> T { if constexpr (GD<TP>::PIN_ALL) return g.c->body_pos[b][kk]; else return mc->body_pos[b][kk]; };
+    if constexpr (!PIN) DL_SPIN(mc);
+    auto body_pos = [&](int b, int kk) -> T { if constexpr (PIN) return g.c->body_pos[b][kk]; else return mc->body_pos[b][kk]; };
     static_for<NX>([&](auto ti) {
         constexpr int t = ti.value;
         if constexpr (TP::dof_axis(t) == 2) rootz += T(TP::dof_sign(t)) * (qx.x[t] - g.c->xs_qpos0[t]);
@@ -1324,10 +1332,10 @@ template <typename T, typename TP> struct GDet {
     static constexpr int NPASS = GD<TP>::NPASS;
     bool act[NPASS], lim;
     int cinf[NPASS], slot[NPASS], nlim, ncon, my_lim;
-    V3<T> cp[NPASS];
+    T cpx[NPASS], cpy[NPASS], cpz[NPASS];
     T cdist[NPASS], ctx[NPASS], cty[NPASS], r_mu[NPASS], r_D[NPASS], r_kd[NPASS], lim_sign, l_D, l_k0;
 };
-template <typename T, typename TP>
+template <typename T, typename TP, bool PIN = GD<TP>::PIN_ALL>
 __device__ __forceinline__ void g_detect_constraints(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, GDet<T, TP>& d) {
     using Ld = GLds<TP>;
     using CM = GCandMask<TP>;
@@ -1337,11 +1345,11 @@ __device__ __forceinline__ void g_detect_constraints(const GCtx<T, TP>& g, const
     // collision candidates and solimp: pinned registers, or (19-dof walker) loads of this evaluation from the model block
     GLaneCand<T, NPASS> cfetch;
     const DL_CONST GModel<T, TP>* mc = g.m;
-    if constexpr (!GD<TP>::PIN_ALL) { int jj = j; DL_VPIN(jj); DL_SPIN(mc); cfetch = mc->lanes[jj].cand; }
-    const GLaneCand<T, NPASS>& cd = GD<TP>::PIN_ALL ? ln.cand : cfetch;
+    if constexpr (!PIN) { int jj = j; DL_VPIN(jj); DL_SPIN(mc); cfetch = mc->lanes[jj].cand; }
+    const GLaneCand<T, NPASS>& cd = PIN ? ln.cand : cfetch;
     struct { T solimp[5], solimp_inv[3]; } simp;
-    for (int k = 0; k < 5; k++) simp.solimp[k] = GD<TP>::PIN_ALL ? g.c->solimp[k] : mc->solimp[k];
-    for (int k = 0; k < 3; k++) simp.solimp_inv[k] = GD<TP>::PIN_ALL ? g.c->solimp_inv[k] : mc->solimp_inv[k];
+    for (int k = 0; k < 5; k++) simp.solimp[k] = PIN ? g.c->solimp[k] : mc->solimp[k];
+    for (int k = 0; k < 3; k++) simp.solimp_inv[k] = PIN ? g.c->solimp_inv[k] : mc->solimp_inv[k];
     const T rootz = *g.rz;
     // ---- joint limits (dof lanes), ranked by dof order through a ballot
     bool lim = false, lim_lo = false;
@@ -1358,8 +1366,8 @@ __device__ __forceinline__ void g_detect_constraints(const GCtx<T, TP>& g, const
     d.lim = lim; d.lim_sign = lim_lo ? T(1) : T(-1);
     // ---- contact candidates: NPASS passes of 16 (capsule ends and box corners in geom order); a candidate is a
     // constant body-local point (GLane), so the test is one frame transform + the floor distance
-#pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) {
+    static_for<NPASS>([&](auto pass_) {
+        constexpr int pass = pass_.value;
         const int cinfo = cd.cinfo[pass];
         d.cinf[pass] = cinfo;
         const int b = (cinfo >> 5) & 15;
@@ -1376,48 +1384,45 @@ __device__ __forceinline__ void g_detect_constraints(const GCtx<T, TP>& g, const
         const T rad = cd.crad[pass];
         const T dist = rootz + pt.z - rad;
         d.act[pass] = (cinfo & 1) && dist < T(0) && !(relz > T(0));
-        d.cp[pass] = mk<T>(pt.x, pt.y, pt.z - (rad + T(0.5) * dist));
+        d.cpx[pass] = pt.x; d.cpy[pass] = pt.y; d.cpz[pass] = pt.z - (rad + T(0.5) * dist);
         d.cdist[pass] = dist; d.ctx[pass] = tx; d.cty[pass] = ty;
-    }
+    });
     // box rule: only the first four qualifying corners of a box make contacts (mjc_PlaneBox)
     auto cand_mask = [&]() {
         CM m = 0;
-#pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) m |= (CM)((__ballot(d.act[pass]) >> (GL * grp)) & 0xFFFFull) << (GL * pass);
+        static_for<NPASS>([&](auto pass_) { constexpr int pass = pass_.value; m |= (CM)((__ballot(d.act[pass]) >> (GL * grp)) & 0xFFFFull) << (GL * pass); });
         return m;
     };
     CM cm = cand_mask();
-#pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) {
+    static_for<NPASS>([&](auto pass_) {
+        constexpr int pass = pass_.value;
         const int c = j + GL * pass;
         if (d.act[pass] && ((d.cinf[pass] >> 1) & 1)) {
             const int first = c - ((d.cinf[pass] >> 2) & 7);                             // first corner of this box in the candidate list
             const CM before = cm & (((CM)1 << c) - (CM)1) & ~(((CM)1 << first) - (CM)1);
             if (g_popc(before) >= 4) d.act[pass] = false;
         }
-    }
+    });
     cm = cand_mask();
     d.ncon = g_popc(cm);
-#pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) d.slot[pass] = g_popc((CM)(cm & (((CM)1 << (j + GL * pass)) - (CM)1)));
+    static_for<NPASS>([&](auto pass_) { constexpr int pass = pass_.value; d.slot[pass] = g_popc((CM)(cm & (((CM)1 << (j + GL * pass)) - (CM)1))); });
     d.my_lim = lim ? 4 * d.ncon + __popc(lmask & ((1u << j) - 1u)) : -1;
     // (the impedance / regulariser chains -- two reciprocals each -- of all passes and of the limit row are computed side by side, for every lane,
     //  and pinned: behind their lanes' predicates they ran one after the other, ~300 cycles of dependent instructions each)
-#pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) {
+    static_for<NPASS>([&](auto pass_) {
+        constexpr int pass = pass_.value;
         const T mu = dl_max(cd.cmu[pass], g.wk->floor_mu), dist = d.cdist[pass];
         const T imp = g_impedance(simp, dist);
         const T diag = cd.cinvw[pass] * (T(1) + mu * mu);
         const T R = T(2) * mu * mu * dl_max(T(1e-15), (T(1) - imp) * diag * dl_rcp(imp));
         d.r_mu[pass] = mu; d.r_D[pass] = dl_rcp(R); d.r_kd[pass] = g.c->solK * imp * dist;
-    }
+    });
     {
         const T imp = g_impedance(simp, lim_dist);
         const T R = dl_max(T(1e-15), (T(1) - imp) * ln.invw * dl_rcp(imp));
         d.l_D = dl_rcp(R); d.l_k0 = g.c->solK * imp * lim_dist;
     }
-#pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) { g_pin(d.r_D[pass]); g_pin(d.r_kd[pass]); g_pin(d.ctx[pass]); g_pin(d.cty[pass]); }
+    static_for<NPASS>([&](auto pass_) { constexpr int pass = pass_.value; g_pin(d.r_D[pass]); g_pin(d.r_kd[pass]); g_pin(d.ctx[pass]); g_pin(d.cty[pass]); });
     g_pin(d.l_D); g_pin(d.l_k0);
 }
 // x0: the solver's start point B v + a of the lane's dof, folded into the limit rows' J a - aref
@@ -1431,19 +1436,23 @@ __device__ __forceinline__ void g_commit_constraints(const GCtx<T, TP>& g, const
     //  the rows written below overwrite the mirror block of the mass matrix, whose reads precede them in program order)
     // ---- the lane of a candidate writes the contact record AND the contact's rows (rows 4c..4c+3: D, K imp r, cleared
     // active flags): nothing about a contact waits for another lane
-#pragma unroll
-    for (int pass = 0; pass < NPASS; pass++) {
+    static_for<NPASS>([&](auto pass_) {
+        constexpr int pass = pass_.value;
         if (d.act[pass]) {
             const int slot = d.slot[pass];
-            const T mu = d.r_mu[pass], dist = d.cdist[pass], D = d.r_D[pass], kd = d.r_kd[pass];
+            const T mu = d.r_mu[pass], D = d.r_D[pass], kd = d.r_kd[pass];
+            // (each value passes through an opaque statement on its way into a 16-byte store: the optimiser otherwise turns the scalar reads of neighbouring
+            //  members of `d` into vector loads of the struct itself, which then has to live in private memory -- across the partner wave's wait, as scratch)
+            T px = d.cpx[pass], py = d.cpy[pass], pz = d.cpz[pass], tx = d.ctx[pass], ty = d.cty[pass], dist = d.cdist[pass];
+            g_pin(px); g_pin(py); g_pin(pz); g_pin(tx); g_pin(ty); g_pin(dist);
             DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * slot;
-            st4(cn, d.cp[pass].x, d.cp[pass].y, d.cp[pass].z, T((d.cinf[pass] >> 5) & 15));
-            st4(cn + 4, d.ctx[pass], d.cty[pass], mu, dist);
+            st4(cn, px, py, pz, T((d.cinf[pass] >> 5) & 15));
+            st4(cn + 4, tx, ty, mu, dist);
             st4(wb + Ld::ROW + Ld::R_D * MAXROW + 4 * slot, D, D, D, D);
             st4(wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * slot, kd, kd, kd, kd);
             st4(wb + Ld::ROW + Ld::R_TMP * MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
         }
-    }
+    });
     // contacts are processed in pairs: a neutral record (world body: no dof moves it; mu = 0) closes an odd count
     if (j == 0 && d.ncon < MAXCON) {
         DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * d.ncon;
@@ -1586,34 +1595,48 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp0 = DL_CLOCK();
 #endif
-        bool answered = false;
+        // (flags are taken through readfirstlane: wave-uniform values in SGPRs, scalar branches instead of exec-mask regions)
+        // what the partner left for this configuration: the lane's kinematics (the frame of its body, its joint axis), the complete row of M (the partner
+        // performed the mirror exchange), the lane's limit row and the counts (records and rows follow with the request).  All loads in flight together; they
+        // are complete (pinned) before the regions are handed back to the partner with the request.
+        auto take = [&]() {
+            const DL_LDS T* f = wb + Sp::BFRX + Ld::BFR_W * g.ln->body;
+            const Q4<T> f0 = ld4(f), f1 = ld4(f + 4), f2 = ld4(f + 8), ax = ld4(wb + Sp::AXX + 4 * j);
+            const DL_LDS T* row = g.mm + j * Ld::MS;
+            const Q4<T> m0 = ld4(row), m1 = ld4(row + 4), m2 = ld4(row + 8), m3 = ld4(row + 12), m4 = ld4(row + 16);
+            T r_lim = g.mbox[Sp::MB_LIM + j], r_ncon = g.mbox[Sp::MB_NCON], r_nlim = g.mbox[Sp::MB_NLIM];
+            lim_sign = g.mbox[Sp::MB_SGN + j];
+            g_pin(r_lim); g_pin(r_ncon); g_pin(r_nlim); g_pin(lim_sign);
+            my_lim = (int)r_lim; ncon = (int)r_ncon; nlim = (int)r_nlim;
+            kin.X = mk<T>(f0.a, f0.b, f0.c); kin.Y = mk<T>(f0.d, f1.a, f1.b); kin.Z = mk<T>(f1.c, f1.d, f2.a); kin.pos = mk<T>(f2.b, f2.c, f2.d);
+            kin.axis = mk<T>(ax.a, ax.b, ax.c); kin.rootz = ax.d;
+            sm.mrow[0] = m0.a; sm.mrow[1] = m0.b; sm.mrow[2] = m0.c; sm.mrow[3] = m0.d; sm.mrow[4] = m1.a; sm.mrow[5] = m1.b; sm.mrow[6] = m1.c; sm.mrow[7] = m1.d;
+            sm.mrow[8] = m2.a; sm.mrow[9] = m2.b; sm.mrow[10] = m2.c; sm.mrow[11] = m2.d; sm.mrow[12] = m3.a; sm.mrow[13] = m3.b; sm.mrow[14] = m3.c; sm.mrow[15] = m3.d;
+            sm.mdiag = m4.a; sm.mcorr = m4.b;
+#pragma unroll
+            for (int a = 0; a < GL; a++) g_pin(sm.mrow[a]);
+            g_pin(sm.mdiag); g_pin(sm.mcorr); g_pin(kin.X.x); g_pin(kin.Y.y); g_pin(kin.Z.z); g_pin(kin.pos.x); g_pin(kin.axis.x);
+        };
+        int answered = 0;
         if (fast) {
-            for (int it = 0; !(answered = fl[Sp::MB_PRE] == seq - 1) && it < g.spin_limit; it++) DL_SLEEP();      // (complete long ago: the partner had a whole solve for it)
+            // the look-ahead of the previous request is complete long ago (the partner had a whole solve for it): the flag is read and the data requested in one
+            // go -- LDS operations of a wave are performed in order, so data requested after a flag read that returns "posted" is the posted data
+            const int pre = fl[Sp::MB_PRE];
+            take();
+            answered = DL_UNIFORM((int)(pre == seq - 1));
+            if (!answered) {
+                for (int it = 0; !(answered = DL_UNIFORM((int)(fl[Sp::MB_PRE] == seq - 1))) && it < g.spin_limit; it++) DL_SLEEP();
+                if (answered) { DL_WG_ACQUIRE(); g_sync<T>(); take(); }
+            }
         } else {
             g_sync<T>();
             DL_WG_RELEASE();
             if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 2; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; }
             DL_WAKE();
-            for (int it = 0; !(answered = fl[Sp::MB_MOK] == seq) && it < g.spin_limit; it++) DL_SLEEP();
+            for (int it = 0; !(answered = DL_UNIFORM((int)(fl[Sp::MB_MOK] == seq))) && it < g.spin_limit; it++) DL_SLEEP();
+            if (answered) { DL_WG_ACQUIRE(); g_sync<T>(); take(); }
         }
         if (answered) {
-            DL_WG_ACQUIRE();
-            g_sync<T>();
-            {   // kinematics of the lane: the frame of its body, its joint axis; the complete row of M (the partner performed the mirror exchange)
-                const DL_LDS T* f = wb + Sp::BFRX + Ld::BFR_W * g.ln->body;
-                const Q4<T> f0 = ld4(f), f1 = ld4(f + 4), f2 = ld4(f + 8), ax = ld4(wb + Sp::AXX + 4 * j);
-                const DL_LDS T* row = g.mm + j * Ld::MS;
-                const Q4<T> m0 = ld4(row), m1 = ld4(row + 4), m2 = ld4(row + 8), m3 = ld4(row + 12), m4 = ld4(row + 16);
-                kin.X = mk<T>(f0.a, f0.b, f0.c); kin.Y = mk<T>(f0.d, f1.a, f1.b); kin.Z = mk<T>(f1.c, f1.d, f2.a); kin.pos = mk<T>(f2.b, f2.c, f2.d);
-                kin.axis = mk<T>(ax.a, ax.b, ax.c); kin.rootz = ax.d;
-                sm.mrow[0] = m0.a; sm.mrow[1] = m0.b; sm.mrow[2] = m0.c; sm.mrow[3] = m0.d; sm.mrow[4] = m1.a; sm.mrow[5] = m1.b; sm.mrow[6] = m1.c; sm.mrow[7] = m1.d;
-                sm.mrow[8] = m2.a; sm.mrow[9] = m2.b; sm.mrow[10] = m2.c; sm.mrow[11] = m2.d; sm.mrow[12] = m3.a; sm.mrow[13] = m3.b; sm.mrow[14] = m3.c; sm.mrow[15] = m3.d;
-                sm.mdiag = m4.a; sm.mcorr = m4.b;
-                // the loads are complete before the regions are handed back to the partner
-#pragma unroll
-                for (int a = 0; a < GL; a++) g_pin(sm.mrow[a]);
-                g_pin(sm.mdiag); g_pin(sm.mcorr); g_pin(kin.X.x); g_pin(kin.Y.y); g_pin(kin.Z.z); g_pin(kin.pos.x); g_pin(kin.axis.x);
-            }
             g_sync<T>();
             DL_WG_RELEASE();
             if (fast) { if (grp == 0 && j == 0) { ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMD] = 1; ((volatile DL_LDS int*)g.mbox0)[Sp::MB_CMDSEQ] = seq; } }
@@ -1627,9 +1650,9 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
 #ifdef DL_EXP_SPLIT_PROF
             const long long tp2 = DL_CLOCK();
 #endif
-            answered = false;
-            for (int it = 0; !(answered = fl[Sp::MB_DONESEQ] == seq) && it < g.spin_limit; it++) DL_SLEEP();
-#ifdef DL_EXP_SPLIT_PROF          // [1]: waiting for the rows (DL_EXP_SPLIT_PROF = 1) or taking kinematics + mass matrix incl. any wait (= 2); [2]: the velocity half
+            answered = 0;
+            for (int it = 0; !(answered = DL_UNIFORM((int)(fl[Sp::MB_DONESEQ] == seq))) && it < g.spin_limit; it++) DL_SLEEP();
+#ifdef DL_EXP_SPLIT_PROF          // [1]: waiting for the rows (DL_EXP_SPLIT_PROF = 1 / 3) or taking kinematics + mass matrix incl. any wait (= 2); [2]: the velocity half
             split_seq[1] += (int)(((DL_EXP_SPLIT_PROF == 2) ? (tp1 - tp0) : (DL_CLOCK() - tp2)) >> 4); split_seq[2] += (int)((tp2 - tp1) >> 4);
 #endif
         }
@@ -1641,8 +1664,6 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         }
         DL_WG_ACQUIRE();
         g_sync<T>();
-        my_lim = (int)g.mbox[Sp::MB_LIM + j]; lim_sign = g.mbox[Sp::MB_SGN + j];
-        ncon = (int)g.mbox[Sp::MB_NCON]; nlim = (int)g.mbox[Sp::MB_NLIM];
         {   // the contact Jacobians are this wave's part of the constraint stage (its partner is the slower of the two otherwise)
             const T x0x[NXA] = {T(0)};
             g_contact_jacobians<T, TP>(g, lt, kin, ncon, (j < N) ? cs.solB * v + warm : T(0), x0x);

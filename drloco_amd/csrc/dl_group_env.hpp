@@ -103,7 +103,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     const DL_CONST GModel<T, TP>* m = (const DL_CONST GModel<T, TP>*)gm;
     const GLane<T, D::NPASS> ln = m->lanes[j];
     GConst<T, TP> cst;
-    g_load_const<T, TP>(*m, cst);
+    g_load_const<T, TP, false>(*m, cst);          // (fetch-at-use policy: this wave's registers hold the detection of the next evaluation across its waits)
     GWalk<T> wk;
     g_load_walk<T, TP>(m, st, w, wk);
     DL_LDS T* wb = smem + (size_t)grp * Sp::TOTAL;
@@ -123,82 +123,93 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     long long srv_busy = 0;
 #endif
     // what this wave holds in advance, for the configuration its partner announced with the last request: body frames, joint axes and mass matrix in LDS
-    // (GSplit::BFRX / AXX, the mirror block) and the configuration half of the constraints in registers (det)
+    // (GSplit::BFRX / AXX, the mirror block), what the dynamics wave needs to know of the constraints in the mailbox (the lanes' limit rows, the counts) and
+    // the configuration half of the constraints in registers (det)
     GDet<T, TP> det;
     GKin<T> kin{};
     const GX<T, 0> noqx{};
-    auto geometry = [&](T qc, bool with_m_first) {
-        // kinematics -> body frames + root height (g_fk publishes into this wave's own region) and the lanes' joint axes; mass matrix; detection
-        g_fk<T, TP, true>(g, lt, qc, noqx, kin);
-        st4(wb + Sp::AXX + 4 * j, kin.axis.x, kin.axis.y, kin.axis.z, kin.rootz);
-        if (with_m_first) {
-            g_mass_rows<T, TP>(g, lt, kin);
-            g_sync<T>();
-            DL_WG_RELEASE();
-            if (lane == 0) flags[Sp::MB_MOK] = seq;
-            DL_WAKE();
-            g_detect_constraints<T, TP>(g, lt, grp, qc, det);
-        } else {
-            g_detect_constraints<T, TP>(g, lt, grp, qc, det);
-            g_mass_rows<T, TP>(g, lt, kin);
-        }
-    };
-    for (;;) {
-        // (sequence number, command) in one 8-byte read: the partner stores the command first, LDS operations of a wave complete in order
-        static_assert(Sp::MB_CMD == Sp::MB_CMDSEQ + 1 && Sp::MB_CMDSEQ % 2 == 0, "the command word pair is one aligned 8-byte word");
-        int cur = seq, cmd = 0, it = 0;
-        for (;;) {
-            const long long wd = *(volatile DL_LDS long long*)(flags + Sp::MB_CMDSEQ);
-            cur = (int)(wd & 0xffffffffll); cmd = (int)(wd >> 32);
-            if (cur != seq || it >= g.spin_limit) break;
-            DL_SLEEP(); it++;
-        }
-        if (cur == seq) {         // timeout: the partner never asked and never released -- say so (the partner's next request then times out as well)
-            if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
-            break;
-        }
-        if (cmd == 0) break;          // released
+    // One code site per job, wave-uniform (scalar) control: a pass of the loop is  [wait for a request]  ->  [commit + post the rows]  ->  [geometry of a
+    // configuration + post that it is there].  A command-2 request (nothing usable in advance) takes two passes: geometry of ITS configuration first
+    // (posted as MB_MOK), then the commit and the look-ahead.
+    bool owe_commit = false;          // a command-2 request whose geometry is done and whose rows are still to be committed
+    int cmd = 0;
 #ifdef DL_EXP_SPLIT_PROF
-        const long long tsrv0 = DL_CLOCK();
+    long long tsrv0 = 0;
 #endif
-        DL_WG_ACQUIRE();
-        seq = cur;
-        g_sync<T>();
-        T q = g.mbox[Sp::MB_Q + j], x0 = g.mbox[Sp::MB_X0 + j], qn = g.mbox[Sp::MB_QN + j];
-        g_pin(q); g_pin(x0); g_pin(qn);
-        // command 2: this evaluation's configuration is not the one announced (first request of a launch, reset, injected state) -- everything now,
-        // the mass matrix first (the dynamics wave waits for it and the kinematics)
-        if (cmd == 2) geometry(q, true);
-        // ---- commit: contact records and rows of this evaluation (the limit rows take the solver's start point), report
-        g_commit_constraints<T, TP>(g, det, x0);
+    for (;;) {
+        if (!owe_commit) {
+            // (sequence number, command) in one 8-byte read: the partner stores the command first, LDS operations of a wave complete in order
+            static_assert(Sp::MB_CMD == Sp::MB_CMDSEQ + 1 && Sp::MB_CMDSEQ % 2 == 0, "the command word pair is one aligned 8-byte word");
+            int cur = seq, it = 0;
+            for (;;) {
+                const long long wd = *(volatile DL_LDS long long*)(flags + Sp::MB_CMDSEQ);
+                cur = DL_UNIFORM((int)(wd & 0xffffffffll)); cmd = DL_UNIFORM((int)(wd >> 32));
+                if (cur != seq || it >= g.spin_limit) break;
+                DL_SLEEP(); it++;
+            }
+            if (cur == seq) {         // timeout: the partner never asked and never released -- say so (the partner's next request then times out as well)
+                if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
+                break;
+            }
+            if (cmd == 0) break;          // released
+#ifdef DL_EXP_SPLIT_PROF
+            tsrv0 = DL_CLOCK();
+#endif
+            DL_WG_ACQUIRE();
+            seq = cur;
+            g_sync<T>();
+        }
+        T qg;                 // the configuration whose geometry this pass computes
+        int post;             // ... and the flag that says it is there
+        if (cmd == 1 || owe_commit) {
+            // ---- commit: contact records and rows of this evaluation from the detection in registers (the limit rows take the solver's start point):
+            // stores only, then the flag
+            const T x0 = g.mbox[Sp::MB_X0 + j];
+            g_commit_constraints<T, TP>(g, det, x0);
+            DL_WG_RELEASE();
+            if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
+            DL_WAKE();
+#if defined(DL_EXP_SPLIT_PROF) && DL_EXP_SPLIT_PROF == 3          // (3: this wave's time from seeing a request to posting its rows, instead of its whole busy time)
+            srv_busy += DL_CLOCK() - tsrv0;
+#endif
+            if (DL_PREFETCH_ACTIONS && actions_all && (seq - 1) % evals_per_step == 0) {
+                const int next = (seq - 1) / evals_per_step + 1;
+                if (next < nsteps && j < TP::NU) pf_sink += actions_all[((size_t)next * n + w) * TP::NU + j];
+            }
+            // in advance, while the dynamics wave solves: the NEXT evaluation's configuration.  (After command 2 the dynamics wave may still be reading what
+            // the previous pass computed: it says when it has it, MB_MFREE.  After command 1 it had taken everything before it sent the request.)
+            if (owe_commit) {
+                int freed = 0;
+                for (int k2 = 0; !(freed = DL_UNIFORM((int)(flags[Sp::MB_MFREE] == seq))) && k2 < g.spin_limit; k2++) DL_SLEEP();
+                if (!freed) {
+                    if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
+                    break;
+                }
+                DL_WG_ACQUIRE();
+                owe_commit = false;
+            }
+            qg = g.mbox[Sp::MB_QN + j]; post = Sp::MB_PRE;
+        } else {
+            // command 2: this evaluation's configuration is not the one announced (first request of a launch, reset, injected state): its geometry now
+            // (the dynamics wave waits for it: MB_MOK), its rows in the next pass
+            qg = g.mbox[Sp::MB_Q + j]; post = Sp::MB_MOK;
+            owe_commit = true;
+        }
+        // ---- geometry: kinematics -> body frames + root height (g_fk publishes into this wave's own region) and the lanes' joint axes; the mass matrix; the
+        // configuration half of the constraints (registers) and what the dynamics wave needs to know of it.  The detection comes last: its results stay in
+        // registers until the next request, across nothing but the wait.
+        g_fk<T, TP, true, false>(g, lt, qg, noqx, kin);
+        st4(wb + Sp::AXX + 4 * j, kin.axis.x, kin.axis.y, kin.axis.z, kin.rootz);
+        g_mass_rows<T, TP>(g, lt, kin);
+        g_detect_constraints<T, TP, false>(g, lt, grp, qg, det);
         g.mbox[Sp::MB_LIM + j] = (T)det.my_lim; g.mbox[Sp::MB_SGN + j] = det.lim_sign;
         if (j == 0) { g.mbox[Sp::MB_NCON] = (T)det.ncon; g.mbox[Sp::MB_NLIM] = (T)det.nlim; }
         g_sync<T>();
         DL_WG_RELEASE();
-        if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
+        if (lane == 0) flags[post] = seq;
         DL_WAKE();
-        if (DL_PREFETCH_ACTIONS && actions_all && (seq - 1) % evals_per_step == 0) {
-            const int next = (seq - 1) / evals_per_step + 1;
-            if (next < nsteps && j < TP::NU) pf_sink += actions_all[((size_t)next * n + w) * TP::NU + j];
-        }
-        // ---- in advance, while the dynamics wave solves: the NEXT evaluation's configuration.  (After command 2 the dynamics wave may still be reading
-        // what was computed above: it says when it has it, MB_MFREE.  After command 1 it had taken everything before it sent the request.)
-        if (cmd == 2) {
-            bool freed = false;
-            for (int k2 = 0; !(freed = flags[Sp::MB_MFREE] == seq) && k2 < g.spin_limit; k2++) DL_SLEEP();
-            if (!freed) {
-                if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
-                break;
-            }
-            DL_WG_ACQUIRE();
-        }
-        geometry(qn, false);
-        g_sync<T>();
-        DL_WG_RELEASE();
-        if (lane == 0) flags[Sp::MB_PRE] = seq;
-        DL_WAKE();
-#ifdef DL_EXP_SPLIT_PROF          // busy cycles of this wave (request seen -> look-ahead finished), summed over the launch: dbg slot 0 (tools/diag_split.py)
-        srv_busy += DL_CLOCK() - tsrv0;
+#if defined(DL_EXP_SPLIT_PROF) && DL_EXP_SPLIT_PROF != 3          // busy cycles of this wave (request seen -> look-ahead finished), summed over the launch: dbg slot 0 (tools/diag_split.py)
+        if (!owe_commit) srv_busy += DL_CLOCK() - tsrv0;
 #endif
     }
 #ifdef DL_EXP_SPLIT_PROF
