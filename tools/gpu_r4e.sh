@@ -8,4 +8,4 @@ for i in 1 2; do
 run product_$i
 
 done
-for v in prof1 prof3; do echo $v; DL_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libdrloco_hip_$v.so timeout 300 python3 tools/diag_split.py 2>&1 | tail -1; done
+
