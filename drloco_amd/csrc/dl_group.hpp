@@ -93,6 +93,9 @@
 #ifndef DL_PREFETCH_REFS
 #define DL_PREFETCH_REFS 0     // experiment switch: 1 advances a copy of the cursor and requests the step's reference sample BEFORE the physics (measured: no gain -- the values wait in scratch, 68 instead of 44 spilled registers)
 #endif
+#ifndef DL_JAC_ON_PARTNER
+#define DL_JAC_ON_PARTNER 0      // experiment switch: 1 = the partner wave of a split workgroup also builds the contact Jacobians (with its commit)
+#endif
 #ifndef DL_PREFETCH_ACTIONS
 #define DL_PREFETCH_ACTIONS 1   // the constraint wave of a split workgroup touches the next control step's action row (0: off, experiment switch)
 #endif
@@ -1664,10 +1667,12 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         }
         DL_WG_ACQUIRE();
         g_sync<T>();
+#if !DL_JAC_ON_PARTNER
         {   // the contact Jacobians are this wave's part of the constraint stage (its partner is the slower of the two otherwise)
             const T x0x[NXA] = {T(0)};
             g_contact_jacobians<T, TP>(g, lt, kin, ncon, (j < N) ? cs.solB * v + warm : T(0), x0x);
         }
+#endif
     } else {
     g_smooth_dynamics<T, TP>(g, lt, q, v, ctrl_force, qx, vx, kin, sm);
     tick(0);

@@ -166,6 +166,9 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
             // stores only, then the flag
             const T x0 = g.mbox[Sp::MB_X0 + j];
             g_commit_constraints<T, TP>(g, det, x0);
+#if DL_JAC_ON_PARTNER
+            { const T x0x[1] = {T(0)}; g_contact_jacobians<T, TP>(g, lt, kin, det.ncon, x0, x0x); }
+#endif
             DL_WG_RELEASE();
             if (lane == 0) flags[Sp::MB_DONESEQ] = seq;
             DL_WAKE();

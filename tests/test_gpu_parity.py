@@ -225,6 +225,44 @@ def test_G4_step_traces_on_device(torch_cuda, model, refs, precision, case, lane
 
 
 @LANES_S
+@pytest.mark.parametrize('mirror', [1, 0], ids=['mirrored-policy', 'plain'])
+def test_G3_reward_obs_on_device(torch_cuda, model, refs, lanes, mirror):
+    """The reference's own get_reward / _get_obs / mirror_obs outputs (golden G3: mimic_env.py:403-480, 592-649) through the DEVICE step kernels: every golden
+    sample is a walker whose cursor sits one refs.next() before the golden cursor and whose post-physics state is injected; the step's observation (the
+    terminal observation where qpos[2] < 0.5 ends the episode) and its reward terms are the reference's."""
+    from drloco_amd.vec_env import HipVecEnv
+    with np.load(os.path.join(GOLDEN, 'G3_reward_obs.npz')) as z:
+        g = {k: z[k] for k in z.files}
+    keep = np.nonzero(g['pos'] >= 2)[0]          # (the golden cursor is reached by one plain advance: no step rollover in front of it)
+    n = len(keep)
+    for precision in ((32,) if lanes == 'split' else (32, 64)):
+        env = HipVecEnv(num_envs=n, precision=precision, model=model, refs=refs, ep_dur_max=10 ** 9, lanes_per_walker=lanes, mirror_policy=mirror, rew_weights=(0.8, 0.2, 0.0))
+        cur = np.zeros((abi.DL_CUR_WORDS, n), np.int32)
+        cur[abi.DL_CUR_I_STEP] = cur[abi.DL_CUR_RSI_STEP] = cur[abi.DL_CUR_READ_STEP] = g['i_step'][keep]
+        cur[abi.DL_CUR_POS], cur[abi.DL_CUR_COUNT] = g['pos'][keep] - 2, g['count'][keep]
+        env.set_state(cursor=cur)
+        env.debug_inject(qpos=g['qpos'][keep].T, qvel=g['qvel'][keep].T, flags=np.ones(n, np.int32))
+        obs, rew, done, infos = env.step(np.zeros((n, 8), np.float32))
+        terms = env.rew_terms.cpu().numpy().astype(np.float64)
+        st = env.get_state()['cursor']
+        fell = g['qpos'][keep, 2] < 0.5
+        assert np.array_equal(done, fell) and fell.any() and (~fell).sum() > 100
+        want = g['obs' if mirror else 'obs_nomirr'][keep]
+        got = np.stack([infos[i]['terminal_observation'] if done[i] else obs[i] for i in range(n)])
+        tol = dict(rtol=1e-5, atol=1e-5) if precision == 32 else dict(rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(got, want, **tol)
+        live = ~fell
+        assert np.array_equal(st[abi.DL_CUR_POS, live], g['pos'][keep][live]) and np.array_equal(st[abi.DL_CUR_I_STEP, live], g['i_step'][keep][live])
+        rt = 2e-5 if precision == 32 else 2e-6
+        np.testing.assert_allclose(terms[live, 0], g['pose'][keep][live], rtol=rt, atol=1e-30)
+        np.testing.assert_allclose(terms[live, 1], g['vel'][keep][live], rtol=rt, atol=1e-30)
+        np.testing.assert_allclose(terms[live, 2], g['com'][keep][live], rtol=20 * rt, atol=1e-12)          # exp(-16 d^2) of a metre-sized d in float32
+        np.testing.assert_allclose(rew[live], 0.8 * g['pose'][keep][live] + 0.2 * g['vel'][keep][live] + 0.2, rtol=rt)
+        assert (rew[fell] == 0).all()
+        env.close()
+
+
+@LANES_S
 def test_G2_cursor_on_device(torch_cuda, model, refs, lanes):
     from drloco_amd.vec_env import HipVecEnv
     with np.load(os.path.join(GOLDEN, 'G2_cursor_traces.npz')) as z:
