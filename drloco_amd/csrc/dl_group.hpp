@@ -1590,7 +1590,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         // request says so and waits for the partner to compute everything now.
         volatile DL_LDS int* fl = (volatile DL_LDS int*)g.mbox0;
         const int seq = ++*split_seq;
-        const bool fast = __all(j >= N || __builtin_bit_cast(uint32_t, (float)q) == __builtin_bit_cast(uint32_t, (float)*q_ann));
+        const bool fast = !__any(j < N && __builtin_bit_cast(uint32_t, (float)q) != __builtin_bit_cast(uint32_t, (float)*q_ann));
         *q_ann = q_next;
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
