@@ -460,7 +460,7 @@ template <typename TP> struct GSplit {
     // look-ahead of the mass matrix: MB_QN = the configuration of the NEXT evaluation (known when this one is requested); MB_MOK = sequence number of
     // the request whose mass matrix is in the mirror block (posted by the partner once it has checked that what it precomputed is for this request's
     // configuration); MB_MFREE = sequence number of the last request whose mass matrix the dynamics wave has taken into registers
-    static constexpr int MB_MOK = 69, MB_MFREE = 70, MB_QN = 72, MB_PRE = 71;          // MB_PRE: sequence number of the last request whose look-ahead is complete
+    static constexpr int MB_MOK = 69, MB_MFREE = 70, MB_QN = 72, MB_PRE = 71;          // MB_PRE: sequence number of the last request whose look-ahead is complete (-1 at launch; 0: the state in memory)
     static_assert(MB_QN % 4 == 0 && MB_QN + GL <= MB_SIZE, "mailbox layout");
     // what the partner wave computes one evaluation ahead and hands over through LDS: the body frames (its own copy: GLds::BFR shares the space of the contact
     // Jacobians, which are live while it works) and, per dof lane, (joint axis x y z, root height)

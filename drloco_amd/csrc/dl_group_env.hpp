@@ -12,6 +12,16 @@
 
 #include "dl_group.hpp"
 
+#ifndef DL_EXP_EXTRAP
+#define DL_EXP_EXTRAP 0          // experiment switch: quadratic (three-point) extrapolation of the solver's start point in RK4 stages 1 and 3, weight DL_EXP_EXTRAP_W
+#endif
+#ifndef DL_EXTRAP_BETA
+#define DL_EXTRAP_BETA 1.0          // weight of the linear extrapolation of the solver's start point in RK4 stages 1 and 3 (lane dofs; 1 = the next stage lies half a step further)
+#endif
+#ifndef DL_EXP_EXTRAP_W
+#define DL_EXP_EXTRAP_W 1.0
+#endif
+
 namespace dl {
 
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.  The SoA
@@ -136,8 +146,16 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
 #ifdef DL_EXP_SPLIT_PROF
     long long tsrv0 = 0;
 #endif
+    // The first evaluation of a launch: its configuration is the walkers' state in memory (unless a test injects another one), so the geometry starts NOW,
+    // next to the dynamics wave's prologue (state, model and action loads), instead of with the first request: posted as the look-ahead of "request 0".
+    bool boot = true;
     for (;;) {
-        if (!owe_commit) {
+        if (boot) {
+            cmd = 3;
+#ifdef DL_EXP_SPLIT_PROF
+            tsrv0 = DL_CLOCK();
+#endif
+        } else if (!owe_commit) {
             // (sequence number, command) in one 8-byte read: the partner stores the command first, LDS operations of a wave complete in order
             static_assert(Sp::MB_CMD == Sp::MB_CMDSEQ + 1 && Sp::MB_CMDSEQ % 2 == 0, "the command word pair is one aligned 8-byte word");
             int cur = seq, it = 0;
@@ -161,7 +179,10 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         }
         T qg;                 // the configuration whose geometry this pass computes
         int post;             // ... and the flag that says it is there
-        if (cmd == 1 || owe_commit) {
+        if (cmd == 3) {
+            qg = j < D::NL ? st.qpos[(size_t)j * n + w] : T(0); post = Sp::MB_PRE;
+            boot = false;
+        } else if (cmd == 1 || owe_commit) {
             // ---- commit: contact records and rows of this evaluation from the detection in registers (the limit rows take the solver's start point):
             // stores only, then the flag
             const T x0 = g.mbox[Sp::MB_X0 + j];
@@ -264,6 +285,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     g_lane_topo<T, TP>(j, lt);
     T q = T(0), v = T(0), warm = T(0);
     if (isdof) { const size_t o = (size_t)jd * n + w1; q = st.qpos[o]; v = st.qvel[o]; warm = st.warm[o]; }
+    if constexpr (SPLIT) q_ann = q;          // the partner wave starts with the geometry of the state in memory (g_constraint_server): "announced" by the launch itself
     GX<T, NX> qx, vx, warmx;
     static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w1; qx.x[t] = st.qpos[o]; vx.x[t] = st.qvel[o]; warmx.x[t] = st.warm[o]; });
     int32_t cur[DL_CUR_WORDS];
@@ -346,6 +368,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         const T h = m->timestep;
         const int fs = m->frame_skip;
         T acc_s2_prev = T(0);
+#if DL_EXP_EXTRAP
+        T acc_s0_prev = T(0), acc_s2_pp = T(0);          // experiment: quadratic extrapolation of the solver's start (lane dofs only)
+#endif
         GX<T, NX> accx_s2_prev;
         static_for<NX>([&](auto ti) { accx_s2_prev.x[ti.value] = T(0); });
 #pragma unroll 1
@@ -369,8 +394,13 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 // (stage 2 of the previous mj_step, stage 0), stage 3 from (stage 0, stage 2)
                 T start = warm;
                 GX<T, NX> startx = warmx, accx;
-                if (stage == 1 && kf > 0) { start = warm + (warm - acc_s2_prev); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s2_prev.x[t]); }); }
-                else if (stage == 3) { start = warm + (warm - acc_s0); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s0.x[t]); }); }
+#if DL_EXP_EXTRAP
+                if (NX == 0 && stage == 1 && kf > 0) { const T lin = warm + (warm - acc_s2_prev), quad = T(3) * warm - T(3) * acc_s2_prev + acc_s0_prev; start = lin + T(DL_EXP_EXTRAP_W) * (quad - lin); }
+                else if (NX == 0 && stage == 3 && kf > 0) { const T lin = warm + (warm - acc_s0), quad = T(3) * warm - T(3) * acc_s0 + acc_s2_pp; start = lin + T(DL_EXP_EXTRAP_W) * (quad - lin); }
+                else
+#endif
+                if (stage == 1 && kf > 0) { start = warm + T(DL_EXTRAP_BETA) * (warm - acc_s2_prev); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s2_prev.x[t]); }); }
+                else if (stage == 3) { start = warm + T(DL_EXTRAP_BETA) * (warm - acc_s0); static_for<NX>([&](auto ti) { constexpr int t = ti.value; startx.x[t] = warmx.x[t] + (warmx.x[t] - accx_s0.x[t]); }); }
                 // RK4: the configuration of the NEXT evaluation depends on this stage's velocity only -- known before this stage's solve.  A split
                 // workgroup hands it to the partner wave, which computes that configuration's mass matrix while this wave solves (g_forward<SPLIT>).
                 const T wgt = (stage == 0 || stage == 3) ? T(1) / T(6) : T(1) / T(3);
@@ -379,6 +409,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 const T q_ahead = stage == 3 ? q0 + h * dq_new : q0 + h * al * vs;          // stage 3: the state after this mj_step = stage 0 of the next
                 const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq, q_ahead, &q_ann);
                 if constexpr (SPLIT) { if (split_seq[3] && simulate) exc = true; }      // the hand-over with the constraint wave failed: MujocoException path
+#if DL_EXP_EXTRAP
+                if (stage == 2) acc_s2_pp = acc_s2_prev;          // (before the overwrite below: the previous mj_step's stage 2)
+#endif
                 if (stage == 0) { acc_s0 = acc; accx_s0 = accx; }
                 if (stage == 2) { acc_s2_prev = acc; accx_s2_prev = accx; }
                 dbg_it += ni; dbg_max = ni > dbg_max ? ni : dbg_max; dbg_rows += ne;
@@ -403,6 +436,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                     qsx.x[t] = qx0.x[t] + h * al * vst; vsx.x[t] = vx0.x[t] + h * al * accx.x[t];
                 });
             }
+#if DL_EXP_EXTRAP
+            acc_s0_prev = acc_s0;
+#endif
             if (simulate && !exc) {
                 q = q_end; v = v0 + h * dv;          // q_end = q0 + h * dq, formed before the last stage's solve
                 static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = qx0.x[t] + h * dqx.x[t]; vx.x[t] = vx0.x[t] + h * dvx.x[t]; });

@@ -108,7 +108,7 @@ void k_env_step_g16_split(const GModel<T, TP>* __restrict__ gm, const DevCfg<T> 
     DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
     if (lane == 0) {               // both waves of a pair clear the pair's flags, then the one barrier of this kernel
         volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
-        f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = 0;
+        f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = -1;
     }
     __syncthreads();
     // the XCD-aware permutation acts on WORKGROUPS (workgroup b runs on XCD b % 8): a workgroup owns sixteen consecutive walkers = one full
@@ -726,7 +726,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         // ---- E: one control step of the sixteen walkers
         if (lane == 0) {
             volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
-            f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = 0;
+            f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = -1;
         }
         __syncthreads();
         {
