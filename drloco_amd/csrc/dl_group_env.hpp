@@ -605,15 +605,19 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         if (lane == 0) { ((volatile DL_LDS int*)g.mbox0)[GSplit<TP>::MB_CMD] = 0; ((volatile DL_LDS int*)g.mbox0)[GSplit<TP>::MB_CMDSEQ] = split_seq[0] + 1; }
         DL_WAKE();
     }
+    // (the walker index is opaque here as well: the addresses of the final stores are formed now -- kept from the loads at the top they were twenty 64-bit
+    //  values per lane that lived, spilled to scratch, through the whole launch)
+    int we = w1;
+    DL_VPIN(we);
     if (valid && j == 0) {
-        st.comz_off[w1] = comz;
-        st.mon[(size_t)MON_POSREW * n + w1] = terms[0]; st.mon[(size_t)MON_VELREW * n + w1] = terms[1]; st.mon[(size_t)MON_COMREW * n + w1] = terms[2];
-        st.walked[w1] = walked;
+        st.comz_off[we] = comz;
+        st.mon[(size_t)MON_POSREW * n + we] = terms[0]; st.mon[(size_t)MON_VELREW * n + we] = terms[1]; st.mon[(size_t)MON_COMREW * n + we] = terms[2];
+        st.walked[we] = walked;
 #pragma unroll
-        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + w1] = cur[k];
-        static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w1; st.qpos[o] = qx.x[t]; st.qvel[o] = vx.x[t]; st.warm[o] = warmx.x[t]; });
+        for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + we] = cur[k];
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + we; st.qpos[o] = qx.x[t]; st.qvel[o] = vx.x[t]; st.warm[o] = warmx.x[t]; });
     }
-    if (valid && isdof) { const size_t o = (size_t)jd * n + w1; st.qpos[o] = q; st.qvel[o] = v; st.warm[o] = warm; }
+    if (valid && isdof) { const size_t o = (size_t)jd * n + we; st.qpos[o] = q; st.qvel[o] = v; st.warm[o] = warm; }
     if constexpr (TIMED) {
         const long long t_end = DL_CLOCK();
         tacc[7] = t_end - t_begin; tacc[9] = t_end - t_phys_end;
