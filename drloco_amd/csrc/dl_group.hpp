@@ -1625,6 +1625,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             // the look-ahead of the previous request is complete long ago (the partner had a whole solve for it): the flag is read and the data requested in one
             // go -- LDS operations of a wave are performed in order, so data requested after a flag read that returns "posted" is the posted data
             const int pre = fl[Sp::MB_PRE];
+            g_sync<T>();          // (compiler fence: the data loads below must not be moved in front of the flag read -- `volatile` orders the flag read against other volatile accesses only)
             take();
             answered = DL_UNIFORM((int)(pre == seq - 1));
             if (!answered) {

@@ -142,6 +142,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     // configuration + post that it is there].  A command-2 request (nothing usable in advance) takes two passes: geometry of ITS configuration first
     // (posted as MB_MOK), then the commit and the look-ahead.
     bool owe_commit = false;          // a command-2 request whose geometry is done and whose rows are still to be committed
+    T rq_q = T(0), rq_x0 = T(0), rq_qn = T(0);          // the request's words: this evaluation's configuration (command 2), the solver's start point, the NEXT configuration
     int cmd = 0;
 #ifdef DL_EXP_SPLIT_PROF
     long long tsrv0 = 0;
@@ -176,6 +177,11 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
             DL_WG_ACQUIRE();
             seq = cur;
             g_sync<T>();
+            // The request is consumed HERE, before anything is posted: the dynamics wave overwrites these mailbox words with its next request, and it can start
+            // that as soon as this request's rows are posted (a solve of walkers in the air takes a few thousand cycles -- less than a cache miss of this wave).
+            rq_x0 = g.mbox[Sp::MB_X0 + j]; rq_qn = g.mbox[Sp::MB_QN + j];
+            if (cmd == 2) rq_q = g.mbox[Sp::MB_Q + j];
+            g_pin(rq_x0); g_pin(rq_qn); g_pin(rq_q);
         }
         T qg;                 // the configuration whose geometry this pass computes
         int post;             // ... and the flag that says it is there
@@ -185,8 +191,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
         } else if (cmd == 1 || owe_commit) {
             // ---- commit: contact records and rows of this evaluation from the detection in registers (the limit rows take the solver's start point):
             // stores only, then the flag
-            const T x0 = g.mbox[Sp::MB_X0 + j];
-            g_commit_constraints<T, TP>(g, det, x0);
+            g_commit_constraints<T, TP>(g, det, rq_x0);
 #if DL_JAC_ON_PARTNER
             { const T x0x[1] = {T(0)}; g_contact_jacobians<T, TP>(g, lt, kin, det.ncon, x0, x0x); }
 #endif
@@ -212,11 +217,11 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
                 DL_WG_ACQUIRE();
                 owe_commit = false;
             }
-            qg = g.mbox[Sp::MB_QN + j]; post = Sp::MB_PRE;
+            qg = rq_qn; post = Sp::MB_PRE;
         } else {
             // command 2: this evaluation's configuration is not the one announced (first request of a launch, reset, injected state): its geometry now
             // (the dynamics wave waits for it: MB_MOK), its rows in the next pass
-            qg = g.mbox[Sp::MB_Q + j]; post = Sp::MB_MOK;
+            qg = rq_q; post = Sp::MB_MOK;
             owe_commit = true;
         }
         // ---- geometry: kinematics -> body frames + root height (g_fk publishes into this wave's own region) and the lanes' joint axes; the mass matrix; the
