@@ -1453,13 +1453,17 @@ __device__ __forceinline__ void g_commit_constraints(const GCtx<T, TP>& g, const
             st4(cn + 4, tx, ty, mu, dist);
             st4(wb + Ld::ROW + Ld::R_D * MAXROW + 4 * slot, D, D, D, D);
             st4(wb + Ld::ROW + Ld::R_JAREF * MAXROW + 4 * slot, kd, kd, kd, kd);
-            st4(wb + Ld::ROW + Ld::R_TMP * MAXROW + 4 * slot, T(0), T(0), T(0), T(0));
+            T zero = T(0);
+            g_pin(zero);          // (formed here: the constant quad is otherwise hoisted out of a caller's step loop, four registers that end up in scratch)
+            st4(wb + Ld::ROW + Ld::R_TMP * MAXROW + 4 * slot, zero, T(0), T(0), T(0));
         }
     });
     // contacts are processed in pairs: a neutral record (world body: no dof moves it; mu = 0) closes an odd count
     if (j == 0 && d.ncon < MAXCON) {
         DL_LDS T* cn = wb + Ld::CON + Ld::CON_W * d.ncon;
-        st4(cn, T(0), T(0), T(0), T(0)); st4(cn + 4, T(1), T(0), T(0), T(0));
+        T one = T(1);
+        g_pin(one);               // (a constant quad {1, 0, 0, 0} is hoisted out of every enclosing loop as four registers and then spilled: formed here)
+        st4(cn, T(0), T(0), T(0), T(0)); st4(cn + 4, one, T(0), T(0), T(0));
         st4(wb + Ld::FC + Ld::FC_W * d.ncon, T(0), T(0), T(0), T(0));
         if constexpr (NX > 0) st4(wb + Ld::FC + Ld::FC_W * d.ncon + 8, T(0), T(0), T(0), T(0));
     }

@@ -297,9 +297,14 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
 #pragma unroll
     for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w1];
     // per-walker words of the environment logic live in registers across the control steps of this launch
-    double walked = st.walked[w1];
+    // the walked distance (a float64 accumulator, touched once per control step) sits in two free words of the walker's LDS region, not in registers across the physics
+    DL_LDS T* const walked_w = smem + (size_t)grp * WSTRIDE + Ld::MISC + 2;
+    auto walked_put = [&](double x) { if (j == 0) { if constexpr (sizeof(T) == 8) walked_w[0] = x; else { const uint64_t b = __builtin_bit_cast(uint64_t, x); uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32); DL_VPIN(lo); DL_VPIN(hi); walked_w[0] = __builtin_bit_cast(T, lo); walked_w[1] = __builtin_bit_cast(T, hi); } } };      // (pinned: a constant 0.0 is otherwise a register pair hoisted out of the step loop)
+    auto walked_get = [&]() -> double { if constexpr (sizeof(T) == 8) return walked_w[0]; else { const T w0 = walked_w[0], w1 = walked_w[1]; return __builtin_bit_cast(double, (uint64_t)__builtin_bit_cast(uint32_t, w0) | ((uint64_t)__builtin_bit_cast(uint32_t, w1) << 32)); } };
+    walked_put(st.walked[w1]);
     T comz = st.comz_off[w1];
-    double terms[3] = {st.mon[(size_t)MON_POSREW * n + w1], st.mon[(size_t)MON_VELREW * n + w1], st.mon[(size_t)MON_COMREW * n + w1]};
+    // (the reward terms of the last step are values of type T held as doubles in the Monitor words: kept as T here, widened where they are used)
+    T terms[3] = {(T)st.mon[(size_t)MON_POSREW * n + w1], (T)st.mon[(size_t)MON_VELREW * n + w1], (T)st.mon[(size_t)MON_COMREW * n + w1]};
     long long t_phys_end = 0;
     // push schedule on the device (BASELINE config 5 without a host round trip per control step)
     const V3<T> push_force = wk.push;
@@ -315,26 +320,27 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         wk.push = on ? push_force : mk<T>(0, 0, 0);
         wk.pushed = on && (push_force.x != T(0) || push_force.y != T(0) || push_force.z != T(0));
     }
-    const float* __restrict__ actions = actions_all + (size_t)step * n * NU;
-    float* obs = obs_all + (size_t)step * n * OBS;
-    float* rew = rew_all + (size_t)step * n;
-    uint8_t* done = done_all + (size_t)step * n;
-    float* term_obs = term_obs_all ? term_obs_all + (size_t)step * n * OBS : nullptr;
-    float* rew_terms = rew_terms_all ? rew_terms_all + (size_t)step * n * 3 : nullptr;
+    const float* aa = actions_all;
+    DL_SPIN(aa);
+    const float* __restrict__ actions = aa + (size_t)step * n * NU;
+    // (the output rows of this step are addressed AFTER the physics, from a step count made opaque there: formed here they are five 64-bit values that live,
+    //  spilled to scratch, through the twenty forward evaluations)
     // ---- _rescale_actions + mirror_action (cursor BEFORE refs.next()), per actuated dof
     bool mirr_a = false;
     if constexpr (TP::ENV_KIND == 0) mirr_a = c.mirror_policy && c.step_is_left[cur[DL_CUR_I_STEP]];
     T ctrl = T(0), force = T(0);
     const int a = isdof ? ln.act : -1;
     if (a >= 0) {
-        const int src = mirr_a ? TP::act_perm(a) : a;
+        int a_o = a;
+        DL_VPIN(a_o);             // (opaque: the addresses formed from it -- the permutation table's entry, the test hook's slot -- are per-lane pointers that would otherwise be hoisted out of the step loop and spilled)
+        const int src = mirr_a ? TP::act_perm(a_o) : a;
         const int jsrc = TP::act_dof(src) - NX;
         const T x = dl_clamp((T)actions[(size_t)w * NU + src], T(-1), T(1));
         const T raw = x > T(0) ? x * m->ctrl_hi[jsrc] : dl_abs(x) * m->ctrl_lo[jsrc];
         ctrl = (mirr_a && TP::act_neg(a)) ? -raw : raw;
         const T u = dl_clamp(ctrl, ln.ctrl_lo, ln.ctrl_hi);
         force = ln.gear * dl_clamp(u, ln.force_lo, ln.force_hi);
-        if (ctrl_out && valid) ctrl_out[(size_t)step * n * NU + (size_t)w * NU + a] = (float)ctrl;      // test hook: sim.data.ctrl as the reference sets it
+        if (ctrl_out && valid) ctrl_out[(size_t)step * n * NU + (size_t)w * NU + a_o] = (float)ctrl;      // test hook: sim.data.ctrl as the reference sets it
     }
     const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
     // ---- what the END of the step will look up does not depend on the physics: refs.next() is a function of the cursor alone.  The cursor
@@ -364,7 +370,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     const int flag = inj_flags ? inj_flags[w] : 0;
     if (flag == 2) exc = true;
     else if (flag == 1) {
-        if (isdof) { q = inj_q[(size_t)jd * n + w]; v = inj_v[(size_t)jd * n + w]; }
+        int jd_o = jd;
+        DL_VPIN(jd_o);            // (opaque: `inj_q + jd * n` is otherwise a per-lane pointer hoisted out of the step loop and kept, spilled, through the launch -- for a test hook)
+        if (isdof) { q = inj_q[(size_t)jd_o * n + w]; v = inj_v[(size_t)jd_o * n + w]; }
         static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = inj_q[(size_t)t * n + w]; vx.x[t] = inj_v[(size_t)t * n + w]; });
     }
     const bool simulate = flag == 0;
@@ -504,9 +512,16 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             }
         }
     };
+    int step_o = step;
+    DL_SPIN(step_o);
+    float* obs = obs_all + (size_t)step_o * n * OBS;
+    float* rew = rew_all + (size_t)step_o * n;
+    uint8_t* done = done_all + (size_t)step_o * n;
+    float* term_obs = term_obs_all ? term_obs_all + (size_t)step_o * n * OBS : nullptr;
+    float* rew_terms = rew_terms_all ? rew_terms_all + (size_t)step_o * n * 3 : nullptr;
     if (exc) {
-        r = 0.0f; dn = true; walked = 0;
-        terms[0] = terms[1] = terms[2] = 1.0;
+        r = 0.0f; dn = true; walked_put(0.0);
+        terms[0] = terms[1] = terms[2] = T(1);
     } else {
         if constexpr (PRE) {
 #pragma unroll
@@ -517,7 +532,9 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         g_sync<T>();
         cur[DL_CUR_EP_DUR] += 1;
         const T vx0 = dl_clamp(g_dof_value<TP, 0>(v, vx), T(-5.5), T(5.5)), vy0 = dl_clamp(g_dof_value<TP, 1>(v, vx), T(-5.5), T(5.5));
-        walked += (double)dl_sqrt(vx0 * vx0 + vy0 * vy0) * (double)c.inv_ctrl_freq;
+        T icf = c.inv_ctrl_freq;
+        DL_VPIN(icf);             // (the widened constant is otherwise hoisted out of the step loop)
+        walked_put(walked_get() + (double)dl_sqrt(vx0 * vx0 + vy0 * vy0) * (double)icf);
         const bool timeout = cur[DL_CUR_EP_DUR] >= c.ep_dur_max;
         const T qz = g_dof_value<TP, 2>(q, qx);
         dn = (qz < c.com_z_min) || timeout;
@@ -546,7 +563,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             gsum_n<3>(s3);
             static_for<NX>([&](auto ti) { constexpr int t = ti.value; const T d1 = qx.x[t] - ref_q(t); s3[2] += d1 * d1; });
             const T tp = dl_exp(T(-3) * s3[0]), tv = dl_exp(T(-0.05) * s3[1]), tc = dl_exp(T(-16) * s3[2]);
-            terms[0] = (double)tp; terms[1] = (double)tv; terms[2] = (double)tc;
+            terms[0] = tp; terms[1] = tv; terms[2] = tc;
             r = (float)((c.rew_w[0] * tp + c.rew_w[1] * tv + c.rew_w[2] * tc) * c.rew_scale + c.alive_bonus);
         }
         write_obs(dn ? term_obs : obs, true);
@@ -561,7 +578,8 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
 #endif
     }
     if (valid && j == 0) {
-        monitor_step(st.mon, n, w, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
+        const double terms_d[3] = {(double)terms[0], (double)terms[1], (double)terms[2]};
+        monitor_step(st.mon, n, w, (double)r, dn, terms_d, tor_mean, walked_get(), cur[DL_CUR_POS]);
         if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
         rew[w] = r == r ? r : 0.0f;          // (a NaN can only come out of a state beyond float32's range: see dl_sat_out)
         done[w] = dn ? 1 : 0;
@@ -602,8 +620,8 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             write_obs((nrep == 2 && rep == 0) ? term_obs : obs, false);
             g_sync<T>();
         }
-        walked = 0;
-        terms[0] = terms[1] = terms[2] = 1.0;       // reset_model's sanity check evaluates the reward terms at the init state (:562)
+        walked_put(0.0);
+        terms[0] = terms[1] = terms[2] = T(1);       // reset_model's sanity check evaluates the reward terms at the init state (:562)
     }
     }   // control steps of this launch
     if constexpr (SPLIT) {      // release the constraint wave
@@ -616,8 +634,8 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     DL_VPIN(we);
     if (valid && j == 0) {
         st.comz_off[we] = comz;
-        st.mon[(size_t)MON_POSREW * n + we] = terms[0]; st.mon[(size_t)MON_VELREW * n + we] = terms[1]; st.mon[(size_t)MON_COMREW * n + we] = terms[2];
-        st.walked[we] = walked;
+        st.mon[(size_t)MON_POSREW * n + we] = (double)terms[0]; st.mon[(size_t)MON_VELREW * n + we] = (double)terms[1]; st.mon[(size_t)MON_COMREW * n + we] = (double)terms[2];
+        st.walked[we] = walked_get();
 #pragma unroll
         for (int k = 0; k < DL_CUR_WORDS; k++) st.cur[(size_t)k * n + we] = cur[k];
         static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + we; st.qpos[o] = qx.x[t]; st.qvel[o] = vx.x[t]; st.warm[o] = warmx.x[t]; });

@@ -513,26 +513,36 @@ __device__ __forceinline__ void vn_chan_merge(double& mean, double& var, double 
 __device__ __forceinline__ void vn_block_sums(const float* __restrict__ x, const float* __restrict__ rew, double* ret, int D, int k, int r0, int r1, double K, double gamma,
                                               double& s_out, double& ss_out) {
     double s = 0, ss = 0;
-    // rows beyond the block are read from its last row and left out of the sums by a select: the loads stay unconditional, i.e. all sixteen
-    // are in flight at once (predicated, every load sits in its own branch and waits for its own round trip: measured 10 k cycles per step)
-    const int rl = r1 - 1;
-    if (k < D) {
-        float a[16];
+    // a full block (every block but a ragged last one): sixteen unconditional loads at constant offsets from one address, all in flight at once
+    // (predicated, every load sits in its own branch and waits for its own round trip: measured 10 k cycles per step), then the sums in row order.
+    // A ragged block takes the same sums in the same order from a plain loop.
+    if (r1 - r0 == 16) {
+        if (k < D) {
+            const float* xb = x + (size_t)r0 * D + k;
+            float a[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { const int rr = r0 + r < r1 ? r0 + r : rl; a[r] = x[(size_t)rr * D + k]; }
+            for (int r = 0; r < 16; r++) a[r] = xb[r * D];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { const double d = (double)a[r] - K; const bool ok = r0 + r < r1; s = ok ? s + d : s; ss = ok ? fma(d, d, ss) : ss; }
+            for (int r = 0; r < 16; r++) { const double d = (double)a[r] - K; s = s + d; ss = fma(d, d, ss); }
+        } else {
+            double o[16]; float w[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) { o[r] = ret[r0 + r]; w[r] = rew[r0 + r]; }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const double rn = fma(o[r], gamma, (double)w[r]);
+                ret[r0 + r] = rn;
+                const double d = rn - K;
+                s = s + d; ss = fma(d, d, ss);
+            }
+        }
     } else {
-        double o[16]; float w[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const int rr = r0 + r < r1 ? r0 + r : rl; o[r] = ret[rr]; w[r] = rew[rr]; }
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const bool ok = r0 + r < r1;
-            const double rn = fma(o[r], gamma, (double)w[r]);
-            if (ok) ret[r0 + r] = rn;
-            const double d = rn - K;
-            s = ok ? s + d : s; ss = ok ? fma(d, d, ss) : ss;
+#pragma unroll 1
+        for (int r = r0; r < r1; r++) {
+            double d;
+            if (k < D) d = (double)x[(size_t)r * D + k] - K;
+            else { const double rn = fma(ret[r], gamma, (double)rew[r]); ret[r] = rn; d = rn - K; }
+            s = s + d; ss = fma(d, d, ss);
         }
     }
     s_out = s; ss_out = ss;
@@ -649,7 +659,7 @@ struct RolloutP {
     int32_t index_base, flags, T, per_rollout, spin_grid;
 };
 constexpr int RP_SYNC_WORDS = 160;
-template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2) * sizeof(double) + 64; }
+template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(4 * (TP::OBS + 1) + 2) * sizeof(double) + 64; }
 
 // All arguments travel as ONE by-value struct: the kernel reads them through the kernarg segment pointer, made opaque at the start of every
 // phase of every control step.  Passed as separate by-value parameters the ~150 uniform words (reference table, state arrays, rollout-buffer
@@ -676,11 +686,12 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     // the first (only) explicit argument sits at offset 0 of the kernarg segment (HSA ABI)
     const DL_CONST Args* const ap0 = (const DL_CONST Args*)__builtin_amdgcn_kernarg_segment_ptr();
     auto args = [&]() { const DL_CONST Args* q = ap0; DL_SPIN(q); return q; };       // a fresh, opaque view: loads through it are not merged with earlier ones
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = wave >> 2, slot = wave & 3;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, role = wave >> 2, slot = wave & 3;      // (wave: a scalar, so that what derives from it -- role, slot, the wave's block -- is too)
     const int gslot = role == 0 ? slot : ((slot + DL_SPLIT_PAIR_OFFSET) & 3);
     DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
     double* vm = (double*)(smem + ENV_LDS);                 // mean[W] (column D: the returns'), var[W], count, ret_count
-    int* shf = (int*)(vm + 2 * W + 2);                      // [0] group-last flag, [1] exchange ok
+    double* accm = vm + 2 * W + 2;                          // per_rollout: [W][2] this workgroup's column sums over the whole rollout (in LDS: nothing of the moment update lives in registers across the env phase)
+    int* shf = (int*)(accm + 2 * W);                        // [0] group-last flag, [1] exchange ok
     const int nblk = gridDim.x;
     const int blk = g_block_of_workgroup(blockIdx.x, gridDim.x);
     int n, nT, flags, per_rollout;
@@ -689,12 +700,12 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         n = p->st.n; nT = p->a.T; flags = p->a.flags; per_rollout = p->a.per_rollout;
         if (tid < D) { vm[tid] = p->a.obs_mean[tid]; vm[W + tid] = p->a.obs_var[tid]; }
         if (tid == D) { vm[D] = *p->a.ret_mean; vm[W + D] = *p->a.ret_var; vm[2 * W] = *p->a.obs_count; vm[2 * W + 1] = *p->a.ret_count; }
+        if (tid < 2 * W) accm[tid] = 0.0;
     }
     const int row0 = blk * 16, row1 = row0 + 16 < n ? row0 + 16 : n;
     const VnBlk vb = vn_blk(n);
     const int grp = blk / vb.gsize, gb0 = grp * vb.gsize, gb1 = gb0 + vb.gsize < nblk ? gb0 + vb.gsize : nblk;
     const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !per_rollout;
-    double acc_s = 0, acc_ss = 0;                           // per_rollout: this thread's column sums over the whole rollout
 #ifdef DL_EXP_ROLLOUT_PROF
     long long prof_acc[4] = {0, 0, 0, 0}, prof_t = DL_CLOCK();
 #define DL_RP_TICK(k) do { const long long now_ = DL_CLOCK(); prof_acc[k] += now_ - prof_t; prof_t = now_; } while (0)
@@ -752,18 +763,21 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         __syncthreads();          // raw observation / reward / done of the workgroup's rows are in memory
         DL_RP_TICK(1);
         // ---- R: VecNormalize's moment update
+        int tid_r = tid;
+        DL_VPIN(tid_r);               // per-step opaque (as in the other phases): the per-thread addresses of the exchange are recomputed every step, not hoisted out of the step loop and spilled
+        const int n_r = n, blk_r = blk, grp_r = grp, gb0_r = gb0, gb1_r = gb1, ngrp_r = vb.ngrp, row0_r = row0, row1_r = row1;          // (the uniform words stay as they are: made opaque as well, the phase measured 2 % slower)
         if (upd_obs || upd_ret) {
             const DL_CONST Args* p = args();
-            const bool mine = tid < W && (tid < D ? upd_obs : upd_ret);
+            const bool mine = tid_r < W && (tid_r < D ? upd_obs : upd_ret);
             if (mine) {
                 double s, ss;
-                vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, tid, row0, row1, vm[tid], p->a.gamma, s, ss);
+                vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, tid_r, row0_r, row1_r, vm[tid_r], p->a.gamma, s, ss);
                 if (exchange) {       // 8-byte agent-scope stores: write-through, so that the hand-over needs no release fence (guideline 16, R1)
-                    __hip_atomic_store(&p->a.partial[((size_t)blk * W + tid) * 2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&p->a.partial[((size_t)blk * W + tid) * 2 + 1], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&p->a.partial[((size_t)blk_r * W + tid_r) * 2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&p->a.partial[((size_t)blk_r * W + tid_r) * 2 + 1], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the flag
                 }
-                else { acc_s += s; acc_ss += ss; }
+                else { accm[2 * tid_r] += s; accm[2 * tid_r + 1] += ss; }
             }
         }
         if (exchange) {
@@ -774,45 +788,36 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             double* partial = p->a.partial;
             double* xpart = p->a.xpart + (size_t)(t & 1) * 8 * W * 2;
             __syncthreads();
-            if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(sync + 16 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                shf[0] = (old + 1u == (unsigned)(gb1 - gb0) * (unsigned)(t + 1)) ? 1 : 0;
+            if (tid_r == 0) {
+                const unsigned old = __hip_atomic_fetch_add(sync + 16 * grp_r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                shf[0] = (old + 1u == (unsigned)(gb1_r - gb0_r) * (unsigned)(t + 1)) ? 1 : 0;
             }
             __syncthreads();
             if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order: every load in flight at once (eight lanes per
                                   // column pair fetch four blocks each into LDS -- the idle env regions --, then the column's lane adds them in order)
                 double* gs = (double*)smem;                         // [32][2 W]
-                const int gn = gb1 - gb0;
-                if (gn <= 32 && tid < 8 * 2 * W) {
-                    const int col = tid % (2 * W), part = tid / (2 * W);
+                const int gn = gb1_r - gb0_r;
+                if (tid_r < 8 * 2 * W) {
+                    const int col = tid_r % (2 * W), part = tid_r / (2 * W);
                     double v4[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { const int b = part * 4 + i; v4[i] = b < gn ? __hip_atomic_load(&partial[(size_t)(gb0 + b) * W * 2 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+                    for (int i = 0; i < 4; i++) { const int b = part * 4 + i; v4[i] = b < gn ? __hip_atomic_load(&partial[(size_t)(gb0_r + b) * W * 2 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
 #pragma unroll
                     for (int i = 0; i < 4; i++) gs[(part * 4 + i) * (2 * W) + col] = v4[i];
                 }
                 __syncthreads();
-                if (tid < 2 * W) {
+                if (tid_r < 2 * W) {
                     double x = 0;
-                    if (gn <= 32) { for (int b = 0; b < gn; b++) x += gs[b * (2 * W) + tid]; }
-                    else {
-                        for (int b0 = gb0; b0 < gb1; b0 += 8) {          // (more than 32 blocks per group: not reachable at one workgroup per CU on 256 CUs; kept general)
-                            double v8[8];
-#pragma unroll
-                            for (int i = 0; i < 8; i++) v8[i] = b0 + i < gb1 ? __hip_atomic_load(&partial[(size_t)(b0 + i) * W * 2 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-                            for (int i = 0; i < 8; i++) if (b0 + i < gb1) x += v8[i];
-                        }
-                    }
-                    __hip_atomic_store(&xpart[(size_t)grp * W * 2 + tid], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int b = 0; b < gn; b++) x += gs[b * (2 * W) + tid_r];          // (a group has <= 32 blocks: <= 256 workgroups in <= 8 groups, dl_rollout_persistent_ok)
+                    __hip_atomic_store(&xpart[(size_t)grp_r * W * 2 + tid_r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid_r == 0) __hip_atomic_fetch_add(sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             DL_RP_TICK(2);
-            if (tid == 0) {
-                const unsigned want = (unsigned)vb.ngrp * (unsigned)(t + 1);
+            if (tid_r == 0) {
+                const unsigned want = (unsigned)ngrp_r * (unsigned)(t + 1);
                 const int budget = p->a.spin_grid;
                 bool ok = false;
                 for (int it = 0; it < budget; it++) {
@@ -825,21 +830,21 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             __syncthreads();
             DL_RP_TICK(3);
             if (!shf[1]) return;          // (uniform) the grid never completed this step: fault word set, nothing further is written
-            if (tid < W && (tid < D ? upd_obs : upd_ret)) {
+            if (tid_r < W && (tid_r < D ? upd_obs : upd_ret)) {
                 double S = 0, SS = 0, xs[8], xq[8];
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
-                    xs[g] = g < vb.ngrp ? __hip_atomic_load(&xpart[((size_t)g * W + tid) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                    xq[g] = g < vb.ngrp ? __hip_atomic_load(&xpart[((size_t)g * W + tid) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    xs[g] = g < ngrp_r ? __hip_atomic_load(&xpart[((size_t)g * W + tid_r) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    xq[g] = g < ngrp_r ? __hip_atomic_load(&xpart[((size_t)g * W + tid_r) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
                 }
 #pragma unroll
-                for (int g = 0; g < 8; g++) if (g < vb.ngrp) { S += xs[g]; SS += xq[g]; }
-                double m = vm[tid], v = vm[W + tid];
-                vn_chan_merge(m, v, tid < D ? vm[2 * W] : vm[2 * W + 1], S, SS, n);
-                vm[tid] = m; vm[W + tid] = v;
+                for (int g = 0; g < 8; g++) if (g < ngrp_r) { S += xs[g]; SS += xq[g]; }
+                double m = vm[tid_r], v = vm[W + tid_r];
+                vn_chan_merge(m, v, tid_r < D ? vm[2 * W] : vm[2 * W + 1], S, SS, n_r);
+                vm[tid_r] = m; vm[W + tid_r] = v;
             }
             __syncthreads();
-            if (tid == 0) { if (upd_obs) vm[2 * W] += (double)n; if (upd_ret) vm[2 * W + 1] += (double)n; }
+            if (tid_r == 0) { if (upd_obs) vm[2 * W] += (double)n_r; if (upd_ret) vm[2 * W + 1] += (double)n_r; }
         }
         __syncthreads();
     }
@@ -860,7 +865,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         if (upd_ret && a.next_done[r]) a.ret[r] = 0;
     }
     if (per_rollout) {            // the workgroup's sums over the whole rollout, merged by k_vn_merge_rollout
-        if (tid < W) { a.partial[((size_t)blk * W + tid) * 2] = acc_s; a.partial[((size_t)blk * W + tid) * 2 + 1] = acc_ss; }
+        if (tid < W) { a.partial[((size_t)blk * W + tid) * 2] = accm[2 * tid]; a.partial[((size_t)blk * W + tid) * 2 + 1] = accm[2 * tid + 1]; }
     } else if (blk == 0) {        // every workgroup holds the same moments: one of them hands them back
         if (tid < D) { a.obs_mean[tid] = vm[tid]; a.obs_var[tid] = vm[W + tid]; }
         if (tid == D) { *a.ret_mean = vm[D]; *a.ret_var = vm[W + D]; *a.obs_count = vm[2 * W]; *a.ret_count = vm[2 * W + 1]; }
@@ -1267,6 +1272,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             if (inj_armed) return no("injected states are pending");
             if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cus = 0; }
             if ((n + 15) / 16 > n_cus) return no("more than sixteen walkers per CU: the workgroups of one launch would not be co-resident");
+            if ((n + 15) / 16 > 256) return no("more than 256 workgroups: a group of the grid-wide exchange holds at most 32 blocks");
             return 1;
         }
     }

@@ -140,7 +140,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
             const int r = row0 + tid;
             const float x = vf.raw_rew[r];
             vf.rew_out[r] = (vf.flags & 8) ? vn_norm_rew(x, *vf.ret_var, vf.eps, vf.clip_rew) : x;
-            if ((vf.flags & 4) && vf.done[r]) vf.ret[r] = 0;
+            if ((vf.flags & 4) && vf.done[r]) { double zero = 0.0; asm volatile("" : "+v"(zero)); vf.ret[r] = zero; }          // (formed here: as a constant pair it is hoisted out of a caller's step loop and spilled)
         }
         if (count_owner && tid == 0) { if (vf.flags & 1) *vf.count += (double)n; if (vf.flags & 4) *vf.ret_count += (double)n; }
     }

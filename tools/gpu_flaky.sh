@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/gpu_flaky.sh [N]  -- the bit-identity test of the benchmark's launch shapes N times with the product build and with every build under build_variants/
-cd $GRAFT_REPO_ROOT
+cd $GRAFT_REPO_ROOT; shopt -s nullglob
 N=${1:-12}
 for lib in product build_variants/*.so; do
   [ "$lib" = product ] && unset DL_LIB_PATH || export DL_LIB_PATH=$GRAFT_REPO_ROOT/$lib
