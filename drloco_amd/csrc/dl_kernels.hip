@@ -1961,3 +1961,7 @@ int dl_adv_normalize(float* adv, int64_t n, const double* sums3, void* stream) {
 }
 
 }  // extern "C"
+
+#ifdef DL_EXP_POL_PROF          // diagnostics build only (tools/diag_policy.py): the section stamps of dl_policy.hpp
+extern "C" int dl_debug_pol_prof(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(dl::g_pol_prof), sizeof(long long) * 16) == hipSuccess ? 0 : -1; }
+#endif

@@ -114,6 +114,12 @@ constexpr size_t pol_packed_floats(int hidden) { return (size_t)hidden * hidden 
 // torch's [out][in] layout the 16 lanes of a quarter-wave (one output column each) read 16 bytes from 16 DIFFERENT 2 KB-apart rows: 64 cache
 // lines per wave instruction, one tag lookup each -- the load path then delivers ~14 bytes per clock and CU and the kernel is bound by it
 // (measured: 13 of 37 us).  Packed, a quarter-wave's 16 x 16 bytes are one contiguous 256-byte run.  Same values, same order of arithmetic.
+#ifdef DL_EXP_POL_PROF          // diagnostics build: shader-clock stamps of workgroup 0's waves 0 and 7 at the section boundaries of the forward pass (tools/diag_policy.py, diag_policy_rollout.py)
+__device__ long long g_pol_prof[2][8];
+#define DL_POL_STAMP(k) do { if (row0 == 0 && l == 0 && (wave == 0 || wave == NW - 1)) g_pol_prof[wave ? 1 : 0][k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DL_POL_STAMP(k) ((void)0)
+#endif
 template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
 __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                  uint64_t seed, uint64_t counter, int index_base, int deterministic,
@@ -134,6 +140,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    DL_POL_STAMP(0);
     // ---- reward normalisation / bookkeeping of the folded VecNormalize step (k_vn_apply's second half)
     if (vf.raw_obs) {
         if (tid < POL_ROWS && row0 + tid < n) {
@@ -189,6 +196,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
             }
         }
         __syncthreads();
+        DL_POL_STAMP(1);
 #pragma unroll
         for (int kb = 0; kb < KB1; kb++) {
             const pf4 v = *(const pf4*)&ostage[lm * OLD + kb * 16 + lk * 4];
@@ -303,7 +311,9 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
             for (int t = 0; t < NTW; t++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) stage[(4 * lk + i) * HLD + n0w + t * 16 + lm] = h1r[t][i];
+            DL_POL_STAMP(2);
             __syncthreads();
+            DL_POL_STAMP(3);
             for (int i0 = 0; i0 < npair; i0 += DEPTH) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) {
@@ -331,6 +341,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DL_POL_STAMP(4);
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
             const float bias = p.b2[n0w + t * 16 + lm];
@@ -362,7 +373,9 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
 #pragma unroll
         for (int i = 0; i < 4; i++) part[(wave * 16 + 4 * lk + i) * 16 + lm] = acc[i];
     }
+    DL_POL_STAMP(5);
     __syncthreads();
+    DL_POL_STAMP(6);
     // ---- epilogue: sample, log-probability, value
     float lp = 0.0f;
     const int row = tid >> 4, col = tid & 15, r = row0 + row;
@@ -387,6 +400,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         for (int a = 0; a < A; a++) s += part[row * 16 + a];
         logp[r] = s;
     }
+    DL_POL_STAMP(7);
 }
 
 template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
