@@ -220,7 +220,7 @@ def main():
     ap.add_argument('--no-overlap', action='store_true', help='run dl_vecnormalize_step on the main stream after every dl_step instead of on a side stream under the next step')
     ap.add_argument('--vn-single-steps', action='store_true', help='normalise the steps of a fixed-action run one dl_vecnormalize_step at a time instead of with dl_vecnormalize_steps (six small launches per run)')
     ap.add_argument('--no-split', action='store_true', help='keep the one-wave-per-four-walkers launch form of the step kernel (dl_set_split 0); the default switches the split workgroup on where it exists (straight walker, float32, 16 lanes, one handle)')
-    ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 16 walkers per CU)')
+    ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 128 walkers per CU)')
     ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="with --policy and the persistent form: 'per_rollout' is the opt-in relaxation (the rollout is normalised with its start-of-rollout moments, one exact merge at its end); not SB3's semantics")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--vn-sync', choices=['per_rollout', 'per_step'], default='per_rollout', help="with --policy on several ranks: 'per_step' = VecNormalize's moments advance with the batch of ALL ranks every control step (SB3's semantics across ranks: one all-reduce of 2 (obs_dim + 1) doubles per control step, host loop); default: per rank, merged exactly between rollouts")

@@ -656,10 +656,12 @@ struct RolloutP {
     unsigned* sync;               // group counters at [16 g], top counter at [128]
     PolPacked pk;                 // the policy's weights in k-chunk-major order (k_pack_policy), packed by the host before the launch
     long long* prof;              // diagnostics (DL_EXP_ROLLOUT_PROF builds): [nblk][4] shader-clock cycles in P, E, R (sums + exchange), waiting in the exchange
-    int32_t index_base, flags, T, per_rollout, spin_grid;
+    int32_t index_base, flags, T, per_rollout, spin_grid, kblocks;
 };
 constexpr int RP_SYNC_WORDS = 160;
-template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(4 * (TP::OBS + 1) + 2) * sizeof(double) + 64; }
+constexpr int RP_MAX_KBLOCKS = 8;          // blocks of sixteen walkers per workgroup: <= 128 walkers per CU, 32768 on 256 CUs
+constexpr int RP_WS = 64;                  // lanes per block in the moment sums (a column per lane: OBS + 1 <= 64)
+template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2 + RP_MAX_KBLOCKS * 2 * (TP::OBS + 1)) * sizeof(double) + 64; }
 
 // All arguments travel as ONE by-value struct: the kernel reads them through the kernarg segment pointer, made opaque at the start of every
 // phase of every control step.  Passed as separate by-value parameters the ~150 uniform words (reference table, state arrays, rollout-buffer
@@ -690,21 +692,23 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     const int gslot = role == 0 ? slot : ((slot + DL_SPLIT_PAIR_OFFSET) & 3);
     DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
     double* vm = (double*)(smem + ENV_LDS);                 // mean[W] (column D: the returns'), var[W], count, ret_count
-    double* accm = vm + 2 * W + 2;                          // per_rollout: [W][2] this workgroup's column sums over the whole rollout (in LDS: nothing of the moment update lives in registers across the env phase)
-    int* shf = (int*)(accm + 2 * W);                        // [0] group-last flag, [1] exchange ok
-    const int nblk = gridDim.x;
-    const int blk = g_block_of_workgroup(blockIdx.x, gridDim.x);
-    int n, nT, flags, per_rollout;
+    double* accm = vm + 2 * W + 2;                          // per_rollout: [kb][W][2] the blocks' column sums over the whole rollout (in LDS: nothing of the moment update lives in registers across the env phase)
+    int* shf = (int*)(accm + RP_MAX_KBLOCKS * 2 * W);       // [0] group-last flags, [1] exchange ok
+    static_assert(RP_MAX_KBLOCKS * RP_WS <= 512 && W <= RP_WS, "a group of RP_WS lanes per block");
+    const int wgi = g_block_of_workgroup(blockIdx.x, gridDim.x);
+    int n, nT, flags, per_rollout, kb;
     {
         const DL_CONST Args* p = args();
-        n = p->st.n; nT = p->a.T; flags = p->a.flags; per_rollout = p->a.per_rollout;
+        n = p->st.n; nT = p->a.T; flags = p->a.flags; per_rollout = p->a.per_rollout; kb = p->a.kblocks;
         if (tid < D) { vm[tid] = p->a.obs_mean[tid]; vm[W + tid] = p->a.obs_var[tid]; }
         if (tid == D) { vm[D] = *p->a.ret_mean; vm[W + D] = *p->a.ret_var; vm[2 * W] = *p->a.obs_count; vm[2 * W + 1] = *p->a.ret_count; }
-        if (tid < 2 * W) accm[tid] = 0.0;
+        for (int i = tid; i < RP_MAX_KBLOCKS * 2 * W; i += 512) accm[i] = 0.0;
     }
-    const int row0 = blk * 16, row1 = row0 + 16 < n ? row0 + 16 : n;
+    // the workgroup owns kb consecutive blocks of sixteen walkers (one on <= 4096 walkers; more walkers than 16 x CUs: the grid stays co-resident and a
+    // workgroup takes its blocks one after the other through the policy and env phases of a step)
     const VnBlk vb = vn_blk(n);
-    const int grp = blk / vb.gsize, gb0 = grp * vb.gsize, gb1 = gb0 + vb.gsize < nblk ? gb0 + vb.gsize : nblk;
+    const int nblk = vb.nblk;
+    const int b0 = wgi * kb, b1 = b0 + kb < nblk ? b0 + kb : nblk;
     const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !per_rollout;
 #ifdef DL_EXP_ROLLOUT_PROF
     long long prof_acc[4] = {0, 0, 0, 0}, prof_t = DL_CLOCK();
@@ -716,6 +720,11 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
 #pragma unroll 1
     for (int t = 0; t < nT; t++) {
         DL_RP_TICK(2);
+#pragma unroll 1
+        for (int blk_i = b0; blk_i < b1; blk_i++) {
+        int blk = blk_i;
+        DL_SPIN(blk);             // (opaque per block: +0.7 % -- what is derived from the block index is formed in the phase that uses it)
+        const int row0 = blk * 16;
         // ---- P: actions, values, log-probs of step t (and observations[t], rewards[t - 1] from the raw outputs of step t - 1)
         {
             const DL_CONST Args* p = args();
@@ -732,7 +741,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             pol_forward_rows<4, 8, true, true>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
                                    a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.pk);
         }
-        __syncthreads();          // the actions of the workgroup's rows are in memory (workgroup scope); the policy's LDS is free again
+        __syncthreads();          // the actions of the block's rows are in memory (workgroup scope); the policy's LDS is free again
         DL_RP_TICK(0);
         // ---- E: one control step of the sixteen walkers
         if (lane == 0) {
@@ -760,24 +769,29 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             else
                 g_constraint_server<T, TP>(lane_t, wblock, base, p->gm, st);
         }
-        __syncthreads();          // raw observation / reward / done of the workgroup's rows are in memory
+        __syncthreads();          // raw observation / reward / done of the block's rows are in memory
         DL_RP_TICK(1);
+        }   // the workgroup's blocks
         // ---- R: VecNormalize's moment update
         int tid_r = tid;
         DL_VPIN(tid_r);               // per-step opaque (as in the other phases): the per-thread addresses of the exchange are recomputed every step, not hoisted out of the step loop and spilled
-        const int n_r = n, blk_r = blk, grp_r = grp, gb0_r = gb0, gb1_r = gb1, ngrp_r = vb.ngrp, row0_r = row0, row1_r = row1;          // (the uniform words stay as they are: made opaque as well, the phase measured 2 % slower)
-        if (upd_obs || upd_ret) {
+        int n_r = n;
+        DL_SPIN(n_r);                 // (opaque: `(double)n` is otherwise a register pair hoisted out of the step loop and spilled; the other uniform words stay as they are -- all of them opaque measured 2 % slower)
+        const int ngrp_r = vb.ngrp, gsize_r = vb.gsize;
+        if (upd_obs || upd_ret) {     // the block sums: a group of WS lanes per block of the workgroup, a column per lane
             const DL_CONST Args* p = args();
-            const bool mine = tid_r < W && (tid_r < D ? upd_obs : upd_ret);
+            const int bi = tid_r / RP_WS, col = tid_r % RP_WS, blk = b0 + bi;
+            const bool mine = col < W && blk < b1 && (col < D ? upd_obs : upd_ret);
             if (mine) {
                 double s, ss;
-                vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, tid_r, row0_r, row1_r, vm[tid_r], p->a.gamma, s, ss);
+                const int row0 = blk * 16, row1 = row0 + 16 < n_r ? row0 + 16 : n_r;
+                vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, col, row0, row1, vm[col], p->a.gamma, s, ss);
                 if (exchange) {       // 8-byte agent-scope stores: write-through, so that the hand-over needs no release fence (guideline 16, R1)
-                    __hip_atomic_store(&p->a.partial[((size_t)blk_r * W + tid_r) * 2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&p->a.partial[((size_t)blk_r * W + tid_r) * 2 + 1], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&p->a.partial[((size_t)blk * W + col) * 2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&p->a.partial[((size_t)blk * W + col) * 2 + 1], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the flag
                 }
-                else { accm[2 * tid_r] += s; accm[2 * tid_r + 1] += ss; }
+                else { accm[(bi * W + col) * 2] += s; accm[(bi * W + col) * 2 + 1] += ss; }
             }
         }
         if (exchange) {
@@ -787,29 +801,42 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             unsigned* sync = p->a.sync;
             double* partial = p->a.partial;
             double* xpart = p->a.xpart + (size_t)(t & 1) * 8 * W * 2;
+            const int g_lo = b0 / gsize_r, g_hi = (b1 - 1) / gsize_r;          // the groups this workgroup's blocks belong to (one; two where its range crosses a group boundary)
             __syncthreads();
-            if (tid_r == 0) {
-                const unsigned old = __hip_atomic_fetch_add(sync + 16 * grp_r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                shf[0] = (old + 1u == (unsigned)(gb1_r - gb0_r) * (unsigned)(t + 1)) ? 1 : 0;
+            if (tid_r == 0) {         // a group's counter counts BLOCKS: complete when all of the group's blocks of this step have been delivered
+                int last = 0;
+                for (int g = g_lo; g <= g_hi; g++) {
+                    const int gb0 = g * gsize_r, gb1 = gb0 + gsize_r < nblk ? gb0 + gsize_r : nblk;
+                    const unsigned mine_n = (unsigned)((b1 < gb1 ? b1 : gb1) - (b0 > gb0 ? b0 : gb0));
+                    const unsigned old = __hip_atomic_fetch_add(sync + 16 * g, mine_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old + mine_n == (unsigned)(gb1 - gb0) * (unsigned)(t + 1)) last |= 1 << (g - g_lo);
+                }
+                shf[0] = last;
             }
             __syncthreads();
-            if (shf[0]) {         // the group's last arriver adds the group's block sums, in block order: every load in flight at once (eight lanes per
-                                  // column pair fetch four blocks each into LDS -- the idle env regions --, then the column's lane adds them in order)
+            const int last = shf[0];
+            for (int g = g_lo; g <= g_hi; g++) {
+                if (!((last >> (g - g_lo)) & 1)) continue;          // (uniform)
+                // the deliverer of a group's last block adds the group's block sums, in block order, 32 blocks at a time: every load of a chunk in flight at once
+                // (eight lanes per column pair fetch four blocks each into LDS -- the idle env regions --, then the column's lane adds them in order)
                 double* gs = (double*)smem;                         // [32][2 W]
-                const int gn = gb1_r - gb0_r;
-                if (tid_r < 8 * 2 * W) {
-                    const int col = tid_r % (2 * W), part = tid_r / (2 * W);
-                    double v4[4];
+                const int gb0 = g * gsize_r, gb1 = gb0 + gsize_r < nblk ? gb0 + gsize_r : nblk, gn = gb1 - gb0;
+                double x = 0;
+                for (int c0 = 0; c0 < gn; c0 += 32) {
+                    if (tid_r < 8 * 2 * W) {
+                        const int col = tid_r % (2 * W), part = tid_r / (2 * W);
+                        double v4[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { const int b = part * 4 + i; v4[i] = b < gn ? __hip_atomic_load(&partial[(size_t)(gb0_r + b) * W * 2 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+                        for (int i = 0; i < 4; i++) { const int b = c0 + part * 4 + i; v4[i] = b < gn ? __hip_atomic_load(&partial[(size_t)(gb0 + b) * W * 2 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
 #pragma unroll
-                    for (int i = 0; i < 4; i++) gs[(part * 4 + i) * (2 * W) + col] = v4[i];
+                        for (int i = 0; i < 4; i++) gs[(part * 4 + i) * (2 * W) + col] = v4[i];
+                    }
+                    __syncthreads();
+                    if (tid_r < 2 * W) { const int cn = gn - c0 < 32 ? gn - c0 : 32; for (int b = 0; b < cn; b++) x += gs[b * (2 * W) + tid_r]; }
+                    __syncthreads();
                 }
-                __syncthreads();
                 if (tid_r < 2 * W) {
-                    double x = 0;
-                    for (int b = 0; b < gn; b++) x += gs[b * (2 * W) + tid_r];          // (a group has <= 32 blocks: <= 256 workgroups in <= 8 groups, dl_rollout_persistent_ok)
-                    __hip_atomic_store(&xpart[(size_t)grp_r * W * 2 + tid_r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&xpart[(size_t)g * W * 2 + tid_r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
@@ -851,9 +878,10 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     // ---- VecNormalize of the last step's outputs (k_vn_apply's work for the workgroup's rows): next_obs, rewards[T - 1], ret
     const DL_CONST Args* p = args();
 #ifdef DL_EXP_ROLLOUT_PROF
-    if (tid == 0 && p->a.prof) for (int k = 0; k < 4; k++) p->a.prof[(size_t)blk * 4 + k] = prof_acc[k];
+    if (tid == 0 && p->a.prof) for (int k = 0; k < 4; k++) p->a.prof[(size_t)wgi * 4 + k] = prof_acc[k];
 #endif
     const RolloutP a = p->a;
+    const int row0 = b0 * 16, row1 = b1 * 16 < n ? b1 * 16 : n;          // all rows of the workgroup's blocks
     for (int idx = tid; idx < (row1 - row0) * D; idx += 512) {
         const size_t e = (size_t)row0 * D + idx;
         const int k = idx % D;
@@ -864,9 +892,10 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         a.rewards[(size_t)(nT - 1) * n + r] = (flags & 8) ? vn_norm_rew(a.raw_rew[r], vm[W + D], a.eps, a.clip_rew) : a.raw_rew[r];
         if (upd_ret && a.next_done[r]) a.ret[r] = 0;
     }
-    if (per_rollout) {            // the workgroup's sums over the whole rollout, merged by k_vn_merge_rollout
-        if (tid < W) { a.partial[((size_t)blk * W + tid) * 2] = accm[2 * tid]; a.partial[((size_t)blk * W + tid) * 2 + 1] = accm[2 * tid + 1]; }
-    } else if (blk == 0) {        // every workgroup holds the same moments: one of them hands them back
+    if (per_rollout) {            // the blocks' sums over the whole rollout, merged by k_vn_merge_rollout
+        const int bi = tid / RP_WS, col = tid % RP_WS, blk = b0 + bi;
+        if (col < W && blk < b1) { a.partial[((size_t)blk * W + col) * 2] = accm[(bi * W + col) * 2]; a.partial[((size_t)blk * W + col) * 2 + 1] = accm[(bi * W + col) * 2 + 1]; }
+    } else if (wgi == 0) {        // every workgroup holds the same moments: one of them hands them back
         if (tid < D) { a.obs_mean[tid] = vm[tid]; a.obs_var[tid] = vm[W + tid]; }
         if (tid == D) { *a.ret_mean = vm[D]; *a.ret_var = vm[W + D]; *a.obs_count = vm[2 * W]; *a.ret_count = vm[2 * W + 1]; }
     }
@@ -1271,8 +1300,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             if (hidden != 512) return no("the persistent rollout kernel is built for hidden = 512 (eight waves per workgroup)");
             if (inj_armed) return no("injected states are pending");
             if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cus = 0; }
-            if ((n + 15) / 16 > n_cus) return no("more than sixteen walkers per CU: the workgroups of one launch would not be co-resident");
-            if ((n + 15) / 16 > 256) return no("more than 256 workgroups: a group of the grid-wide exchange holds at most 32 blocks");
+            if (n_cus <= 0 || (n + 15) / 16 > n_cus * RP_MAX_KBLOCKS) return no("more than 128 walkers per CU: a workgroup of the persistent rollout kernel takes at most eight blocks of sixteen walkers");
             return 1;
         }
     }
@@ -1302,12 +1330,15 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync; a.prof = rp_prof;
             if ((rc = pack_policy(pol, &a.pk, s))) return rc;
             a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid;
+            // at most one workgroup per CU (co-resident by construction): with more than sixteen walkers per CU a workgroup takes kblocks consecutive blocks
+            a.kblocks = (nblk + n_cus - 1) / n_cus;
+            const int nwg = (nblk + a.kblocks - 1) / a.kblocks;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
-            hipLaunchKernelGGL((k_rollout_persistent<TP>), dim3(nblk), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            hipLaunchKernelGGL((k_rollout_persistent<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
             prof_end(s);
             HIPCHK(hipGetLastError());

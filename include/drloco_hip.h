@@ -413,7 +413,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
  *       control step, the policy forward of its own rows (matrix cores), MimicEnv.step of its walkers (the split-workgroup step kernel's code)
  *       and VecNormalize's moment update through one grid-wide exchange.  Exact SB3 semantics (every step normalises with the moments of all
  *       walkers up to that step); bit-identical to mode 0 when `vn->flags` selects the blocked reduction order (bit 32) and dl_set_split is on.
- *       Needs: straight walker, float32, 16 lanes per walker, hidden = 512, at most 16 walkers per CU (4096 on an MI355X) -- query with
+ *       Needs: straight walker, float32, 16 lanes per walker, hidden = 512, at most 128 walkers per CU (32768 on an MI355X; above 16 per CU a workgroup takes several blocks of sixteen walkers per control step) -- query with
  *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  EXCLUSIVE GPU: the grid-wide exchange needs every workgroup of the launch resident at
  *       the same time (one per CU), so no other process, stream or handle may hold CUs while it runs -- dl_rollout_persistent_ok only checks the
  *       walker count, it cannot see other users of the device.  A grid exchange that does not complete within its (bounded, ~2 s) poll budget raises

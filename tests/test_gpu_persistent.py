@@ -33,7 +33,9 @@ def _setup(torch, model, refs, n, T, seed=21, **vn_kw):
     return venv, vn, pol, buf, vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
 
 
-@pytest.mark.parametrize('n,T', [(4096, 40), (1000, 33), (16, 25), (5, 9)], ids=['full-size', 'ragged-63-workgroups', 'one-workgroup', 'partly-filled-workgroup'])
+@pytest.mark.parametrize('n,T', [(4096, 40), (1000, 33), (16, 25), (5, 9), (8192, 12), (5000, 10), (12000, 8)],
+                         ids=['full-size', 'ragged-63-workgroups', 'one-workgroup', 'partly-filled-workgroup', 'two-blocks-per-workgroup', 'ragged-two-blocks',
+                              'three-blocks-crossing-group-boundaries'])
 def test_persistent_rollout_is_the_launch_path_bit_for_bit(torch_cuda, model, refs, n, T):
     torch = torch_cuda
     res = []
@@ -56,7 +58,7 @@ def test_persistent_rollout_is_the_launch_path_bit_for_bit(torch_cuda, model, re
     a, b = res
     for k in a:
         assert torch.equal(a[k], b[k]), (k, float((a[k].double() - b[k].double()).abs().max()))
-    assert (a['episode_starts'].sum() > 0 or n < 100) and a['counter'] == 2 * T
+    assert (a['episode_starts'].sum() > 0 or n < 100 or T < 20) and a['counter'] == 2 * T
 
 
 @pytest.mark.parametrize('kw', [dict(training=False), dict(norm_reward=False), dict(norm_obs=False)], ids=['frozen', 'raw-rewards', 'raw-observations'])
@@ -76,10 +78,11 @@ def test_persistent_rollout_flag_combinations(torch_cuda, model, refs, kw):
         assert torch.equal(x, y), kw
 
 
-def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs):
+@pytest.mark.parametrize('n', [1000, 6000], ids=['one-block-per-workgroup', 'two-blocks-per-workgroup'])
+def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs, n):
     torch = torch_cuda
     from drloco_amd.vec_env import HipVecEnv
-    n, T = 1000, 48
+    T = 48
     venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
     # give the moments a non-trivial start: one exact rollout first
     buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
@@ -198,7 +201,7 @@ def test_persistent_form_refusals(torch_cuda, model, refs):
         return buf.last_form
     # other hidden sizes, float64, one lane per walker, too many walkers: the automatic choice is the launch form, an explicit request raises
     for venv, pol in ((HipVecEnv(num_envs=64, model=model, refs=refs), HipPolicy(hidden=128)), (HipVecEnv(num_envs=64, model=model, refs=refs, precision=64), HipPolicy(hidden=512)),
-                      (HipVecEnv(num_envs=64, model=model, refs=refs, lanes_per_walker=1), HipPolicy(hidden=512)), (HipVecEnv(num_envs=4112, model=model, refs=refs), HipPolicy(hidden=512))):
+                      (HipVecEnv(num_envs=64, model=model, refs=refs, lanes_per_walker=1), HipPolicy(hidden=512)), (HipVecEnv(num_envs=32784, model=model, refs=refs), HipPolicy(hidden=512))):
         assert attempt(venv, pol) == 'launches'
         with pytest.raises(L.DrlocoError):
             attempt(venv, pol, persistent=True)
