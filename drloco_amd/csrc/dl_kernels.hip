@@ -675,7 +675,9 @@ template <typename TP> struct RolloutArgs {
     RolloutP a;
     int32_t eval_mode;
 };
-template <typename TP>
+// MULTI: the instantiation for workgroups that own several blocks (more than sixteen walkers per CU): the policy phase takes TWO blocks per pass (32 rows share
+// every weight register set, dl_policy.hpp RB), the env phase one block after the other.  A kernel of its own so that each stays under the instruction cache.
+template <typename TP, bool MULTI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -684,7 +686,8 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     using Args = RolloutArgs<TP>;
     constexpr int D = TP::OBS, W = D + 1, NU = TP::NU;
     constexpr size_t ENV_LDS = (size_t)4 * GW * Sp::TOTAL * sizeof(T);
-    static_assert(pol_lds_bytes_whole(8, 512) <= ENV_LDS, "the policy's LDS aliases the walkers' regions between two env steps");
+    constexpr int RBK = MULTI ? 2 : 1;          // blocks per pass of the policy phase
+    static_assert(pol_lds_bytes_whole(8, 512, RBK) <= ENV_LDS, "the policy's LDS aliases the walkers' regions between two env steps");
     // the first (only) explicit argument sits at offset 0 of the kernarg segment (HSA ABI)
     const DL_CONST Args* const ap0 = (const DL_CONST Args*)__builtin_amdgcn_kernarg_segment_ptr();
     auto args = [&]() { const DL_CONST Args* q = ap0; DL_SPIN(q); return q; };       // a fresh, opaque view: loads through it are not merged with earlier ones
@@ -721,7 +724,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     for (int t = 0; t < nT; t++) {
         DL_RP_TICK(2);
 #pragma unroll 1
-        for (int blk_i = b0; blk_i < b1; blk_i++) {
+        for (int blk_i = b0; blk_i < b1; blk_i += RBK) {
         int blk = blk_i;
         DL_SPIN(blk);             // (opaque per block: +0.7 % -- what is derived from the block index is formed in the phase that uses it)
         const int row0 = blk * 16;
@@ -738,11 +741,15 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 vf.obs_out = a.observations + (size_t)t * n * D; vf.rew_out = a.rewards + (size_t)(t - 1) * n;
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
-            pol_forward_rows<4, 8, true, true>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
+            const int nlim = b1 * 16 < n ? b1 * 16 : n;          // rows of THIS workgroup's blocks only (a pass of two blocks may reach beyond its last one)
+            pol_forward_rows<4, 8, true, true, RBK>(a.pol, a.observations + (size_t)t * n * D, nlim, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
                                    a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.pk);
         }
-        __syncthreads();          // the actions of the block's rows are in memory (workgroup scope); the policy's LDS is free again
+        __syncthreads();          // the actions of the pass's rows are in memory (workgroup scope); the policy's LDS is free again
         DL_RP_TICK(0);
+#pragma unroll 1
+        for (int sub = 0; sub < RBK; sub++) {
+        if (sub > 0) { blk += 1; if (blk >= b1) break; }
         // ---- E: one control step of the sixteen walkers
         if (lane == 0) {
             volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
@@ -771,6 +778,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         }
         __syncthreads();          // raw observation / reward / done of the block's rows are in memory
         DL_RP_TICK(1);
+        }   // the blocks of the pass
         }   // the workgroup's blocks
         // ---- R: VecNormalize's moment update
         int tid_r = tid;
@@ -1319,7 +1327,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 if ((rc = dalloc(&rp_xpart, (size_t)2 * 8 * W * 2))) return rc;
                 if ((rc = dalloc(&rp_sync, (size_t)RP_SYNC_WORDS))) return rc;
                 if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11))) return rc;
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
             }
             RolloutP a{};
             a.pol = pol; a.seed = seed; a.counter0 = counter0; a.index_base = index_base;
@@ -1338,7 +1347,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             prof_begin(s);
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
-            hipLaunchKernelGGL((k_rollout_persistent<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            if (a.kblocks > 1) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            else hipLaunchKernelGGL((k_rollout_persistent<TP, false>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
             prof_end(s);
             HIPCHK(hipGetLastError());

@@ -63,7 +63,7 @@ constexpr size_t pol_lds_bytes(int nw) { return ((size_t)2 * POL_ROWS * POL_SLD 
 // reduction then runs WITHOUT workgroup barriers -- the two waves of a SIMD drift apart and one's weight-load latency falls under the other's
 // MFMAs.  51 KB for hidden 512: for callers with the CU's LDS to themselves (<= 4096 rows, one handle; the persistent rollout kernel, whose
 // env regions are idle during the policy phase).  Same accumulation order as the lean form: bit-identical results.
-constexpr size_t pol_lds_bytes_whole(int nw, int hidden) { return ((size_t)POL_ROWS * (hidden + 4) + (size_t)nw * POL_ROWS * POL_PLD + (size_t)nw * 256) * sizeof(float); }
+constexpr size_t pol_lds_bytes_whole(int nw, int hidden, int rb = 1) { return ((size_t)rb * POL_ROWS * (hidden + 4) + (size_t)nw * POL_ROWS * POL_PLD + (size_t)rb * nw * 256) * sizeof(float); }
 
 // VecNormalize.step_wait's second half (k_vn_apply) folded into the policy's input stage: with raw_obs != NULL the kernel reads the
 // raw observation / reward of the last env step, normalises them with the (already updated) moments exactly as k_vn_apply does,
@@ -120,19 +120,22 @@ __device__ long long g_pol_prof[2][8];
 #else
 #define DL_POL_STAMP(k) ((void)0)
 #endif
-template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false>
+// RB = row blocks per call (barrier-free packed form only): RB x 16 rows share every weight register set -- the hidden layer's stream per row halves with RB = 2 and the
+// layer is bound by the matrix pipe again (a caller that owns several blocks of sixteen walkers: the persistent rollout kernel).  Per row the arithmetic is that of RB = 1.
+template <int NTW, int NW, bool WHOLE_H1 = false, bool PACKED = false, int RB = 1>
 __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps,
                                                  uint64_t seed, uint64_t counter, int index_base, int deterministic,
                                                  float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse& vf,
                                                  float* sm, int row0, bool count_owner, int tid, const PolPacked pk = PolPacked{nullptr, nullptr, nullptr}) {
     constexpr int H = 16 * NTW * NW, ntw = NTW;
+    static_assert(RB == 1 || (WHOLE_H1 && PACKED), "several row blocks per call exist for the barrier-free packed form");
     const int D = p.obs_dim, A = p.act_dim;
     const int wave = tid >> 6, l = tid & 63, lm = l & 15, lk = l >> 4;
     constexpr int HLD = H + 4;                                             // row stride of the whole-h1 block
-    constexpr int STAGE_WORDS = WHOLE_H1 ? POL_ROWS * HLD : 2 * POL_ROWS * POL_SLD;
-    float* stage = sm;                                                     // [2][16][POL_SLD], or [16][HLD]
+    constexpr int STAGE_WORDS = WHOLE_H1 ? RB * POL_ROWS * HLD : 2 * POL_ROWS * POL_SLD;
+    float* stage = sm;                                                     // [2][16][POL_SLD], or [RB][16][HLD]
     float* priv = sm + STAGE_WORDS + wave * (POL_ROWS * POL_PLD);          // this wave's [16][POL_PLD]
-    float* part = sm + STAGE_WORDS + NW * (POL_ROWS * POL_PLD);            // [NW][16][16] partial head tiles, then [16][16] log-prob terms
+    float* part = sm + STAGE_WORDS + NW * (POL_ROWS * POL_PLD);            // [RB][NW][16][16] partial head tiles, then [RB][16][16] log-prob terms
     constexpr int ncw = H / NW;
     const int n0w = wave * ncw;
     auto wave_sync = [&]() {      // LDS operations of one wave execute in order: exchanging data inside the wave needs no s_barrier
@@ -143,7 +146,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
     DL_POL_STAMP(0);
     // ---- reward normalisation / bookkeeping of the folded VecNormalize step (k_vn_apply's second half)
     if (vf.raw_obs) {
-        if (tid < POL_ROWS && row0 + tid < n) {
+        if (tid < RB * POL_ROWS && row0 + tid < n) {
             const int r = row0 + tid;
             const float x = vf.raw_rew[r];
             vf.rew_out[r] = (vf.flags & 8) ? vn_norm_rew(x, *vf.ret_var, vf.eps, vf.clip_rew) : x;
@@ -153,11 +156,11 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
     }
     // ---- layer 1: [16, D] x [D, H].  D is small (29): all operand loads of the wave are issued before the first MFMA
     // (one memory latency for the layer instead of one per tile).  h1 stays in registers (accumulator layout).
-    float h1r[NTW][4];
+    float h1r[RB][NTW][4];
     {
         constexpr int KB1 = 3;                                      // obs_dim <= 48 (checked by the host): 29 (straight walker), 47 (165 cm walker)
         constexpr int OLD = 52;                                     // row stride of the staged observation block (conflict-free ds_read_b128)
-        float a1[KB1 * 4], b1v[NTW][KB1 * 4];
+        float a1[RB][KB1 * 4], b1v[NTW][KB1 * 4];
         // the weights first (their latency covers the staging below) ...
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -182,7 +185,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         float* ostage = part;
         {
             const float* src = vf.raw_obs ? vf.raw_obs : obs;
-            for (int e = tid; e < POL_ROWS * 48; e += 64 * NW) {
+            for (int e = tid; e < RB * POL_ROWS * 48; e += 64 * NW) {
                 const int rr = e / 48, k = e % 48, r = row0 + rr;
                 float x = 0.0f;
                 if (k < D && r < n) {
@@ -198,19 +201,24 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         __syncthreads();
         DL_POL_STAMP(1);
 #pragma unroll
-        for (int kb = 0; kb < KB1; kb++) {
-            const pf4 v = *(const pf4*)&ostage[lm * OLD + kb * 16 + lk * 4];
-            a1[kb * 4] = v.x; a1[kb * 4 + 1] = v.y; a1[kb * 4 + 2] = v.z; a1[kb * 4 + 3] = v.w;
-        }
+        for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+            for (int kb = 0; kb < KB1; kb++) {
+                const pf4 v = *(const pf4*)&ostage[(rb * POL_ROWS + lm) * OLD + kb * 16 + lk * 4];
+                a1[rb][kb * 4] = v.x; a1[rb][kb * 4 + 1] = v.y; a1[rb][kb * 4 + 2] = v.z; a1[rb][kb * 4 + 3] = v.w;
+            }
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
             const int ncol = n0w + t * 16 + lm;
-            pf4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < KB1 * 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1v[t][q], acc, 0, 0, 0);
             const float bias = p.b1[ncol];
 #pragma unroll
-            for (int i = 0; i < 4; i++) h1r[t][i] = pol_tanh(acc[i] + bias);
+            for (int rb = 0; rb < RB; rb++) {
+                pf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < KB1 * 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][q], b1v[t][q], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) h1r[rb][t][i] = pol_tanh(acc[i] + bias);
+            }
         }
     }
     // the two 16-column tiles of k pair kp, staged by the wave(s) that own them
@@ -225,17 +233,19 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
                 for (int t = 0; t < NTW; t++)
                     if (t == lt) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) buf[(4 * lk + i) * POL_SLD + half * 16 + lm] = h1r[t][i];
+                        for (int i = 0; i < 4; i++) buf[(4 * lk + i) * POL_SLD + half * 16 + lm] = h1r[0][t][i];
                     }
             }
         }
     };
     // ---- layer 2: [16, H] x [H, H]; the weight rows of this wave's tiles stream from L2 one k block ahead
-    float h2r[NTW][4];
+    float h2r[RB][NTW][4];
     {
-        pf4 acc[NTW];
+        pf4 acc[RB][NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; t++) acc[t] = pf4{0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+            for (int t = 0; t < NTW; t++) acc[rb][t] = pf4{0.f, 0.f, 0.f, 0.f};
         const float* wbase = PACKED ? pk.w2p + ((size_t)lk * H + n0w + lm) * 4 : p.w2 + (size_t)(n0w + lm) * H + lk * 4;
         // two k blocks (32 k = one 128-byte line per weight row) per step: both halves of every line a wave touches are
         // consumed together.  Explicit ping-pong register sets: the loads of the next step are issued BEFORE the 64 MFMAs
@@ -279,15 +289,17 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         auto compute = [&](const pf4 (&b4)[NTW][2], int kp) {
             const float* buf = WHOLE_H1 ? stage + kp * 32 : stage + (kp & 1) * (POL_ROWS * POL_SLD);
             constexpr int LD = WHOLE_H1 ? HLD : POL_SLD;
-            const pf4 a4a = *(const pf4*)&buf[lm * LD + lk * 4], a4b = *(const pf4*)&buf[lm * LD + 16 + lk * 4];
+            pf4 a4a[RB], a4b[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) { a4a[rb] = *(const pf4*)&buf[(rb * POL_ROWS + lm) * LD + lk * 4]; a4b[rb] = *(const pf4*)&buf[(rb * POL_ROWS + lm) * LD + 16 + lk * 4]; }
             // k step outermost: consecutive MFMAs go to different accumulator tiles (no back-to-back dependent issue)
 #ifndef DL_EXP_POL_NOMFMA
-#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b4[t][H2].C, acc[t], 0, 0, 0);
+#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) _Pragma("unroll") for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[rb].C, b4[t][H2].C, acc[rb][t], 0, 0, 0);
 #else
-#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[t].x += AV * b4[t][H2].C;
+#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) _Pragma("unroll") for (int rb = 0; rb < RB; rb++) acc[rb][t].x += AV[rb].C * b4[t][H2].C;
 #endif
-            DL_POL_KSTEP(a4a.x, 0, x) DL_POL_KSTEP(a4a.y, 0, y) DL_POL_KSTEP(a4a.z, 0, z) DL_POL_KSTEP(a4a.w, 0, w)
-            DL_POL_KSTEP(a4b.x, 1, x) DL_POL_KSTEP(a4b.y, 1, y) DL_POL_KSTEP(a4b.z, 1, z) DL_POL_KSTEP(a4b.w, 1, w)
+            DL_POL_KSTEP(a4a, 0, x) DL_POL_KSTEP(a4a, 0, y) DL_POL_KSTEP(a4a, 0, z) DL_POL_KSTEP(a4a, 0, w)
+            DL_POL_KSTEP(a4b, 1, x) DL_POL_KSTEP(a4b, 1, y) DL_POL_KSTEP(a4b, 1, z) DL_POL_KSTEP(a4b, 1, w)
 #undef DL_POL_KSTEP
         };
         // DEPTH register sets, DEPTH - 1 of them in flight while one is consumed (4 sets were measured no faster than 2: the hidden
@@ -308,9 +320,11 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         if constexpr (WHOLE_H1) {
             // every wave stages the 64 columns of h1 it owns, ONE barrier, then the reduction runs free
 #pragma unroll
-            for (int t = 0; t < NTW; t++)
+            for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) stage[(4 * lk + i) * HLD + n0w + t * 16 + lm] = h1r[t][i];
+                for (int t = 0; t < NTW; t++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) stage[(rb * POL_ROWS + 4 * lk + i) * HLD + n0w + t * 16 + lm] = h1r[rb][t][i];
             DL_POL_STAMP(2);
             __syncthreads();
             DL_POL_STAMP(3);
@@ -346,43 +360,49 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         for (int t = 0; t < NTW; t++) {
             const float bias = p.b2[n0w + t * 16 + lm];
 #pragma unroll
-            for (int i = 0; i < 4; i++) h2r[t][i] = pol_tanh(acc[t][i] + bias);
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) h2r[rb][t][i] = pol_tanh(acc[rb][t][i] + bias);
         }
     }
     // ---- heads: one 16 x 16 tile (columns 0..A-1 action means, column A the value); the reduction is split over the waves, each
     // over the h2 columns it owns: a tile goes from the accumulator layout to the A-operand layout through the wave's private tile
     {
-        pf4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* wrow = lm < A ? p.wa + (size_t)lm * H : (lm == A ? p.wv : nullptr);
 #pragma unroll
-        for (int t = 0; t < NTW; t++) {
-            wave_sync();
+        for (int rb = 0; rb < RB; rb++) {
+            pf4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; i++) priv[(4 * lk + i) * POL_PLD + lm] = h2r[t][i];
-            wave_sync();
-            const int k0 = n0w + t * 16 + lk * 4;
-            const pf4 a4 = *(const pf4*)&priv[lm * POL_PLD + lk * 4];
-            pf4 b4;
-            if constexpr (PACKED) b4 = *(const pf4*)(pk.whp + ((size_t)(k0 >> 2) * 16 + lm) * 4);
-            else b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+            for (int t = 0; t < NTW; t++) {
+                wave_sync();
+#pragma unroll
+                for (int i = 0; i < 4; i++) priv[(4 * lk + i) * POL_PLD + lm] = h2r[rb][t][i];
+                wave_sync();
+                const int k0 = n0w + t * 16 + lk * 4;
+                const pf4 a4 = *(const pf4*)&priv[lm * POL_PLD + lk * 4];
+                pf4 b4;
+                if constexpr (PACKED) b4 = *(const pf4*)(pk.whp + ((size_t)(k0 >> 2) * 16 + lm) * 4);
+                else b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) part[((rb * NW + wave) * 16 + 4 * lk + i) * 16 + lm] = acc[i];
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) part[(wave * 16 + 4 * lk + i) * 16 + lm] = acc[i];
     }
     DL_POL_STAMP(5);
     __syncthreads();
     DL_POL_STAMP(6);
     // ---- epilogue: sample, log-probability, value
     float lp = 0.0f;
-    const int row = tid >> 4, col = tid & 15, r = row0 + row;
-    if (tid < 256) {
+    const int row = tid >> 4, col = tid & 15, r = row0 + row;          // row: 0 .. 16 RB - 1
+    constexpr int EPI = 256 * RB;
+    if (tid < EPI) {
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) v += part[(w * 16 + row) * 16 + col];
+        for (int w = 0; w < NW; w++) v += part[(((row >> 4) * NW + w) * 16 + (row & 15)) * 16 + col];
         if (r < n) {
             if (col < A) {
                 const float mean = v + p.ba[col], ls = p.log_std[col];
@@ -393,9 +413,9 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         }
     }
     __syncthreads();
-    if (tid < 256) part[tid] = lp;
+    if (tid < EPI) part[tid] = lp;
     __syncthreads();
-    if (tid < 256 && col == 0 && r < n) {
+    if (tid < EPI && col == 0 && r < n) {
         float s = 0.0f;
         for (int a = 0; a < A; a++) s += part[row * 16 + a];
         logp[r] = s;
