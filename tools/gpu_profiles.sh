@@ -23,7 +23,7 @@ pol policy_launches --rollout-form launches
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_policy
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --policy --steps 2 --warmup 1 > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --policy --steps 2 --warmup 1 > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_IFETCH --kernel-trace --output-format csv -d $OUT/pmc2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --policy --steps 2 --warmup 1 > $OUT/pmc2.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/diag_sections.py > gpurun_out/${TAG}_sum_sections_straight.txt 2>&1
 S=gpurun_out/${TAG}_sum

@@ -16,3 +16,7 @@ run loco3d --walker loco3d
 run envs8192 --envs-per-gpu 8192
 run envs32768 --envs-per-gpu 32768
 run policy_32768_h2 --policy --envs-per-gpu 32768 --handles 2
+run policy_8192 --policy --envs-per-gpu 8192
+run policy_16384 --policy --envs-per-gpu 16384
+run policy_32768 --policy --envs-per-gpu 32768
+run policy_32768_per_rollout --policy --envs-per-gpu 32768 --moments per_rollout
