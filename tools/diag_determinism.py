@@ -43,3 +43,25 @@ for multi in FORMS:
 if len(FORMS) == 2:
     a, b = ref['multi'], ref['single']
     print('multi == single:', all(np.array_equal(x, y) for x, y in zip(a, b)))
+
+# ---- the persistent rollout kernel (policy in the loop): DET_PERSISTENT=<walkers> repeats one rollout of T steps R times from the same start
+if os.environ.get('DET_PERSISTENT'):
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecNormalize
+    npers = int(os.environ['DET_PERSISTENT'])
+    first = None
+    ndiff = 0
+    for rep in range(R):
+        venv = HipVecEnv(num_envs=npers, seed=1234)
+        vn = HipVecNormalize(venv); vn.blocked_reduce = True; vn.reset()
+        pol = HipPolicy(hidden=512, seed=99)
+        buf = HipRolloutBuffer(T, npers, 29, 8, torch.device('cuda'))
+        last_obs, last_done = vn.norm_obs_t.clone(), torch.ones(npers, dtype=torch.uint8, device='cuda')
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+        torch.cuda.synchronize()
+        h = hashlib.sha1(b''.join(x.cpu().numpy().tobytes() for x in (buf.observations, buf.actions, buf.rewards, buf.values, buf.log_probs, buf.episode_starts, last_obs))).hexdigest()[:16]
+        if first is None: first = h
+        elif h != first: ndiff += 1; print('persistent', rep, 'DIFFERS', h, flush=True)
+        venv.close()
+    print(f'persistent kernel, {npers} walkers x {T} steps: {ndiff} of {R - 1} repetitions differ from the first ({first})')
