@@ -61,11 +61,12 @@ def test_persistent_rollout_is_the_launch_path_bit_for_bit(torch_cuda, model, re
     assert (a['episode_starts'].sum() > 0 or n < 100 or T < 20) and a['counter'] == 2 * T
 
 
+@pytest.mark.parametrize('n', [300, 4500], ids=['one-block-per-workgroup', 'two-blocks-per-workgroup'])
 @pytest.mark.parametrize('kw', [dict(training=False), dict(norm_reward=False), dict(norm_obs=False)], ids=['frozen', 'raw-rewards', 'raw-observations'])
-def test_persistent_rollout_flag_combinations(torch_cuda, model, refs, kw):
+def test_persistent_rollout_flag_combinations(torch_cuda, model, refs, kw, n):
     """VecNormalize's switches (load_env's evaluation env: training = False / norm_reward = False, drloco/common/utils.py:234-240) in both forms."""
     torch = torch_cuda
-    n, T = 300, 20
+    T = 20 if n < 1000 else 8
     res = []
     for persistent in (False, True):
         venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T, **kw)
