@@ -14,6 +14,7 @@
 
 #include "dl_host.hpp"
 #include "dl_policy.hpp"
+#include "dl_policy_pair.hpp"
 
 using namespace dl;
 
@@ -1916,6 +1917,15 @@ int dl_policy_forward_packed(const dl_policy_params* p, const float* packed, con
         pk.w2p = packed; pk.w1p = packed + (size_t)512 * 512; pk.whp = pk.w1p + (size_t)48 * 512;
     }
     return policy_launch(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, none, stream, pk);
+}
+int dl_policy_forward_pair(const dl_policy_params* p, const float* packed, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                           int32_t deterministic, float* actions, float* values, float* log_probs, void* stream) {
+    if (!p || !packed || !obs || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward_pair: bad arguments");
+    if (p->hidden != 512 || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15) return fail(DL_E_INVAL, "dl_policy_forward_pair: hidden = 512, obs_dim <= 48, act_dim <= 15");
+    PolPacked pk{packed, packed + (size_t)512 * 512, packed + (size_t)512 * 512 + (size_t)48 * 512};
+    hipLaunchKernelGGL(k_policy_forward_pair, dim3((n + 3) / 4), dim3(128), 0, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, pk);
+    HIPCHK(hipGetLastError());
+    return DL_OK;
 }
 int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
                       float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,

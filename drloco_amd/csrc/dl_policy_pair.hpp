@@ -1,0 +1,192 @@
+// drloco_amd -- the policy forward for FOUR rows on two waves (a wave pair of a split workgroup), float32, hidden = 512, packed weights.
+//
+// Why: the 16-row MFMA tile of pol_forward_rows makes the four wave pairs of a persistent workgroup meet at every control step (they wait for the
+// slowest pair: 17 % of the env phase).  v_mfma_f32_4x4x1_16B_f32 multiplies sixteen independent 4 x 4 blocks per instruction: with the four rows of
+// ONE pair as the A operand of every block and 64 different columns as the B operands it runs four rows at the rate at which 16x16x4 runs sixteen, so a
+// pair can evaluate the policy of its own four walkers on its own SIMD (drloco/custom/policies.py:13-51, the same network as dl_policy.hpp).
+//
+// Same bits as pol_forward_rows: v_mfma_f32_16x16x4_f32 rounds like four fused multiply-adds in ascending k, and one 4x4x1 instruction is one such
+// multiply-add (tools/ubench/mfma_round.hip: 512 000 / 128 000 random cases identical).  pol_forward_rows hands the lanes of a quarter wave lk the
+// k = 16 b + 4 lk + c of every block of sixteen, component c per instruction, so a sum runs over k = c, 4 + c, 8 + c, 12 + c for c = 0 .. 3, block after
+// block: the single-k instructions below are issued in exactly that order.  The heads' partial sums per group of 64 columns and their final order are kept too.
+//
+// Lane layout of a 4x4x1 instruction: lane l belongs to block l / 4; it supplies A[row l % 4] and B[column l % 4 of the block] and receives, in its four
+// accumulator registers, the block's column l % 4 for rows 0 .. 3.  With block b = columns 4 b .. 4 b + 3 of a group of 64, lane l owns column l of the group.
+#pragma once
+
+#include "dl_policy.hpp"
+
+namespace dl {
+
+constexpr int POLP_H = 512, POLP_HLD = POLP_H + 4, POLP_OLD = 52;
+// LDS of one pair (floats): staged observation [4][52], activations [4][516] (h1, then h2), head partials [8][4][16] (then the log-prob terms [4][16])
+constexpr int POLP_XS = 0, POLP_HS = 4 * POLP_OLD, POLP_PART = POLP_HS + 4 * POLP_HLD, POLP_WORDS = POLP_PART + 8 * 4 * 16;
+constexpr size_t pol_pair_lds_bytes() { return (size_t)POLP_WORDS * sizeof(float); }
+
+// h: which wave of the pair (0 / 1: columns 256 h .. 256 h + 255), l: lane.  sync(): a barrier of the pair's two waves that also orders their LDS and global
+// accesses (stand-alone kernel: __syncthreads of a two-wave workgroup).  sm: POLP_WORDS floats of LDS owned by the pair.  Rows row0 .. row0 + 3 (those < n).
+template <typename SYNC>
+__device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, const float* __restrict__ obs, int n, const float* __restrict__ eps, uint64_t seed, uint64_t counter, int index_base,
+                                                 int deterministic, float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolVnFuse& vf,
+                                                 float* sm, int row0, int h, int l, const PolPacked pk, SYNC sync) {
+    constexpr int H = POLP_H, HLD = POLP_HLD, OLD = POLP_OLD;
+    const int D = p.obs_dim, A = p.act_dim;
+    float* xs = sm + POLP_XS; float* hs = sm + POLP_HS; float* part = sm + POLP_PART;
+    const int tid = h * 64 + l, rsel = l & 3;
+    // ---- the folded VecNormalize step's reward half (as in pol_forward_rows)
+    if (vf.raw_obs && tid < 4 && row0 + tid < n) {
+        const int r = row0 + tid;
+        const float x = vf.raw_rew[r];
+        vf.rew_out[r] = (vf.flags & 8) ? vn_norm_rew(x, *vf.ret_var, vf.eps, vf.clip_rew) : x;
+        if ((vf.flags & 4) && vf.done[r]) { double zero = 0.0; asm volatile("" : "+v"(zero)); vf.ret[r] = zero; }
+    }
+    // ---- the four observation rows, normalised where a VecNormalize step is folded in, staged for both waves
+    {
+        const float* src = vf.raw_obs ? vf.raw_obs : obs;
+        for (int e = tid; e < 4 * 48; e += 128) {
+            const int rr = e / 48, k = e % 48, r = row0 + rr;
+            float x = 0.0f;
+            if (k < D && r < n) {
+                x = src[(size_t)r * D + k];
+                if (vf.raw_obs) {
+                    if (vf.flags & 2) x = vn_norm_obs(x, vf.mean[k], vf.var[k], vf.eps, vf.clip_obs);
+                    vf.obs_out[(size_t)r * D + k] = x;
+                }
+            }
+            xs[rr * OLD + k] = x;
+        }
+    }
+    sync();
+    const int colb = h * 256 + l;                 // this lane's column of column group cb: colb + 64 cb
+    // one block of sixteen k: A fragments a[j] (k = 4 j .. 4 j + 3 of the lane's row), B fragments b[cb][j] (the same k of the lane's column in group cb)
+#define DL_POLP_BLOCK(ACC, AF, BF)                                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 4; c++) _Pragma("unroll") for (int j = 0; j < 4; j++) _Pragma("unroll") for (int cb = 0; cb < 4; cb++) \
+        ACC[cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(AF[j][c], BF[cb][j][c], ACC[cb], 0, 0, 0);
+    // ---- layer 1: three blocks of sixteen inputs (obs_dim <= 48)
+    pf4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) acc[cb] = pf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 3; kb++) {
+        pf4 a[4], b[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = *(const pf4*)&xs[rsel * OLD + kb * 16 + 4 * j];
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[cb][j] = *(const pf4*)(pk.w1p + ((size_t)(kb * 4 + j) * H + colb + 64 * cb) * 4);
+        DL_POLP_BLOCK(acc, a, b)
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) {
+        const float bias = p.b1[colb + 64 * cb];
+#pragma unroll
+        for (int i = 0; i < 4; i++) hs[i * HLD + colb + 64 * cb] = pol_tanh(acc[cb][i] + bias);
+    }
+    sync();
+    // ---- layer 2: 32 blocks of sixteen k; the weights of the next block are requested before the MFMAs of the current one (inline asm: see dl_policy.hpp)
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) acc[cb] = pf4{0.f, 0.f, 0.f, 0.f};
+    {
+        const float* wb = pk.w2p + (size_t)colb * 4;
+        auto load_set = [&](pf4 (&b)[4][4], int kb) {
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float* q = wb + ((size_t)(kb * 4 + j) * H + 64 * cb) * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[cb][j]) : "v"(q) : "memory");
+                }
+        };
+        auto wait_set = [&](pf4 (&b)[4][4], bool newer) {
+            if (newer) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) asm volatile("" : "+v"(b[cb][j]));
+        };
+        pf4 bs[2][4][4];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the compiler's own loads may be counted against the sets
+        load_set(bs[0], 0);
+        for (int kb0 = 0; kb0 < 32; kb0 += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const int kb = kb0 + d;
+                if (kb + 1 < 32) load_set(bs[d ^ 1], kb + 1);
+                pf4 a[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) a[j] = *(const pf4*)&hs[rsel * HLD + kb * 16 + 4 * j];
+                wait_set(bs[d], kb + 1 < 32);
+                DL_POLP_BLOCK(acc, a, bs[d])
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    sync();                                   // both waves have read all of h1: its space takes h2
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) {
+        const float bias = p.b2[colb + 64 * cb];
+#pragma unroll
+        for (int i = 0; i < 4; i++) hs[i * HLD + colb + 64 * cb] = pol_tanh(acc[cb][i] + bias);
+    }
+    sync();
+#undef DL_POLP_BLOCK
+    // ---- heads: the partial sums of pol_forward_rows' eight waves (64 columns each), four per wave here: block b = 4 wq + jq is partial w = 4 h + wq,
+    // outputs 4 jq .. 4 jq + 3 (columns 0 .. A - 1 action means, column A the value)
+    {
+        const int wq = l >> 4, jq = (l >> 2) & 3, w = 4 * h + wq, jo = 4 * jq + rsel;
+        pf4 ha = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            pf4 a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k0 = w * 64 + t * 16 + 4 * j;
+                a[j] = *(const pf4*)&hs[rsel * HLD + k0];
+                b[j] = *(const pf4*)(pk.whp + ((size_t)(k0 >> 2) * 16 + jo) * 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) ha = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][c], b[j][c], ha, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) part[(w * 4 + i) * 16 + jo] = ha[i];
+    }
+    sync();
+    // ---- epilogue: sample, log-probability, value (the order of pol_forward_rows: partials added w = 0 .. 7)
+    float lp = 0.0f;
+    const int row = tid >> 4, col = tid & 15, r = row0 + row;
+    if (tid < 64) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v += part[(w * 4 + row) * 16 + col];
+        if (r < n) {
+            if (col < A) {
+                const float mean = v + p.ba[col], ls = p.log_std[col];
+                const float e = deterministic ? 0.0f : (eps ? eps[(size_t)r * A + col] : pol_gauss(seed, counter, (uint32_t)(index_base + r), (uint32_t)col));
+                actions[(size_t)r * A + col] = mean + __expf(ls) * e;
+                lp = -0.5f * e * e - ls - 0.91893853320467274178f;
+            } else if (col == A) values[r] = v + p.bv[0];
+        }
+    }
+    sync();
+    if (tid < 64) part[tid] = lp;
+    sync();
+    if (tid < 64 && col == 0 && r < n) {
+        float s = 0.0f;
+        for (int a = 0; a < A; a++) s += part[row * 16 + a];
+        logp[r] = s;
+    }
+}
+
+// stand-alone form (tests, tools): a workgroup of two waves per four rows
+__global__ __launch_bounds__(128) void k_policy_forward_pair(const dl_policy_params p, const float* __restrict__ obs, int n, const float* __restrict__ eps, uint64_t seed, uint64_t counter,
+                                                             int index_base, int deterministic, float* __restrict__ actions, float* __restrict__ values, float* __restrict__ logp, const PolPacked pk) {
+    __shared__ __attribute__((aligned(16))) float sm[POLP_WORDS];
+    PolVnFuse none{};
+    pol_forward_pair(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, logp, none, sm, (int)blockIdx.x * 4, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, pk,
+                     [] { __syncthreads(); });
+}
+
+}  // namespace dl

@@ -107,6 +107,7 @@ _SIGNATURES = {
     'dl_policy_forward': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _I, _P, C.c_uint64, C.c_uint64, _I, _I, _P, _P, _P, _P]),
     'dl_policy_pack': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _P]),
     'dl_policy_forward_packed': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _I, _P, _P, _P, _P]),
+    'dl_policy_forward_pair': (C.c_int, [C.POINTER(abi.PolicyParams), _P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _I, _P, _P, _P, _P]),
     'dl_rollout_policy': (C.c_int, [_V, C.POINTER(abi.PolicyParams), C.c_uint64, C.c_uint64, _I, C.POINTER(abi.VecNormState), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'dl_rollout_persistent_ok': (C.c_int, [_V, C.POINTER(abi.PolicyParams)]),
     'dl_collect_rollouts': (C.c_int, [_V, C.POINTER(abi.PolicyParams), C.c_uint64, C.c_uint64, _I, C.POINTER(abi.VecNormState), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

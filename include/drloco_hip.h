@@ -368,6 +368,13 @@ int dl_policy_forward_packed(const dl_policy_params* params, const float* packed
                              const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
                              int32_t deterministic, float* actions, float* values, float* log_probs, void* stream);
 
+/* The same forward pass in its four-rows-per-wave-pair form (packed weights, hidden = 512): a workgroup of two waves per four rows on
+ * v_mfma_f32_4x4x1_16B_f32, every sum in the order of dl_policy_forward -- bit-identical outputs (tests/test_gpu_policy.py).  It is the building
+ * block that lets a wave pair of the persistent rollout kernel evaluate the policy of its own four walkers; stand-alone it is a reference for that. */
+int dl_policy_forward_pair(const dl_policy_params* params, const float* packed, const float* obs, int32_t n,
+                           const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
+                           int32_t deterministic, float* actions, float* values, float* log_probs, void* stream);
+
 /* VecNormalize state as dl_vecnormalize_step takes it, bundled for dl_rollout_policy (all DEVICE pointers). */
 typedef struct dl_vecnorm_state {
     double* obs_mean; double* obs_var; double* obs_count;     /* [D], [D], [1] */

@@ -350,3 +350,27 @@ def test_policy_forms_agree_bit_for_bit(torch_cuda):
     ref, _, _ = pol.torch_reference(obs[:64], eps[:64])
     torch.cuda.synchronize()
     assert not torch.equal(a9, a4[:64]) and torch.allclose(a9, ref, atol=2e-5)
+
+def test_policy_pair_form_is_the_forward_pass_bit_for_bit(torch_cuda):
+    """dl_policy_forward_pair (four rows per wave pair on v_mfma_f32_4x4x1_16B_f32, single-k instructions issued in the order in which the 16x16x4 tiles of
+    dl_policy_forward accumulate) gives the same bits: sampled actions with given draws and with the counter-based stream, deterministic actions, values,
+    log-probabilities; ragged row counts."""
+    torch = torch_cuda
+    import ctypes as C
+    from drloco_amd import lib as L
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.vec_env import _ptr, _stream
+    pol = HipPolicy(hidden=512, seed=11)
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for n in (4096, 1001, 6, 3):
+        obs = 3.0 * torch.randn(n, 29, device='cuda', generator=g)
+        eps = torch.randn(n, 8, device='cuda', generator=g)
+        for mode in ('eps', 'stream', 'deterministic'):
+            pol.counter = 7
+            a0, v0, l0 = pol.forward(obs, eps=eps if mode == 'eps' else None, deterministic=mode == 'deterministic')
+            a, v, lp = torch.empty(n, 8, device='cuda'), torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+            p = pol._params()
+            L.check(pol._lib.dl_policy_forward_pair(C.byref(p), _ptr(pol._packed_weights()), _ptr(obs), n, _ptr(eps) if mode == 'eps' else None, pol.seed, 7, pol.index_base,
+                                                    int(mode == 'deterministic'), _ptr(a), _ptr(v), _ptr(lp), _stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(a, a0) and torch.equal(v, v0) and torch.equal(lp, l0), (n, mode, float((a - a0).abs().max()), float((v - v0).abs().max()))
