@@ -909,6 +909,145 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         if (tid == D) { *a.ret_mean = vm[D]; *a.ret_var = vm[W + D]; *a.obs_count = vm[2 * W]; *a.ret_count = vm[2 * W + 1]; }
     }
 }
+#ifdef DL_EXP_ROLLOUT_PAIRS          // EXPERIMENT, not in the product build: measured 27.4 M env-steps/s (k_rollout_persistent with per-rollout moments: 26.2 M), but about one row in a
+                                    // thousand row-steps -- always the third walker of a pair, only while other pairs of the workgroup are running -- leaves the policy phase with
+                                    // outputs that are off by ~1e-2 although its staged observation is the recorded one (EXPERIMENTS.md, round 4).  dl_policy_forward_pair, the
+                                    // building block, is exact stand-alone (tests/test_gpu_persistent.py).
+#ifndef DL_EXP_PAIR_SM_OFF
+#define DL_EXP_PAIR_SM_OFF 0
+#endif
+// ---- per-rollout moments (DL_ROLLOUT_MOMENTS_PER_ROLLOUT), every wave PAIR on its own.  With the moments frozen nothing couples the walkers of a rollout, and the only
+// reason the four pairs of a workgroup met at every control step was the policy's 16-row tile (17 % of the env phase went into waiting for the slowest pair).  Here a pair
+// evaluates the policy of its own four walkers (pol_forward_pair: v_mfma_f32_4x4x1, the bits of dl_policy_forward), steps them, adds their samples to its own sums and
+// goes on: a pair takes its four walkers of a block through all T steps, then those of the workgroup's next block.  The two waves of a pair meet through two counters in
+// their mailbox (pair_sync); no s_barrier after the kernel's prologue.  The pair's shifted sums live in memory (partial[(4 block + pair)][W][2], zeroed by the host): k_vn_merge_rollout
+// adds them in row order.
+template <typename TP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using T = float;
+    using Sp = GSplit<TP>;
+    using Args = RolloutArgs<TP>;
+    constexpr int D = TP::OBS, W = D + 1, NU = TP::NU;
+    constexpr size_t ENV_LDS = (size_t)4 * GW * Sp::TOTAL * sizeof(T);
+    static_assert(POLP_WORDS <= 3 * Sp::TOTAL, "the pair's policy works in the regions of its walkers 1 .. 3 (walker 0's mailbox holds the pair's counters)");
+    const DL_CONST Args* const ap0 = (const DL_CONST Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto args = [&]() { const DL_CONST Args* q = ap0; DL_SPIN(q); return q; };
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, role = wave >> 2, slot = wave & 3;
+    const int gslot = role == 0 ? slot : ((slot + DL_SPLIT_PAIR_OFFSET) & 3);          // the pair: the dynamics wave and the partner wave of one group of four walkers
+    DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
+    double* vm = (double*)(smem + ENV_LDS);                 // mean[W] (column D: the returns'), var[W]: frozen for the whole rollout
+    const int wgi = g_block_of_workgroup(blockIdx.x, gridDim.x);
+    int n, nT, flags, kb;
+    {
+        const DL_CONST Args* p = args();
+        n = p->st.n; nT = p->a.T; flags = p->a.flags; kb = p->a.kblocks;
+        if (tid < D) { vm[tid] = p->a.obs_mean[tid]; vm[W + tid] = p->a.obs_var[tid]; }
+        if (tid == D) { vm[D] = *p->a.ret_mean; vm[W + D] = *p->a.ret_var; }
+        if (lane == 0 && role == 0) { volatile DL_LDS int* ps = (volatile DL_LDS int*)(base + Sp::MB); ps[90] = 0; ps[91] = 0; }
+    }
+    const int nblk = (n + 15) / 16;
+    const int b0 = wgi * kb, b1 = b0 + kb < nblk ? b0 + kb : nblk;
+    const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0;
+    __syncthreads();
+    int epoch = 0;
+    int32_t* const fault_w = args()->st.fault;
+    auto pair_sync = [&]() {          // the two waves of the pair: everything either has written (LDS, memory) is visible to the other afterwards
+        volatile DL_LDS int* ps = (volatile DL_LDS int*)(base + Sp::MB);
+        DL_WG_RELEASE();
+        epoch += 1;
+        if (lane == 0) ps[90 + role] = epoch;
+        int budget = 1 << 22;
+        while (DL_UNIFORM(ps[91 - role]) < epoch && --budget > 0) __builtin_amdgcn_s_sleep(1);
+#ifdef DL_EXP_PAIR_SLOWSYNC
+        __builtin_amdgcn_s_sleep(20); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        if (budget <= 0 && fault_w && lane == 0) DL_FAULT_OR(fault_w, DL_FAULT_SRV_TIMEOUT);          // (bounded like every poll of the split form: an error, never a hung GPU)
+        DL_WG_ACQUIRE();
+    };
+#pragma unroll 1
+    for (int blk_i = b0; blk_i < b1; blk_i++) {
+    const int row0 = blk_i * 16 + gslot * 4, row1 = row0 + 4 < n ? row0 + 4 : n;
+#pragma unroll 1
+    for (int t = 0; t < nT; t++) {
+        if (row0 >= n) break;         // (uniform per pair) a pair beyond the last walker has nothing to do
+#ifdef DL_EXP_PAIR_ONLY0
+        if (gslot != 0) break;
+#endif
+        int blk = blk_i;
+        DL_SPIN(blk);
+        // ---- P: the policy of the pair's four rows (and observations[t], rewards[t - 1] from the raw outputs of step t - 1)
+        {
+            const DL_CONST Args* p = args();
+            const RolloutP a = p->a;
+            int lane_p = lane;
+            DL_VPIN(lane_p);
+            PolVnFuse vf{};
+            if (t > 0) {
+                vf.raw_obs = a.raw_obs; vf.raw_rew = a.raw_rew; vf.done = a.episode_starts + (size_t)t * n;
+                vf.mean = vm; vf.var = vm + W; vf.count = nullptr; vf.ret = a.ret; vf.ret_var = vm + W + D; vf.ret_count = nullptr;
+                vf.obs_out = a.observations + (size_t)t * n * D; vf.rew_out = a.rewards + (size_t)(t - 1) * n;
+                vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
+            }
+            pol_forward_pair(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0, a.actions + (size_t)t * n * NU,
+                             a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)(base + Sp::TOTAL + DL_EXP_PAIR_SM_OFF), blk * 16 + gslot * 4, role, lane_p, a.pk, pair_sync);
+        }
+        // ---- E: one control step of the four walkers
+        if (lane == 0 && role == 0) {
+            volatile DL_LDS int* f = (volatile DL_LDS int*)(base + Sp::MB);
+            f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = -1;
+        }
+        pair_sync();                  // the actions are in memory, the policy's LDS is free, the mailbox is reset
+        {
+            const DL_CONST Args* p = args();
+            DevState<T> st = p->st;
+            st.push_step0 += t;
+            const DevCfg<T> c = p->c;
+            uint8_t* done = t + 1 == nT ? p->a.next_done : p->a.episode_starts + (size_t)(t + 1) * n;
+            const int wblock = blk * 4 + gslot;
+            int lane_t = lane;
+            DL_VPIN(lane_t);
+            if (role == 0)
+                g_wave_env_step<T, TP, false, true>(lane_t, wblock, 0, 1, base, p->gm, c, st, p->a.actions + (size_t)t * n * NU, p->a.raw_obs, p->a.raw_rew, done, (float*)nullptr, (float*)nullptr,
+                                                    (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, p->eval_mode, 1, nullptr);
+            else
+                g_constraint_server<T, TP>(lane_t, wblock, base, p->gm, st);
+        }
+        pair_sync();                  // raw observation / reward / done of the pair's rows are in memory
+        // ---- R: the pair's samples of this step join its shifted sums (and the discounted returns advance)
+        if (role == 0 && (upd_obs || upd_ret)) {
+            const DL_CONST Args* p = args();
+            int col = lane;
+            DL_VPIN(col);
+            if (col < W && (col < D ? upd_obs : upd_ret)) {
+                double s, ss;
+                vn_block_sums(p->a.raw_obs, p->a.raw_rew, p->a.ret, D, col, row0, row1, vm[col], p->a.gamma, s, ss);
+                double* acc = p->a.partial + ((size_t)(blk * 4 + gslot) * W + col) * 2;
+                acc[0] += s; acc[1] += ss;
+            }
+        }
+    }
+    // ---- VecNormalize of the last step's outputs for the pair's rows: next_obs, rewards[T - 1], ret
+    if (row0 < n) {
+        const DL_CONST Args* p = args();
+        const RolloutP a = p->a;
+        const int t2 = role * 64 + lane;
+        for (int idx = t2; idx < (row1 - row0) * D; idx += 128) {
+            const size_t e = (size_t)row0 * D + idx;
+            const int k = idx % D;
+            a.next_obs[e] = (flags & 2) ? vn_norm_obs(a.raw_obs[e], vm[k], vm[W + k], a.eps, a.clip_obs) : a.raw_obs[e];
+        }
+        if (t2 < row1 - row0) {
+            const int r = row0 + t2;
+            a.rewards[(size_t)(nT - 1) * n + r] = (flags & 8) ? vn_norm_rew(a.raw_rew[r], vm[W + D], a.eps, a.clip_rew) : a.raw_rew[r];
+            if (upd_ret && a.next_done[r]) a.ret[r] = 0;
+        }
+        pair_sync();                  // (the next block's first policy pass reuses the regions)
+    }
+    }
+}
+#endif          // DL_EXP_ROLLOUT_PAIRS
 // per_rollout: one exact Chan merge of the T x N samples of a rollout from the workgroups' shifted sums (groups, then blocks, in order)
 __global__ __launch_bounds__(64) void k_vn_merge_rollout(const double* __restrict__ partial, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
                                                        int nblk, int D, long long samples, int flags) {
@@ -1324,12 +1463,15 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             const int nblk = (n + 15) / 16;
             int rc;
             if (!rp_partial) {
-                if ((rc = dalloc(&rp_partial, (size_t)nblk * W * 2))) return rc;
+                if ((rc = dalloc(&rp_partial, (size_t)nblk * 4 * W * 2))) return rc;          // (per-rollout moments: a slot per wave pair)
                 if ((rc = dalloc(&rp_xpart, (size_t)2 * 8 * W * 2))) return rc;
                 if ((rc = dalloc(&rp_sync, (size_t)RP_SYNC_WORDS))) return rc;
                 if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11))) return rc;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
+#ifdef DL_EXP_ROLLOUT_PAIRS
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_pairs<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
+#endif
             }
             RolloutP a{};
             a.pol = pol; a.seed = seed; a.counter0 = counter0; a.index_base = index_base;
@@ -1344,10 +1486,17 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.kblocks = (nblk + n_cus - 1) / n_cus;
             const int nwg = (nblk + a.kblocks - 1) / a.kblocks;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
+#ifdef DL_EXP_ROLLOUT_PAIRS
+            if (per_rollout) HIPCHK(hipMemsetAsync(rp_partial, 0, (size_t)nblk * 4 * W * 2 * sizeof(double), s));          // the pairs' sums start at zero
+#endif
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
+#ifdef DL_EXP_ROLLOUT_PAIRS
+            if (per_rollout) hipLaunchKernelGGL((k_rollout_pairs<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            else
+#endif
             if (a.kblocks > 1) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             else hipLaunchKernelGGL((k_rollout_persistent<TP, false>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
@@ -1355,7 +1504,12 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             HIPCHK(hipGetLastError());
             if (per_rollout && (vn.flags & 5))
                 hipLaunchKernelGGL(k_vn_merge_rollout, dim3(1), dim3(64), 0, s, (const double*)rp_partial, vn.obs_mean, vn.obs_var, vn.obs_count, vn.ret_mean, vn.ret_var, vn.ret_count,
-                                   nblk, (int)TP::OBS, (long long)n * nT, vn.flags);
+#ifdef DL_EXP_ROLLOUT_PAIRS
+                                   nblk * 4,
+#else
+                                   nblk,
+#endif
+                                   (int)TP::OBS, (long long)n * nT, vn.flags);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
