@@ -909,13 +909,6 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         if (tid == D) { *a.ret_mean = vm[D]; *a.ret_var = vm[W + D]; *a.obs_count = vm[2 * W]; *a.ret_count = vm[2 * W + 1]; }
     }
 }
-#ifdef DL_EXP_ROLLOUT_PAIRS          // EXPERIMENT, not in the product build: measured 27.4 M env-steps/s (k_rollout_persistent with per-rollout moments: 26.2 M), but about one row in a
-                                    // thousand row-steps -- always the third walker of a pair, only while other pairs of the workgroup are running -- leaves the policy phase with
-                                    // outputs that are off by ~1e-2 although its staged observation is the recorded one (EXPERIMENTS.md, round 4).  dl_policy_forward_pair, the
-                                    // building block, is exact stand-alone (tests/test_gpu_persistent.py).
-#ifndef DL_EXP_PAIR_SM_OFF
-#define DL_EXP_PAIR_SM_OFF 0
-#endif
 // ---- per-rollout moments (DL_ROLLOUT_MOMENTS_PER_ROLLOUT), every wave PAIR on its own.  With the moments frozen nothing couples the walkers of a rollout, and the only
 // reason the four pairs of a workgroup met at every control step was the policy's 16-row tile (17 % of the env phase went into waiting for the slowest pair).  Here a pair
 // evaluates the policy of its own four walkers (pol_forward_pair: v_mfma_f32_4x4x1, the bits of dl_policy_forward), steps them, adds their samples to its own sums and
@@ -960,9 +953,6 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
         if (lane == 0) ps[90 + role] = epoch;
         int budget = 1 << 22;
         while (DL_UNIFORM(ps[91 - role]) < epoch && --budget > 0) __builtin_amdgcn_s_sleep(1);
-#ifdef DL_EXP_PAIR_SLOWSYNC
-        __builtin_amdgcn_s_sleep(20); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         if (budget <= 0 && fault_w && lane == 0) DL_FAULT_OR(fault_w, DL_FAULT_SRV_TIMEOUT);          // (bounded like every poll of the split form: an error, never a hung GPU)
         DL_WG_ACQUIRE();
     };
@@ -972,9 +962,6 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
 #pragma unroll 1
     for (int t = 0; t < nT; t++) {
         if (row0 >= n) break;         // (uniform per pair) a pair beyond the last walker has nothing to do
-#ifdef DL_EXP_PAIR_ONLY0
-        if (gslot != 0) break;
-#endif
         int blk = blk_i;
         DL_SPIN(blk);
         // ---- P: the policy of the pair's four rows (and observations[t], rewards[t - 1] from the raw outputs of step t - 1)
@@ -991,7 +978,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
             pol_forward_pair(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0, a.actions + (size_t)t * n * NU,
-                             a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)(base + Sp::TOTAL + DL_EXP_PAIR_SM_OFF), blk * 16 + gslot * 4, role, lane_p, a.pk, pair_sync);
+                             a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)(base + Sp::TOTAL), blk * 16 + gslot * 4, role, lane_p, a.pk, pair_sync);
         }
         // ---- E: one control step of the four walkers
         if (lane == 0 && role == 0) {
@@ -1047,7 +1034,6 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
     }
     }
 }
-#endif          // DL_EXP_ROLLOUT_PAIRS
 // per_rollout: one exact Chan merge of the T x N samples of a rollout from the workgroups' shifted sums (groups, then blocks, in order)
 __global__ __launch_bounds__(64) void k_vn_merge_rollout(const double* __restrict__ partial, double* mean, double* var, double* count, double* ret_mean, double* ret_var, double* ret_count,
                                                        int nblk, int D, long long samples, int flags) {
@@ -1469,9 +1455,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11))) return rc;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
-#ifdef DL_EXP_ROLLOUT_PAIRS
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_pairs<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
-#endif
             }
             RolloutP a{};
             a.pol = pol; a.seed = seed; a.counter0 = counter0; a.index_base = index_base;
@@ -1486,30 +1470,20 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.kblocks = (nblk + n_cus - 1) / n_cus;
             const int nwg = (nblk + a.kblocks - 1) / a.kblocks;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
-#ifdef DL_EXP_ROLLOUT_PAIRS
             if (per_rollout) HIPCHK(hipMemsetAsync(rp_partial, 0, (size_t)nblk * 4 * W * 2 * sizeof(double), s));          // the pairs' sums start at zero
-#endif
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
-#ifdef DL_EXP_ROLLOUT_PAIRS
             if (per_rollout) hipLaunchKernelGGL((k_rollout_pairs<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
-            else
-#endif
-            if (a.kblocks > 1) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            else if (a.kblocks > 1) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             else hipLaunchKernelGGL((k_rollout_persistent<TP, false>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
             prof_end(s);
             HIPCHK(hipGetLastError());
             if (per_rollout && (vn.flags & 5))
                 hipLaunchKernelGGL(k_vn_merge_rollout, dim3(1), dim3(64), 0, s, (const double*)rp_partial, vn.obs_mean, vn.obs_var, vn.obs_count, vn.ret_mean, vn.ret_var, vn.ret_count,
-#ifdef DL_EXP_ROLLOUT_PAIRS
-                                   nblk * 4,
-#else
-                                   nblk,
-#endif
-                                   (int)TP::OBS, (long long)n * nT, vn.flags);
+                                   nblk * 4, (int)TP::OBS, (long long)n * nT, vn.flags);
             HIPCHK(hipGetLastError());
             return DL_OK;
         }

@@ -59,9 +59,16 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
     sync();
     const int colb = h * 256 + l;                 // this lane's column of column group cb: colb + 64 cb
     // one block of sixteen k: A fragments a[j] (k = 4 j .. 4 j + 3 of the lane's row), B fragments b[cb][j] (the same k of the lane's column in group cb)
+    // The 4x4x1 instructions are written as inline asm with the accumulator tied to the destination ("+v"): as a builtin the compiler is free to place the DESTINATION on the
+    // register of a B fragment that dies with the instruction (it does so under register pressure -- inside the rollout kernel, not in the stand-alone one), and the two-pass
+    // instruction then computed its third row from the overwritten register: one row in a thousand wrong by ~1e-2, only while another wave kept the SIMD busy.  Tied, source C
+    // and destination are the same registers and the other operands cannot overlap them.  Dependent instructions on the same accumulator are interlocked by the hardware
+    // (same registers, same size); the wait states before anything else reads an accumulator follow the block (DL_POLP_SETTLE).
+#define DL_POLP_MFMA(ACC, AV, BV) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
+#define DL_POLP_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]))
 #define DL_POLP_BLOCK(ACC, AF, BF)                                                                                       \
     _Pragma("unroll") for (int c = 0; c < 4; c++) _Pragma("unroll") for (int j = 0; j < 4; j++) _Pragma("unroll") for (int cb = 0; cb < 4; cb++) \
-        ACC[cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(AF[j][c], BF[cb][j][c], ACC[cb], 0, 0, 0);
+        DL_POLP_MFMA(ACC[cb], AF[j][c], BF[cb][j][c]);
     // ---- layer 1: three blocks of sixteen inputs (obs_dim <= 48)
     pf4 acc[4];
 #pragma unroll
@@ -77,6 +84,7 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
             for (int j = 0; j < 4; j++) b[cb][j] = *(const pf4*)(pk.w1p + ((size_t)(kb * 4 + j) * H + colb + 64 * cb) * 4);
         DL_POLP_BLOCK(acc, a, b)
     }
+    DL_POLP_SETTLE(acc);
 #pragma unroll
     for (int cb = 0; cb < 4; cb++) {
         const float bias = p.b1[colb + 64 * cb];
@@ -122,6 +130,7 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    DL_POLP_SETTLE(acc);
     sync();                                   // both waves have read all of h1: its space takes h2
 #pragma unroll
     for (int cb = 0; cb < 4; cb++) {
@@ -130,7 +139,6 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
         for (int i = 0; i < 4; i++) hs[i * HLD + colb + 64 * cb] = pol_tanh(acc[cb][i] + bias);
     }
     sync();
-#undef DL_POLP_BLOCK
     // ---- heads: the partial sums of pol_forward_rows' eight waves (64 columns each), four per wave here: block b = 4 wq + jq is partial w = 4 h + wq,
     // outputs 4 jq .. 4 jq + 3 (columns 0 .. A - 1 action means, column A the value)
     {
@@ -148,11 +156,15 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) ha = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][c], b[j][c], ha, 0, 0, 0);
+                for (int j = 0; j < 4; j++) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ha) : "v"(a[j][c]), "v"(b[j][c]));          // (one accumulator, back to back: the wait states a dependent instruction needs)
         }
+        asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ha));
 #pragma unroll
         for (int i = 0; i < 4; i++) part[(w * 4 + i) * 16 + jo] = ha[i];
     }
+#undef DL_POLP_BLOCK
+#undef DL_POLP_MFMA
+#undef DL_POLP_SETTLE
     sync();
     // ---- epilogue: sample, log-probability, value (the order of pol_forward_rows: partials added w = 0 .. 7)
     float lp = 0.0f;

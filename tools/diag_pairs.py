@@ -9,7 +9,7 @@ from drloco_amd import lib as L
 from drloco_amd.policy import HipPolicy
 from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize, _ptr, _stream
-n, T = 1000, 8
+n, T = 1000, 24
 venv = HipVecEnv(num_envs=n, seed=21); venv.set_split(True)
 vn = HipVecNormalize(venv); vn.blocked_reduce = True; vn.reset()
 pol = HipPolicy(hidden=512, seed=4)
