@@ -464,13 +464,13 @@ def main():
                        'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else ('side stream, one dl_vecnormalize_steps call per run' if not args.vn_single_steps else 'side stream, under the following run of env steps'),
                        'step_kernel_form': 'split workgroups: 4 dynamics + 4 constraint waves per 16 walkers (dl_set_split 1)' if split else 'one wave per 4 walkers',
-                       'env_launches': (('ONE persistent launch per rollout (k_rollout_persistent: policy + env step + moment exchange per control step)' + (', moments per rollout (relaxation)' if args.moments == 'per_rollout' else ', exact per-step moments'))
+                       'env_launches': (('ONE persistent launch per rollout (k_rollout_pairs: every wave pair takes its four walkers through policy + env step, moments per rollout (relaxation))' if args.moments == 'per_rollout' else 'ONE persistent launch per rollout (k_rollout_persistent: policy + env step + moment exchange per control step), exact per-step moments')
                                         if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else 'one per control step') if (args.policy or args.no_overlap) else
                                        'dl_rollout_fixed, runs of ' + ' + '.join(str(r) for _, r in run_starts) + ' control steps per launch',
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes on a device-resident schedule (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
-                                   ('k_rollout_persistent<TopoStraight>' if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>'))), 'avg_launch_us': avg_launch_s * 1e6,
+                                   (('k_rollout_pairs<TopoStraight>' if args.moments == 'per_rollout' else 'k_rollout_persistent<TopoStraight>') if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>'))), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
                          'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},

@@ -22,7 +22,7 @@ if stats:
     lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
     for r in rows[:14]:
         lines.append(f'{r["Name"][:70]:70s} {r["Calls"]:>7s} {float(r["AverageNs"]) / 1e3:12.2f} {float(r["MinNs"]) / 1e3:10.2f} {float(r["MaxNs"]) / 1e3:10.2f} {float(r["Percentage"]):7.2f}')
-        if 'k_env_step' in r['Name'] or 'k_rollout_persistent' in r['Name']:
+        if 'k_env_step' in r['Name'] or 'k_rollout_persistent' in r['Name'] or 'k_rollout_pairs' in r['Name']:
             out['k_env_step_avg_us'] = float(r['AverageNs']) / 1e3
             out['k_env_step_calls'] = int(r['Calls'])
 pmc = {}
@@ -30,7 +30,7 @@ for p in sorted(glob.glob(os.path.join(src, 'pmc*', '*', '*counter_collection.cs
     acc = collections.defaultdict(list)
     meta = None
     for r in csv.DictReader(open(p)):
-        if 'k_env_step' in r['Kernel_Name'] or 'k_rollout_persistent' in r['Kernel_Name']:
+        if 'k_env_step' in r['Kernel_Name'] or 'k_rollout_persistent' in r['Kernel_Name'] or 'k_rollout_pairs' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
             meta = r
     for k, v in acc.items():
