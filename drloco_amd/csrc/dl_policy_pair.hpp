@@ -59,11 +59,12 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
     sync();
     const int colb = h * 256 + l;                 // this lane's column of column group cb: colb + 64 cb
     // one block of sixteen k: A fragments a[j] (k = 4 j .. 4 j + 3 of the lane's row), B fragments b[cb][j] (the same k of the lane's column in group cb)
-    // The 4x4x1 instructions are written as inline asm with the accumulator tied to the destination ("+v"): as a builtin the compiler is free to place the DESTINATION on the
-    // register of a B fragment that dies with the instruction (it does so under register pressure -- inside the rollout kernel, not in the stand-alone one), and the two-pass
-    // instruction then computed its third row from the overwritten register: one row in a thousand wrong by ~1e-2, only while another wave kept the SIMD busy.  Tied, source C
-    // and destination are the same registers and the other operands cannot overlap them.  Dependent instructions on the same accumulator are interlocked by the hardware
-    // (same registers, same size); the wait states before anything else reads an accumulator follow the block (DL_POLP_SETTLE).
+    // The 4x4x1 instructions are written as inline asm with the accumulator tied to the destination ("+v").  As builtins, under the register pressure of the rollout kernel (not in
+    // the stand-alone one), the compiler RELOCATED accumulators inside the dense chains -- destination != source C, the destination laid over the register of a B fragment that
+    // dies with the instruction -- and about one row in a thousand (always the third of the four) came out wrong by ~1e-2 while another wave kept the SIMD busy.  An isolated
+    // instruction with that overlap is exact (tools/ubench/mfma_overlap.hip), so the failure needs the back-to-back context; tied, source C and destination are the same
+    // registers, nothing is relocated and the other operands cannot overlap them.  The wait states are written by hand: dependent instructions on different accumulators are
+    // four apart in a block, the heads' single-accumulator chain carries s_nop, and DL_POLP_SETTLE precedes every other reader of an accumulator.
 #define DL_POLP_MFMA(ACC, AV, BV) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
 #define DL_POLP_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]))
 #define DL_POLP_BLOCK(ACC, AF, BF)                                                                                       \
