@@ -2,7 +2,8 @@
 """bench.py -- throughput of the DRLoco hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -- or plainly as above:
+   without WORLD_SIZE in the environment the process starts its N ranks itself as a child torch.distributed.run and forwards rank 0's line)
 
 Workload (BASELINE.json configs[1], per GPU; configs[2] is the same per GPU at N = 8):
   straight_walking 3D walker, 4096 parallel walkers per GPU, fixed 512-step synthetic rollout.
@@ -203,6 +204,24 @@ def cpu_baseline_all_cores(n_envs=64, n_steps=256, max_procs=32):
                 sample=f'{n_procs} processes x {n_envs} walkers x {n_steps} control steps (oracle, environments only), {dt:.1f} s')
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher around it: this process -- which has not imported torch, let alone touched a GPU -- starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>` as a CHILD (never an exec), passes the
+    ranks' output through (rank 0 prints the one JSON line) and returns the child's exit code.  The reference starts its N environment
+    processes with one call, too (drloco/common/utils.py:121-125)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -227,6 +246,9 @@ def main():
     ap.add_argument('--dump', type=str, default='', help='after the run every rank saves what its LAST rollout produced (episode starts, action tape, raw step outputs, moments) to <path>.rank<r>.npz (tests/test_gpu_distributed.py compares ranks with a single-process run)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))       # plain `python bench.py --gpus N`: start the N ranks (nothing here has touched the GPU)
+
     import torch
     import torch.distributed as dist
     from drloco_amd import lib
@@ -238,7 +260,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and --gpus disagree (plain `python bench.py --gpus N` starts its own N ranks)')
     # the CPU baselines run BEFORE this process touches the GPU (the worker processes of the second one are forked)
     cpu_base = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -252,6 +274,8 @@ def main():
         except Exception as e:
             cpu_base['all_host_cores'] = {'error': repr(e)}
     if local_rank >= torch.cuda.device_count():      # test rigs with fewer GPUs than ranks (DL_BENCH_BACKEND=gloo): share the last device
+        if os.environ.get('DL_BENCH_BACKEND', 'nccl') == 'nccl':
+            raise SystemExit(f'--gpus {args.gpus} on a box with {torch.cuda.device_count()} GPU(s): RCCL needs one GPU per rank (DL_BENCH_BACKEND=gloo shares a device, for tests)')
         local_rank = torch.cuda.device_count() - 1
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or 'RANK' in os.environ          # under torch.distributed.run the RCCL path runs even with one rank
@@ -427,10 +451,14 @@ def main():
         np.savez(f'{args.dump}.rank{rank}.npz', starts=buf._starts.cpu().numpy(), actions=buf.actions.cpu().numpy(), values=buf.values.cpu().numpy(), observations=buf.observations.cpu().numpy(),
                  rewards=buf.rewards.cpu().numpy(), advantages=buf.advantages.cpu().numpy(), obs_mean=vn.obs_rms.mean, obs_var=vn.obs_rms.var, obs_count=vn.obs_rms.count,
                  ret_mean=vn.ret_rms.mean, ret_var=vn.ret_rms.var, ret_count=vn.ret_rms.count, cursor=venv.get_state()['cursor'], qpos=venv.get_state()['qpos'], **ring)
+    ranks_seen = 1
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        seen = torch.ones(1, dtype=torch.int64, device=dev)          # every rank adds 1: what the collective library saw, not what the environment claims
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks_seen = int(seen.item())
 
     if rank == 0:
         env_steps = n * T * args.steps * world
@@ -475,7 +503,7 @@ def main():
                          'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
-        out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'backend': dist.get_backend() if use_dist else None, 'vn_sync': vn.sync,
+        out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'ranks_seen': ranks_seen, 'backend': dist.get_backend() if use_dist else None, 'vn_sync': vn.sync,
                               'collectives_per_control_step': 'all-reduce of 2 x (obs_dim + 1) doubles (VecNormalize batch sums: exact per-step moments over all ranks)' if (use_dist and vn.sync == 'per_step') else None,
                               'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None}
         out['self_check'] = checks

@@ -93,3 +93,16 @@ def test_bench_two_ranks_match_one_process(tmp_path, extra):
         np.testing.assert_allclose(ranks[0]['obs_mean'], ref['obs_mean'], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(ranks[0]['obs_var'], ref['obs_var'], rtol=1e-10)
         np.testing.assert_allclose([float(ranks[0]['ret_mean']), float(ranks[0]['ret_var'])], [float(ref['ret_mean']), float(ref['ret_var'])], rtol=1e-10)
+
+
+@pytest.mark.timeout(900)
+def test_plain_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it and no WORLD_SIZE in the environment (how the driver starts N = 1): the parent
+    starts the two ranks itself, forwards rank 0's single JSON line and exits with the children's code.  `ranks_seen` is an all-reduced 1 per
+    rank: what the process group saw, not what the environment claimed."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['DL_BENCH_BACKEND'] = 'gloo'          # two ranks on the one GPU of this box; on a node the default (RCCL) runs
+    out = _run([sys.executable, 'bench.py', '--gpus', '2', '--envs-per-gpu', '512', '--rollout-len', '64', '--steps', '1', '--warmup', '1'], env)
+    assert out['n_gpus'] == 2 and out['distributed']['world_size'] == 2 and out['distributed']['ranks_seen'] == 2
+    assert out['value'] > 0 and out['self_check']['finite'] and out['scaling'] == 'weak'
+    assert 'cpu_baseline' not in out          # rank 0 at N = 1 only

@@ -349,3 +349,34 @@ def test_bench_tapes_are_keyed_by_the_global_walker_index():
     assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1) < 5e-3 and float(big.abs().max()) < 6.5
     k = float(((big - big.mean()) ** 4).mean() / big.var() ** 2)
     assert abs(k - 3) < 0.05          # kurtosis of a normal
+
+
+def test_bench_gpus_n_self_launch(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it: the parent -- before importing torch -- starts N ranks as a CHILD
+    `python -m torch.distributed.run` on 127.0.0.1 with the same arguments and returns the child's exit code (never an exec: a process that
+    touched the GPU must not be replaced)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1'])
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and 0 < int(cmd[cmd.index('--master-port') + 1]) < 65536
+    assert cmd[-7] == os.path.join(ROOT, 'bench.py') and cmd[-6:] == ['--gpus', '8', '--steps', '2', '--warmup', '1']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # under a launcher (WORLD_SIZE set) nothing is started; a launcher that disagrees with --gpus is an error, not a silent resize
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not seen and 'disagree' in str(e.value.code)
