@@ -29,6 +29,21 @@ namespace dl {
 
 typedef float pf4 __attribute__((ext_vector_type(4)));
 
+// EVERY MFMA of the policy kernels is inline asm with the accumulator TIED to the destination ("+v": source C and destination are the same
+// registers, so the allocator cannot relocate an accumulator inside a chain and cannot lay the destination over an A / B operand).  As builtins,
+// 71 of the 16x16x4 instructions of the product build had destination != source C with the destination over a dying A / B register -- the form
+// in which the 4x4x1 chains of dl_policy_pair.hpp produced about one wrong row in a thousand inside the per-rollout kernel.  Nothing ever failed
+// in the 16x16x4 kernels, but nothing explained why it could not; tied, the pattern cannot be emitted, and tools/check_mfma_overlap.py proves on
+// the listing of every build (rules R1 .. R5) that it was not and that the hand-written wait states below are in place:
+//   DL_MFMA16       the chain form: back to back on one accumulator (the 8-pass shape interlocks on an exactly matching source C) or interleaved;
+//   DL_MFMA16_OPEN  the first instruction after a VALU write of an operand (the zero-initialised accumulator): two wait states in front;
+//   DL_MFMA16_SETTLE before any other reader or writer of the accumulator: 12 wait states (8 passes + 4), more than the 10 hipcc puts
+//                   behind its own 16x16x4 (`s_nop 8` + the reader's own issue).
+#define DL_MFMA16(ACC, AV, BV) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
+#define DL_MFMA16_OPEN(ACC, AV, BV) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
+#define DL_MFMA16_PAD(ACC) asm volatile("s_nop 1" : "+v"(ACC))          // behind a VALU write of an accumulator whose first MFMA is a plain DL_MFMA16
+#define DL_MFMA16_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ACC))
+
 __device__ __forceinline__ float pol_tanh(float x) {
     // 1 - 2 / (exp(2x) + 1); |error| < 2e-7 absolute
     const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
@@ -214,8 +229,10 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
                 pf4 acc = {0.f, 0.f, 0.f, 0.f};
+                DL_MFMA16_OPEN(acc, a1[rb][0], b1v[t][0]);
 #pragma unroll
-                for (int q = 0; q < KB1 * 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rb][q], b1v[t][q], acc, 0, 0, 0);
+                for (int q = 1; q < KB1 * 4; q++) DL_MFMA16(acc, a1[rb][q], b1v[t][q]);
+                DL_MFMA16_SETTLE(acc);
 #pragma unroll
                 for (int i = 0; i < 4; i++) h1r[rb][t][i] = pol_tanh(acc[i] + bias);
             }
@@ -245,7 +262,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
 #pragma unroll
         for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-            for (int t = 0; t < NTW; t++) acc[rb][t] = pf4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NTW; t++) { acc[rb][t] = pf4{0.f, 0.f, 0.f, 0.f}; DL_MFMA16_PAD(acc[rb][t]); }
         const float* wbase = PACKED ? pk.w2p + ((size_t)lk * H + n0w + lm) * 4 : p.w2 + (size_t)(n0w + lm) * H + lk * 4;
         // two k blocks (32 k = one 128-byte line per weight row) per step: both halves of every line a wave touches are
         // consumed together.  Explicit ping-pong register sets: the loads of the next step are issued BEFORE the 64 MFMAs
@@ -294,7 +311,7 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
             for (int rb = 0; rb < RB; rb++) { a4a[rb] = *(const pf4*)&buf[(rb * POL_ROWS + lm) * LD + lk * 4]; a4b[rb] = *(const pf4*)&buf[(rb * POL_ROWS + lm) * LD + 16 + lk * 4]; }
             // k step outermost: consecutive MFMAs go to different accumulator tiles (no back-to-back dependent issue)
 #ifndef DL_EXP_POL_NOMFMA
-#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) _Pragma("unroll") for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[rb].C, b4[t][H2].C, acc[rb][t], 0, 0, 0);
+#define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) _Pragma("unroll") for (int rb = 0; rb < RB; rb++) DL_MFMA16(acc[rb][t], AV[rb].C, b4[t][H2].C);
 #else
 #define DL_POL_KSTEP(AV, H2, C) _Pragma("unroll") for (int t = 0; t < NTW; t++) _Pragma("unroll") for (int rb = 0; rb < RB; rb++) acc[rb][t].x += AV[rb].C * b4[t][H2].C;
 #endif
@@ -355,6 +372,12 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
         }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DL_EXP_POL_NOMFMA
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+            for (int t = 0; t < NTW; t++) DL_MFMA16_SETTLE(acc[rb][t]);          // (the first statement waits, the others find the pipe drained: 12 states each, once per forward pass)
+#endif
         DL_POL_STAMP(4);
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -383,11 +406,12 @@ __device__ __forceinline__ void pol_forward_rows(const dl_policy_params& p, cons
                 pf4 b4;
                 if constexpr (PACKED) b4 = *(const pf4*)(pk.whp + ((size_t)(k0 >> 2) * 16 + lm) * 4);
                 else b4 = wrow ? *(const pf4*)(wrow + k0) : pf4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+                if (t == 0) DL_MFMA16_OPEN(acc, a4.x, b4.x); else DL_MFMA16(acc, a4.x, b4.x);
+                DL_MFMA16(acc, a4.y, b4.y);
+                DL_MFMA16(acc, a4.z, b4.z);
+                DL_MFMA16(acc, a4.w, b4.w);
             }
+            DL_MFMA16_SETTLE(acc);
 #pragma unroll
             for (int i = 0; i < 4; i++) part[((rb * NW + wave) * 16 + 4 * lk + i) * 16 + lm] = acc[i];
         }

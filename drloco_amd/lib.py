@@ -68,6 +68,17 @@ def check_dpp_hazards():
     return p.stdout.strip().splitlines()[-1]
 
 
+def check_mfma_overlap():
+    """Run tools/check_mfma_overlap.py over the listing of the product build (building it if needed); raises on a violation: an MFMA whose
+    destination differs from its source C and lies over an A / B operand, a relocated 4x4x1 accumulator, or a missing hand-written wait state."""
+    build(listing=True)
+    tool = os.path.join(os.path.dirname(_HERE), 'tools', 'check_mfma_overlap.py')
+    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, LISTING], capture_output=True, text=True)
+    if p.returncode != 0:
+        raise DrlocoError('MFMA operand overlap / wait-state violation in the device code:\n' + p.stdout[-4000:] + p.stderr[-2000:])
+    return p.stdout.strip().splitlines()[-1]
+
+
 _V, _I, _P = C.c_void_p, C.c_int32, C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)       -- every symbol include/drloco_hip.h declares
