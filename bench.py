@@ -41,19 +41,12 @@ ALGO_BYTES_PER_ENV_STEP_LOCO3D = 916   # the same count for the 19-dof walker: 4
 HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def kernel_sources_sha16():
-    """Identity of the kernel build a profile was taken with: sha256 over drloco_amd/csrc/*.{hip,hpp}, the C-ABI header and the product
-    build's extra compiler flags."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, 'drloco_amd', 'csrc')
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith(('.hip', '.hpp')):
-            h.update(f.encode()); h.update(open(os.path.join(csrc, f), 'rb').read())
-    h.update(open(os.path.join(ROOT, 'include', 'drloco_hip.h'), 'rb').read())
+def kernel_code_sha16():
+    """Identity of the kernel build a profile was taken with: sha256 over the device code object embedded in the built library
+    (drloco_amd.lib.device_code_sha16).  Round 4 hashed the SOURCES, comments included: a comment-only commit forced a re-stamp of every
+    PMC pass; the code object only moves when a kernel does."""
     from drloco_amd import lib
-    h.update(' '.join(lib.EXTRA_FLAGS).encode())          # the compiler flags of the product build are part of what was measured
-    return h.hexdigest()[:16]
+    return lib.device_code_sha16()
 
 
 def _shr(x, k):
@@ -476,11 +469,11 @@ def main():
         if os.path.exists(tfile) and default_cfg:
             try:
                 pj = json.load(open(tfile))
-                if pj.get('kernel_sources_sha16') == kernel_sources_sha16():
+                if pj.get('kernel_code_sha16') == kernel_code_sha16():
                     traffic, valu_busy = pj.get('hbm_bytes_per_launch'), (pj.get('valu_busy_frac_simd') if split else pj.get('valu_busy_frac'))
-                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'tag': pj.get('tag'), 'kernel_sources_sha16': pj.get('kernel_sources_sha16')}
+                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'tag': pj.get('tag'), 'kernel_code_sha16': pj.get('kernel_code_sha16')}
                 else:
-                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'stale': True, 'measured_sha16': pj.get('kernel_sources_sha16'), 'built_sha16': kernel_sources_sha16()}
+                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'stale': True, 'measured_sha16': pj.get('kernel_code_sha16') or pj.get('kernel_sources_sha16'), 'built_sha16': kernel_code_sha16()}
             except Exception:
                 traffic = None
         out = {

@@ -5,7 +5,7 @@ library's own view (dl_abi_sizeof) and that every declared symbol is exported.
 """
 import ctypes as C
 
-DL_ABI_VERSION = 5
+DL_ABI_VERSION = 6
 DL_ADV_WORKSPACE_BYTES = (2 * 512 + 2) * 8
 
 
@@ -26,7 +26,7 @@ DL_GEOM_CAPSULE, DL_GEOM_BOX = 0, 1
  DL_CUR_EPISODE, DL_CUR_READ_STEP, DL_CUR_EVAL_K) = range(9)
 DL_CUR_WORDS = 9
 EVAL_N_TIMES = 20        # drloco/config/config.py:23
-DL_ROLLOUT_PERSISTENT, DL_ROLLOUT_MOMENTS_PER_ROLLOUT = 1, 2
+DL_ROLLOUT_PERSISTENT, DL_ROLLOUT_MOMENTS_PER_ROLLOUT, DL_ROLLOUT_WORKGROUP_TILES, DL_ROLLOUT_DETERMINISTIC = 1, 2, 4, 8
 DL_OK, DL_E_INVAL, DL_E_NODEVICE, DL_E_HIP, DL_E_NOMEM, DL_E_FAULT = 0, -1, -2, -3, -4, -5
 DL_FAULT_DYN_TIMEOUT, DL_FAULT_SRV_TIMEOUT, DL_FAULT_GRID_TIMEOUT = 1, 2, 4          # bits of the fault word (dl_fault_check)
 

@@ -261,9 +261,13 @@ def write_model_zip(policy, path, observation_space=None, action_space=None, opt
         h = dict(learning_rate=5e-4, lr_start=5e-4, lr_final=1e-6, gamma=0.995, gae_lambda=0.95, n_steps=2048, batch_size=2048, n_epochs=4, ent_coef=-0.0075, vf_coef=0.5,
                  max_grad_norm=0.5, clip_range=0.15, clip_range_vf=0.15, n_envs=8, num_timesteps=0, seed=None, verbose=1, sde_sample_freq=-1, use_sde=False, target_kl=None,
                  tensorboard_log=None, log_std_init=-0.75)
+        h['log_std_init'] = float(getattr(policy, 'log_std_init', h['log_std_init']))          # the policy's own constructor value
         h.update(hyper or {})
         if (h['n_steps'] * h['n_envs']) % h['batch_size']:
-            raise ValueError(f"n_steps * n_envs = {h['n_steps'] * h['n_envs']} is not a multiple of the minibatch size {h['batch_size']} (SB3's PPO warns about a truncated last minibatch; the reference uses 2048 x 8 / 2048)")
+            # as SB3's PPO does: a warning, never an exception -- this runs AFTER training and must not lose the model
+            import warnings
+            warnings.warn(f"n_steps * n_envs = {h['n_steps'] * h['n_envs']} is not a multiple of the minibatch size {h['batch_size']}: the last minibatch of an epoch is truncated "
+                          '(the reference uses 2048 x 8 / 2048)')
         meta = dict(h)
         meta['policy_class'] = _serialized(pol_cls)
         meta['policy_kwargs'] = dict(log_std_init=float(meta.pop('log_std_init')))          # the CONSTRUCTOR value (hypers.init_logstd), not the trained log_std (that is in policy.pth)

@@ -23,7 +23,11 @@ enum {
     MON_MOVED, MON_HAS, MON_POSREW, MON_VELREW, MON_COMREW,
     // what the host needs to keep Monitor's per-episode lists (monitor_wrapper.py:93,107,123,131-132): reference-cursor position at the
     // first step and at the end of the episode, the step's mean absolute torque, "shorter than 0.75 x the smoothed length" flag
-    MON_INIT_POS, MON_ET_POS, MON_TOR_LAST, MON_DIFFICULT, MON_WORDS
+    MON_INIT_POS, MON_ET_POS, MON_TOR_LAST, MON_DIFFICULT,
+    // the FIRST episode a walker finished since the handle was created or all its walkers were reset (dl_reset without a mask), as
+    // TrainingMonitor.eval_walking measures an episode (callback.py:300-317: duration incl. the terminal step, walked distance and reward sum
+    // WITHOUT it): length, walked distance after the last non-terminal step, reward sum -- what a batched evaluation reads after ONE rollout call
+    MON_FIRST_LEN, MON_FIRST_MOVED, MON_FIRST_RET, MON_WALKED_LAST, MON_WORDS
 };
 
 constexpr int DL_DBG_EVALS = 40;      // evaluations per control step the diagnostics record (4 x frame_skip: 20 / 40)
@@ -176,8 +180,10 @@ DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const 
         W(MON_DIFFICULT) = (len < W(MON_S_EP_LEN) * 0.75) ? 1.0 : 0.0;                    // :122-123 (after the smoothing update)
         mon_smooth(mon, n, i, MON_S_TOR, 6, W(MON_TOR) / len, 0.75);
         W(MON_MOVED) = walked;
+        if (W(MON_FIRST_LEN) == 0) { W(MON_FIRST_LEN) = len; W(MON_FIRST_MOVED) = W(MON_WALKED_LAST); W(MON_FIRST_RET) = W(MON_RET) - W(MON_LAST); }
         W(MON_EP_LEN) = 0; W(MON_RET) = 0; W(MON_TOR) = 0;
     }
+    W(MON_WALKED_LAST) = done ? 0.0 : walked;          // the walked distance after this step if the episode goes on (the next step may be terminal)
 }
 
 // one control step of walker i.  Writes obs only for walkers that continue; finished walkers get

@@ -462,6 +462,9 @@ template <typename TP> struct GSplit {
     // configuration); MB_MFREE = sequence number of the last request whose mass matrix the dynamics wave has taken into registers
     static constexpr int MB_MOK = 69, MB_MFREE = 70, MB_QN = 72, MB_PRE = 71;          // MB_PRE: sequence number of the last request whose look-ahead is complete (-1 at launch; 0: the state in memory)
     static_assert(MB_QN % 4 == 0 && MB_QN + GL <= MB_SIZE, "mailbox layout");
+    // the two epoch counters through which the waves of a pair meet in k_rollout_pairs (pair_sync): words of walker 0's mailbox behind the announced configuration
+    static constexpr int MB_PAIR0 = 90, MB_PAIR1 = 91;
+    static_assert(MB_PAIR0 >= MB_QN + GL && MB_PAIR1 == MB_PAIR0 + 1 && MB_PAIR1 < MB_SIZE, "the pair counters lie behind every other mailbox field");
     // what the partner wave computes one evaluation ahead and hands over through LDS: the body frames (its own copy: GLds::BFR shares the space of the contact
     // Jacobians, which are live while it works) and, per dof lane, (joint axis x y z, root height)
     static constexpr int BFRX = MB + MB_SIZE;                    // body frames [MAXB][BFR_W]
@@ -1594,7 +1597,8 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         // request says so and waits for the partner to compute everything now.
         volatile DL_LDS int* fl = (volatile DL_LDS int*)g.mbox0;
         const int seq = ++*split_seq;
-        const bool fast = !__any(j < N && __builtin_bit_cast(uint32_t, (float)q) != __builtin_bit_cast(uint32_t, (float)*q_ann));
+        using QBits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;          // the announced configuration must be THIS one to the last bit of its own type
+        const bool fast = !__any(j < N && __builtin_bit_cast(QBits, q) != __builtin_bit_cast(QBits, *q_ann));
         *q_ann = q_next;
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);

@@ -657,7 +657,7 @@ struct RolloutP {
     unsigned* sync;               // group counters at [16 g], top counter at [128]
     PolPacked pk;                 // the policy's weights in k-chunk-major order (k_pack_policy), packed by the host before the launch
     long long* prof;              // diagnostics (DL_EXP_ROLLOUT_PROF builds): [nblk][4] shader-clock cycles in P, E, R (sums + exchange), waiting in the exchange
-    int32_t index_base, flags, T, per_rollout, spin_grid, kblocks;
+    int32_t index_base, flags, T, per_rollout, spin_grid, kblocks, deterministic;
 };
 constexpr int RP_SYNC_WORDS = 160;
 constexpr int RP_MAX_KBLOCKS = 8;          // blocks of sixteen walkers per workgroup: <= 128 walkers per CU, 32768 on 256 CUs
@@ -743,7 +743,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
             const int nlim = b1 * 16 < n ? b1 * 16 : n;          // rows of THIS workgroup's blocks only (a pass of two blocks may reach beyond its last one)
-            pol_forward_rows<4, 8, true, true, RBK>(a.pol, a.observations + (size_t)t * n * D, nlim, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0,
+            pol_forward_rows<4, 8, true, true, RBK>(a.pol, a.observations + (size_t)t * n * D, nlim, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, a.deterministic,
                                    a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.pk);
         }
         __syncthreads();          // the actions of the pass's rows are in memory (workgroup scope); the policy's LDS is free again
@@ -938,7 +938,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
         n = p->st.n; nT = p->a.T; flags = p->a.flags; kb = p->a.kblocks;
         if (tid < D) { vm[tid] = p->a.obs_mean[tid]; vm[W + tid] = p->a.obs_var[tid]; }
         if (tid == D) { vm[D] = *p->a.ret_mean; vm[W + D] = *p->a.ret_var; }
-        if (lane == 0 && role == 0) { volatile DL_LDS int* ps = (volatile DL_LDS int*)(base + Sp::MB); ps[90] = 0; ps[91] = 0; }
+        if (lane == 0 && role == 0) { volatile DL_LDS int* ps = (volatile DL_LDS int*)(base + Sp::MB); ps[Sp::MB_PAIR0] = 0; ps[Sp::MB_PAIR1] = 0; }
     }
     const int nblk = (n + 15) / 16;
     const int b0 = wgi * kb, b1 = b0 + kb < nblk ? b0 + kb : nblk;
@@ -946,14 +946,25 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
     __syncthreads();
     int epoch = 0;
     int32_t* const fault_w = args()->st.fault;
-    auto pair_sync = [&]() {          // the two waves of the pair: everything either has written (LDS, memory) is visible to the other afterwards
+    const int pair_spin = args()->a.spin_grid;          // polls before a wave gives its partner up (dl_debug_set_grid_spin; 1 << 22 ~ seconds)
+    // The two waves of the pair meet: everything either has written (LDS, memory) is visible to the other afterwards.  Bounded like every poll of the split form -- an
+    // error, never a hung GPU -- and, like there, a wave never carries on with stale data: a wave whose partner did not arrive sets the handle's fault word
+    // (DL_FAULT_SRV_TIMEOUT), the pair is dead from then on (every later pair_sync returns at once) and the wave LEAVES the kernel at the next phase boundary
+    // (`if (!pair_alive) return` below; no s_barrier follows the prologue, so a wave may end early).  The rows of the rollout buffer the pair owned stay incomplete, as
+    // a workgroup's do after DL_FAULT_GRID_TIMEOUT: the host must see the fault word before it reads the buffer (include/drloco_hip.h).
+    bool pair_alive = true;
+    auto pair_sync = [&]() {
+        if (!pair_alive) return;
         volatile DL_LDS int* ps = (volatile DL_LDS int*)(base + Sp::MB);
         DL_WG_RELEASE();
         epoch += 1;
-        if (lane == 0) ps[90 + role] = epoch;
-        int budget = 1 << 22;
-        while (DL_UNIFORM(ps[91 - role]) < epoch && --budget > 0) __builtin_amdgcn_s_sleep(1);
-        if (budget <= 0 && fault_w && lane == 0) DL_FAULT_OR(fault_w, DL_FAULT_SRV_TIMEOUT);          // (bounded like every poll of the split form: an error, never a hung GPU)
+        if (lane == 0) ps[Sp::MB_PAIR0 + role] = epoch;
+        int budget = pair_spin;
+        while (DL_UNIFORM(ps[Sp::MB_PAIR1 - role]) < epoch && --budget > 0) __builtin_amdgcn_s_sleep(1);
+        if (budget <= 0) {
+            pair_alive = false;
+            if (fault_w && lane == 0) DL_FAULT_OR(fault_w, DL_FAULT_SRV_TIMEOUT);
+        }
         DL_WG_ACQUIRE();
     };
 #pragma unroll 1
@@ -977,7 +988,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
                 vf.obs_out = a.observations + (size_t)t * n * D; vf.rew_out = a.rewards + (size_t)(t - 1) * n;
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
-            pol_forward_pair(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, 0, a.actions + (size_t)t * n * NU,
+            pol_forward_pair(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, a.deterministic, a.actions + (size_t)t * n * NU,
                              a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)(base + Sp::TOTAL), blk * 16 + gslot * 4, role, lane_p, a.pk, pair_sync);
         }
         // ---- E: one control step of the four walkers
@@ -986,6 +997,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
             f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = -1;
         }
         pair_sync();                  // the actions are in memory, the policy's LDS is free, the mailbox is reset
+        if (!pair_alive) return;
         {
             const DL_CONST Args* p = args();
             DevState<T> st = p->st;
@@ -1002,6 +1014,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
                 g_constraint_server<T, TP>(lane_t, wblock, base, p->gm, st);
         }
         pair_sync();                  // raw observation / reward / done of the pair's rows are in memory
+        if (!pair_alive) return;
         // ---- R: the pair's samples of this step join its shifted sums (and the discounted returns advance)
         if (role == 0 && (upd_obs || upd_ret)) {
             const DL_CONST Args* p = args();
@@ -1031,6 +1044,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
             if (upd_ret && a.next_done[r]) a.ret[r] = 0;
         }
         pair_sync();                  // (the next block's first policy pass reuses the regions)
+        if (!pair_alive) return;
     }
     }
 }
@@ -1100,7 +1114,7 @@ struct dl_env_s {
     virtual int pack_policy(const dl_policy_params& pol, PolPacked* out, hipStream_t s) = 0;
     virtual int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t T, float* observations,
                                    float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
-                                   float* raw_rew, int per_rollout, hipStream_t s) = 0;
+                                   float* raw_rew, int per_rollout, int deterministic, hipStream_t s) = 0;
     virtual int forward_timed(const void*, void*, long long*, hipStream_t) = 0;
     virtual int step_timed(const float*, float*, float*, uint8_t*, long long*, hipStream_t) = 0;
     // per-launch timing of the dominant kernel (k_env_step) with HIP events on the launch stream
@@ -1241,6 +1255,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int reset(const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs, hipStream_t s) override {
         if ((is == nullptr) != (ip == nullptr)) return fail(DL_E_INVAL, "init_step and init_pos must be given together");
+        if (!mask) HIPCHK(hipMemsetAsync(st.mon + (size_t)MON_FIRST_LEN * n, 0, (size_t)4 * n * sizeof(double), s));          // a reset of ALL walkers opens a new "first episode" record (MON_FIRST_*, MON_WALKED_LAST)
+        static_assert(MON_FIRST_MOVED == MON_FIRST_LEN + 1 && MON_FIRST_RET == MON_FIRST_LEN + 2 && MON_WALKED_LAST == MON_FIRST_LEN + 3, "cleared as one run");
         hipLaunchKernelGGL((k_env_reset<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr, eval_mode);
         HIPCHK(hipGetLastError());
         return DL_OK;
@@ -1440,7 +1456,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t nT, float* observations,
                            float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
-                           float* raw_rew, int per_rollout, hipStream_t s) override {
+                           float* raw_rew, int per_rollout, int deterministic, hipStream_t s) override {
         if constexpr (!CAN_SPLIT) return fail(DL_E_INVAL, "dl_collect_rollouts: no persistent form for this walker / precision");
         else {
             std::string why;
@@ -1465,17 +1481,17 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.episode_starts = episode_starts; a.next_done = next_done;
             a.partial = rp_partial; a.xpart = rp_xpart; a.sync = rp_sync; a.prof = rp_prof;
             if ((rc = pack_policy(pol, &a.pk, s))) return rc;
-            a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid;
+            a.T = nT; a.per_rollout = per_rollout ? 1 : 0; a.spin_grid = spin_grid; a.deterministic = deterministic ? 1 : 0;
             // at most one workgroup per CU (co-resident by construction): with more than sixteen walkers per CU a workgroup takes kblocks consecutive blocks
             a.kblocks = (nblk + n_cus - 1) / n_cus;
             const int nwg = (nblk + a.kblocks - 1) / a.kblocks;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
-            if (per_rollout) HIPCHK(hipMemsetAsync(rp_partial, 0, (size_t)nblk * 4 * W * 2 * sizeof(double), s));          // the pairs' sums start at zero
+            if (per_rollout == 1) HIPCHK(hipMemsetAsync(rp_partial, 0, (size_t)nblk * 4 * W * 2 * sizeof(double), s));          // the pairs' sums start at zero (the workgroup form writes every slot it owns)
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
-            if (per_rollout) hipLaunchKernelGGL((k_rollout_pairs<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            if (per_rollout == 1) hipLaunchKernelGGL((k_rollout_pairs<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             else if (a.kblocks > 1) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             else hipLaunchKernelGGL((k_rollout_persistent<TP, false>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
@@ -1483,7 +1499,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             HIPCHK(hipGetLastError());
             if (per_rollout && (vn.flags & 5))
                 hipLaunchKernelGGL(k_vn_merge_rollout, dim3(1), dim3(64), 0, s, (const double*)rp_partial, vn.obs_mean, vn.obs_var, vn.obs_count, vn.ret_mean, vn.ret_var, vn.ret_count,
-                                   nblk * 4, (int)TP::OBS, (long long)n * nT, vn.flags);
+                                   per_rollout == 1 ? nblk * 4 : nblk, (int)TP::OBS, (long long)n * nT, vn.flags);          // a slot per wave pair (k_rollout_pairs) or per block of sixteen (k_rollout_persistent)
             HIPCHK(hipGetLastError());
             return DL_OK;
         }
@@ -1719,7 +1735,7 @@ int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) 
         {"ep_len_smoothed", MON_S_EP_LEN}, {"ep_ret_smoothed", MON_S_EP_RET}, {"mean_reward_smoothed", MON_S_MEAN_REW},
         {"moved_distance", MON_MOVED}, {"mean_ep_pos_rew_smoothed", MON_S_POS}, {"mean_ep_vel_rew_smoothed", MON_S_VEL},
         {"mean_ep_com_rew_smoothed", MON_S_COM}, {"mean_abs_ep_torque_smoothed", MON_S_TOR}, {"ep_len", MON_EP_LEN},
-        {"init_pos", MON_INIT_POS}, {"et_pos", MON_ET_POS}, {"last_abs_torque", MON_TOR_LAST}, {"difficult", MON_DIFFICULT}};
+        {"first_ep_len", MON_FIRST_LEN}, {"first_ep_moved", MON_FIRST_MOVED}, {"first_ep_ret", MON_FIRST_RET}, {"init_pos", MON_INIT_POS}, {"et_pos", MON_ET_POS}, {"last_abs_torque", MON_TOR_LAST}, {"difficult", MON_DIFFICULT}};
     for (const auto& t : tab)
         if (!strcmp(name, t.name)) return h->snapshot(t.word, out, (hipStream_t)stream);
     return fail(DL_E_INVAL, std::string("dl_stats_snapshot: unknown attribute ") + name);
@@ -2055,9 +2071,17 @@ int dl_policy_forward_pair(const dl_policy_params* p, const float* packed, const
     HIPCHK(hipGetLastError());
     return DL_OK;
 }
+static int rollout_policy_launches(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
+                                   float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
+                                   float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, int deterministic, void* stream);
 int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
                       float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
                       float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, void* stream) {
+    return rollout_policy_launches(h, pol, seed, counter0, index_base, vn, T, observations, actions, values, log_probs, rewards, episode_starts, next_obs, next_done, raw_obs, raw_rew, 0, stream);
+}
+static int rollout_policy_launches(dl_handle h, const dl_policy_params* pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state* vn, int32_t T,
+                                   float* observations, float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts,
+                                   float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, int deterministic, void* stream) {
     NEED(h);
     NOFAULT(h);
     if (!pol || !vn || T <= 0 || !observations || !actions || !values || !log_probs || !rewards || !episode_starts || !next_obs || !next_done || !raw_obs || !raw_rew)
@@ -2079,7 +2103,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* pol, uint64_t seed, u
             vf.obs_out = observations + t * n * od; vf.rew_out = rewards + (t - 1) * n;
             vf.eps = vn->eps; vf.clip_obs = vn->clip_obs; vf.clip_rew = vn->clip_rew; vf.flags = vn->flags;
         }
-        int rc = policy_launch(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, 0,
+        int rc = policy_launch(pol, observations + t * n * od, (int32_t)n, nullptr, seed, counter0 + (uint64_t)t, index_base, deterministic,
                                actions + t * n * ad, values + t * n, log_probs + t * n, vf, stream, pk);
         if (rc) return rc;
         uint8_t* done = last ? next_done : episode_starts + (t + 1) * n;
@@ -2103,10 +2127,12 @@ int dl_collect_rollouts(dl_handle h, const dl_policy_params* pol, uint64_t seed,
                         float* next_obs, uint8_t* next_done, float* raw_obs, float* raw_rew, int32_t mode, void* stream) {
     NEED(h);
     NOFAULT(h);
-    if (mode & ~(DL_ROLLOUT_PERSISTENT | DL_ROLLOUT_MOMENTS_PER_ROLLOUT)) return fail(DL_E_INVAL, "dl_collect_rollouts: unknown mode bits");
+    if (mode & ~(DL_ROLLOUT_PERSISTENT | DL_ROLLOUT_MOMENTS_PER_ROLLOUT | DL_ROLLOUT_WORKGROUP_TILES | DL_ROLLOUT_DETERMINISTIC)) return fail(DL_E_INVAL, "dl_collect_rollouts: unknown mode bits");
+    if ((mode & DL_ROLLOUT_WORKGROUP_TILES) && !(mode & DL_ROLLOUT_MOMENTS_PER_ROLLOUT)) return fail(DL_E_INVAL, "dl_collect_rollouts: DL_ROLLOUT_WORKGROUP_TILES selects the kernel of the per-rollout relaxation (the exact form always runs workgroup tiles)");
     if (!(mode & DL_ROLLOUT_PERSISTENT)) {
         if (mode & DL_ROLLOUT_MOMENTS_PER_ROLLOUT) return fail(DL_E_INVAL, "dl_collect_rollouts: per-rollout moments exist in the persistent form only");
-        return dl_rollout_policy(h, pol, seed, counter0, index_base, vn, T, observations, actions, values, log_probs, rewards, episode_starts, next_obs, next_done, raw_obs, raw_rew, stream);
+        return rollout_policy_launches(h, pol, seed, counter0, index_base, vn, T, observations, actions, values, log_probs, rewards, episode_starts, next_obs, next_done, raw_obs, raw_rew,
+                                       (mode & DL_ROLLOUT_DETERMINISTIC) != 0, stream);
     }
     if (!pol || !vn || T <= 0 || !observations || !actions || !values || !log_probs || !rewards || !episode_starts || !next_obs || !next_done || !raw_obs || !raw_rew)
         return fail(DL_E_INVAL, "dl_collect_rollouts: bad arguments");
@@ -2114,7 +2140,7 @@ int dl_collect_rollouts(dl_handle h, const dl_policy_params* pol, uint64_t seed,
     if (!pol->w1 || !pol->b1 || !pol->w2 || !pol->b2 || !pol->wa || !pol->ba || !pol->wv || !pol->bv || !pol->log_std) return fail(DL_E_INVAL, "dl_collect_rollouts: NULL parameter array");
     if (!vn->obs_mean || !vn->obs_var || !vn->obs_count || !vn->ret || !vn->ret_mean || !vn->ret_var || !vn->ret_count) return fail(DL_E_INVAL, "dl_collect_rollouts: NULL state array");
     return h->collect_persistent(*pol, seed, counter0, index_base, *vn, T, observations, actions, values, log_probs, rewards, episode_starts, next_obs, next_done, raw_obs, raw_rew,
-                                 (mode & DL_ROLLOUT_MOMENTS_PER_ROLLOUT) != 0, (hipStream_t)stream);
+                                 (mode & DL_ROLLOUT_MOMENTS_PER_ROLLOUT) ? ((mode & DL_ROLLOUT_WORKGROUP_TILES) ? 2 : 1) : 0, (mode & DL_ROLLOUT_DETERMINISTIC) != 0, (hipStream_t)stream);
 }
 int dl_gae(const float* rew, const float* val, const uint8_t* ep_start, const float* last_val, const uint8_t* last_done, float gamma, float lam, int32_t T, int32_t N, float* adv, float* ret, void* stream) {
     if (!rew || !val || !ep_start || !last_val || !last_done || !adv || !ret || T <= 0 || N <= 0) return fail(DL_E_INVAL, "dl_gae: bad arguments");

@@ -5,8 +5,11 @@ The reference saves model + VecNormalize, reloads both around a 1-env DummyVecEn
 `activate_evaluation()` and plays EVAL_N_TIMES = 20 episodes one after the other with
 `predict(obs, deterministic=True)`; episode i starts from `_get_deterministic_init_state` with k = i
 (straight_walk_trajecs.py:237-265).  Here the 20 episodes are 20 walkers of one handle: walker i gets the
-evaluation counter k = i, every control step is policy forward -> dl_step -> dl_vecnormalize_step (moments
-frozen), nothing returns to the host until all walkers have finished their first episode.
+evaluation counter k = i, and the whole evaluation is ONE dl_collect_rollouts call in its deterministic mode
+(DL_ROLLOUT_DETERMINISTIC: the policy returns the mean action; moments frozen) -- one persistent launch where that form
+exists -- after which the device's first-episode Monitor words (first_ep_len / first_ep_moved / first_ep_ret) hold what
+eval_walking measures per episode.  The step-by-step host loop of earlier rounds stays as `evaluate_walking_host_loop`: the
+restatement of the reference's loop the one-call form is tested against.
 
 Differences from the reference loop, on purpose:
   * the evaluation copy of VecNormalize does not keep training its moments (the reference's reloaded copy does,
@@ -60,11 +63,67 @@ def make_eval_env(train_env, n_episodes=EVAL_N_TIMES, history='fresh', **kw):
     return vn
 
 
-def evaluate_walking(eval_env, policy, n_saved_models=0, check_every=250):
-    """Play the first episode of every walker of `eval_env` (from make_eval_env) with the deterministic policy and
-    return the statistics eval_walking computes (same names as the TrainingMonitor attributes,
-    callback.py:322-345,367-378).  `policy.forward(obs, deterministic=True)` -> (actions, values, log_probs) on the
-    device (HipPolicy, or any callable object with that method)."""
+def _summary(moved, ep_durs, mean_rewards, n, n_saved_models):
+    """callback.py:322-345,367-378 from the per-episode numbers"""
+    return _summary(moved, ep_durs, mean_rewards, n, n_saved_models)
+
+
+def evaluate_walking(eval_env, policy, n_saved_models=0, chunk=None, persistent=None):
+    """Play the first episode of every walker of `eval_env` (from make_eval_env) with the deterministic policy and return the statistics
+    eval_walking computes (same names as the TrainingMonitor attributes, callback.py:322-345,367-378).
+    ONE device call: dl_collect_rollouts over `ep_dur_max` control steps with DL_ROLLOUT_DETERMINISTIC (the persistent one-launch form
+    where it exists: straight walker, float32, hidden = 512; three launches per control step enqueued without a host round trip
+    otherwise), then three dl_stats_snapshot reads.  chunk: control steps per call (default: the whole episode budget in one call); with a
+    smaller chunk the host looks between calls whether every walker has finished and stops early.  `policy`: a HipPolicy."""
+    import ctypes as C
+    venv = eval_env.venv
+    n, dev = venv.num_envs, venv.device
+    eval_env.training = False
+    eval_env.reset()                                                   # (a reset of all walkers also opens a new first-episode record)
+    horizon = int(venv.cfg.ep_dur_max)
+    T = horizon if chunk is None else max(1, min(int(chunk), horizon))
+    f = lambda *s: torch.empty(*s, device=dev)
+    obs_buf, act_buf = f(T, n, venv.obs_dim), f(T, n, venv.nu)
+    val_buf, lp_buf, rew_buf = f(T, n), f(T, n), f(T, n)
+    starts = torch.zeros(T, n, dtype=torch.uint8, device=dev)
+    last_obs, last_done = eval_env.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device=dev)
+    p, st = policy._params(), eval_env.state_struct()
+    ok = bool(venv._lib.dl_rollout_persistent_ok(venv._h, C.byref(p)))
+    use_persistent = ok if persistent is None else bool(persistent)
+    mode = abi.DL_ROLLOUT_DETERMINISTIC | (abi.DL_ROLLOUT_PERSISTENT if use_persistent else 0)
+    first_len = torch.zeros(n, dtype=torch.float64, device=dev)
+    steps = 0
+    while steps < horizon:
+        obs_buf[0].copy_(last_obs); starts[0].copy_(last_done)
+        lib.check(venv._lib.dl_collect_rollouts(venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), T, _ptr(obs_buf), _ptr(act_buf),
+                                                _ptr(val_buf), _ptr(lp_buf), _ptr(rew_buf), _ptr(starts), _ptr(last_obs), _ptr(last_done), _ptr(venv.obs), _ptr(venv.rew),
+                                                mode, _stream()))
+        policy.counter += T
+        steps += T
+        if use_persistent:
+            torch.cuda.current_stream().synchronize()
+            lib.check(venv._lib.dl_fault_check(venv._h, None))             # a persistent launch is complete only with a clear fault word
+        lib.check(venv._lib.dl_stats_snapshot(venv._h, b'first_ep_len', _ptr(first_len), _stream()))
+        if steps < horizon and bool((first_len > 0).all()):
+            break
+    moved_t, ret_t = torch.zeros_like(first_len), torch.zeros_like(first_len)
+    lib.check(venv._lib.dl_stats_snapshot(venv._h, b'first_ep_moved', _ptr(moved_t), _stream()))
+    lib.check(venv._lib.dl_stats_snapshot(venv._h, b'first_ep_ret', _ptr(ret_t), _stream()))
+    ep_durs = first_len.cpu().numpy().astype(np.int64)
+    if (ep_durs <= 0).any():
+        raise lib.DrlocoError('evaluate_walking: a walker has not finished an episode within ep_dur_max control steps')
+    moved = moved_t.cpu().numpy()
+    with np.errstate(invalid='ignore', divide='ignore'):
+        mean_rewards = ret_t.cpu().numpy() / (ep_durs - 1)                 # np.mean(rewards) over the ep_dur - 1 non-terminal steps
+    res = _summary(moved, ep_durs, mean_rewards, n, n_saved_models)
+    res['device_calls'], res['form'] = steps // T, 'persistent' if use_persistent else 'launches'
+    return res
+
+
+def evaluate_walking_host_loop(eval_env, policy, n_saved_models=0, check_every=250):
+    """The same evaluation as a step-by-step host loop (policy forward -> dl_step -> dl_vecnormalize_step, one dl_get_state per step): the
+    literal restatement of the reference's loop, kept as the reference `evaluate_walking` is tested against and for policies that are not a
+    HipPolicy (`policy.forward(obs, deterministic=True)` -> (actions, values, log_probs) on the device)."""
     venv = eval_env.venv
     n, dev = venv.num_envs, venv.device
     eval_env.training = False
@@ -91,16 +150,4 @@ def evaluate_walking(eval_env, policy, n_saved_models=0, check_every=250):
     moved = walked.cpu().numpy()
     with np.errstate(invalid='ignore', divide='ignore'):
         mean_rewards = rew_sum.cpu().numpy() / (ep_durs - 1)          # np.mean(rewards) over the ep_dur - 1 non-terminal steps
-    vels = moved / (ep_durs / CTRL_FREQ)
-    res = dict(moved_distances=moved.tolist(), ep_durs=ep_durs.tolist(), mean_rewards=mean_rewards.tolist())
-    res['mean_walked_distance'], res['min_walked_distance'] = float(np.mean(moved)), float(np.min(moved))
-    res['mean_episode_duration'], res['min_episode_duration'] = float(np.mean(ep_durs) / EP_DUR_MAX), int(np.min(ep_durs))
-    res['mean_walking_speed'], res['min_walking_speed'] = float(np.mean(vels)), float(np.min(vels))
-    res['mean_reward_means'] = float((np.mean(mean_rewards) - ALIVE_BONUS) / REW_SCALE)
-    below = np.where(moved < MIN_STABLE_DISTANCE)[0]
-    no_fall = np.where((ep_durs == EP_DUR_MAX) & (moved >= 0.5 * MIN_STABLE_DISTANCE))[0]
-    res['failed_eval_runs_indices'] = below.tolist()
-    res['count_stable_walks'] = int(max(n - len(below), len(no_fall)))
-    walks_humanlike = res['mean_reward_means'] >= 0.5 * (1 + n_saved_models / 10)
-    res['is_stable_humanlike_walking'] = bool(res['count_stable_walks'] == n and walks_humanlike)
-    return res
+    return _summary(moved, ep_durs, mean_rewards, n, n_saved_models)

@@ -58,6 +58,28 @@ def build(force=False, verbose=False, listing=False):
     return LIB_PATH
 
 
+def device_code_sha16(path=None):
+    """Identity of the DEVICE code of a built library: sha256 over its `.hip_fatbin` section (the gfx950 code object hipcc embedded), first 16
+    hex digits.  Comments, host code and anything else that leaves the compiled kernels alone do not move it; profiles/*.json carry it so that
+    bench.py replays counter-derived figures only for the kernels they were measured on."""
+    import hashlib
+    import struct
+    with open(path or LIB_PATH, 'rb') as f:
+        data = f.read()
+    if data[:4] != b'\x7fELF' or data[4] != 2:
+        raise DrlocoError(f'{path or LIB_PATH}: not a 64-bit ELF file')
+    shoff, = struct.unpack_from('<Q', data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from('<HHH', data, 0x3A)
+    sec = lambda i: struct.unpack_from('<IIQQQQIIQQ', data, shoff + i * shentsize)          # name, type, flags, addr, offset, size, ...
+    str_off = sec(shstrndx)[4]
+    for i in range(shnum):
+        name_off, _, _, _, off, size = sec(i)[:6]
+        name = data[str_off + name_off:data.index(b'\0', str_off + name_off)]
+        if name == b'.hip_fatbin':
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    raise DrlocoError(f'{path or LIB_PATH}: no .hip_fatbin section (not a hipcc build?)')
+
+
 def check_dpp_hazards():
     """Run tools/check_dpp_hazards.py over the listing of the product build (building it if needed); raises on a violation."""
     build(listing=True)

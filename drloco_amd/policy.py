@@ -29,6 +29,7 @@ class HipPolicy:
         self.w2, self.b2 = linear(hidden, hidden)
         self.wa, self.ba = linear(act_dim, hidden)
         self.wv, self.bv = linear(1, hidden)
+        self.log_std_init = float(log_std_init)          # the constructor value (SB3's policy_kwargs; checkpoint.write_model_zip stores it)
         self.log_std = torch.full((act_dim,), float(log_std_init), device=device)
         self.seed, self.counter, self.index_base = int(seed), 0, int(index_base)
         self._packed, self._packed_key, self._packed_stream = None, None, None

@@ -36,7 +36,7 @@ class HipRolloutBuffer:
         self.episode_starts[t].copy_(episode_start); self.values[t].copy_(value); self.log_probs[t].copy_(log_prob)
         self.pos += 1
 
-    def collect_rollouts(self, vn, policy, last_obs, last_done, persistent=None, moments='per_step'):
+    def collect_rollouts(self, vn, policy, last_obs, last_done, persistent=None, moments='per_step', workgroup_tiles=False):
         """SB3 1.0 OnPolicyAlgorithm.collect_rollouts (the loop between two PPO updates) as ONE C-ABI call, dl_collect_rollouts:
         T x (policy forward -> env step -> VecNormalize), every result written straight into this buffer.  vn: HipVecNormalize;
         policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]: the normalised observation and episode-start flags that
@@ -46,7 +46,17 @@ class HipRolloutBuffer:
         the exchange timed out), False = three launches per control step, None = persistent where it exists, falling back to the launch form
         (walkers reset, moments restored, a warning) if the exchange times out.
         moments: 'per_step' (SB3's semantics, default) or 'per_rollout' (opt-in relaxation, persistent form only: the whole rollout is
-        normalised with the moments at its start, which are advanced once, by all T x N samples, at its end -- include/drloco_hip.h)."""
+        normalised with the moments at its start, which are advanced once, by all T x N samples, at its end -- include/drloco_hip.h).
+        workgroup_tiles (with 'per_rollout'): run the relaxation on the exact form's kernel (sixteen-row policy tiles, the workgroup's pairs meet
+        every step) instead of the pair-by-pair kernel: the selectable fallback, about 4 % slower (DL_ROLLOUT_WORKGROUP_TILES).
+
+        What the automatic mode (persistent=None) does when the exchange times out, so that nobody is surprised by it: (1) the fault is cleared
+        and VecNormalize's moments are restored to their pre-launch snapshot; (2) ALL walkers are reset (vn.reset()): every episode in flight
+        is discarded -- the Monitor statistics lose them, and the redone rollout starts from fresh reference-state initialisations instead of
+        the states the walkers had reached; (3) the handle's push-schedule clock has advanced by 2 T (the failed launch and the redone one);
+        (4) this buffer keeps the launch form from then on (`_persistent_off`): a transient co-tenant downgrades it for good, with only the
+        warning as a record -- call `enable_persistent()` to try the persistent form again.  Only DL_FAULT_GRID_TIMEOUT with per-step moments
+        takes this path; per-rollout launches and pair / split hand-over faults raise DrlocoFault in every mode."""
         if moments not in ('per_step', 'per_rollout'):
             raise ValueError("moments must be 'per_step' or 'per_rollout'")
         if getattr(vn, 'sync', 'per_rollout') == 'per_step':
@@ -89,7 +99,8 @@ class HipRolloutBuffer:
             # itself has returned DL_OK long before.  So the rollout is complete only once the launch has finished with a clear fault word: wait and look
             # (a rollout lasts tens of milliseconds; the learner needs it finished anyway) instead of handing a half-written buffer to the PPO update.
             snap = [t.clone() for t in (vn.obs_rms._mean, vn.obs_rms._var, vn.obs_rms._count, vn.ret_rms._mean, vn.ret_rms._var, vn.ret_rms._count)] if auto else None
-            launch(abi.DL_ROLLOUT_PERSISTENT | (abi.DL_ROLLOUT_MOMENTS_PER_ROLLOUT if moments == 'per_rollout' else 0))
+            launch(abi.DL_ROLLOUT_PERSISTENT | (abi.DL_ROLLOUT_MOMENTS_PER_ROLLOUT if moments == 'per_rollout' else 0) |
+                   (abi.DL_ROLLOUT_WORKGROUP_TILES if (moments == 'per_rollout' and workgroup_tiles) else 0))
             torch.cuda.current_stream().synchronize()
             code = C.c_int32(0)
             rc = self._lib.dl_fault_check(vn.venv._h, C.byref(code))
@@ -115,6 +126,10 @@ class HipRolloutBuffer:
         policy.counter += self.T
         self.pos = self.T
         self.last_form = 'persistent' if persistent else 'launches'
+
+    def enable_persistent(self):
+        """Let the automatic mode of collect_rollouts try the persistent form again after a grid-exchange timeout switched it off."""
+        self._persistent_off = False
 
     def compute_returns_and_advantage(self, last_values, dones):
         lv = last_values.to(torch.float32).contiguous()

@@ -45,6 +45,9 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
         dist.init_process_group(backend, rank=rank, world_size=world, **({'device_id': dev} if backend == 'nccl' else {}))
     quiet = quiet or rank != 0
     assert n_envs % world == 0 and batch % n_envs == 0
+    if batch % minibatch:          # said at the START of a run (SB3's PPO warns at construction): the last minibatch of every epoch is truncated
+        import warnings
+        warnings.warn(f'batch {batch} is not a multiple of minibatch {minibatch}: the last minibatch of an epoch has {batch % minibatch} samples')
     n_global, n_envs = n_envs, n_envs // world          # --envs is the global walker count; this rank owns [rank * n_envs, (rank + 1) * n_envs)
     torch.manual_seed(seed)                             # the same initial policy on every rank
     venv = HipVecEnv(num_envs=n_envs, seed=seed, device=dev.index, env_index_base=rank * n_envs)
@@ -135,7 +138,7 @@ def train(mio=2.0, n_envs=128, batch=16384, minibatch=2048, epochs=4, seed=0, lo
         ckpt = f'{int(total / 1e5)}'
         # SB3 1.0's save_to_zip_file layout: data (spaces, policy class, hyperparameters), policy.pth, policy.optimizer.pth (Adam's moments)
         checkpoint.write_model_zip(pol, os.path.join(save_path, 'models', f'model_{ckpt}.zip'), observation_space=venv.observation_space, action_space=venv.action_space, optimizer=opt,
-                                   hyper=dict(n_envs=n_envs, num_timesteps=int(total), n_steps=batch // n_envs, batch_size=minibatch, n_epochs=epochs))
+                                   hyper=dict(n_envs=n_envs, num_timesteps=int(total), n_steps=batch // n_envs, batch_size=minibatch, n_epochs=epochs, learning_rate=float(lr)))
         vn.save(os.path.join(save_path, 'envs', f'env_{ckpt}'), sb3_format=True)
         if not quiet:
             print('saved', os.path.join(save_path, 'models', f'model_{ckpt}.zip'), 'and', os.path.join(save_path, 'envs', f'env_{ckpt}'))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 5   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed, dl_vn_local_sums / dl_vn_merge_sums (flag 64) */
+#define DL_ABI_VERSION 6   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed, dl_vn_local_sums / dl_vn_merge_sums (flag 64).  6: dl_policy_forward_pair, DL_ROLLOUT_WORKGROUP_TILES, DL_ROLLOUT_DETERMINISTIC, dl_stats_snapshot first_ep_* */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -265,7 +265,9 @@ int dl_terminate_early(dl_handle h, int32_t* flags, void* stream);
 /* Monitor attributes (drloco/mujoco/monitor_wrapper.py:88-133) kept per walker on device.
  * name: one of ep_len_smoothed, ep_ret_smoothed, mean_reward_smoothed, moved_distance,
  * mean_ep_pos_rew_smoothed, mean_ep_vel_rew_smoothed, mean_ep_com_rew_smoothed,
- * mean_abs_ep_torque_smoothed.  out: double[N] device. */
+ * mean_abs_ep_torque_smoothed; first_ep_len, first_ep_moved, first_ep_ret: the FIRST episode a walker finished since dl_create or the last dl_reset of all
+ * walkers (mask NULL), measured as TrainingMonitor.eval_walking measures an episode (drloco/common/callback.py:300-317: length incl. the terminal step;
+ * walked distance and reward sum without it; 0 = no episode finished yet).  out: double[N] device. */
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream);
 
 /* Measurement hooks (no reference counterpart): enable = k > 0 brackets every k-th launch of the
@@ -369,7 +371,7 @@ int dl_policy_forward_packed(const dl_policy_params* params, const float* packed
                              int32_t deterministic, float* actions, float* values, float* log_probs, void* stream);
 
 /* The same forward pass in its four-rows-per-wave-pair form (packed weights, hidden = 512): a workgroup of two waves per four rows on
- * v_mfma_f32_4x4x1_16B_f32, every sum in the order of dl_policy_forward -- bit-identical outputs (tests/test_gpu_policy.py).  It is the building
+ * v_mfma_f32_4x4x1_16B_f32, every sum in the order of dl_policy_forward -- bit-identical outputs (tests/test_gpu_persistent.py::test_policy_pair_form_is_the_forward_pass_bit_for_bit).  It is the building
  * block that lets a wave pair of the persistent rollout kernel evaluate the policy of its own four walkers; stand-alone it is a reference for that. */
 int dl_policy_forward_pair(const dl_policy_params* params, const float* packed, const float* obs, int32_t n,
                            const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
@@ -430,9 +432,17 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
  *   DL_ROLLOUT_PERSISTENT | DL_ROLLOUT_MOMENTS_PER_ROLLOUT   opt-in relaxation: observations and rewards of the whole rollout are normalised
  *       with the moments at its START, workgroups exchange nothing during the rollout (they run free; a rollout lasts as long as its slowest
  *       workgroup's sum of steps), and ONE exact Chan merge of all T x N samples follows -- RunningMeanStd.update fed the rollout as one batch.
- *       Not SB3's per-step update; the same relaxation the cross-rank merge C3 applies. */
+ *       Not SB3's per-step update; the same relaxation the cross-rank merge C3 applies.
+ *       Kernel: every wave PAIR takes its own four walkers through the rollout (k_rollout_pairs: the policy on v_mfma_f32_4x4x1 chains, no meeting of the
+ *       workgroup's pairs per step).  A pair whose two waves fail to meet within the poll budget raises DL_FAULT_SRV_TIMEOUT and stops; its rows of the
+ *       buffers stay incomplete -- same rule as above: fault check before reading.
+ *   ... | DL_ROLLOUT_WORKGROUP_TILES   the same relaxation on the exact form's kernel (k_rollout_persistent: sixteen-row policy tiles on v_mfma_f32_16x16x4, the
+ *       workgroup's four pairs meet at every control step): the selectable fallback for the pair kernel, about 4 % slower; same buffers, the same moments after
+ *       the merge up to the grouping of the float64 sums. */
 #define DL_ROLLOUT_PERSISTENT 1
 #define DL_ROLLOUT_MOMENTS_PER_ROLLOUT 2
+#define DL_ROLLOUT_WORKGROUP_TILES 4
+#define DL_ROLLOUT_DETERMINISTIC 8   /* any form: the policy returns the mean action (predict(deterministic=True), drloco/common/callback.py:297): evaluation as one call */
 int dl_rollout_persistent_ok(dl_handle h, const dl_policy_params* policy);
 int dl_collect_rollouts(dl_handle h, const dl_policy_params* policy, uint64_t seed, uint64_t counter0,
                         int32_t index_base, const dl_vecnorm_state* vn, int32_t T, float* observations,

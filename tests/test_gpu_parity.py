@@ -1017,6 +1017,44 @@ def test_batched_evaluation_matches_the_serial_loop(torch_cuda, model, refs):
     assert res['mean_walked_distance'] == pytest.approx(np.mean(res['moved_distances']))
 
 
+@pytest.mark.parametrize('hidden,kw', [(128, {}), (512, {}), (512, dict(chunk=100)), (512, dict(persistent=False))],
+                         ids=['launch-form', 'one-persistent-launch', 'chunks-of-100-steps', 'hidden-512-launch-form'])
+def test_one_call_evaluation_is_the_host_loop(torch_cuda, model, refs, hidden, kw):
+    """evaluate_walking = ONE dl_collect_rollouts call in its deterministic mode (DL_ROLLOUT_DETERMINISTIC) + the device's first-episode Monitor words,
+    against evaluate_walking_host_loop, the step-by-step restatement of TrainingMonitor.eval_walking (callback.py:294-317): the same episode
+    lengths, walked distances and reward means for all 20 walkers -- bit for bit (same kernels on the same states; with hidden = 512 the one-call form
+    is the persistent kernel, whose bits are the split step kernel's)."""
+    import torch
+    from drloco_amd.evaluation import evaluate_walking, evaluate_walking_host_loop, make_eval_env
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.vec_env import vec_env
+    train = vec_env(num_envs=64, seed=3, model=model, refs=refs)
+    train.reset()
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        train.step(np.clip(0.5 * rng.standard_normal((64, 8)), -1, 1))
+    pol = HipPolicy(hidden=hidden, seed=11)
+    envs = [make_eval_env(train, ep_dur_max=400) for _ in range(2)]
+    for e in envs:
+        e.venv.set_split(True)
+    one = evaluate_walking(envs[0], pol, **kw)
+    loop = evaluate_walking_host_loop(envs[1], pol)
+    assert one['form'] == ('persistent' if hidden == 512 and kw.get('persistent', True) else 'launches')
+    assert one['device_calls'] == (1 if 'chunk' not in kw else -(-max(one['ep_durs']) // 100))
+    assert one['ep_durs'] == loop['ep_durs'] and len(one['ep_durs']) == 20 and min(one['ep_durs']) >= 2
+    assert one['moved_distances'] == loop['moved_distances'] and one['mean_rewards'] == loop['mean_rewards']
+    for k in ('mean_walked_distance', 'min_walked_distance', 'mean_episode_duration', 'mean_walking_speed', 'mean_reward_means', 'count_stable_walks', 'is_stable_humanlike_walking'):
+        assert one[k] == loop[k], k
+    # a second evaluation on the same handle: the reset of all walkers opens a new first-episode record (other episodes: the evaluation counter k of
+    # every walker has moved on, straight_walk_trajecs.py:237-265) -- and the host loop on ITS handle, with the same history, sees the same episodes
+    again, loop2 = evaluate_walking(envs[0], pol, **kw), evaluate_walking_host_loop(envs[1], pol)
+    assert len(again['ep_durs']) == 20 and min(again['ep_durs']) >= 2 and again['ep_durs'] != one['ep_durs']
+    if 'chunk' not in kw:          # (chunked calls stop early: fewer auto-resets have advanced the counters than in the host loop's 250-step checks)
+        assert again['ep_durs'][0] >= 2
+    for e in envs:
+        e.close()
+
+
 def test_overlapped_vecnormalize_is_identical(torch_cuda, model, refs):
     """HipVecNormalize.enable_overlap(): the normalisation of step t on a side stream under the simulation of step t + 1
     gives bit-identical buffers and moments."""

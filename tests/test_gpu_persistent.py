@@ -322,6 +322,59 @@ def test_grid_exchange_timeout_raises(torch_cuda, model, refs):
     venv.close()
 
 
+def test_pair_meeting_timeout_raises(torch_cuda, model, refs):
+    """The per-rollout kernel's wave pairs meet through two mailbox counters (pair_sync).  A wave whose partner does not arrive within the poll budget
+    (forced: budget 0) sets DL_FAULT_SRV_TIMEOUT and LEAVES the kernel -- it never carries on with stale data -- so the launch ends, the host sees the
+    fault before it reads the buffer, and dl_fault_clear + reset bring the handle back (the header's contract for every bounded poll)."""
+    torch = torch_cuda
+    import ctypes as C
+    from drloco_amd import abi, lib as L
+    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, 200, 6)
+    L.check(venv._lib.dl_debug_set_grid_spin(venv._h, 0))
+    with pytest.raises(L.DrlocoFault):
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True, moments='per_rollout')
+    code = C.c_int32(0)
+    assert venv._lib.dl_fault_check(venv._h, C.byref(code)) == abi.DL_E_FAULT and (code.value & abi.DL_FAULT_SRV_TIMEOUT)
+    L.check(venv._lib.dl_fault_clear(venv._h))
+    L.check(venv._lib.dl_debug_set_grid_spin(venv._h, -1))
+    vn.reset()
+    last_obs = vn.norm_obs_t.clone(); last_done.fill_(1)
+    buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True, moments='per_rollout')
+    torch.cuda.synchronize()
+    L.check(venv._lib.dl_fault_check(venv._h, None))
+    assert torch.isfinite(buf.observations).all() and (buf.rewards >= 0).all()
+    venv.close()
+
+
+@pytest.mark.parametrize('n', [1000, 6000], ids=['one-block-per-workgroup', 'two-blocks-per-workgroup'])
+def test_per_rollout_moments_on_workgroup_tiles_is_the_pair_kernel(torch_cuda, model, refs, n):
+    """DL_ROLLOUT_WORKGROUP_TILES: the per-rollout relaxation on the exact form's kernel (sixteen-row 16x16x4 policy tiles, the workgroup's pairs in
+    lockstep) -- the selectable fallback for the pair-by-pair kernel (4x4x1 chains).  With frozen moments nothing couples the walkers, both policy forms
+    give the bits of dl_policy_forward and both run the same step code: every buffer is identical; the merged moments differ only by the grouping of
+    the float64 sums (a slot per block of sixteen instead of per pair)."""
+    torch = torch_cuda
+    T, res = 24, []
+    for tiles in (False, True):
+        venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)                       # a non-trivial start for the moments
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True, moments='per_rollout', workgroup_tiles=tiles)
+        torch.cuda.synchronize()
+        from drloco_amd import lib as L
+        L.check(venv._lib.dl_fault_check(venv._h, None))
+        res.append((dict(observations=buf.observations.cpu().clone(), actions=buf.actions.cpu().clone(), values=buf.values.cpu().clone(), log_probs=buf.log_probs.cpu().clone(),
+                         rewards=buf.rewards.cpu().clone(), episode_starts=buf.episode_starts.cpu().clone(), last_obs=last_obs.cpu().clone(), last_done=last_done.cpu().clone(),
+                         ret=vn.ret.cpu().clone(), qpos=torch.as_tensor(venv.get_state()['qpos'])),
+                    dict(om=vn.obs_rms.mean.copy(), ov=vn.obs_rms.var.copy(), oc=vn.obs_rms.count, rm=float(vn.ret_rms.mean), rv=float(vn.ret_rms.var), rc=vn.ret_rms.count)))
+        venv.close()
+    (a, ma), (b, mb) = res
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert ma['oc'] == mb['oc'] and ma['rc'] == mb['rc']
+    np.testing.assert_allclose(ma['om'], mb['om'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(ma['ov'], mb['ov'], rtol=1e-11)
+    np.testing.assert_allclose([ma['rm'], ma['rv']], [mb['rm'], mb['rv']], rtol=1e-11)
+
+
 def test_grid_exchange_timeout_falls_back_in_auto_mode(torch_cuda, model, refs):
     """persistent=None (what examples/train_ppo.py uses): when the persistent kernel's grid-wide exchange times out (forced here; in the field: another
     process or stream holding CUs) the SAME call clears the fault, restores the moments, resets the walkers and redoes the rollout with the launch

@@ -329,7 +329,7 @@ def test_bench_cpu_baselines_run(oracle):
     for d, cores in ((one, 1), (sub, 3), (many, 2)):
         assert d['unit'] == 'env-steps/s' and d['value'] > 0 and d['cores'] == cores and isinstance(d['sample'], str)
     assert one['kind'] == 'port'
-    assert len(bench.kernel_sources_sha16()) == 16
+    assert len(bench.kernel_code_sha16()) == 16 and bench.kernel_code_sha16() == bench.kernel_code_sha16()
 
 
 def test_bench_tapes_are_keyed_by_the_global_walker_index():

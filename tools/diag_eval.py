@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import train_ppo
 from drloco_amd import checkpoint
-from drloco_amd.evaluation import evaluate_walking, make_eval_env
+from drloco_amd.evaluation import evaluate_walking, evaluate_walking_host_loop, make_eval_env
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 d = tempfile.mkdtemp()
@@ -34,13 +34,13 @@ show('(a) deterministic init states, mean action (eval_walking)', evaluate_walki
 ev = make_eval_env(train_vn)
 ev.venv.activate_evaluation(False)
 show('(b) RSI init states, mean action', evaluate_walking(ev, pol))
-show('(c) deterministic init states, sampled actions', evaluate_walking(make_eval_env(train_vn), Sampled(pol)))
+show('(c) deterministic init states, sampled actions', evaluate_walking_host_loop(make_eval_env(train_vn), Sampled(pol)))
 ev = make_eval_env(train_vn)
 ev.venv.activate_evaluation(False)
-show('(d) RSI init states, sampled actions (= training episodes)', evaluate_walking(ev, Sampled(pol)))
+show('(d) RSI init states, sampled actions (= training episodes)', evaluate_walking_host_loop(ev, Sampled(pol)))
 ev = make_eval_env(vn_mem)
 ev.venv.activate_evaluation(False)
-show('(e) as (d) with the in-memory policy and moments', evaluate_walking(ev, Sampled(pol_mem)))
+show('(e) as (d) with the in-memory policy and moments', evaluate_walking_host_loop(ev, Sampled(pol_mem)))
 show('(g) eval_walking with the training walkers\' step counter (history=training)', evaluate_walking(make_eval_env(vn_mem, history='training'), pol_mem))
 for k in ('w1', 'b1', 'w2', 'b2', 'wa', 'ba', 'wv', 'bv', 'log_std'):
     assert torch.equal(getattr(pol, k), getattr(pol_mem, k).detach()), k

@@ -67,8 +67,8 @@ if 'hbm_bytes_per_launch' in out:
             # every 4 clocks, 1024 SIMDs -- the figure that stays meaningful when a SIMD holds two waves of which one mostly sleeps (split workgroups)
             extra['valu_busy_frac_simd'] = pmc['SQ_ACTIVE_INST_VALU'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 32)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import kernel_sources_sha16          # the kernel sources these counters belong to: bench.py reports them only while they match
-    json.dump({**extra, 'tag': tag, 'kernel_sources_sha16': kernel_sources_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
+    from bench import kernel_code_sha16          # the device code these counters belong to: bench.py reports them only while it matches
+    json.dump({**extra, 'tag': tag, 'kernel_code_sha16': kernel_code_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
                'source': f'profiles/{tag}_summary.txt', 'correction': 'FETCH_SIZE doubled (gfx950: 128 B requests tallied at 64 B), WRITE_SIZE as reported'},
               open(os.path.join(dst, 'traffic_env_step.json' if walker == 'straight' else f'traffic_env_step_{walker}.json'), 'w'))
 print('\n'.join(lines))
