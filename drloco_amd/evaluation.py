@@ -65,7 +65,19 @@ def make_eval_env(train_env, n_episodes=EVAL_N_TIMES, history='fresh', **kw):
 
 def _summary(moved, ep_durs, mean_rewards, n, n_saved_models):
     """callback.py:322-345,367-378 from the per-episode numbers"""
-    return _summary(moved, ep_durs, mean_rewards, n, n_saved_models)
+    vels = moved / (ep_durs / CTRL_FREQ)
+    res = dict(moved_distances=moved.tolist(), ep_durs=ep_durs.tolist(), mean_rewards=mean_rewards.tolist())
+    res['mean_walked_distance'], res['min_walked_distance'] = float(np.mean(moved)), float(np.min(moved))
+    res['mean_episode_duration'], res['min_episode_duration'] = float(np.mean(ep_durs) / EP_DUR_MAX), int(np.min(ep_durs))
+    res['mean_walking_speed'], res['min_walking_speed'] = float(np.mean(vels)), float(np.min(vels))
+    res['mean_reward_means'] = float((np.mean(mean_rewards) - ALIVE_BONUS) / REW_SCALE)
+    below = np.where(moved < MIN_STABLE_DISTANCE)[0]
+    no_fall = np.where((ep_durs == EP_DUR_MAX) & (moved >= 0.5 * MIN_STABLE_DISTANCE))[0]
+    res['failed_eval_runs_indices'] = below.tolist()
+    res['count_stable_walks'] = int(max(n - len(below), len(no_fall)))
+    walks_humanlike = res['mean_reward_means'] >= 0.5 * (1 + n_saved_models / 10)
+    res['is_stable_humanlike_walking'] = bool(res['count_stable_walks'] == n and walks_humanlike)
+    return res
 
 
 def evaluate_walking(eval_env, policy, n_saved_models=0, chunk=None, persistent=None):

@@ -10,7 +10,7 @@ import numpy as np
 from drloco_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, 'libdl_oracle.so')
+_LIB = os.environ.get('DL_ORACLE_LIB') or os.path.join(_HERE, 'libdl_oracle.so')          # DL_ORACLE_LIB: the sanitizer build (make SAN=1), tests/test_sanitizers.py
 DLO_MAXCON = 32
 DLO_MAXEFC = 4 * DLO_MAXCON + 2 * abi.DL_MAX_DOF
 
@@ -20,7 +20,7 @@ F_NOCONTACT, F_NOLIMIT, F_NODAMP, F_NOGRAV, F_NOACT = 1, 2, 4, 8, 16
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ('dl_oracle.c', 'dl_oracle.h')] + [os.path.join(_HERE, '..', 'include', 'drloco_hip.h')]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
-        subprocess.check_call(['make', '-s', '-C', _HERE, '-B'])
+        subprocess.check_call(['make', '-s', '-C', _HERE, '-B'] + (['SAN=1'] if _LIB.endswith('_san.so') else []))
     return _LIB
 
 

@@ -9,7 +9,8 @@ from drloco_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-_LIB = os.path.join(_HERE, 'libdl_emu.so')
+_SAN = os.environ.get('DL_EMU_SANITIZE') == '1'          # UBSan build of the kernel source on the host (tests/test_sanitizers.py); ASan and the fibers' hand-made stacks do not mix
+_LIB = os.path.join(_HERE, 'libdl_emu_ubsan.so' if _SAN else 'libdl_emu.so')
 _lib = None
 
 
@@ -18,7 +19,7 @@ def build(force=False):
         + [os.path.join(_ROOT, 'drloco_amd', 'csrc', f) for f in ('dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp', 'dl_group.hpp', 'dl_group_env.hpp')] \
         + [os.path.join(_ROOT, 'include', 'drloco_hip.h')]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + (['-g', '-fsanitize=undefined', '-fno-sanitize-recover=all'] if _SAN else []) + [
                                '-I' + os.path.join(_ROOT, 'include'), '-I' + os.path.join(_ROOT, 'drloco_amd', 'csrc'), '-I' + _HERE,
                                '-o', _LIB, srcs[0]])
     return _LIB
