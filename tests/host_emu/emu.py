@@ -19,7 +19,7 @@ def build(force=False):
         + [os.path.join(_ROOT, 'drloco_amd', 'csrc', f) for f in ('dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp', 'dl_group.hpp', 'dl_group_env.hpp')] \
         + [os.path.join(_ROOT, 'include', 'drloco_hip.h')]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + (['-g', '-fsanitize=undefined', '-fno-sanitize-recover=all'] if _SAN else []) + [
+        subprocess.check_call(['g++', '-O1' if _SAN else '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + (['-fsanitize=undefined', '-fno-sanitize-recover=all'] if _SAN else []) + [
                                '-I' + os.path.join(_ROOT, 'include'), '-I' + os.path.join(_ROOT, 'drloco_amd', 'csrc'), '-I' + _HERE,
                                '-o', _LIB, srcs[0]])
     return _LIB
