@@ -660,6 +660,7 @@ struct RolloutP {
     int32_t index_base, flags, T, per_rollout, spin_grid, kblocks, deterministic;
 };
 constexpr int RP_SYNC_WORDS = 160;
+constexpr int RP_PROF_STEPS = 512;        // DL_EXP_ROLLOUT_PROF builds: control steps with per-step section records
 constexpr int RP_MAX_KBLOCKS = 8;          // blocks of sixteen walkers per workgroup: <= 128 walkers per CU, 32768 on 256 CUs
 constexpr int RP_WS = 64;                  // lanes per block in the moment sums (a column per lane: OBS + 1 <= 64)
 template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2 + RP_MAX_KBLOCKS * 2 * (TP::OBS + 1)) * sizeof(double) + 64; }
@@ -716,13 +717,18 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     const bool upd_obs = (flags & 1) != 0, upd_ret = (flags & 4) != 0, exchange = (upd_obs || upd_ret) && !per_rollout;
 #ifdef DL_EXP_ROLLOUT_PROF
     long long prof_acc[4] = {0, 0, 0, 0}, prof_t = DL_CLOCK();
-#define DL_RP_TICK(k) do { const long long now_ = DL_CLOCK(); prof_acc[k] += now_ - prof_t; prof_t = now_; } while (0)
+    int t_prof = 0;
+    long long* const pstep = args()->a.prof ? args()->a.prof + (size_t)nblk * 4 * 11 : nullptr;          // [T][workgroups][4]: the same sections per control step (tools/diag_rollout_floor.py)
+#define DL_RP_TICK(k) do { const long long now_ = DL_CLOCK(); prof_acc[k] += now_ - prof_t; if (tid == 0 && pstep) pstep[((size_t)t_prof * gridDim.x + wgi) * 4 + (k)] += now_ - prof_t; prof_t = now_; } while (0)
 #else
 #define DL_RP_TICK(k) ((void)0)
 #endif
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < nT; t++) {
+#ifdef DL_EXP_ROLLOUT_PROF
+        t_prof = t;
+#endif
         DL_RP_TICK(2);
 #pragma unroll 1
         for (int blk_i = b0; blk_i < b1; blk_i += RBK) {
@@ -1468,7 +1474,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 if ((rc = dalloc(&rp_partial, (size_t)nblk * 4 * W * 2))) return rc;          // (per-rollout moments: a slot per wave pair)
                 if ((rc = dalloc(&rp_xpart, (size_t)2 * 8 * W * 2))) return rc;
                 if ((rc = dalloc(&rp_sync, (size_t)RP_SYNC_WORDS))) return rc;
+#ifdef DL_EXP_ROLLOUT_PROF
+                if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11 + (size_t)RP_PROF_STEPS * nblk * 4))) return rc;
+#else
                 if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11))) return rc;
+#endif
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_pairs<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
@@ -1486,6 +1496,10 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             a.kblocks = (nblk + n_cus - 1) / n_cus;
             const int nwg = (nblk + a.kblocks - 1) / a.kblocks;
             HIPCHK(hipMemsetAsync(rp_sync, 0, RP_SYNC_WORDS * sizeof(unsigned), s));
+#ifdef DL_EXP_ROLLOUT_PROF
+            if (nT > RP_PROF_STEPS) return fail(DL_E_INVAL, "DL_EXP_ROLLOUT_PROF build: at most 512 control steps per rollout");
+            HIPCHK(hipMemsetAsync(rp_prof + (size_t)nblk * 4 * 11, 0, (size_t)RP_PROF_STEPS * nblk * 4 * sizeof(long long), s));
+#endif
             if (per_rollout == 1) HIPCHK(hipMemsetAsync(rp_partial, 0, (size_t)nblk * 4 * W * 2 * sizeof(double), s));          // the pairs' sums start at zero (the workgroup form writes every slot it owns)
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
@@ -1506,7 +1520,11 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int rollout_prof(long long* out, hipStream_t s) override {
         if (!rp_prof || !out) return fail(DL_E_INVAL, "dl_debug_rollout_prof: no persistent rollout has run on this handle");
+#ifdef DL_EXP_ROLLOUT_PROF          // + int64[512][workgroups][4]: P, E, R, exchange wait per control step (workgroup-major inside a step; rows of workgroups that do not exist stay 0)
+        HIPCHK(hipMemcpyAsync(out, rp_prof, ((size_t)((n + 15) / 16) * 4 * 11 + (size_t)RP_PROF_STEPS * ((n + 15) / 16) * 4) * sizeof(long long), hipMemcpyDeviceToDevice, s));
+#else
         HIPCHK(hipMemcpyAsync(out, rp_prof, (size_t)((n + 15) / 16) * 4 * 11 * sizeof(long long), hipMemcpyDeviceToDevice, s));
+#endif
         return DL_OK;
     }
     int last_ctrl(float* out, hipStream_t s) override {

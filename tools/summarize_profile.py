@@ -66,6 +66,9 @@ if 'hbm_bytes_per_launch' in out:
             # the same against the SIMDs' time instead of the waves': GRBM_GUI_ACTIVE sums the 8 XCDs' clocks over the launch, the SQ cycle counters tick
             # every 4 clocks, 1024 SIMDs -- the figure that stays meaningful when a SIMD holds two waves of which one mostly sleeps (split workgroups)
             extra['valu_busy_frac_simd'] = pmc['SQ_ACTIVE_INST_VALU'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 32)
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in pmc:      # counts shader cycles (not quad-cycles: MI355X_MICROARCH.md), summed over the SIMDs: against 1024 SIMDs x the launch's cycles
+                extra['mfma_busy_frac_simd'] = pmc['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 8)
+                extra['mfma_insts_per_launch'] = pmc.get('SQ_INSTS_MFMA')
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_code_sha16          # the device code these counters belong to: bench.py reports them only while it matches
     json.dump({**extra, 'tag': tag, 'kernel_code_sha16': kernel_code_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
