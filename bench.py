@@ -463,17 +463,27 @@ def main():
         achieved = algo_bytes * n_prof * steps_per_launch / avg_launch_s / 1e9
         # counter-derived figures come from a committed rocprofv3 PMC pass (profiles/traffic_env_step.json, tools/gpu_round_profile.sh): they are
         # reported only for the configuration that pass measured AND only while the kernel sources are the ones it measured
-        traffic = valu_busy = prof_origin = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic_env_step.json')
-        default_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.policy and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs and not args.no_split and not args.vn_single_steps
-        if os.path.exists(tfile) and default_cfg:
+        traffic = valu_busy = mfma_busy = prof_origin = None
+        base_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs and not args.no_split and not args.vn_single_steps
+        persistent_line = args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent' and args.handles == 1
+        tname = None          # which committed pass belongs to this command line (profiles/, written by tools/summarize_profile.py)
+        if base_cfg and not args.policy:
+            tname = 'traffic_env_step.json'
+        elif base_cfg and persistent_line:
+            tname = 'traffic_env_step_policy_per_rollout.json' if args.moments == 'per_rollout' else 'traffic_env_step_policy.json'
+        elif args.walker == 'loco3d' and args.lanes in (0, 16) and not args.policy and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs:
+            tname = 'traffic_env_step_loco3d.json'
+        tfile = os.path.join(ROOT, 'profiles', tname) if tname else None
+        if tfile and os.path.exists(tfile):
             try:
                 pj = json.load(open(tfile))
                 if pj.get('kernel_code_sha16') == kernel_code_sha16():
-                    traffic, valu_busy = pj.get('hbm_bytes_per_launch'), (pj.get('valu_busy_frac_simd') if split else pj.get('valu_busy_frac'))
-                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'tag': pj.get('tag'), 'kernel_code_sha16': pj.get('kernel_code_sha16')}
+                    two_waves = split or persistent_line          # two waves per SIMD of which one mostly sleeps: busy cycles against the SIMDs' time, not the waves'
+                    traffic, valu_busy = pj.get('hbm_bytes_per_launch'), (pj.get('valu_busy_frac_simd') if two_waves else pj.get('valu_busy_frac'))
+                    mfma_busy = pj.get('mfma_busy_frac_simd')
+                    prof_origin = {'file': 'profiles/' + tname, 'tag': pj.get('tag'), 'kernel_code_sha16': pj.get('kernel_code_sha16')}
                 else:
-                    prof_origin = {'file': 'profiles/traffic_env_step.json', 'stale': True, 'measured_sha16': pj.get('kernel_code_sha16') or pj.get('kernel_sources_sha16'), 'built_sha16': kernel_code_sha16()}
+                    prof_origin = {'file': 'profiles/' + tname, 'stale': True, 'measured_sha16': pj.get('kernel_code_sha16') or pj.get('kernel_sources_sha16'), 'built_sha16': kernel_code_sha16()}
             except Exception:
                 traffic = None
         out = {
@@ -493,7 +503,7 @@ def main():
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
                                    (('k_rollout_pairs<TopoStraight>' if args.moments == 'per_rollout' else 'k_rollout_persistent<TopoStraight>') if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else ('k_env_step_g16<float,TopoWalker165>' if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>'))), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
-                         'valu_busy_frac': valu_busy, 'from_profile': prof_origin,
+                         'valu_busy_frac': valu_busy, 'mfma_busy_frac': mfma_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
         out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'ranks_seen': ranks_seen, 'backend': dist.get_backend() if use_dist else None, 'vn_sync': vn.sync,

@@ -719,7 +719,9 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     long long prof_acc[4] = {0, 0, 0, 0}, prof_t = DL_CLOCK();
     int t_prof = 0;
     long long* const pstep = args()->a.prof ? args()->a.prof + (size_t)nblk * 4 * 11 : nullptr;          // [T][workgroups][4]: the same sections per control step (tools/diag_rollout_floor.py)
-#define DL_RP_TICK(k) do { const long long now_ = DL_CLOCK(); prof_acc[k] += now_ - prof_t; if (tid == 0 && pstep) pstep[((size_t)t_prof * gridDim.x + wgi) * 4 + (k)] += now_ - prof_t; prof_t = now_; } while (0)
+    long long prof_rt = (long long)__builtin_amdgcn_s_memrealtime();          // the per-step records use the constant 100 MHz counter: the XCDs' shader clocks differ, and these records are compared ACROSS workgroups
+#define DL_RP_TICK(k) do { const long long now_ = DL_CLOCK(); prof_acc[k] += now_ - prof_t; prof_t = now_; \
+        if (pstep) { const long long rt_ = (long long)__builtin_amdgcn_s_memrealtime(); if (tid == 0) pstep[((size_t)t_prof * gridDim.x + wgi) * 4 + (k)] += rt_ - prof_rt; prof_rt = rt_; } } while (0)
 #else
 #define DL_RP_TICK(k) ((void)0)
 #endif
@@ -773,7 +775,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
             int lane_t = lane;
             DL_VPIN(lane_t);          // per-step opaque (as above): lane topology, lane records and pinned constants are this phase's only
             if (role == 0)
-#ifdef DL_EXP_ROLLOUT_PROF        // per-section cycles of the LAST control step's env phase, per dynamics wave: prof[nblk * 4 + k * (nblk * 4) + wave block], k as in g_wave_env_step<TIMED>
+#if defined(DL_EXP_ROLLOUT_PROF) && DL_EXP_ROLLOUT_PROF != 2        // (2: the per-step phase records only, the env step itself uninstrumented -- tools/diag_rollout_floor.py)  per-section cycles of the LAST control step's env phase, per dynamics wave: prof[nblk * 4 + k * (nblk * 4) + wave block], k as in g_wave_env_step<TIMED>
                 g_wave_env_step<T, TP, true, true>(lane_t, wblock, wblock, nblk * 4, base, p->gm, c, st, p->a.actions + (size_t)t * n * NU, p->a.raw_obs, p->a.raw_rew, done, (float*)nullptr, (float*)nullptr,
                                                    (const T*)nullptr, (const T*)nullptr, (const int32_t*)nullptr, (float*)nullptr, p->eval_mode, 1, p->a.prof + (size_t)nblk * 4);
 #else

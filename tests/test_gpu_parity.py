@@ -1416,7 +1416,8 @@ def test_f32_error_growth_over_steps(torch_cuda, oracle, model, refs, lanes):
     _sync_from(orc, e32); _sync_from(orc, e64)
     same = np.ones(n, bool)
     curve, flipped = [], []
-    FLIP_BOUND = [0.05 * (k + 1) for k in range(K)]          # (placeholder until measured: see below)
+    # measured (2048 walkers, both launch forms alike): 0 .0010 .0010 .0010 .0024 .0044 .0044 .0049 cumulative -- about 0.06 % of the walkers per control step
+    FLIP_BOUND = [0.002, 0.003, 0.004, 0.005, 0.007, 0.009, 0.011, 0.012]
     for k in range(K):
         a = np.clip(0.5 * rng.standard_normal((n, 8)), -1, 1).astype(np.float32)
         o64, r64, d64, _ = e64.step(a)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How far is the exact mode of the persistent rollout kernel (SB3's per-step VecNormalize: every workgroup meets every other workgroup at every control
-step) from its STRUCTURAL floor?  Needs a -DDL_EXP_ROLLOUT_PROF build (DL_LIB_PATH): the kernel then records, per control step and workgroup, the shader-clock
-cycles of the policy phase P, the env phase E and the moment sums + exchange R (waiting included).
+step) from its STRUCTURAL floor?  Needs a -DDL_EXP_ROLLOUT_PROF=2 build (DL_LIB_PATH): the kernel then records, per control step and workgroup, the time (s_memrealtime: the constant
+100 MHz counter -- the XCDs' shader clocks differ, and these records are compared across workgroups) of the policy phase P, the env phase E and the moment sums +
+exchange R (waiting included).
   floor      = sum_t [ min_wg P_t + max_wg E_t + min_wg R_t ]     -- with per-step coupling a step cannot end before its slowest workgroup's env phase; the
                policy phase and the exchange are the same work for every workgroup (their minimum over workgroups = the work without waiting)
   measured   = max_wg sum_t (P + E + R)                           -- what the launch takes
@@ -44,9 +45,9 @@ for r in range(R + 1):
     free = (P.min(1)[:, None] + E).sum(0).max()
     ms = ev0.elapsed_time(ev1)
     rows.append((measured, floor, free, ms, E.mean(), E.max(1).mean(), P.min(1).mean(), Rr.min(1).mean()))
-    print(f'rollout {r}: measured {measured / 1e6:8.2f} M cycles ({ms:6.2f} ms incl. launch: {measured / ms / 1e3:.0f} MHz shader clock)   floor {floor / 1e6:8.2f} M   measured / floor {measured / floor:.3f}   '
-          f'free-running structure {free / 1e6:8.2f} M ({free / measured:.3f} x measured)')
-    print(f'           per step: env phase mean over workgroups {E.mean():8.0f}, slowest workgroup {E.max(1).mean():8.0f} ({E.max(1).mean() / E.mean():.3f} x mean); policy phase {P.min(1).mean():7.0f}; sums + exchange without waiting {Rr.min(1).mean():6.0f}')
+    print(f'rollout {r}: measured {measured / 1e5:8.2f} ms ({ms:6.2f} ms by events incl. launch)   floor {floor / 1e5:8.2f} ms   measured / floor {measured / floor:.3f}   '
+          f'free-running structure {free / 1e5:8.2f} ms ({free / measured:.3f} x measured)')
+    print(f'           per step: [us] env phase mean over workgroups {E.mean() / 100:8.2f}, slowest workgroup {E.max(1).mean() / 100:8.2f} ({E.max(1).mean() / E.mean():.3f} x mean); policy phase {P.min(1).mean() / 100:7.2f}; sums + exchange without waiting {Rr.min(1).mean() / 100:6.2f}')
 a = np.array(rows).mean(0)
 print(f'mean of {R} rollouts: measured / floor = {a[0] / a[1]:.3f}   (floor {a[1] / a[0] * a[3]:.1f} ms of {a[3]:.1f} ms)   slowest / mean env phase {a[5] / a[4]:.3f}')
 venv.close()
