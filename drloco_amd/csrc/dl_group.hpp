@@ -135,6 +135,15 @@ template <typename TP> struct GD {
     // replicated dofs' state): what is used ONCE per evaluation -- collision candidates, body offsets, solimp -- is fetched at
     // its point of use from the L1-resident model block instead (a few hundred cycles per evaluation against scratch spills).
     static constexpr bool PIN_ALL = (NX == 0) && DL_PIN_STRAIGHT;
+    // Contact Jacobians in LDS: one 16-byte record (normal, tangent 1, tangent 2, owner) per contact and dof lane.  A contact's column is non-zero only for
+    // the lanes on the chain root -> the contact's body, and the lanes of a chain have distinct depths: the 19-dof walker stores a contact's records BY DEPTH
+    // (JCL = deepest chain = 8 slots instead of 16 lanes; the record's fourth word names the lane that owns the slot, a lane off the chain finds another
+    // owner -- or none -- at its depth and takes zero).  24 contacts x 16 lanes were 6 KB of the walker's 9.98 KB; packed, a split workgroup of sixteen
+    // 19-dof walkers fits the CU's LDS.  The lane-only walker keeps the lane-major layout (JCL = 16: nothing to mask).
+    static constexpr int lane_depth(int l) { int d = 0; for (int p = TP::dof_parent(l + NX) - NX; p >= 0; p = TP::dof_parent(p + NX) - NX) d++; return d; }
+    static constexpr int max_depth_() { int m = 0; for (int l = 0; l < NL; l++) if (lane_depth(l) > m) m = lane_depth(l); return m; }
+    static constexpr bool JC_PACKED = NX > 0 && max_depth_() + 1 <= GL / 2;
+    static constexpr int JCL = JC_PACKED ? ((max_depth_() + 2) & ~1) : GL;
     static_assert(slides_ok_(), "the dofs beyond 16 must be leading root translations");
     static_assert(NL <= GL && MAXB <= 16 && NCAND <= 64 && TP::NS <= GL, "model too large for a 16-lane row");
 };
@@ -198,13 +207,14 @@ template <typename TP> struct GLds {
     static constexpr int FC = CON + CON_W * MAXCON;                  // contact-frame force and Hessian weights [MAXCON][FC_W]
     static constexpr int Q = FC, V = Q + D::NV;                      // q, v staged for the observation writer
     static constexpr int MISC = FC + FC_W * MAXCON;                  // rootz ... [8]
-    static constexpr int JC = MISC + 8;                              // contact Jacobians, dof-lane major [MAXCON][16 lanes][4]: normal, tangent 1, tangent 2, -
+    static constexpr int JCL = D::JCL;                               // record slots per contact: 16 lanes, or (GD::JC_PACKED) the depth of the deepest chain
+    static constexpr int JC = MISC + 8;                              // contact Jacobians [MAXCON][JCL][4]: normal, tangent 1, tangent 2, owner lane (packed form)
     static constexpr int BFR_W = 12;                                 // body frame record: X (3) Y (3) Z (3) pos (3) = three 16-byte groups
     static constexpr int BFR = JC;                                   // body frames [MAXB][BFR_W]
-    static constexpr int TOTAL_RAW = JC + MAXCON * GL * 4;
+    static constexpr int TOTAL_RAW = JC + MAXCON * JCL * 4;
     // walker regions are offset by 16 (mod 32) words so that the two rows of a half-wave use disjoint banks
     static constexpr int TOTAL = ((TOTAL_RAW + 31) / 32) * 32 + 16;
-    static_assert(GL * MS <= 4 * MAXROW && 2 * D::NV <= FC_W * MAXCON && D::MAXB * BFR_W <= MAXCON * GL * 4, "aliased regions must fit");
+    static_assert(GL * MS <= 4 * MAXROW && 2 * D::NV <= FC_W * MAXCON && D::MAXB * BFR_W <= MAXCON * JCL * 4, "aliased regions must fit");
     static_assert(MS % 4 == 0 && CON % 4 == 0 && FC % 4 == 0 && JC % 4 == 0 && MAXROW % 4 == 0 && TOTAL % 4 == 0, "16-byte groups must stay aligned");
 };
 
@@ -456,7 +466,10 @@ template <typename TP> struct GSplit {
     using Ld = GLds<TP>;
     static constexpr int MMX = Ld::TOTAL;                        // M mirror [16][MS]
     static constexpr int MB = MMX + GL * Ld::MS;                 // mailbox
-    static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_CMD = 67, MB_DONESEQ = 68, MB_SIZE = 96;      // (CMDSEQ, CMD): one aligned 8-byte word
+    static constexpr int MB_Q = 0, MB_X0 = 16, MB_LIM = 32, MB_SGN = 48, MB_NCON = 64, MB_NLIM = 65, MB_CMDSEQ = 66, MB_CMD = 67, MB_DONESEQ = 68;      // (CMDSEQ, CMD): one aligned 8-byte word
+    // replicated root translations (NX > 0): the request's words for them -- configuration (command 2), solver start point, NEXT configuration -- one 16-byte group each
+    static constexpr int MB_QX = 96, MB_X0X = 100, MB_QNX = 104;
+    static constexpr int MB_SIZE = GD<TP>::NX > 0 ? 112 : 96;
     // look-ahead of the mass matrix: MB_QN = the configuration of the NEXT evaluation (known when this one is requested); MB_MOK = sequence number of
     // the request whose mass matrix is in the mirror block (posted by the partner once it has checked that what it precomputed is for this request's
     // configuration); MB_MFREE = sequence number of the last request whose mass matrix the dynamics wave has taken into registers
@@ -470,8 +483,11 @@ template <typename TP> struct GSplit {
     static constexpr int BFRX = MB + MB_SIZE;                    // body frames [MAXB][BFR_W]
     static constexpr int AXX = BFRX + ((GD<TP>::MAXB * Ld::BFR_W + 31) / 32) * 32;      // [16 lanes][4]: axis, root height
     static constexpr int RZX = AXX + 3;                          // the root height of lane 0's record
-    static constexpr int TOTAL = AXX + GL * 4;                   // per walker; 16 (mod 32) like GLds::TOTAL
-    static_assert(TOTAL % 32 == 16 && MB % 4 == 0, "walker regions keep their bank offset");
+    // replicated root translations: per dof lane (M[j][t] for the NX translations, M[t][t] of translation 0 = the walker's mass + armature), the partner's g_mass_rows
+    static constexpr int MXL = AXX + GL * 4;                     // [16 lanes][4]
+    static constexpr int TOTAL_RAW = MXL + (GD<TP>::NX > 0 ? GL * 4 : 0);
+    static constexpr int TOTAL = ((TOTAL_RAW - 16 + 31) / 32) * 32 + 16;          // per walker; 16 (mod 32) like GLds::TOTAL
+    static_assert(TOTAL % 32 == 16 && MB % 4 == 0 && TOTAL >= TOTAL_RAW && GD<TP>::NX <= 3, "walker regions keep their bank offset");
     // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
     // wave sets the handle's fault word, its walkers take the reference's exception path (mimic_env.py:86-91) and the host raises DL_E_FAULT
     static constexpr int SPIN_LIMIT = 1 << 16;
@@ -842,7 +858,6 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
         Ic.I.xx = cs16[4]; Ic.I.xy = cs16[5]; Ic.I.xz = cs16[6]; Ic.I.yy = cs16[7]; Ic.I.yz = cs16[8]; Ic.I.zz = cs16[9];
         W = {mk<T>(cs16[10], cs16[11], cs16[12]), mk<T>(cs16[13], cs16[14], cs16[15])};
     } else {
-        static_assert(WITH_M || NX == 0, "the velocity-only half is built for the lane-only walker");
         T cs6[6] = {F.w.x, F.w.y, F.w.z, F.v.x, F.v.y, F.v.z};
         g_subtree_sum_n<T, TP, 6>(cs6, j, lt);
         W = {mk<T>(cs6[0], cs6[1], cs6[2]), mk<T>(cs6[3], cs6[4], cs6[5])};
@@ -916,7 +931,8 @@ template <typename T, typename TP>
 __device__ __forceinline__ void g_mass_rows(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, const GKin<T>& k) {
     using Ld = GLds<TP>;
     constexpr int NL = GD<TP>::NL;
-    static_assert(GD<TP>::NX == 0 && Ld::MS >= GL + 2, "lane-only walker; two spare words per row of the mirror block");
+    static_assert(Ld::MS >= GL + 2, "two spare words per row of the mirror block");
+    constexpr int NX = GD<TP>::NX;
     const int j = g.j;
     const auto& ln = *g.ln;
     const bool isdof = j < NL;
@@ -972,6 +988,14 @@ __device__ __forceinline__ void g_mass_rows(const GCtx<T, TP>& g, const GLaneTop
     st4(row, mr[0], mr[1], mr[2], mr[3]); st4(row + 4, mr[4], mr[5], mr[6], mr[7]);
     st4(row + 8, mr[8], mr[9], mr[10], mr[11]); st4(row + 12, mr[12], mr[13], mr[14], mr[15]);
     st4(row + 16, isdof ? mjj + ln.armature : T(1), isdof ? ln.armature - mjj : T(0), T(0), T(0));
+    if constexpr (NX > 0) {
+        // replicated root translations (as g_smooth_dynamics<WITH_M> forms them): M[j][t] = S_t . (Ic_j S_j), M[t][t] = the walker's mass + armature
+        static_assert(GTopo<TP>::rooted(), "lane 0 must be the root of the lane tree");
+        const T mtot = rbcast<0>(Ic.m);
+        T mx[4] = {T(0), T(0), T(0), mtot};
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value, ax = TP::dof_axis(t); mx[t] = isdof ? T(TP::dof_sign(t)) * vcomp<ax>(f.v) : T(0); });
+        st4(g.wb + GSplit<TP>::MXL + 4 * j, mx[0], mx[1], mx[2], mx[3]);
+    }
     g_sync<T>();
 }
 
@@ -1272,6 +1296,18 @@ template <typename TP> using GCandMask = std::conditional_t<(GD<TP>::NPASS > 2),
 __device__ __forceinline__ int g_popc(uint32_t x) { return __popc(x); }
 __device__ __forceinline__ int g_popc(uint64_t x) { return __popcll(x); }
 
+// lane j's column (normal, tangent 1, tangent 2) of contact c's Jacobian: its own record, or -- packed layout -- the record at the lane's depth if the lane owns it
+template <typename T, typename TP> __device__ __forceinline__ Q4<T> g_jc_load(const DL_LDS T* wb, int c, int j, int depth) {
+    using Ld = GLds<TP>;
+    if constexpr (!GD<TP>::JC_PACKED) return ld4(wb + Ld::JC + (c * GL + j) * 4);
+    else {
+        const Q4<T> r = ld4(wb + Ld::JC + (c * Ld::JCL + depth) * 4);
+        const T m = r.d == T(j) ? T(1) : T(0);
+        return {m * r.a, m * r.b, m * r.c, r.d};
+    }
+}
+template <typename T> __device__ __forceinline__ int g_lane_depth(const GLaneTopo<T>& lt) { const int d = __popc(lt.anc) - 1; return d < 0 ? 0 : d; }
+
 // ------------------------------------------------------------------------------------------
 // [3P] mj_collision + position part of mj_makeConstraint for one walker (all 16 lanes).
 // Returns (nlim, ncon) identical in every lane of the row.  `grp` = row index inside the wave.
@@ -1285,6 +1321,7 @@ __device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const 
     DL_LDS T* wb = g.wb;
     const int j = g.j;
     const auto& ln = *g.ln;
+    const int jdepth = g_lane_depth(lt);
     // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
     // every contact from its joint axis / anchor in registers (dofs that do not move the contact's body write zeros),
     // two contacts per trip; the same trip adds J x0 to the contacts' rows (six interleaved row sums, expanded to the
@@ -1317,8 +1354,16 @@ __device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const 
         if (!((lt.bodies >> (int)A1n.d) & 1u)) w1 = mk<T>(0, 0, 0);
         const T j0n = w0.z, j0a = B0n.a * w0.x + B0n.b * w0.y, j0b = -B0n.b * w0.x + B0n.a * w0.y;
         const T j1n = w1.z, j1a = B1n.a * w1.x + B1n.b * w1.y, j1b = -B1n.b * w1.x + B1n.a * w1.y;
+        if constexpr (GD<TP>::JC_PACKED) {
+            // every slot of the two contacts is cleared (owner -1) by the lane of its number, then the lanes on a contact's chain write their records at their depth:
+            // LDS operations of a wave are performed in order, the later store stands
+            if (j < Ld::JCL) { st4(wb + Ld::JC + (c * Ld::JCL + j) * 4, T(0), T(0), T(0), T(-1)); st4(wb + Ld::JC + ((c + 1) * Ld::JCL + j) * 4, T(0), T(0), T(0), T(-1)); }
+            if ((lt.bodies >> (int)A0n.d) & 1u) st4(wb + Ld::JC + (c * Ld::JCL + jdepth) * 4, j0n, j0a, j0b, T(j));
+            if ((lt.bodies >> (int)A1n.d) & 1u) st4(wb + Ld::JC + ((c + 1) * Ld::JCL + jdepth) * 4, j1n, j1a, j1b, T(j));
+        } else {
         st4(wb + Ld::JC + (c * GL + j) * 4, j0n, j0a, j0b, T(0));
         st4(wb + Ld::JC + ((c + 1) * GL + j) * 4, j1n, j1a, j1b, T(0));
+        }
         T r[6] = {j0n * x0, j0a * x0, j0b * x0, j1n * x0, j1a * x0, j1b * x0};
         gsum_n<6>(r);
         if constexpr (NX > 0) { g_slide_jx<T, TP>(B0n.a, B0n.b, x0x, r[0], r[1], r[2]); g_slide_jx<T, TP>(B1n.a, B1n.b, x0x, r[3], r[4], r[5]); }
@@ -1499,7 +1544,7 @@ template <> struct GEps<double> { static constexpr double value = 2.220446049250
 // the lane's row of M.  J x: the limit row of a dof is +-x_j; per contact the three contact-frame components are row sums of the
 // lane's own Jacobian column times x_j, expanded to the four pyramid rows by lanes 0..3.
 template <typename T, typename TP>
-__device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim, T lim_sign, T x, const T (&xx)[GD<TP>::NXA], const GSmooth<T, TP>& sm, T (&mxx_out)[GD<TP>::NXA]) {
+__device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim, T lim_sign, T x, const T (&xx)[GD<TP>::NXA], const GSmooth<T, TP>& sm, T (&mxx_out)[GD<TP>::NXA], int jdepth) {
     using Ld = GLds<TP>;
     constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, MAXROW = Ld::MAXROW;
     DL_LDS T* wb = g.wb;
@@ -1519,7 +1564,7 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
     // two contacts per trip (the Jacobian record after the last contact is zero): six interleaved row sums
     DL_UNROLL(DL_UNROLL_APPLY)
     for (int c = 0; c < ncon; c += 2) {
-        const Q4<T> ja = ld4(wb + Ld::JC + (c * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c + 1) * GL + j) * 4);
+        const Q4<T> ja = g_jc_load<T, TP>(wb, c, j, jdepth), jb = g_jc_load<T, TP>(wb, c + 1, j, jdepth);
         T mua, mub;
         T r[6] = {ja.a * x, ja.b * x, ja.c * x, jb.a * x, jb.b * x, jb.c * x};
         if constexpr (NX > 0) {
@@ -1560,7 +1605,8 @@ __device__ __forceinline__ T g_apply(const GCtx<T, TP>& g, int ncon, int my_lim,
 template <typename T, typename TP, bool TIMED = false, bool SPLIT = false>
 __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>& lt, int grp, T q, T v, T ctrl_force, T warm,
                                        const GX<T, GD<TP>::NX>& qx, const GX<T, GD<TP>::NX>& vx, const GX<T, GD<TP>::NX>& warmx, GX<T, GD<TP>::NX>& qaccx,
-                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr, T q_next = T(0), T* q_ann = nullptr) {
+                                       int& ncon_o, int& nefc_o, int& niter_o, long long* tacc = nullptr, int* split_seq = nullptr, T q_next = T(0), T* q_ann = nullptr,
+                                       const GX<T, GD<TP>::NX>* qx_next = nullptr, GX<T, GD<TP>::NX>* qx_ann = nullptr) {
     constexpr int N = GD<TP>::NL, NX = GD<TP>::NX, NXA = GD<TP>::NXA;
     using Ld = GLds<TP>;
     constexpr int MAXROW = Ld::MAXROW;
@@ -1577,13 +1623,13 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
 #endif
     DL_LDS T* wb = g.wb;
     const int j = g.j;
+    const int jdepth = g_lane_depth(lt);          // (packed contact Jacobians: the slot of this lane's records)
     GKin<T> kin;
     GSmooth<T, TP> sm;
     const GConst<T, TP>& cs = *g.c;
     int nlim, ncon, my_lim;
     T lim_sign;
     if constexpr (SPLIT) {
-        static_assert(NX == 0, "the split workgroup is built for the lane-only walker");
         using Sp = GSplit<TP>;
         // a pair whose hand-over has failed once (split_seq[3]) takes no further part in the protocol: its walkers are on the exception path
         if (split_seq[3]) { ncon_o = 0; nefc_o = 0; niter_o = 0; return warm; }
@@ -1598,11 +1644,23 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         volatile DL_LDS int* fl = (volatile DL_LDS int*)g.mbox0;
         const int seq = ++*split_seq;
         using QBits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;          // the announced configuration must be THIS one to the last bit of its own type
-        const bool fast = !__any(j < N && __builtin_bit_cast(QBits, q) != __builtin_bit_cast(QBits, *q_ann));
+        bool differs = j < N && __builtin_bit_cast(QBits, q) != __builtin_bit_cast(QBits, *q_ann);
+        static_for<NX>([&](auto ti) { constexpr int t = ti.value; differs = differs || __builtin_bit_cast(QBits, qx.x[t]) != __builtin_bit_cast(QBits, qx_ann->x[t]); });
+        const bool fast = !__any(differs);
         *q_ann = q_next;
         g.mbox[Sp::MB_Q + j] = q;
         g.mbox[Sp::MB_X0 + j] = (j < N) ? cs.solB * v + warm : T(0);
         g.mbox[Sp::MB_QN + j] = q_next;
+        T x0x_s[NXA] = {T(0)};          // the solver's start point of the replicated dofs (uniform over the row)
+        if constexpr (NX > 0) {
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; x0x_s[t] = cs.solB * vx.x[t] + warmx.x[t]; });
+            *qx_ann = *qx_next;
+            if (j == 0) {
+                st4(g.mbox + Sp::MB_QX, qx.x[0], qx.x[NX > 1 ? 1 : 0], qx.x[NX > 2 ? 2 : 0], T(0));
+                st4(g.mbox + Sp::MB_X0X, x0x_s[0], x0x_s[NX > 1 ? 1 : 0], x0x_s[NX > 2 ? 2 : 0], T(0));
+                st4(g.mbox + Sp::MB_QNX, qx_next->x[0], qx_next->x[NX > 1 ? 1 : 0], qx_next->x[NX > 2 ? 2 : 0], T(0));
+            }
+        }
 #ifdef DL_EXP_SPLIT_PROF
         const long long tp0 = DL_CLOCK();
 #endif
@@ -1624,6 +1682,12 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             sm.mrow[0] = m0.a; sm.mrow[1] = m0.b; sm.mrow[2] = m0.c; sm.mrow[3] = m0.d; sm.mrow[4] = m1.a; sm.mrow[5] = m1.b; sm.mrow[6] = m1.c; sm.mrow[7] = m1.d;
             sm.mrow[8] = m2.a; sm.mrow[9] = m2.b; sm.mrow[10] = m2.c; sm.mrow[11] = m2.d; sm.mrow[12] = m3.a; sm.mrow[13] = m3.b; sm.mrow[14] = m3.c; sm.mrow[15] = m3.d;
             sm.mdiag = m4.a; sm.mcorr = m4.b;
+            if constexpr (NX > 0) {
+                Q4<T> mx = ld4(wb + Sp::MXL + 4 * j);
+                g_pin(mx.a); g_pin(mx.d);
+                const T mxv[3] = {mx.a, mx.b, mx.c};
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; sm.mxl[t] = mxv[t]; sm.mxx[t] = mx.d + cs.xs_armature[t]; });
+            }
 #pragma unroll
             for (int a = 0; a < GL; a++) g_pin(sm.mrow[a]);
             g_pin(sm.mdiag); g_pin(sm.mcorr); g_pin(kin.X.x); g_pin(kin.Y.y); g_pin(kin.Z.z); g_pin(kin.pos.x); g_pin(kin.axis.x);
@@ -1678,8 +1742,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         g_sync<T>();
 #if !DL_JAC_ON_PARTNER
         {   // the contact Jacobians are this wave's part of the constraint stage (its partner is the slower of the two otherwise)
-            const T x0x[NXA] = {T(0)};
-            g_contact_jacobians<T, TP>(g, lt, kin, ncon, (j < N) ? cs.solB * v + warm : T(0), x0x);
+            g_contact_jacobians<T, TP>(g, lt, kin, ncon, (j < N) ? cs.solB * v + warm : T(0), x0x_s);
         }
 #endif
     } else {
@@ -1769,7 +1832,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         DL_UNROLL(DL_UNROLL_JTF)
         for (int c2 = 0; c2 < ncon; c2 += 2) {
             const DL_LDS T* fca = wb + Ld::FC + Ld::FC_W * c2;
-            const Q4<T> Fa = ld4(fca), Fb = ld4(fca + Ld::FC_W), ja = ld4(wb + Ld::JC + (c2 * GL + j) * 4), jb = ld4(wb + Ld::JC + ((c2 + 1) * GL + j) * 4);
+            const Q4<T> Fa = ld4(fca), Fb = ld4(fca + Ld::FC_W), ja = g_jc_load<T, TP>(wb, c2, j, jdepth), jb = g_jc_load<T, TP>(wb, c2 + 1, j, jdepth);
             fcon += (ja.a * Fa.a + ja.b * Fa.b + ja.c * Fa.c) + (jb.a * Fb.a + jb.b * Fb.b + jb.c * Fb.c);
             if constexpr (NX > 0) {
                 const Q4<T> Ga = ld4(fca + 8), Gb = ld4(fca + Ld::FC_W + 8);      // (w22, Fx, Fy, Fz)
@@ -1857,7 +1920,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         }
         tick(3);
         T Mdx[NXA];
-        const T Md = g_apply<T, TP>(g, ncon, my_lim, lim_sign, dir, dirx, sm, Mdx);      // rows JV = J dir
+        const T Md = g_apply<T, TP>(g, ncon, my_lim, lim_sign, dir, dirx, sm, Mdx, jdepth);      // rows JV = J dir
         g_sync<T>();
         tick(4);
         // ---- the common case: the full Newton step leaves the active set as it is.  The cost is quadratic on that

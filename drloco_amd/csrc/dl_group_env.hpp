@@ -106,7 +106,8 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     using D = GD<TP>;
     using Ld = GLds<TP>;
     using Sp = GSplit<TP>;
-    static_assert(D::NX == 0, "the split workgroup is built for the lane-only walker");
+    constexpr int NX = D::NX;
+    static_assert(!DL_JAC_ON_PARTNER || NX == 0, "the partner-side contact Jacobians (experiment) exist for the lane-only walker");
     const int grp = lane >> 4, j = lane & 15, n = st.n;
     const int w0 = wblock * GW + grp;
     const int w = w0 < n ? w0 : n - 1;
@@ -137,7 +138,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
     // the configuration half of the constraints in registers (det)
     GDet<T, TP> det;
     GKin<T> kin{};
-    const GX<T, 0> noqx{};
+    GX<T, NX> rq_qx{}, rq_qnx{};          // replicated root translations: the request's configuration (command 2) and NEXT configuration (uniform over a walker's row)
     // One code site per job, wave-uniform (scalar) control: a pass of the loop is  [wait for a request]  ->  [commit + post the rows]  ->  [geometry of a
     // configuration + post that it is there].  A command-2 request (nothing usable in advance) takes two passes: geometry of ITS configuration first
     // (posted as MB_MOK), then the commit and the look-ahead.
@@ -182,11 +183,18 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
             rq_x0 = g.mbox[Sp::MB_X0 + j]; rq_qn = g.mbox[Sp::MB_QN + j];
             if (cmd == 2) rq_q = g.mbox[Sp::MB_Q + j];
             g_pin(rq_x0); g_pin(rq_qn); g_pin(rq_q);
+            if constexpr (NX > 0) {
+                const Q4<T> a = ld4(g.mbox + Sp::MB_QNX), b = ld4(g.mbox + Sp::MB_QX);
+                const T an[3] = {a.a, a.b, a.c}, bn[3] = {b.a, b.b, b.c};
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; rq_qnx.x[t] = an[t]; rq_qx.x[t] = bn[t]; g_pin(rq_qnx.x[t]); g_pin(rq_qx.x[t]); });
+            }
         }
         T qg;                 // the configuration whose geometry this pass computes
+        GX<T, NX> qxg{};
         int post;             // ... and the flag that says it is there
         if (cmd == 3) {
-            qg = j < D::NL ? st.qpos[(size_t)j * n + w] : T(0); post = Sp::MB_PRE;
+            qg = j < D::NL ? st.qpos[(size_t)(j + NX) * n + w] : T(0); post = Sp::MB_PRE;
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; qxg.x[t] = st.qpos[(size_t)t * n + w]; });
             boot = false;
         } else if (cmd == 1 || owe_commit) {
             // ---- commit: contact records and rows of this evaluation from the detection in registers (the limit rows take the solver's start point):
@@ -217,17 +225,17 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
                 DL_WG_ACQUIRE();
                 owe_commit = false;
             }
-            qg = rq_qn; post = Sp::MB_PRE;
+            qg = rq_qn; qxg = rq_qnx; post = Sp::MB_PRE;
         } else {
             // command 2: this evaluation's configuration is not the one announced (first request of a launch, reset, injected state): its geometry now
             // (the dynamics wave waits for it: MB_MOK), its rows in the next pass
-            qg = rq_q; post = Sp::MB_MOK;
+            qg = rq_q; qxg = rq_qx; post = Sp::MB_MOK;
             owe_commit = true;
         }
         // ---- geometry: kinematics -> body frames + root height (g_fk publishes into this wave's own region) and the lanes' joint axes; the mass matrix; the
         // configuration half of the constraints (registers) and what the dynamics wave needs to know of it.  The detection comes last: its results stay in
         // registers until the next request, across nothing but the wait.
-        g_fk<T, TP, true, false>(g, lt, qg, noqx, kin);
+        g_fk<T, TP, true, false>(g, lt, qg, qxg, kin);
         st4(wb + Sp::AXX + 4 * j, kin.axis.x, kin.axis.y, kin.axis.z, kin.rootz);
         g_mass_rows<T, TP>(g, lt, kin);
         g_detect_constraints<T, TP, false>(g, lt, grp, qg, det);
@@ -293,6 +301,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     if constexpr (SPLIT) q_ann = q;          // the partner wave starts with the geometry of the state in memory (g_constraint_server): "announced" by the launch itself
     GX<T, NX> qx, vx, warmx;
     static_for<NX>([&](auto ti) { constexpr int t = ti.value; const size_t o = (size_t)t * n + w1; qx.x[t] = st.qpos[o]; vx.x[t] = st.qvel[o]; warmx.x[t] = st.warm[o]; });
+    GX<T, NX> qx_ann = qx;                   // (the replicated dofs of the announced configuration)
     int32_t cur[DL_CUR_WORDS];
 #pragma unroll
     for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = st.cur[(size_t)k * n + w1];
@@ -397,7 +406,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             const T q0 = q, v0 = v;
             T dq = T(0), dv = T(0), qs = q, vs = v, q_end = q;
             T acc_s0 = warm;
-            GX<T, NX> qx0 = qx, vx0 = vx, dqx, dvx, qsx = qx, vsx = vx, accx_s0 = warmx;
+            GX<T, NX> qx0 = qx, vx0 = vx, dqx, dvx, qsx = qx, vsx = vx, accx_s0 = warmx, qx_end = qx;
             static_for<NX>([&](auto ti) { dqx.x[ti.value] = T(0); dvx.x[ti.value] = T(0); });
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
@@ -420,7 +429,13 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 const T al = stage == 2 ? T(1) : T(0.5);
                 const T dq_new = dq + wgt * vs;
                 const T q_ahead = stage == 3 ? q0 + h * dq_new : q0 + h * al * vs;          // stage 3: the state after this mj_step = stage 0 of the next
-                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq, q_ahead, &q_ann);
+                GX<T, NX> dqx_new, qx_ahead;          // the same for the replicated dofs: formed ONCE, used for the announcement and as the next stage's configuration (the same bits)
+                static_for<NX>([&](auto ti) {
+                    constexpr int t = ti.value;
+                    dqx_new.x[t] = dqx.x[t] + wgt * vsx.x[t];
+                    qx_ahead.x[t] = stage == 3 ? qx0.x[t] + h * dqx_new.x[t] : qx0.x[t] + h * al * vsx.x[t];
+                });
+                const T acc = g_forward<T, TP, TIMED, SPLIT>(g, lt, grp, qs, vs, force, start, qsx, vsx, startx, accx, nc, ne, ni, tacc, split_seq, q_ahead, &q_ann, &qx_ahead, &qx_ann);
                 if constexpr (SPLIT) { if (split_seq[3] && simulate) exc = true; }      // the hand-over with the constraint wave failed: MujocoException path
 #if DL_EXP_EXTRAP
                 if (stage == 2) acc_s2_pp = acc_s2_prev;          // (before the overwrite below: the previous mj_step's stage 2)
@@ -444,17 +459,17 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 qs = q_ahead; vs = v0 + h * al * acc;
                 static_for<NX>([&](auto ti) {
                     constexpr int t = ti.value;
-                    dqx.x[t] += wgt * vsx.x[t]; dvx.x[t] += wgt * accx.x[t];
-                    const T vst = vsx.x[t];
-                    qsx.x[t] = qx0.x[t] + h * al * vst; vsx.x[t] = vx0.x[t] + h * al * accx.x[t];
+                    dqx.x[t] = dqx_new.x[t]; dvx.x[t] += wgt * accx.x[t];
+                    qsx.x[t] = qx_ahead.x[t]; vsx.x[t] = vx0.x[t] + h * al * accx.x[t];
                 });
+                qx_end = qx_ahead;
             }
 #if DL_EXP_EXTRAP
             acc_s0_prev = acc_s0;
 #endif
             if (simulate && !exc) {
                 q = q_end; v = v0 + h * dv;          // q_end = q0 + h * dq, formed before the last stage's solve
-                static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = qx0.x[t] + h * dqx.x[t]; vx.x[t] = vx0.x[t] + h * dvx.x[t]; });
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; qx.x[t] = qx_end.x[t]; vx.x[t] = vx0.x[t] + h * dvx.x[t]; });          // qx_end = qx0 + h * dqx, formed before the last stage's solve
             }
         }
     }

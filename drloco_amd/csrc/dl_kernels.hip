@@ -1155,7 +1155,9 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     std::vector<void*> allocs;
     GModel<T, TP>* gmd = nullptr;    // table-driven model of the 16-lane kernels
     static constexpr size_t GLDS = (size_t)GW * GLds<TP>::TOTAL * sizeof(T);      // LDS of one wave (four walkers) of the 16-lane kernels
-    static constexpr bool CAN_SPLIT = sizeof(T) == 4 && GD<TP>::NX == 0;             // the split workgroup exists for the lane-only walker in float32
+    static constexpr size_t SLDS_ = (size_t)4 * GW * GSplit<TP>::TOTAL * sizeof(T);
+    static constexpr bool CAN_SPLIT = sizeof(T) == 4 && SLDS_ <= 160 * 1024;         // the split workgroup (step kernel): float32, sixteen walkers' regions within a CU's LDS
+    static constexpr bool CAN_PERSIST = CAN_SPLIT && GD<TP>::NX == 0;                // the persistent rollout kernels: the lane-only walker
     static constexpr size_t SLDS = (size_t)4 * GW * GSplit<TP>::TOTAL * sizeof(T);   // LDS of a split workgroup (four wave pairs, sixteen walkers)
     bool split = false;              // dl_set_split: step launches use k_env_step_g16_split
     float* ctrl_dbg = nullptr;       // test hook (dl_debug_last_ctrl): sim.data.ctrl of the last single-step launch, float[N, nu]
@@ -1429,7 +1431,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     void set_grid_spin(int polls) override { spin_grid = polls >= 0 ? polls : (1 << 22); }
     void set_spin_limits(int dyn, int srv) override { st.spin_dyn = dyn >= 0 ? dyn : GSplit<TP>::SPIN_LIMIT; st.spin_srv = srv >= 0 ? srv : GSplit<TP>::SPIN_LIMIT; }
     int set_split(int on) override {
-        if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels of the lane-only (straight) walker");
+        if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels");
         split = on != 0;
         return DL_OK;
     }
@@ -1452,7 +1454,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int persistent_ok(int hidden, std::string* why) override {
         auto no = [&](const char* w) { if (why) *why = w; return 0; };
-        if constexpr (!CAN_SPLIT) return no("the persistent rollout kernel exists for the 16-lane float32 kernels of the lane-only (straight) walker");
+        if constexpr (!CAN_PERSIST) return no("the persistent rollout kernel exists for the 16-lane float32 kernels of the lane-only (straight) walker");
         else {
             if (!(variant == 1 && gmd)) return no("the persistent rollout kernel needs the 16-lane kernels (lanes_per_walker = 16)");
             if (hidden != 512) return no("the persistent rollout kernel is built for hidden = 512 (eight waves per workgroup)");
@@ -1465,7 +1467,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     int collect_persistent(const dl_policy_params& pol, uint64_t seed, uint64_t counter0, int32_t index_base, const dl_vecnorm_state& vn, int32_t nT, float* observations,
                            float* actions, float* values, float* log_probs, float* rewards, uint8_t* episode_starts, float* next_obs, uint8_t* next_done, float* raw_obs,
                            float* raw_rew, int per_rollout, int deterministic, hipStream_t s) override {
-        if constexpr (!CAN_SPLIT) return fail(DL_E_INVAL, "dl_collect_rollouts: no persistent form for this walker / precision");
+        if constexpr (!CAN_PERSIST) return fail(DL_E_INVAL, "dl_collect_rollouts: no persistent form for this walker / precision");
         else {
             std::string why;
             if (!persistent_ok(pol.hidden, &why)) return fail(DL_E_INVAL, "dl_collect_rollouts: " + why);

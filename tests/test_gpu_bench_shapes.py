@@ -127,17 +127,19 @@ def test_rollout_fixed_beyond_the_launch_cap(torch_cuda, model, refs, split):
     a.close(); b.close()
 
 
-def test_loco3d_full_size_properties(torch_cuda):
+@pytest.mark.parametrize('lanes', [16, 'split'], ids=['one-wave-form', 'split-workgroups'])
+def test_loco3d_full_size_properties(torch_cuda, lanes):
     """BASELINE configs[3]'s walker at the per-GPU size of the configs (4096 walkers): size-independent properties of a 24-step rollout on
-    the synthetic loco3d table."""
+    the synthetic loco3d table, in the one-wave form and in the look-ahead split workgroups (`bench.py --walker loco3d` times the latter)."""
     torch = torch_cuda
     from drloco_amd import mocap, models
     from drloco_amd.vec_env import HipVecEnv
     n, T = 4096, 24
     ang, vel = mocap.synthetic_loco3d(L=20000, seed=0)
     table = mocap.loco3d_table(ang, vel)
-    mk = lambda num, base=0: HipVecEnv(models.WALKER_165CM, num_envs=num, seed=77, refs=table, env_index_base=base)
+    mk = lambda num, base=0: HipVecEnv(models.WALKER_165CM, num_envs=num, seed=77, refs=table, env_index_base=base, lanes_per_walker=lanes)
     env = mk(n)
+    assert env.split == (lanes == 'split')
     env.reset_tensors()
     assert (env.get_state()['cursor'][abi.DL_CUR_EPISODE] == 1).all()
     g = torch.Generator(device='cuda'); g.manual_seed(4321)

@@ -894,7 +894,7 @@ def test_loco3d_rollout_f64_matches_oracle(torch_cuda, oracle, lanes):
     np.testing.assert_allclose(s2['walked'], s1['walked'], rtol=1e-6, atol=1e-9)
 
 
-@LANES
+@LANES_S
 def test_loco3d_single_step_f32(torch_cuda, oracle, lanes):
     n = 1024
     dev, orc = _loco3d_pair(oracle, n, 32, lanes_per_walker=lanes)
@@ -909,7 +909,7 @@ def test_loco3d_single_step_f32(torch_cuda, oracle, lanes):
     assert np.array_equal(d1.astype(bool), d2)
     live = ~d2
     rel = np.abs(r1 - r2)[live] / np.abs(r1[live])
-    print('loco3d f32 one-step reward error: q50 %.2e q99 %.2e max %.2e (lanes %d)' % (np.median(rel), np.quantile(rel, 0.99), rel.max(), lanes))
+    print('loco3d f32 one-step reward error: q50 %.2e q99 %.2e max %.2e (lanes %s)' % (np.median(rel), np.quantile(rel, 0.99), rel.max(), lanes))
     assert rel.max() < 1e-4, (np.quantile(rel, 0.99), rel.max())
     assert np.array_equal(orc.get_state()['cursor'], dev.get_state()['cursor'])
 
@@ -1306,7 +1306,7 @@ def test_split_workgroups(torch_cuda, oracle, model, refs):
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     assert outs[0][2].sum() > 0
-    # the form does not exist for float64, one lane per walker and the 19-dof walker
+    # the form does not exist for float64 and for one lane per walker
     for kw in (dict(precision=64), dict(lanes_per_walker=1)):
         env = HipVecEnv(num_envs=8, model=model, refs=refs, **kw)
         with pytest.raises(dl_lib.DrlocoError):
@@ -1314,10 +1314,84 @@ def test_split_workgroups(torch_cuda, oracle, model, refs):
         env.set_split(False)
         env.close()
     ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
-    env = HipVecEnv(models.WALKER_165CM, num_envs=8, refs=mocap.loco3d_table(ang, vel))
+    env = HipVecEnv(models.WALKER_165CM, num_envs=8, refs=mocap.loco3d_table(ang, vel), precision=64)
     with pytest.raises(dl_lib.DrlocoError):
         env.set_split(True)
     env.close()
+
+
+def test_loco3d_split_workgroups(torch_cuda, oracle):
+    """The look-ahead split workgroup for the 19-dof walker (round 5; BASELINE config 4's launch form): the replicated root translations travel with the
+    request (three more words each for configuration, start point and announced configuration), the partner's mass matrix carries the lanes' M[j][t]
+    block, the contact Jacobians are stored by chain depth so that sixteen walkers fit a CU's LDS.
+      * ragged sizes against the oracle from identical states (one control step = 40 forward evaluations: the one-step float32 bar);
+      * one launch of T control steps == T launches, bit for bit, with randomisation, a push schedule and resets inside the window (every reset is a
+        configuration that was not announced: the command-2 path);
+      * against the one-wave form of the same kernels: the same done flags and episode counts, observations of walkers that never fell within float32
+        rollout tolerance (the two forms are different instruction streams: the mass matrix is formed by the partner)."""
+    import torch
+    from drloco_amd import mocap, models
+    from drloco_amd.vec_env import HipVecEnv
+    for n in (1, 5, 17, 70):
+        dev, orc = _loco3d_pair(oracle, n, 32, lanes_per_walker='split')
+        assert dev.split
+        rng = np.random.default_rng(n)
+        orc.reset(); dev.reset()
+        for t in range(8):
+            orc.step(np.clip(0.3 * rng.standard_normal((n, 13)), -1, 1))
+        st = orc.get_state()
+        dev.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=st['warm'], cursor=st['cursor'], walked=st['walked'])
+        a = np.clip(0.5 * rng.standard_normal((n, 13)), -1, 1).astype(np.float32)
+        o1, r1, d1, _, _ = orc.step(a.astype(np.float64)); o2, r2, d2, _ = dev.step(a)
+        assert np.array_equal(d1.astype(bool), d2)
+        live = ~d2
+        if live.any():
+            assert (np.abs(r1 - r2)[live] / np.abs(r1[live])).max() < 1e-4
+        np.testing.assert_allclose(o2[live], o1[live], atol=2e-2, rtol=1e-3)
+        from drloco_amd import lib as L
+        L.check(dev._lib.dl_fault_check(dev._h, None))
+        dev.close()
+    ang, vel = mocap.synthetic_loco3d(L=6000, seed=0)
+    table = mocap.loco3d_table(ang, vel)
+    n, T = 200, 23
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    acts = torch.clamp(0.6 * torch.randn(T, n, 13, device='cuda', generator=g), -1, 1)
+    outs = []
+    for multi in (False, True):
+        env = HipVecEnv(models.WALKER_165CM, num_envs=n, seed=3, refs=table, lanes_per_walker='split', ep_dur_max=12)       # episodes end (and reset) inside the window
+        env.set_randomization(np.linspace(0.8, 1.2, n), np.linspace(0.5, 1.1, n))
+        ang_p = np.linspace(0, 6.28, n)
+        env.set_push_schedule(np.stack([50 * np.cos(ang_p), 50 * np.sin(ang_p), 0 * ang_p], 1), (np.arange(n) % 13).astype(np.int32), period=13, duration=3)
+        env.reset_tensors()
+        if multi:
+            o, r, d = env.rollout_fixed(acts)
+            outs.append((o.cpu().clone(), r.cpu().clone(), d.cpu().clone()))
+        else:
+            O, R, D = [], [], []
+            for t in range(T):
+                env.step_tensors(acts[t]); O.append(env.obs.cpu().clone()); R.append(env.rew.cpu().clone()); D.append(env.done.cpu().clone())
+            outs.append((torch.stack(O), torch.stack(R), torch.stack(D)))
+        env.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert outs[0][2].sum() > 0
+    # split against the one-wave form over a short rollout
+    n, T = 1000, 6
+    acts = torch.clamp(0.5 * torch.randn(T, n, 13, device='cuda', generator=g), -1, 1)
+    res = []
+    for lanes in (16, 'split'):
+        env = HipVecEnv(models.WALKER_165CM, num_envs=n, seed=9, refs=table, lanes_per_walker=lanes)
+        env.reset_tensors()
+        o, r, d = env.rollout_fixed(acts)
+        res.append((o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), env.get_state()['cursor'].copy()))
+        env.close()
+    (o1, r1, d1, c1), (o2, r2, d2, c2) = res
+    agree = (d1 == d2).all(0)
+    assert agree.mean() > 0.99                       # (a fall decided by the last bit may land one step apart)
+    calm = agree & (d1.sum(0) == 0)
+    rel = np.abs(r1 - r2)[:, calm] / np.abs(r1[:, calm])
+    print('19-dof walker, split vs one-wave form over %d steps: %d of %d walkers without a fall; reward rel. error median %.2e q99 %.2e max %.2e' % (T, calm.sum(), n, np.median(rel), np.quantile(rel, 0.99), rel.max()))
+    assert np.median(rel) < 1e-5 and np.quantile(rel, 0.99) < 1e-3
 
 
 @pytest.mark.parametrize('lanes', [16, 'split'], ids=['16-lanes-per-walker', '16-lanes-split-workgroups'])

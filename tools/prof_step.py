@@ -23,8 +23,8 @@ if args.walker == 'loco3d':
     env = HipVecEnv(models.WALKER_165CM, num_envs=args.envs, lanes_per_walker=args.variant, refs=mocap.loco3d_table(ang, vel))
 else:
     env = HipVecEnv(num_envs=args.envs, lanes_per_walker=args.variant)
-    if args.variant in (0, 16) and not args.no_split:
-        env.set_split(True)          # the launch form of the benchmark
+if args.variant in (0, 16) and not args.no_split:
+    env.set_split(True)          # the launch form of the benchmark (both walkers since round 5)
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
 acts = torch.clamp(0.5 * torch.randn(args.warm + args.steps, args.envs, env.nu, device='cuda', generator=g), -1, 1)
