@@ -485,7 +485,12 @@ template <typename TP> struct GSplit {
     static constexpr int RZX = AXX + 3;                          // the root height of lane 0's record
     // replicated root translations: per dof lane (M[j][t] for the NX translations, M[t][t] of translation 0 = the walker's mass + armature), the partner's g_mass_rows
     static constexpr int MXL = AXX + GL * 4;                     // [16 lanes][4]
-    static constexpr int TOTAL_RAW = MXL + (GD<TP>::NX > 0 ? GL * 4 : 0);
+    // the dynamics wave's lane file (19-dof walker): per dof lane (motor force of this control step, joint damping, -, -).  Values used once per evaluation that
+    // the 256-register wave cannot hold across the solver: as registers they were spilled to scratch and reloaded one by one, each behind its own s_waitcnt
+    // (five dependent memory round trips per evaluation); one ds_read_b128 instead.  The replicated dofs' damping sits in GLds::MISC + 4 .. 6.
+    static constexpr int LSP = MXL + (GD<TP>::NX > 0 ? GL * 4 : 0);
+    static constexpr bool LANE_FILE = GD<TP>::NX > 0;
+    static constexpr int TOTAL_RAW = LSP + (LANE_FILE ? GL * 4 : 0);
     static constexpr int TOTAL = ((TOTAL_RAW - 16 + 31) / 32) * 32 + 16;          // per walker; 16 (mod 32) like GLds::TOTAL
     static_assert(TOTAL % 32 == 16 && MB % 4 == 0 && TOTAL >= TOTAL_RAW && GD<TP>::NX <= 3, "walker regions keep their bank offset");
     // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
@@ -910,14 +915,23 @@ __device__ __forceinline__ void g_smooth_dynamics(const GCtx<T, TP>& g, const GL
         const V3<T> pc = mk<T>(rbcast<RL>(com.x), rbcast<RL>(com.y), rbcast<RL>(com.z));
         if ((lt.bodies >> 1) & 1u) push_q = dot(S.w, cross(pc, g.wk->push)) + dot(S.v, g.wk->push);
     }
-    sm.smooth = isdof ? -ln.damping * v - bias + ctrl_force + push_q : T(0);
+    T damping = ln.damping, cforce = ctrl_force, xsd[GD<TP>::NXA];
+    if constexpr (!WITH_M && GSplit<TP>::LANE_FILE) {          // the dynamics wave of the 19-dof walker's split workgroup: from its lane file in LDS (GSplit::LSP)
+        const Q4<T> lf = ld4(wb + GSplit<TP>::LSP + 4 * j), xd = ld4(wb + Ld::MISC + 4);
+        cforce = lf.a; damping = lf.b;
+        const T xdv[3] = {xd.a, xd.b, xd.c};
+        static_for<NX>([&](auto ti) { xsd[ti.value] = xdv[ti.value]; });
+    } else {
+        static_for<NX>([&](auto ti) { xsd[ti.value] = g.c->xs_damping[ti.value]; });
+    }
+    sm.smooth = isdof ? -damping * v - bias + cforce + push_q : T(0);
     if constexpr (NX > 0) {
         // total wrench of the walker = composite wrench of lane 0 (the total mass: above, with M)
         const V3<T> Wv = mk<T>(rbcast<0>(W.v.x), rbcast<0>(W.v.y), rbcast<0>(W.v.z));
         static_for<NX>([&](auto ti) {
             constexpr int t = ti.value, ax = TP::dof_axis(t);
             const T sg = T(TP::dof_sign(t));
-            T fs = -g.c->xs_damping[t] * vx.x[t] - sg * vcomp<ax>(Wv);
+            T fs = -xsd[t] * vx.x[t] - sg * vcomp<ax>(Wv);
             if (g.wk->pushed) fs += sg * vcomp<ax>(g.wk->push);
             sm.smoothx[t] = fs;
         });
@@ -1319,6 +1333,13 @@ __device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const 
     using Ld = GLds<TP>;
     constexpr int NX = GD<TP>::NX, MAXROW = Ld::MAXROW;
     DL_LDS T* wb = g.wb;
+#if !defined(DL_GROUP_EMU)
+    if constexpr (!GD<TP>::PIN_ALL) {          // (opaque: the loop's per-lane base addresses are otherwise formed once per control step and spilled -- four scratch reloads per evaluation)
+        uint32_t wbo = (uint32_t)(uintptr_t)wb;
+        DL_VPIN(wbo);
+        wb = (DL_LDS T*)(uintptr_t)wbo;
+    }
+#endif
     const int j = g.j;
     const auto& ln = *g.ln;
     const int jdepth = g_lane_depth(lt);

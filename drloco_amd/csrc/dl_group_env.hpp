@@ -352,6 +352,12 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         if (ctrl_out && valid) ctrl_out[(size_t)step * n * NU + (size_t)w * NU + a_o] = (float)ctrl;      // test hook: sim.data.ctrl as the reference sets it
     }
     const T tor_sum = gsum(a >= 0 ? dl_abs(dl_clamp(ctrl, ln.force_lo, ln.force_hi)) : T(0));
+    if constexpr (SPLIT) {
+        if constexpr (GSplit<TP>::LANE_FILE) {          // the lane file of this control step (g_smooth_dynamics reads it once per evaluation)
+            st4(wb + GSplit<TP>::LSP + 4 * j, force, ln.damping, T(0), T(0));
+            if (j == 0) st4(wb + Ld::MISC + 4, cst.xs_damping[0], cst.xs_damping[NX > 1 ? 1 : 0], cst.xs_damping[NX > 2 ? 2 : 0], T(0));
+        }
+    }
     // ---- what the END of the step will look up does not depend on the physics: refs.next() is a function of the cursor alone.  The cursor
     // is advanced on a copy here and the reference sample, the step length and the desired velocity behind it are requested BEFORE the
     // physics (chains of dependent table reads: a lone wave per SIMD would wait out three or four memory round trips after the physics);
