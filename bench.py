@@ -285,7 +285,7 @@ def main():
     n, T = args.envs_per_gpu, args.rollout_len
     # the split workgroups fill the GPU: good for the policy-free rollout at any size and for a policy in the loop at the benchmark size;
     # with a policy and more walkers the one-wave form leaves room for the policy kernel next to the env steps (measured: 18.7 vs 20.0 M at 32 768)
-    split = (not args.no_split) and args.lanes in (0, 16) and not (args.policy and (args.handles > 1 or n > 4096 or args.walker != 'straight'))
+    split = (not args.no_split) and args.lanes in (0, 16) and not (args.policy and (args.handles > 1 or n > 4096))
     # launch schedule of the policy-free rollout: ONE launch covers the rollout (<= 512 steps) and its normalisations follow as one
     # dl_vecnormalize_steps call.  (Round 2 ran 448 + 64 steps with the normalisations of the long launch "on the side stream under the short
     # one": the split workgroups -- two waves x 256 registers -- and the 19-dof kernel -- 508 registers -- hold every SIMD's whole register
@@ -501,7 +501,7 @@ def main():
                        'dynamics': 'per-walker mass/friction randomisation + 50 N pushes on a device-resident schedule (config 5 stress test)' if args.randomize else 'nominal'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
-                                   (('k_rollout_pairs<TopoStraight>' if args.moments == 'per_rollout' else 'k_rollout_persistent<TopoStraight>') if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else (('k_env_step_g16_split<float,TopoWalker165>' if split else 'k_env_step_g16<float,TopoWalker165>') if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>'))), 'avg_launch_us': avg_launch_s * 1e6,
+                                   ((('k_rollout_pairs<%s>' if args.moments == 'per_rollout' else 'k_rollout_persistent<%s>') % ('TopoWalker165' if args.walker == 'loco3d' else 'TopoStraight')) if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else (('k_env_step_g16_split<float,TopoWalker165>' if split else 'k_env_step_g16<float,TopoWalker165>') if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>'))), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
                          'valu_busy_frac': valu_busy, 'mfma_busy_frac': mfma_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},

@@ -663,7 +663,9 @@ constexpr int RP_SYNC_WORDS = 160;
 constexpr int RP_PROF_STEPS = 512;        // DL_EXP_ROLLOUT_PROF builds: control steps with per-step section records
 constexpr int RP_MAX_KBLOCKS = 8;          // blocks of sixteen walkers per workgroup: <= 128 walkers per CU, 32768 on 256 CUs
 constexpr int RP_WS = 64;                  // lanes per block in the moment sums (a column per lane: OBS + 1 <= 64)
-template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2 + RP_MAX_KBLOCKS * 2 * (TP::OBS + 1)) * sizeof(double) + 64; }
+// blocks per workgroup a walker type allows: the 19-dof walker's sixteen regions leave 3 KB of the CU's LDS -- room for the moments and ONE block's rollout sums
+template <typename TP> constexpr int rp_kblocks() { return GD<TP>::NX > 0 ? 1 : RP_MAX_KBLOCKS; }
+template <typename TP> constexpr size_t rollout_lds_extra() { return (size_t)(2 * (TP::OBS + 1) + 2 + rp_kblocks<TP>() * 2 * (TP::OBS + 1)) * sizeof(double) + 64; }
 
 // All arguments travel as ONE by-value struct: the kernel reads them through the kernarg segment pointer, made opaque at the start of every
 // phase of every control step.  Passed as separate by-value parameters the ~150 uniform words (reference table, state arrays, rollout-buffer
@@ -698,8 +700,10 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
     DL_LDS T* base = (DL_LDS T*)smem + (size_t)gslot * GW * Sp::TOTAL;
     double* vm = (double*)(smem + ENV_LDS);                 // mean[W] (column D: the returns'), var[W], count, ret_count
     double* accm = vm + 2 * W + 2;                          // per_rollout: [kb][W][2] the blocks' column sums over the whole rollout (in LDS: nothing of the moment update lives in registers across the env phase)
-    int* shf = (int*)(accm + RP_MAX_KBLOCKS * 2 * W);       // [0] group-last flags, [1] exchange ok
-    static_assert(RP_MAX_KBLOCKS * RP_WS <= 512 && W <= RP_WS, "a group of RP_WS lanes per block");
+    constexpr int KBMAX = rp_kblocks<TP>();
+    static_assert(!MULTI || KBMAX > 1, "several blocks per workgroup: not for this walker");
+    int* shf = (int*)(accm + KBMAX * 2 * W);       // [0] group-last flags, [1] exchange ok
+    static_assert(KBMAX * RP_WS <= 512 && W <= RP_WS, "a group of RP_WS lanes per block");
     const int wgi = g_block_of_workgroup(blockIdx.x, gridDim.x);
     int n, nT, flags, per_rollout, kb;
     {
@@ -707,7 +711,7 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
         n = p->st.n; nT = p->a.T; flags = p->a.flags; per_rollout = p->a.per_rollout; kb = p->a.kblocks;
         if (tid < D) { vm[tid] = p->a.obs_mean[tid]; vm[W + tid] = p->a.obs_var[tid]; }
         if (tid == D) { vm[D] = *p->a.ret_mean; vm[W + D] = *p->a.ret_var; vm[2 * W] = *p->a.obs_count; vm[2 * W + 1] = *p->a.ret_count; }
-        for (int i = tid; i < RP_MAX_KBLOCKS * 2 * W; i += 512) accm[i] = 0.0;
+        for (int i = tid; i < KBMAX * 2 * W; i += 512) accm[i] = 0.0;
     }
     // the workgroup owns kb consecutive blocks of sixteen walkers (one on <= 4096 walkers; more walkers than 16 x CUs: the grid stays co-resident and a
     // workgroup takes its blocks one after the other through the policy and env phases of a step)
@@ -840,8 +844,8 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 const int gb0 = g * gsize_r, gb1 = gb0 + gsize_r < nblk ? gb0 + gsize_r : nblk, gn = gb1 - gb0;
                 double x = 0;
                 for (int c0 = 0; c0 < gn; c0 += 32) {
-                    if (tid_r < 8 * 2 * W) {
-                        const int col = tid_r % (2 * W), part = tid_r / (2 * W);
+                    for (int e = tid_r; e < 8 * 2 * W; e += 512) {          // (one trip for the straight walker: 8 x 60 <= 512 lanes; two for the 19-dof walker's 8 x 96)
+                        const int col = e % (2 * W), part = e / (2 * W);
                         double v4[4];
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const int b = c0 + part * 4 + i; v4[i] = b < gn ? __hip_atomic_load(&partial[(size_t)(gb0 + b) * W * 2 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
@@ -1157,7 +1161,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     static constexpr size_t GLDS = (size_t)GW * GLds<TP>::TOTAL * sizeof(T);      // LDS of one wave (four walkers) of the 16-lane kernels
     static constexpr size_t SLDS_ = (size_t)4 * GW * GSplit<TP>::TOTAL * sizeof(T);
     static constexpr bool CAN_SPLIT = sizeof(T) == 4 && SLDS_ <= 160 * 1024;         // the split workgroup (step kernel): float32, sixteen walkers' regions within a CU's LDS
-    static constexpr bool CAN_PERSIST = CAN_SPLIT && GD<TP>::NX == 0;                // the persistent rollout kernels: the lane-only walker
+    static constexpr bool CAN_PERSIST = CAN_SPLIT && SLDS_ + rollout_lds_extra<TP>() <= 160 * 1024;          // the persistent rollout kernels: the split regions + the moments' block fit the CU's LDS
+    static constexpr bool CAN_PERSIST_MULTI = CAN_PERSIST && rp_kblocks<TP>() > 1;
     static constexpr size_t SLDS = (size_t)4 * GW * GSplit<TP>::TOTAL * sizeof(T);   // LDS of a split workgroup (four wave pairs, sixteen walkers)
     bool split = false;              // dl_set_split: step launches use k_env_step_g16_split
     float* ctrl_dbg = nullptr;       // test hook (dl_debug_last_ctrl): sim.data.ctrl of the last single-step launch, float[N, nu]
@@ -1460,7 +1465,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             if (hidden != 512) return no("the persistent rollout kernel is built for hidden = 512 (eight waves per workgroup)");
             if (inj_armed) return no("injected states are pending");
             if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cus = 0; }
-            if (n_cus <= 0 || (n + 15) / 16 > n_cus * RP_MAX_KBLOCKS) return no("more than 128 walkers per CU: a workgroup of the persistent rollout kernel takes at most eight blocks of sixteen walkers");
+            if (n_cus <= 0 || (n + 15) / 16 > n_cus * rp_kblocks<TP>()) return no(rp_kblocks<TP>() > 1 ? "more than 128 walkers per CU: a workgroup of the persistent rollout kernel takes at most eight blocks of sixteen walkers" : "more than 16 walkers per CU: this walker's workgroups take one block of sixteen walkers");
             return 1;
         }
     }
@@ -1484,7 +1489,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
                 if ((rc = dalloc(&rp_prof, (size_t)nblk * 4 * 11))) return rc;
 #endif
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
+                if constexpr (CAN_PERSIST_MULTI) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_persistent<TP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_pairs<TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SLDS + rollout_lds_extra<TP>())));
             }
             RolloutP a{};
@@ -1510,7 +1515,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
             if (per_rollout == 1) hipLaunchKernelGGL((k_rollout_pairs<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
-            else if (a.kblocks > 1) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
+            else if (a.kblocks > 1) { if constexpr (CAN_PERSIST_MULTI) hipLaunchKernelGGL((k_rollout_persistent<TP, true>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra); }
             else hipLaunchKernelGGL((k_rollout_persistent<TP, false>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
             if (prof_open) prof_steps += nT;
             prof_end(s);

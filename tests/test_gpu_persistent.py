@@ -218,6 +218,61 @@ def test_per_step_sync_refusals(torch_cuda, model, refs):
     venv.close()
 
 
+@pytest.mark.parametrize('n,T', [(4096, 12), (1000, 17), (5, 9)], ids=['full-size', 'ragged', 'partly-filled-workgroup'])
+def test_persistent_rollout_19dof_walker(torch_cuda, n, T):
+    """BASELINE config 4's walker with a policy in the loop as ONE launch per rollout (round 5: the look-ahead split workgroups exist for the 19-dof walker,
+    sixteen of its regions + the moments fit a CU's LDS): k_rollout_persistent<TopoWalker165> in the exact mode is the launch-per-step form bit for bit (split step
+    kernel, blocked reduction order), and the per-rollout relaxation gives the same buffers on both of its kernels (pair by pair on v_mfma_f32_4x4x1, workgroup
+    tiles on 16x16x4)."""
+    torch = torch_cuda
+    from drloco_amd import lib as L, mocap, models
+    from drloco_amd.policy import HipPolicy
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    ang, vel = mocap.synthetic_loco3d(L=6000, seed=0)
+    table = mocap.loco3d_table(ang, vel)
+
+    def setup():
+        venv = HipVecEnv(models.WALKER_165CM, num_envs=n, seed=21, refs=table, ep_dur_max=10)          # episodes end (time-out) and reset inside the window
+        venv.set_split(True)
+        vn = HipVecNormalize(venv); vn.blocked_reduce = True
+        pol = HipPolicy(obs_dim=47, act_dim=13, hidden=512, seed=4)
+        buf = HipRolloutBuffer(T, n, 47, 13, torch.device('cuda'))
+        vn.reset()
+        return venv, vn, pol, buf, vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
+
+    def snapshot(venv, vn, buf, last_obs, last_done):
+        torch.cuda.synchronize()
+        L.check(venv._lib.dl_fault_check(venv._h, None))
+        return dict(observations=buf.observations.cpu().clone(), actions=buf.actions.cpu().clone(), values=buf.values.cpu().clone(), log_probs=buf.log_probs.cpu().clone(),
+                    rewards=buf.rewards.cpu().clone(), episode_starts=buf.episode_starts.cpu().clone(), last_obs=last_obs.cpu().clone(), last_done=last_done.cpu().clone(),
+                    om=torch.as_tensor(vn.obs_rms.mean), ov=torch.as_tensor(vn.obs_rms.var), oc=torch.tensor(vn.obs_rms.count), rv=torch.as_tensor(vn.ret_rms.var),
+                    ret=vn.ret.cpu().clone(), qpos=torch.as_tensor(venv.get_state()['qpos']), cursor=torch.as_tensor(venv.get_state()['cursor']))
+    res = []
+    for persistent in (False, True):
+        venv, vn, pol, buf, last_obs, last_done = setup()
+        for rollout in range(2):
+            buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=persistent)
+            assert buf.last_form == ('persistent' if persistent else 'launches')
+        res.append(snapshot(venv, vn, buf, last_obs, last_done))
+        venv.close()
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), (k, float((res[0][k].double() - res[1][k].double()).abs().max()))
+    assert torch.isfinite(res[0]['observations']).all() and (res[0]['episode_starts'].sum() > 0 or n < 100)
+    rel = []
+    for tiles in (False, True):
+        venv, vn, pol, buf, last_obs, last_done = setup()
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True, moments='per_rollout', workgroup_tiles=tiles)
+        rel.append(snapshot(venv, vn, buf, last_obs, last_done))
+        venv.close()
+    for k in rel[0]:
+        if k in ('om', 'ov', 'rv'):
+            np.testing.assert_allclose(rel[0][k].numpy(), rel[1][k].numpy(), rtol=1e-10, atol=1e-12)
+        else:
+            assert torch.equal(rel[0][k], rel[1][k]), k
+
+
 def test_persistent_form_refusals(torch_cuda, model, refs):
     torch = torch_cuda
     from drloco_amd import lib as L, mocap, models
@@ -240,9 +295,15 @@ def test_persistent_form_refusals(torch_cuda, model, refs):
         with pytest.raises(L.DrlocoError):
             attempt(venv, pol, persistent=False, moments='per_rollout')
         venv.close()
+    # the 19-dof walker: persistent since round 5 (one block of sixteen walkers per workgroup: <= 4096 walkers on 256 CUs), launch form beyond
     ang, vel = mocap.synthetic_loco3d(L=4000, seed=1)
     venv = HipVecEnv(models.WALKER_165CM, num_envs=32, refs=mocap.loco3d_table(ang, vel))
+    assert attempt(venv, HipPolicy(obs_dim=47, act_dim=13, hidden=512)) == 'persistent'
+    venv.close()
+    venv = HipVecEnv(models.WALKER_165CM, num_envs=4112, refs=mocap.loco3d_table(ang, vel))
     assert attempt(venv, HipPolicy(obs_dim=47, act_dim=13, hidden=512)) == 'launches'
+    with pytest.raises(L.DrlocoError):
+        attempt(venv, HipPolicy(obs_dim=47, act_dim=13, hidden=512), persistent=True)
     venv.close()
     venv = HipVecEnv(num_envs=64, model=model, refs=refs)
     assert attempt(venv, HipPolicy(hidden=512)) == 'persistent'          # (dl_set_split need not be on: the persistent kernel IS the split form)
