@@ -16,7 +16,7 @@ stats = glob.glob(os.path.join(src, 'bench_trace', '*', '*kernel_stats.csv'))
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    flags = {'straight': '', 'policy': ' --policy', 'policy_per_rollout': ' --policy --moments per_rollout', 'policy_launches': ' --policy --rollout-form launches',
+    flags = {'straight': '', 'randomize': ' --randomize', 'policy': ' --policy', 'policy_per_rollout': ' --policy --moments per_rollout', 'policy_launches': ' --policy --rollout-form launches',
              'policy_32768_h2': ' --policy --envs-per-gpu 32768 --handles 2 --steps 2'}.get(walker, f' --walker {walker}')
     lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' + flags + '   (kernel_stats.csv, top rows)')
     lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
@@ -49,6 +49,13 @@ lines.append('')
 lines.append('PMC counters of the dominant kernel (k_env_step* / k_rollout_persistent; average per launch over the launch schedule of the benchmark (dl_rollout_fixed: one launch of 512 control steps), whole grid; separate rocprofv3 --pmc passes on tools/prof_step.py):')
 for k in sorted(pmc):
     lines.append(f'  {k:24s} {pmc[k]:16.1f}')
+if 'SQ_ACTIVE_INST_VALU' in pmc and 'GRBM_GUI_ACTIVE' in pmc:
+    lines.append('')
+    lines.append('  VALU busy / SIMD time (SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 32)): %.3f' % (pmc['SQ_ACTIVE_INST_VALU'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 32)))
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in pmc:
+        lines.append('  MFMA busy / SIMD time (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)): %.3f' % (pmc['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 8)))
+    if 'TCP_TCC_READ_REQ_sum' in pmc and 'k_env_step_avg_us' in out:
+        lines.append('  L2 -> CU read requests: %.3g per launch = %.2f TB/s at 64 B per request over the %.1f ms of the launch' % (pmc['TCP_TCC_READ_REQ_sum'], pmc['TCP_TCC_READ_REQ_sum'] * 64 / out['k_env_step_avg_us'] / 1e6, out['k_env_step_avg_us'] / 1e3))
 lines.append('')
 lines.append(json.dumps({k: v for k, v in out.items() if k != 'pmc_per_launch'}))
 b = os.path.join(src, 'bench.json')
