@@ -27,11 +27,11 @@
 #define DL_VPIN(x) ((void)0)
 #define DL_SPIN(x) ((void)0)
 #define DL_CLOCK() 0ll
-#define DL_SLEEP() ((void)0)
-#define DL_WAKE() ((void)0)
+#define DL_SLEEP() dlemu::sync(dlemu::TAG_SLEEP)          // a poll's sleep is where the emulated wave yields to its partner (run_pair)
+#define DL_WAKE() dlemu::sync(dlemu::TAG_YIELD)          // every flag post is followed by s_wakeup: in the emulation the point where the posting wave may lose the SIMD to its partner
 #define DL_WG_RELEASE() ((void)0)
 #define DL_WG_ACQUIRE() ((void)0)
-#define DL_FAULT_OR(p, code) ((void)0)
+#define DL_FAULT_OR(p, code) ((void)(*(p) |= (code)))
 #define DL_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>

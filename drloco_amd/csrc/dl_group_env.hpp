@@ -99,7 +99,6 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
 // (ncon, nlim, the lanes' limit rows); the contact Jacobians are the dynamics wave's.
 // Waits are bounded polls (never a hung GPU); a wait that runs out sets the handle's fault word and ends this wave -- the dynamics wave's
 // next request then runs out too, its walkers take the exception path and the host raises DL_E_FAULT (dl_fault_check).
-#if !defined(DL_GROUP_EMU)
 template <typename T, typename TP>
 __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS T* smem, const GModel<T, TP>* __restrict__ gm, const DevState<T>& st,
                                                     const float* __restrict__ actions_all = nullptr, int nsteps = 0) {
@@ -225,6 +224,9 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
                 DL_WG_ACQUIRE();
                 owe_commit = false;
             }
+#ifdef DL_EXP_R4_LATE_READ          // TEST SWITCH (tests/host_emu only): the round-4 defect re-introduced -- the announced configuration is read AFTER the rows' flag was posted,
+            rq_qn = g.mbox[Sp::MB_QN + j];          // when the word may already carry the dynamics wave's NEXT request (a mailbox word belongs to the dynamics wave again once the rows are posted)
+#endif
             qg = rq_qn; qxg = rq_qnx; post = Sp::MB_PRE;
         } else {
             // command 2: this evaluation's configuration is not the one announced (first request of a launch, reset, injected state): its geometry now
@@ -254,7 +256,6 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
 #endif
     if (DL_PREFETCH_ACTIONS && actions_all && pf_sink == 12345.678f) g.mbox[Sp::MB_SIZE - 1] = pf_sink;      // (keeps the prefetch loads alive)
 }
-#endif
 
 // `nsteps` control steps (time-major arrays: step s uses actions[s], writes obs[s], rew[s], done[s]).  More than one
 // step per launch is for callers whose actions do not depend on the observations (dl_rollout_fixed): the launch then

@@ -80,14 +80,11 @@ inline void trampoline() {
     abort();                              // a finished lane is never resumed
 }
 
-// run body(lane) for lanes 0..nlanes-1 as one wave
-inline void run_wave(int nlanes, const std::function<void(int)>& body) {
-    Wave w;
+// prepare the fibers of a wave (nothing runs yet)
+inline void wave_begin(Wave& w, int nlanes, const std::function<void(int)>& body) {
     w.nlanes = nlanes;
     w.body = body;
     w.stacks.resize(STACK * (size_t)nlanes);
-    Wave* prev = wave();
-    wave() = &w;
     for (int l = 0; l < nlanes; l++) {
         w.done[l] = false; w.tag[l] = -1; w.slot[0][l] = w.slot[1][l] = 0; w.parity[l] = 0; w.pred[l] = false;
         // a fresh stack as dlemu_swap expects it: six register slots, then the entry point as return address
@@ -98,36 +95,85 @@ inline void run_wave(int nlanes, const std::function<void(int)>& body) {
         f[7] = nullptr;
         w.sp[l] = (void*)f;
     }
-    for (;;) {
-        int live = 0, waiting = 0;
-        for (int l = 0; l < nlanes; l++) {
-            if (w.done[l]) continue;
-            w.cur = l;
-            dlemu_swap(&w.main_sp, w.sp[l]);
-            if (w.done[l]) continue;
-            live++;
-            if (w.tag[l] == TAG_BALLOT) waiting++;
-        }
-        if (!live) break;
-        // the 16 lanes of a row move in lockstep
-        for (int r = 0; r < nlanes; r += 16) {
-            int tag0 = -2;
-            for (int l = r; l < r + 16 && l < nlanes; l++) {
-                const int t = w.done[l] ? -3 : w.tag[l];
-                if (tag0 == -2) tag0 = t;
-                else if (t != tag0) { fprintf(stderr, "dlemu: the lanes of a row diverged at a cross-lane operation (lane %d: op %d, lane %d: op %d)\n", r, tag0, l, t); abort(); }
-            }
-        }
-        // a wave-wide ballot completes once every live lane has arrived
-        if (waiting == live) {
-            uint64_t m = 0;
-            for (int l = 0; l < nlanes; l++) if (!w.done[l] && w.pred[l]) m |= 1ull << l;
-            w.ballot_result = m;
-            w.ballot_gen++;
-        }
-        w.syncs++;
+}
+// one round of a wave: every live lane runs to its next rendezvous; the rows' lockstep is checked, a complete ballot is resolved.  Returns false once every lane has
+// finished.  `sleeping` (if given) tells whether the wave ended the round with every live lane in a poll's sleep (TAG_SLEEP): it cannot make progress by itself.
+constexpr int TAG_SLEEP = 990, TAG_YIELD = 991;
+inline bool wave_round(Wave& w, bool* sleeping = nullptr, bool* posted = nullptr) {
+    Wave* prev = wave();
+    wave() = &w;
+    const int nlanes = w.nlanes;
+    int live = 0, waiting = 0, asleep = 0, yielded = 0;
+    for (int l = 0; l < nlanes; l++) {
+        if (w.done[l]) continue;
+        w.cur = l;
+        dlemu_swap(&w.main_sp, w.sp[l]);
+        if (w.done[l]) continue;
+        live++;
+        if (w.tag[l] == TAG_BALLOT) waiting++;
+        if (w.tag[l] == TAG_SLEEP) asleep++;
+        if (w.tag[l] == TAG_YIELD) yielded++;
     }
     wave() = prev;
+    if (sleeping) *sleeping = live > 0 && asleep == live;
+    if (posted) *posted = live > 0 && yielded == live;          // the wave has just posted a flag (DL_WAKE follows every flag store): its partner's poll may succeed now
+    if (!live) return false;
+    // the 16 lanes of a row move in lockstep
+    for (int r = 0; r < nlanes; r += 16) {
+        int tag0 = -2;
+        for (int l = r; l < r + 16 && l < nlanes; l++) {
+            const int t = w.done[l] ? -3 : w.tag[l];
+            if (tag0 == -2) tag0 = t;
+            else if (t != tag0) { fprintf(stderr, "dlemu: the lanes of a row diverged at a cross-lane operation (lane %d: op %d, lane %d: op %d)\n", r, tag0, l, t); abort(); }
+        }
+    }
+    // a wave-wide ballot completes once every live lane has arrived
+    if (waiting == live) {
+        uint64_t m = 0;
+        for (int l = 0; l < nlanes; l++) if (!w.done[l] && w.pred[l]) m |= 1ull << l;
+        w.ballot_result = m;
+        w.ballot_gen++;
+    }
+    w.syncs++;
+    return true;
+}
+// run body(lane) for lanes 0..nlanes-1 as one wave
+inline void run_wave(int nlanes, const std::function<void(int)>& body) {
+    Wave w;
+    wave_begin(w, nlanes, body);
+    while (wave_round(w)) {}
+}
+
+// TWO waves that share memory (the dynamics wave and the partner wave of a split workgroup, tests/host_emu/emu.cpp): rounds of the two are interleaved by `policy`:
+//   0  seeded random: each round goes to wave A with probability 1/2 (xorshift on `seed`)
+//   1  A first: A runs whenever it is not asleep in a poll; B only while A sleeps          (the dynamics wave races ahead of its partner)
+//   2  B first: B runs whenever it is not asleep; A only while B sleeps                      (the partner races ahead)
+//   3  seeded random bursts: a wave keeps the SIMD for 1 .. 64 rounds
+// Every cross-lane operation of the kernel source is a round boundary, so a hand-over protocol sees its partner's stores at thousands of different points of its own
+// execution.  A wave asleep in a poll (DL_SLEEP) yields; two sleeping waves that stay asleep for `stall_limit` consecutive rounds are a deadlock: abort.
+inline void run_pair(int nlanes, const std::function<void(int)>& body_a, const std::function<void(int)>& body_b, int policy, uint64_t seed, long stall_limit = 4000000) {
+    Wave a, b;
+    wave_begin(a, nlanes, body_a);
+    wave_begin(b, nlanes, body_b);
+    bool alive_a = true, alive_b = true, sleep_a = false, sleep_b = false;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    long stall = 0, burst = 0;
+    bool cur_a = true;
+    while (alive_a || alive_b) {
+        bool pick_a;
+        if (!alive_b) pick_a = true;
+        else if (!alive_a) pick_a = false;
+        else if (policy == 1) pick_a = !sleep_a || sleep_b;
+        else if (policy == 2) pick_a = sleep_b && !sleep_a;
+        else if (policy == 3) { if (burst <= 0) { cur_a = (rnd() >> 33) & 1; burst = 1 + (long)((rnd() >> 20) & 63); } burst--; pick_a = cur_a; }
+        else pick_a = (rnd() >> 33) & 1;
+        if ((policy == 1 || policy == 2) && sleep_a && sleep_b) pick_a = (rnd() >> 33) & 1;      // both in a poll: either may be the one whose flag has been posted
+        bool posted = false;
+        if (pick_a) { alive_a = wave_round(a, &sleep_a, &posted); if (posted) sleep_b = false; } else { alive_b = wave_round(b, &sleep_b, &posted); if (posted) sleep_a = false; }
+        if ((sleep_a || !alive_a) && (sleep_b || !alive_b) && (alive_a || alive_b)) { if (++stall > stall_limit) { fprintf(stderr, "dlemu: both waves of a pair are asleep in their polls: deadlock\n"); abort(); } }
+        else stall = 0;
+    }
 }
 
 // one 32-bit word per lane: publish, rendezvous, read lane `src` (or 0 if src < 0)

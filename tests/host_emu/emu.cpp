@@ -27,6 +27,7 @@ template <typename T, typename TP> struct Emu {
     std::vector<T> rnd, smem;
     std::vector<int32_t> push_phase;
     int push_step = 0;
+    int32_t fault_word = 0;
 };
 
 template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_desc* d, const dl_refs_desc* r, const dl_config* cfg, int n) {
@@ -118,6 +119,31 @@ template <typename T, typename TP> static int emu_gstep(Emu<T, TP>* e, int nstep
     for (int i = 0; i < e->n; i++) e->inj_flags[i] = 0;
     return 0;
 }
+// ---- the split workgroup's wave PAIR on the host: the dynamics wave (g_wave_env_step<SPLIT>) and its partner (g_constraint_server) as two emulated waves that share the
+// pair's LDS block, their rounds interleaved by dlemu::run_pair's schedule (`policy`, `seed`).  One pair (four walkers) after the other.
+template <typename T, typename TP> static int emu_gstep_split(Emu<T, TP>* e, int nsteps, const float* act, float* obs, float* rew, uint8_t* done, int policy, uint64_t seed) {
+    if (!e->gm_ok) return -1;
+    using Sp = GSplit<TP>;
+    const int npair = (e->n + GW - 1) / GW;
+    std::vector<T> smem((size_t)GW * Sp::TOTAL, 0);
+    e->fault_word = 0;
+    e->st.fault = &e->fault_word; e->st.spin_dyn = Sp::SPIN_LIMIT; e->st.spin_srv = Sp::SPIN_LIMIT;
+    e->st.push_step0 = e->push_step; e->push_step += nsteps;
+    for (int pr = 0; pr < npair; pr++) {
+        std::fill(smem.begin(), smem.end(), T(0));
+        volatile int* f = (volatile int*)(smem.data() + Sp::MB);
+        f[Sp::MB_CMDSEQ] = 0; f[Sp::MB_DONESEQ] = 0; f[Sp::MB_CMD] = 1; f[Sp::MB_MOK] = 0; f[Sp::MB_MFREE] = 0; f[Sp::MB_PRE] = -1;
+        dlemu::run_pair(64,
+            [&](int lane) { g_wave_env_step<T, TP, false, true>(lane, pr, pr, npair, smem.data(), &e->gm, e->c, e->st, act, obs, rew, done, (float*)nullptr, (float*)nullptr,
+                                                                 e->inj_q.data(), e->inj_v.data(), nullptr, (float*)nullptr, e->eval_mode, nsteps, nullptr); },
+            [&](int lane) { g_constraint_server<T, TP>(lane, pr, smem.data(), &e->gm, e->st, nsteps > 1 ? act : nullptr, nsteps); },
+            policy, seed + 7919ull * (uint64_t)pr);
+    }
+    const int fw = e->fault_word;
+    e->st.fault = nullptr;
+    return fw;          // 0, or the fault bits a wave raised (DL_FAULT_*)
+}
+
 template <typename T, typename TP> static void emu_set_rnd(Emu<T, TP>* e, const float* mass_scale, const float* floor_mu, const float* push) {
     const int n = e->n;
     if (e->rnd.empty()) { e->rnd.assign((size_t)5 * n, 0); for (int i = 0; i < n; i++) { e->rnd[i] = 1; e->rnd[(size_t)n + i] = e->gm.floor_friction; } e->st.rnd = e->rnd.data(); }
@@ -136,6 +162,7 @@ template <typename T, typename TP> static void emu_set_push_schedule(Emu<T, TP>*
 }
 
 #define EMU_API(SUF, T, TP) \
+    extern "C" int dle_gstep_split_##SUF(void* h, int k, const float* a, float* o, float* r, uint8_t* d, int policy, uint64_t seed) { return emu_gstep_split<T, TP>((Emu<T, TP>*)h, k, a, o, r, d, policy, seed); } \
     extern "C" void dle_set_push_schedule_##SUF(void* h, const float* f, const int32_t* ph, int per, int dur) { emu_set_push_schedule<T, TP>((Emu<T, TP>*)h, f, ph, per, dur); } \
     extern "C" int dle_gforward_##SUF(void* h, const T* u, T* qa, int32_t* nc, int32_t* ne, int32_t* ni) { return emu_gforward<T, TP>((Emu<T, TP>*)h, u, qa, nc, ne, ni); } \
     extern "C" int dle_gstep_##SUF(void* h, int k, const float* a, float* o, float* r, uint8_t* d, float* t, float* tt, float* cu) { return emu_gstep<T, TP>((Emu<T, TP>*)h, k, a, o, r, d, t, tt, cu); } \
@@ -163,7 +190,9 @@ template <typename T, typename TP> static void emu_set_push_schedule(Emu<T, TP>*
     extern "C" void dle_set_eval_##SUF(void* h, int on) { ((Emu<T, TP>*)h)->eval_mode = on; }                                \
     extern "C" void dle_mon_##SUF(void* h, int word, double* out) { auto* e = (Emu<T, TP>*)h; memcpy(out, e->mon.data() + (size_t)word * e->n, e->n * 8); }
 
-EMU_API(f64, double, TopoStraight)
 EMU_API(f32, float, TopoStraight)
+#ifndef DL_EMU_ONLY_F32          // (the defect-injection build of tests/test_split_protocol_emu.py needs one instantiation only)
+EMU_API(f64, double, TopoStraight)
 EMU_API(f64_165, double, TopoWalker165)
 EMU_API(f32_165, float, TopoWalker165)
+#endif

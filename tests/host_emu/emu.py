@@ -10,7 +10,8 @@ from drloco_amd import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SAN = os.environ.get('DL_EMU_SANITIZE') == '1'          # UBSan build of the kernel source on the host (tests/test_sanitizers.py); ASan and the fibers' hand-made stacks do not mix
-_LIB = os.path.join(_HERE, 'libdl_emu_ubsan.so' if _SAN else 'libdl_emu.so')
+_R4BUG = os.environ.get('DL_EMU_R4BUG') == '1'          # -DDL_EXP_R4_LATE_READ: the round-4 hand-over defect re-introduced (tests/test_split_protocol_emu.py shows that the schedules catch it)
+_LIB = os.path.join(_HERE, 'libdl_emu_r4bug.so' if _R4BUG else ('libdl_emu_ubsan.so' if _SAN else 'libdl_emu.so'))
 _lib = None
 
 
@@ -19,7 +20,7 @@ def build(force=False):
         + [os.path.join(_ROOT, 'drloco_amd', 'csrc', f) for f in ('dl_core.hpp', 'dl_env.hpp', 'dl_host.hpp', 'dl_group.hpp', 'dl_group_env.hpp')] \
         + [os.path.join(_ROOT, 'include', 'drloco_hip.h')]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(['g++', '-O1' if _SAN else '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + (['-fsanitize=undefined', '-fno-sanitize-recover=all'] if _SAN else []) + [
+        subprocess.check_call(['g++', '-O1' if _SAN else '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + (['-fsanitize=undefined', '-fno-sanitize-recover=all'] if _SAN else []) + (['-DDL_EXP_R4_LATE_READ', '-DDL_EMU_ONLY_F32'] if _R4BUG else []) + [
                                '-I' + os.path.join(_ROOT, 'include'), '-I' + os.path.join(_ROOT, 'drloco_amd', 'csrc'), '-I' + _HERE,
                                '-o', _LIB, srcs[0]])
     return _LIB
@@ -29,7 +30,7 @@ def lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
-        for suf in ('f32', 'f64', 'f32_165', 'f64_165'):
+        for suf in (('f32',) if _R4BUG else ('f32', 'f64', 'f32_165', 'f64_165')):
             getattr(_lib, 'dle_create_' + suf).restype = C.c_void_p
     return _lib
 
@@ -116,6 +117,19 @@ class EmuEnv:
         assert rc == 0
         out = (obs, rew, done, term, terms) if multi else (obs[0], rew[0], done[0], term[0], terms[0])
         return out + ((ctrl if multi else ctrl[0]),) if return_ctrl else out
+
+    def gstep_split(self, actions, policy=0, seed=0):
+        """The split workgroup's wave pair (dynamics wave + look-ahead partner, drloco_amd/csrc/dl_group_env.hpp) as two emulated waves sharing the pair's LDS;
+        `policy` / `seed` select how their rounds are interleaved (dl_group_emu.hpp run_pair).  actions [T, N, nu] or [N, nu]; returns (obs, rew, done, fault bits)."""
+        a = np.ascontiguousarray(actions, np.float32)
+        multi = a.ndim == 3
+        T = a.shape[0] if multi else 1
+        obs = np.zeros((T, self.n, self.obs_dim), np.float32); rew = np.zeros((T, self.n), np.float32); done = np.zeros((T, self.n), np.uint8)
+        f = self._f('gstep_split')
+        f.restype = C.c_int
+        rc = f(self.h, C.c_int(T), _p(a, C.c_float), _p(obs, C.c_float), _p(rew, C.c_float), _p(done, C.c_uint8), C.c_int(policy), C.c_uint64(seed))
+        assert rc >= 0
+        return (obs, rew, done, rc) if multi else (obs[0], rew[0], done[0], rc)
 
     def set_randomization(self, mass_scale=None, floor_friction=None, push=None):
         f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)

@@ -39,6 +39,7 @@ def test_oracle_under_asan_and_ubsan():
 
 @pytest.mark.timeout(900)
 def test_kernel_source_on_host_under_ubsan():
-    out = _child({'DL_EMU_SANITIZE': '1', 'UBSAN_OPTIONS': 'print_stacktrace=1:halt_on_error=1'}, ['tests/test_host_logic.py', '-k', 'kernel_source'], 800)
+    out = _child({'DL_EMU_SANITIZE': '1', 'UBSAN_OPTIONS': 'print_stacktrace=1:halt_on_error=1'},
+                 ['tests/test_host_logic.py', 'tests/test_split_protocol_emu.py', '-k', 'kernel_source or schedule_independent or 19dof'], 800)          # incl. the two-wave hand-over of the split workgroups
     assert ' passed' in out, out[-500:]
     assert os.path.exists(os.path.join(ROOT, 'tests', 'host_emu', 'libdl_emu_ubsan.so'))
