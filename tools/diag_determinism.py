@@ -8,15 +8,21 @@ from drloco_amd.vec_env import HipVecEnv
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 n = 4096
+LOCO3D = os.environ.get('DET_WALKER') == 'loco3d'          # the 19-dof walker's split workgroups (round 5)
+NU, OBS = (13, 47) if LOCO3D else (8, 29)
+if LOCO3D:
+    from drloco_amd import mocap, models
+    _ang, _vel = mocap.synthetic_loco3d(L=60000, seed=0)
+    _table = mocap.loco3d_table(_ang, _vel)
 g = torch.Generator(device='cuda'); g.manual_seed(4321)
-acts = torch.clamp(0.5 * torch.randn(T, n, 8, device='cuda', generator=g), -1, 1)
+acts = torch.clamp(0.5 * torch.randn(T, n, NU, device='cuda', generator=g), -1, 1)
 def run(multi):
-    env = HipVecEnv(num_envs=n, seed=1234, lanes_per_walker='split')
+    env = HipVecEnv(models.WALKER_165CM, num_envs=n, seed=1234, refs=_table, lanes_per_walker='split') if LOCO3D else HipVecEnv(num_envs=n, seed=1234, lanes_per_walker='split')
     env.reset_tensors()
     if multi:
         o, r, d = env.rollout_fixed(acts)
     else:
-        o = torch.zeros(T, n, 29, device='cuda'); r = torch.zeros(T, n, device='cuda'); d = torch.zeros(T, n, dtype=torch.uint8, device='cuda')
+        o = torch.zeros(T, n, OBS, device='cuda'); r = torch.zeros(T, n, device='cuda'); d = torch.zeros(T, n, dtype=torch.uint8, device='cuda')
         for t in range(T):
             env.step_tensors(acts[t], obs_out=o[t], rew_out=r[t], done_out=d[t])
     torch.cuda.synchronize()
