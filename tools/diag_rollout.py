@@ -21,9 +21,9 @@ for moments in ('per_step', 'per_rollout'):
     for _ in range(3):
         buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True, moments=moments)
     torch.cuda.synchronize()
-    prof = torch.zeros(n // 16 * 4 * 11, dtype=torch.int64, device='cuda')
+    prof = torch.zeros(n // 16 * 4 * 11 + 512 * (n // 16) * 4, dtype=torch.int64, device='cuda')          # (+ the per-step records of the PROF builds since round 5)
     lib.check(venv._lib.dl_debug_rollout_prof(venv._h, C.c_void_p(prof.data_ptr()), None))
-    sec = prof[n // 16 * 4:].view(10, n // 4).cpu().numpy().astype(np.float64)
+    sec = prof[n // 16 * 4:n // 16 * 4 * 11].view(10, n // 4).cpu().numpy().astype(np.float64)
     p = prof[:n // 16 * 4].view(n // 16, 4).cpu().numpy().astype(np.float64) / T
     tot = p[:, :3].sum(1)
     print(f'{moments}: cycles per control step and workgroup (mean / min / max over {n // 16} workgroups; shader clock)')
