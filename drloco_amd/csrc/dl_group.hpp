@@ -87,6 +87,9 @@
 #ifndef DL_CHOL_SHORT_CHAIN
 #define DL_CHOL_SHORT_CHAIN 1   // 0: round-2 form of the leaf-first factorisation / substitutions (experiment switch)
 #endif
+#ifndef DL_CHOL_X_LAST
+#define DL_CHOL_X_LAST 1        // walkers with replicated root translations: eliminate them LAST, the lane block leaf-first (0: round-2 form -- replicated dofs first, dense lane block)
+#endif
 #ifndef DL_CHOL_LEAF_FIRST
 #define DL_CHOL_LEAF_FIRST 1    // 0: the root-first dense row-per-lane Cholesky for every model (experiment switch)
 #endif
@@ -1285,6 +1288,81 @@ template <typename T, int NX, int NL> __device__ __forceinline__ T g_chol_solve_
     }
 }
 
+// ---- the replicated dofs eliminated LAST (round 5).  Eliminated first (g_chol_x) they couple every pair of lanes: the lane block fills in and needs the dense
+// factorisation -- sixteen pivots in one dependent chain.  Ordered [lanes leaf-first | replicated] the lane block keeps its tree pattern (g_chol_rev: no fill-in, the
+// branches' pivot chains side by side) and the replicated dofs become a 3 x 3 Schur complement:
+//   H_ll = U U^T (g_chol_rev);  W = U^-1 H_lx (the forward substitution for NX right-hand sides, row j of W in lane j);  S = H_xx - W^T W = Ls Ls^T (uniform).
+// Solve: y = U^-1 b_l;  z_x = Ls^-1 (b_x - W^T y);  x_x = Ls^-T z_x;  x_l = U^-T (y - W x_x).
+template <typename T, int NXA> struct GCholXL { T w[NXA], ls[NXA][NXA], invs[NXA]; };
+template <typename T, typename TP> __device__ __forceinline__ void g_chol_x_last(const T (&lo)[GL], T invd, const T (&hxl)[GD<TP>::NXA], const T (&hxx)[GD<TP>::NXA][GD<TP>::NXA],
+                                                                                  GCholXL<T, GD<TP>::NXA>& cx, T floor_) {
+    using TPL = GTopo<TP>;
+    constexpr int N = GD<TP>::NL, NX = GD<TP>::NX;
+    static_assert(DL_CHOL_SHORT_CHAIN, "written for the multiplier form of g_chol_rev (lo[k] = -U[j][k] / U[k][k])");
+    T acc[NX];
+    static_for<NX>([&](auto ti) { acc[ti.value] = hxl[ti.value]; });
+    static_for<N>([&](auto ss) {          // NX independent chains, interleaved
+        constexpr int k = TPL::order.at[ss.value];
+        if constexpr (k > 0) static_for<NX>([&](auto ti) { fmac_bcast_chain<k>(acc[ti.value], lo[k]); });
+    });
+    static_for<NX>([&](auto ti) { cx.w[ti.value] = acc[ti.value] * invd; });
+    // S = H_xx - W^T W (lower triangle), summed over the lanes of the row
+    constexpr int NS = NX * (NX + 1) / 2;
+    T sp[NS];
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; static_for<t + 1>([&](auto ui) { constexpr int u = ui.value; sp[t * (t + 1) / 2 + u] = cx.w[t] * cx.w[u]; }); });
+    gsum_n<NS>(sp);
+    T S[NX][NX];
+    static_for<NX>([&](auto ti) { constexpr int t = ti.value; static_for<t + 1>([&](auto ui) { constexpr int u = ui.value; S[t][u] = hxx[t][u] - sp[t * (t + 1) / 2 + u]; }); });
+    static_for<NX>([&](auto kk) {
+        constexpr int k = kk.value;
+        const T inv = dl_rsqrt_pivot(dl_max(S[k][k], floor_));
+        cx.invs[k] = inv;
+        static_for<NX - 1 - k>([&](auto tt) { constexpr int t = k + 1 + tt.value; cx.ls[t][k] = S[t][k] * inv; });
+        static_for<NX - 1 - k>([&](auto tt) {
+            constexpr int t = k + 1 + tt.value;
+            static_for<t - k>([&](auto uu) { constexpr int u = k + 1 + uu.value; S[t][u] -= cx.ls[t][k] * cx.ls[u][k]; });
+        });
+    });
+}
+template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev_x(const T (&lo)[GL], const T (&up)[GL], T invd, const GCholXL<T, GD<TP>::NXA>& cx, T b,
+                                                                                    const T (&bx)[GD<TP>::NXA], T (&xx)[GD<TP>::NXA], int j) {
+    using TPL = GTopo<TP>;
+    constexpr int N = GD<TP>::NL, NX = GD<TP>::NX;
+    T acc = b;
+    static_for<N>([&](auto ss) {
+        constexpr int k = TPL::order.at[ss.value];
+        if constexpr (k > 0) fmac_bcast_chain<k>(acc, lo[k]);
+    });
+    const T y = acc * invd;
+    T r[NX];
+    static_for<NX>([&](auto ti) { r[ti.value] = cx.w[ti.value] * y; });
+    gsum_n<NX>(r);
+    T zx[NX];
+    static_for<NX>([&](auto kk) {
+        constexpr int k = kk.value;
+        T a = bx[k] - r[k];
+        static_for<k>([&](auto tt) { a -= cx.ls[k][tt.value] * zx[tt.value]; });
+        zx[k] = a * cx.invs[k];
+    });
+    static_for<NX>([&](auto kk) {
+        constexpr int k = NX - 1 - kk.value;
+        T a = zx[k];
+        static_for<NX - 1 - k>([&](auto tt) { constexpr int t = k + 1 + tt.value; a -= cx.ls[t][k] * xx[t]; });
+        xx[k] = a * cx.invs[k];
+    });
+    T yl = y;
+    static_for<NX>([&](auto ti) { yl -= cx.w[ti.value] * xx[ti.value]; });
+    const T s2 = -invd * invd;
+    T u = yl * invd;
+    T up2[GL];
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = (j > k) ? s2 * up[k] : T(0); });
+    static_for<N>([&](auto ss) {
+        constexpr int k = TPL::order.at[N - 1 - ss.value];
+        if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
+    });
+    return u;
+}
+
 // contact-frame Jacobian of the replicated root translations: the columns are the contact frame itself (normal = floor
 // normal z, tangent 1 = (tx, ty, 0), tangent 2 = (-ty, tx, 0)), whatever body the contact is on.
 // (dn, d1, d2) += J_x xs
@@ -1924,12 +2002,19 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
 #pragma unroll
             for (int a = 0; a < GL; a++) { up[a] = h[a]; lo[a] = T(0); }
             GCholX<T, NXA> cx;
-            if constexpr (NX > 0) {
+            constexpr bool X_LAST = NX > 0 && DL_CHOL_X_LAST && DL_CHOL_LEAF_FIRST && DL_CHOL_SHORT_CHAIN;
+            if constexpr (NX > 0 && !X_LAST) {
                 T wxx[NXA][NXA], wxl[NXA];
                 static_for<NX>([&](auto ti) { constexpr int t = ti.value; wxl[t] = hxl[t]; static_for<NX>([&](auto ui) { wxx[t][ui.value] = hxx[t][ui.value]; }); });
                 g_chol_x<T, NX, N>(wxx, wxl, up, hdk, cx, T(1e-10));
             }
             T sx[NXA];
+            if constexpr (X_LAST) {
+                GCholXL<T, NXA> cl;
+                g_chol_rev<T, TP>(up, lo, hdk, invd, j, T(1e-10));
+                g_chol_x_last<T, TP>(lo, invd, hxl, hxx, cl, T(1e-10));
+                dir = -g_chol_solve_rev_x<T, TP>(lo, up, invd, cl, grad, gradx, sx, j);
+            } else
             if constexpr (NX == 0 && DL_CHOL_LEAF_FIRST) {
                 g_chol_rev<T, TP>(up, lo, hdk, invd, j, T(1e-10));
                 dir = -g_chol_solve_rev<T, TP>(lo, up, invd, grad, j);
