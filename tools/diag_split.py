@@ -6,7 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from drloco_amd.vec_env import HipVecEnv
 n, T = 4096, 64
-env = HipVecEnv(num_envs=n, seed=1, lanes_per_walker="split")
+if len(sys.argv) > 1 and sys.argv[1] == 'loco3d':          # the 19-dof walker's split workgroups (round 5)
+    from drloco_amd import mocap, models
+    _ang, _vel = mocap.synthetic_loco3d(L=60000, seed=0)
+    env = HipVecEnv(models.WALKER_165CM, num_envs=n, seed=1, refs=mocap.loco3d_table(_ang, _vel), lanes_per_walker="split")
+else:
+    env = HipVecEnv(num_envs=n, seed=1, lanes_per_walker="split")
 env.reset_tensors()
 g = torch.Generator(device='cuda'); g.manual_seed(3)
 acts = torch.clamp(0.5 * torch.randn(T, n, env.nu, device='cuda', generator=g), -1, 1)
