@@ -39,7 +39,7 @@
 #define DL_SPIN(x) asm volatile("" : "+s"(x))
 #define DL_CLOCK() ((long long)__builtin_readcyclecounter())
 #ifndef DL_SLEEP_N
-#define DL_SLEEP_N 16
+#define DL_SLEEP_N 1        // s_sleep argument of a poll (64 cycles per unit).  Round 5, A/B on one box against 16 (rounds 2-4) / 4 / 2 / 48: 1 is best on every line (+0.6 % headline, +1.4 % 19-dof walker, +0.8 / +1.1 % policy lines): the partner's reaction time is on the dynamics wave's critical path at every commit
 #endif
 #define DL_SLEEP() __builtin_amdgcn_s_sleep(DL_SLEEP_N)        // a waiting wave of a split workgroup: 64 x N cycles, cut short by the partner's s_wakeup
 #define DL_WAKE() asm volatile("s_wakeup")
@@ -498,7 +498,11 @@ template <typename TP> struct GSplit {
     static_assert(TOTAL % 32 == 16 && MB % 4 == 0 && TOTAL >= TOTAL_RAW && GD<TP>::NX <= 3, "walker regions keep their bank offset");
     // polls (s_sleep 16: ~1000 cycles each, ~30 ms in all) before a wave gives up waiting for its partner: no hang on a protocol error -- the
     // wave sets the handle's fault word, its walkers take the reference's exception path (mimic_env.py:86-91) and the host raises DL_E_FAULT
+#if defined(DL_GROUP_EMU)
     static constexpr int SPIN_LIMIT = 1 << 16;
+#else
+    static constexpr int SPIN_LIMIT = (1 << 20) / DL_SLEEP_N;          // the same ~30 ms of patience whatever the length of a poll's sleep
+#endif
 };
 
 // ------------------------------------------------------------------------------------------
