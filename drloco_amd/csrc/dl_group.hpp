@@ -501,7 +501,7 @@ template <typename TP> struct GSplit {
 #if defined(DL_GROUP_EMU)
     static constexpr int SPIN_LIMIT = 1 << 16;
 #else
-    static constexpr int SPIN_LIMIT = (1 << 20) / DL_SLEEP_N;          // the same ~30 ms of patience whatever the length of a poll's sleep
+    static constexpr int SPIN_LIMIT = (1 << 20) / (DL_SLEEP_N > 0 ? DL_SLEEP_N : 1);          // the same ~30 ms of patience whatever the length of a poll's sleep
 #endif
 };
 
