@@ -234,7 +234,7 @@ class HipVecEnv(_VecEnvBase):
         torch.cuda.current_stream().synchronize()
 
     def set_split(self, on=True):
-        """dl_set_split: the eight-wave workgroup form of the step kernel (dynamics waves + constraint waves; straight walker, float32,
+        """dl_set_split: the eight-wave workgroup form of the step kernel (dynamics waves + look-ahead partner waves; both walkers, float32,
         16 lanes per walker).  Shorter launches, but nothing else runs next to it: for single-handle use (bench.py switches it on)."""
         lib.check(self._lib.dl_set_split(self._h, int(bool(on))))
         self.split = bool(on)

@@ -237,12 +237,13 @@ int dl_set_push(dl_handle h, const float* force, void* stream);
 int dl_set_push_schedule(dl_handle h, const float* force, const int32_t* phase, int32_t period, int32_t duration,
                          void* stream);
 
-/* Launch form of the step kernel for the straight walker in float32 (16 lanes per walker): on = 1 launches workgroups of eight waves for
- * sixteen walkers -- four dynamics waves and four constraint waves that build the collision / contact / limit rows of the same walkers
- * while the dynamics waves run the smooth dynamics (two waves per SIMD, registers capped at 256, 143 KB of LDS per workgroup) -- instead of
- * one wave per four walkers.  6 % shorter launches at 4096 walkers; nothing else fits on the GPU next to it, so callers that overlap
- * other kernels with the step (several handles with a policy in the loop) keep the default, 0.  Same algorithm; the float32 results of the
- * two forms differ in the last bit (two instantiations).  Returns DL_E_INVAL for the other walker / float64 / one lane per walker. */
+/* Launch form of the step kernel in float32 (16 lanes per walker; both walkers since ABI 6): on = 1 launches workgroups of eight waves for
+ * sixteen walkers -- four dynamics waves and four partner waves that work one forward evaluation AHEAD of them (kinematics, mass matrix and the
+ * configuration half of the constraint stage of the next RK4 stage while the dynamics wave solves this one; two waves per SIMD, registers capped
+ * at 256, 153 / 157 KB of LDS per workgroup) -- instead of one wave per four walkers.  36.1 against 30.1 M env-steps/s at 4096 straight walkers,
+ * 16.3 against 13.1 M for the 19-dof walker; nothing else fits on the GPU next to it, so callers that overlap other kernels with the step (several
+ * handles with a policy in the loop) keep the default, 0.  Same algorithm; the float32 results of the two forms may differ in the last bit (two
+ * instantiations).  Returns DL_E_INVAL for float64 / one lane per walker. */
 int dl_set_split(dl_handle h, int32_t on);
 
 /* Device faults.  The reference turns a diverging simulation into an ended episode (MujocoException -> reward 0, done, reset:
@@ -422,8 +423,8 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
  *       control step, the policy forward of its own rows (matrix cores), MimicEnv.step of its walkers (the split-workgroup step kernel's code)
  *       and VecNormalize's moment update through one grid-wide exchange.  Exact SB3 semantics (every step normalises with the moments of all
  *       walkers up to that step); bit-identical to mode 0 when `vn->flags` selects the blocked reduction order (bit 32) and dl_set_split is on.
- *       Needs: straight walker, float32, 16 lanes per walker, hidden = 512, at most 128 walkers per CU (32768 on an MI355X; above 16 per CU a workgroup takes several blocks of sixteen walkers per control step) -- query with
- *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  EXCLUSIVE GPU: the grid-wide exchange needs every workgroup of the launch resident at
+ *       Needs: float32, 16 lanes per walker, hidden = 512, at most 128 walkers per CU for the straight walker (32768 on an MI355X; above 16 per CU a workgroup takes several blocks of sixteen walkers per control step) -- query with
+ *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  The 19-dof walker (ABI 6): one block per workgroup, i.e. at most 16 walkers per CU (4096).  EXCLUSIVE GPU: the grid-wide exchange needs every workgroup of the launch resident at
  *       the same time (one per CU), so no other process, stream or handle may hold CUs while it runs -- dl_rollout_persistent_ok only checks the
  *       walker count, it cannot see other users of the device.  A grid exchange that does not complete within its (bounded, ~2 s) poll budget raises
  *       the handle's fault word (DL_FAULT_GRID_TIMEOUT = 4) and the workgroup stops: the call has returned DL_OK by then, so the caller must
