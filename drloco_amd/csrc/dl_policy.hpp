@@ -30,19 +30,20 @@ namespace dl {
 typedef float pf4 __attribute__((ext_vector_type(4)));
 
 // EVERY MFMA of the policy kernels is inline asm with the accumulator TIED to the destination ("+v": source C and destination are the same
-// registers, so the allocator cannot relocate an accumulator inside a chain and cannot lay the destination over an A / B operand).  As builtins,
-// 71 of the 16x16x4 instructions of the product build had destination != source C with the destination over a dying A / B register -- the form
-// in which the 4x4x1 chains of dl_policy_pair.hpp produced about one wrong row in a thousand inside the per-rollout kernel.  Nothing ever failed
-// in the 16x16x4 kernels, but nothing explained why it could not; tied, the pattern cannot be emitted, and tools/check_mfma_overlap.py proves on
-// the listing of every build (rules R1 .. R5) that it was not and that the hand-written wait states below are in place:
+// registers) and every wait state around it written by hand -- hipcc pads nothing around inline asm, which is the point: its own padding behind
+// a v_mfma_f32_4x4x1 (4 wait states before an LDS store of the result) is what let one row in a thousand go stale inside the per-rollout kernel
+// (dl_policy_pair.hpp; found by patching the assembly in round 5 -- the relocated accumulators round 4 blamed are innocent, but the tied form
+// stays: it keeps the register allocator out of the chains and lets tools/check_mfma_overlap.py prove the listing of every build, rules R1 .. R5).
+// Measured on gfx950 (tools/ubench/mfma_ds_store.hip, profiles/r05_mfma_ds_store.txt): a reader of a 16x16x4 result needs 9 (LDS store) / 10 (VALU)
+// wait states, hipcc emits 10; of a 4x4x1 result 3 / 4, hipcc emits 4 -- and the kernel showed an event worth 2 more that no micro test reproduces.
 //   DL_MFMA16       the chain form: back to back on one accumulator (the 8-pass shape interlocks on an exactly matching source C) or interleaved;
 //   DL_MFMA16_OPEN  the first instruction after a VALU write of an operand (the zero-initialised accumulator): two wait states in front;
-//   DL_MFMA16_SETTLE before any other reader or writer of the accumulator: 12 wait states (8 passes + 4), more than the 10 hipcc puts
-//                   behind its own 16x16x4 (`s_nop 8` + the reader's own issue).
+//   DL_MFMA16_SETTLE before any other reader or writer of the accumulator: 20 wait states (the measured 10 + the 2 of the event + 8 of margin;
+//                   three times per forward pass and tile: nothing against the ~2000 MFMAs in between).
 #define DL_MFMA16(ACC, AV, BV) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
 #define DL_MFMA16_OPEN(ACC, AV, BV) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
 #define DL_MFMA16_PAD(ACC) asm volatile("s_nop 1" : "+v"(ACC))          // behind a VALU write of an accumulator whose first MFMA is a plain DL_MFMA16
-#define DL_MFMA16_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ACC))
+#define DL_MFMA16_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(ACC))
 
 __device__ __forceinline__ float pol_tanh(float x) {
     // 1 - 2 / (exp(2x) + 1); |error| < 2e-7 absolute

@@ -59,14 +59,26 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
     sync();
     const int colb = h * 256 + l;                 // this lane's column of column group cb: colb + 64 cb
     // one block of sixteen k: A fragments a[j] (k = 4 j .. 4 j + 3 of the lane's row), B fragments b[cb][j] (the same k of the lane's column in group cb)
-    // The 4x4x1 instructions are written as inline asm with the accumulator tied to the destination ("+v").  As builtins, under the register pressure of the rollout kernel (not in
-    // the stand-alone one), the compiler RELOCATED accumulators inside the dense chains -- destination != source C, the destination laid over the register of a B fragment that
-    // dies with the instruction -- and about one row in a thousand (always the third of the four) came out wrong by ~1e-2 while another wave kept the SIMD busy.  An isolated
-    // instruction with that overlap is exact (tools/ubench/mfma_overlap.hip), so the failure needs the back-to-back context; tied, source C and destination are the same
-    // registers, nothing is relocated and the other operands cannot overlap them.  The wait states are written by hand: dependent instructions on different accumulators are
-    // four apart in a block, the heads' single-accumulator chain carries s_nop, and DL_POLP_SETTLE precedes every other reader of an accumulator.
+    // The 4x4x1 instructions are inline asm with the accumulator tied to the destination ("+v") and EVERY wait state behind them is written by hand.  History: as builtins, inside the
+    // rollout kernel (not in the stand-alone one), about one row in a thousand -- always the third of the four -- came out wrong by ~1e-2 while other pairs of the workgroup ran.
+    // Round 4 blamed the relocated accumulators the listing showed (destination != source C over a dying B register) and tied them.  Round 5 bisected the builtin build by patching
+    // its assembly (EXPERIMENTS.md, "the 4x4x1 defect, found"): ONE site carries the defect -- the last MFMA of the heads' single-accumulator chain, `s_nop 3`, then
+    // `ds_write2_b32 v0, v8, v9` storing rows 2 and 3 of the heads' partial sums.  hipcc's 4 wait states are one more than the store needs in isolation (3; a VALU reader needs 4:
+    // tools/ubench/mfma_ds_store.hip, where too few states give exactly this signature -- a stale FIRST data register = row 2), yet inside the kernel 3 and 4 states fail equally
+    // (~7e-4 of the rows) and 5 never did (0 of 10.5 M rows): some event delays that MFMA by two states and the compiler's padding does not cover it.  Relocation is innocent; what the
+    // tied form changed was that hipcc pads nothing around inline asm and the hand-written 12 states replaced its 4.  Now 20 before any reader (DL_POLP_SETTLE; measured need 3 / 4,
+    // plus the 2 of the event, plus margin), dependent instructions on different accumulators four apart in a block, the heads' single-accumulator chain four states apart.
+#ifdef DL_EXP_POLP_BUILTIN          // the round-4 form, for tools/asm_bisect.sh only: builtins, hipcc's own padding -- reproduces the stale row
+#define DL_POLP_MFMA(ACC, AV, BV) ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(AV, BV, ACC, 0, 0, 0)
+#define DL_POLP_SETTLE(ACC) ((void)0)
+#define DL_POLP_HEAD_MFMA(ACC, AV, BV) ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(AV, BV, ACC, 0, 0, 0)
+#define DL_POLP_HEAD_SETTLE(ACC) ((void)0)
+#else
 #define DL_POLP_MFMA(ACC, AV, BV) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
-#define DL_POLP_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]))
+#define DL_POLP_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]))
+#define DL_POLP_HEAD_MFMA(ACC, AV, BV) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))          // one accumulator, back to back: the wait states a dependent instruction needs
+#define DL_POLP_HEAD_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(ACC))
+#endif
 #define DL_POLP_BLOCK(ACC, AF, BF)                                                                                       \
     _Pragma("unroll") for (int c = 0; c < 4; c++) _Pragma("unroll") for (int j = 0; j < 4; j++) _Pragma("unroll") for (int cb = 0; cb < 4; cb++) \
         DL_POLP_MFMA(ACC[cb], AF[j][c], BF[cb][j][c]);
@@ -157,15 +169,17 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ha) : "v"(a[j][c]), "v"(b[j][c]));          // (one accumulator, back to back: the wait states a dependent instruction needs)
+                for (int j = 0; j < 4; j++) DL_POLP_HEAD_MFMA(ha, a[j][c], b[j][c]);
         }
-        asm volatile("s_nop 7\n\ts_nop 3" : "+v"(ha));
+        DL_POLP_HEAD_SETTLE(ha);          // <- the site of the round-4 defect: hipcc put `s_nop 3` here
 #pragma unroll
         for (int i = 0; i < 4; i++) part[(w * 4 + i) * 16 + jo] = ha[i];
     }
 #undef DL_POLP_BLOCK
 #undef DL_POLP_MFMA
 #undef DL_POLP_SETTLE
+#undef DL_POLP_HEAD_MFMA
+#undef DL_POLP_HEAD_SETTLE
     sync();
     // ---- epilogue: sample, log-probability, value (the order of pol_forward_rows: partials added w = 0 .. 7)
     float lp = 0.0f;

@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """Static check of a `hipcc -S` listing for the MFMA forms the policy kernels rely on.
 
-Background (drloco_amd/csrc/dl_policy_pair.hpp): written as builtins, a dense chain of v_mfma_f32_4x4x1 inside the per-rollout kernel had accumulators
-RELOCATED by the register allocator (destination != source C, the destination laid over an A / B operand that dies with the instruction) and about
-one row in a thousand came out wrong while another wave kept the SIMD busy.  The isolated instruction is exact (tools/ubench/mfma_overlap.hip); the
-mechanism is not known.  The product therefore writes EVERY MFMA as inline asm with the accumulator tied to the destination, and this tool proves
-on the listing of the product build that the tied form is what was emitted and that the hand-written wait states are in place:
+Background (drloco_amd/csrc/dl_policy_pair.hpp, EXPERIMENTS.md "the 4x4x1 defect, found"): written as builtins, the per-rollout kernel stored a stale row of a
+v_mfma_f32_4x4x1 result about once in a thousand rows.  Round 4 blamed the relocated accumulators the listing showed (destination != source C, laid over a dying
+A / B operand) and tied every MFMA as inline asm; round 5 bisected the builtin build by patching its assembly and found ONE site: hipcc's 4 wait states between the
+last MFMA of a chain and the `ds_write2_b32` of its rows 2, 3 -- one more than the store needs in a micro test (tools/ubench/mfma_ds_store.hip: 3 for an LDS
+store, 4 for a VALU reader; 9 / 10 behind a 16x16x4), two fewer than it needed inside the kernel.  Because hipcc pads nothing around inline asm, the tied form
+puts every wait state in the source, and this tool proves on the listing of the product build that they are there, with margin:
 
-  R1  vdst != srcC and vdst overlaps srcA or srcB                                   (the pattern of the defect; any MFMA shape)
-  R2  vdst != srcC for a 4x4x1                                                      (the shape the defect was seen with: no relocation at all)
+  R1  vdst != srcC and vdst overlaps srcA or srcB                                   (what round 4 blamed; any MFMA shape)        
+  R2  vdst != srcC for a 4x4x1                                                      (no relocation at all in the small shape)                 
   R3  a VALU write of an A / B / C register less than 2 wait states before an MFMA  (hipcc pads nothing in front of inline asm)
-  R4  an MFMA's D read or written by anything but an MFMA taking it whole as srcC less than passes + 4 wait states later
-                                                                                    (2-pass 4x4x1: 6, 8-pass 16x16x4: 12; asm MFMAs only -- behind a
-                                                                                     builtin the compiler's hazard recogniser pads itself)
+  R4  an MFMA's D read or written by anything but an MFMA taking it whole as srcC less than passes + 10 wait states later
+                                                                                    (2-pass 4x4x1: 12, 8-pass 16x16x4: 18 = the measured need of a VALU
+                                                                                     reader, passes + 2, the 2 states of the event seen in the kernel, and
+                                                                                     6 of margin; asm MFMAs only)
   R5  dependent 4x4x1 on the same accumulator less than 2 wait states apart         (asm MFMAs only; the larger shapes interlock)
 
 usage: tools/check_mfma_overlap.py <listing.s> [substring of a kernel name]      exit code 1 if a rule is violated.
@@ -143,7 +145,7 @@ def check(path, name, items, report):
         if not in_asm:
             continue
         # R4 / R5: look ahead along every path (fall-through and branch targets) until D has settled
-        need4, need5 = passes(op) + 4, 2
+        need4, need5 = passes(op) + 10, 2
         seen, work, hit = set(), [(i + 1, 0)], None
         while work and hit is None:
             j, gone = work.pop()
