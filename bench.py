@@ -225,6 +225,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='lanes per walker of the dynamics kernels: 0 auto (16), 1, 16')
     ap.add_argument('--walker', choices=['straight', 'loco3d'], default='straight', help='loco3d: BASELINE configs[3] (19-dof walker, synthetic loco3d table); not the benchmark configuration')
     ap.add_argument('--policy', action='store_true', help='not the benchmark configuration: put the fused device policy (dl_policy_forward, 29-512-512-{8,1}) into the loop instead of pre-generated actions/values')
+    ap.add_argument('--hidden', type=int, default=512, choices=[64, 128, 256, 512], help='with --policy: the hidden size of the 2-layer trunk (the reference default is 512, drloco/config/hypers.py:98-99; 64 has the launch form only)')
     ap.add_argument('--randomize', action='store_true', help='not the benchmark configuration: BASELINE config 5 stress test -- per-walker mass scale U[0.8,1.2], floor friction U[0.5,1.1], 50 N horizontal pushes on the torso for 0.1 s every 2 s at a random phase (keyed by the global walker index)')
     ap.add_argument('--profile-every', type=int, default=1, help='bracket every k-th launch of the env-step kernel with HIP events (roofline.avg_launch_us); events between kernels cost launch gap, so the default samples')
     ap.add_argument('--runs', type=str, default='', help='control steps per dl_rollout_fixed call = per launch of the 16-lane kernel (each <= 512) in the policy-free configuration, e.g. 448,64; default: ONE launch for the rollout (the 16-lane kernels; tools/prof_step.py issues the same schedule for the PMC passes)')
@@ -341,7 +342,7 @@ def main():
     policy = None
     if args.policy:
         from drloco_amd.policy import HipPolicy
-        policy = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=512, seed=99, index_base=rank * n)
+        policy = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=args.hidden, seed=99, index_base=rank * n)
 
     group = None
     if args.policy and args.handles > 1:
@@ -465,7 +466,7 @@ def main():
         # reported only for the configuration that pass measured AND only while the kernel sources are the ones it measured
         traffic = valu_busy = mfma_busy = prof_origin = None
         base_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs and not args.no_split and not args.vn_single_steps
-        persistent_line = args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent' and args.handles == 1
+        persistent_line = args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent' and args.handles == 1 and args.hidden == 512
         tname = None          # which committed pass belongs to this command line (profiles/, written by tools/summarize_profile.py)
         if base_cfg and not args.policy:
             tname = 'traffic_env_step.json'
@@ -492,7 +493,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('loco3d 19-dof walker (synthetic mocap table), ' if args.walker == 'loco3d' else 'straight_walking 3D walker, ') + f'{n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
-                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': ('device policy (dl_policy_forward)' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': (f'device policy (dl_policy_forward, {venv.obs_dim}-{args.hidden}-{args.hidden}-{{{venv.nu},1}})' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else ('side stream, one dl_vecnormalize_steps call per run' if not args.vn_single_steps else 'side stream, under the following run of env steps'),
                        'step_kernel_form': 'split workgroups: 4 dynamics + 4 constraint waves per 16 walkers (dl_set_split 1)' if split else 'one wave per 4 walkers',
                        'env_launches': (('ONE persistent launch per rollout (k_rollout_pairs: every wave pair takes its four walkers through policy + env step, moments per rollout (relaxation))' if args.moments == 'per_rollout' else 'ONE persistent launch per rollout (k_rollout_persistent: policy + env step + moment exchange per control step), exact per-step moments')

@@ -755,8 +755,11 @@ void k_rollout_persistent(const RolloutArgs<TP> args_by_value) {
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
             const int nlim = b1 * 16 < n ? b1 * 16 : n;          // rows of THIS workgroup's blocks only (a pass of two blocks may reach beyond its last one)
-            pol_forward_rows<4, 8, true, true, RBK>(a.pol, a.observations + (size_t)t * n * D, nlim, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, a.deterministic,
-                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.pk);
+#define DL_RP_ROWS(NTW) pol_forward_rows<NTW, 8, true, true, RBK>(a.pol, a.observations + (size_t)t * n * D, nlim, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, a.deterministic, \
+                                   a.actions + (size_t)t * n * NU, a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)smem, row0, false, tid_t, a.pk)
+            const int hid = a.pol.hidden;          // (uniform; checked by the host: 512 / 256 / 128 = eight waves x 4 / 2 / 1 tiles -- drloco/config/hypers.py:98-99 makes the hidden sizes a config)
+            if (hid == 512) DL_RP_ROWS(4); else if (hid == 256) DL_RP_ROWS(2); else DL_RP_ROWS(1);
+#undef DL_RP_ROWS
         }
         __syncthreads();          // the actions of the pass's rows are in memory (workgroup scope); the policy's LDS is free again
         DL_RP_TICK(0);
@@ -1000,8 +1003,11 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
                 vf.obs_out = a.observations + (size_t)t * n * D; vf.rew_out = a.rewards + (size_t)(t - 1) * n;
                 vf.eps = a.eps; vf.clip_obs = a.clip_obs; vf.clip_rew = a.clip_rew; vf.flags = flags;
             }
-            pol_forward_pair(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, a.deterministic, a.actions + (size_t)t * n * NU,
-                             a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)(base + Sp::TOTAL), blk * 16 + gslot * 4, role, lane_p, a.pk, pair_sync);
+#define DL_RP_PAIR(HH) pol_forward_pair<HH>(a.pol, a.observations + (size_t)t * n * D, n, nullptr, a.seed, a.counter0 + (uint64_t)t, a.index_base, a.deterministic, a.actions + (size_t)t * n * NU, \
+                             a.values + (size_t)t * n, a.log_probs + (size_t)t * n, vf, (float*)(base + Sp::TOTAL), blk * 16 + gslot * 4, role, lane_p, a.pk, pair_sync)
+            const int hid = a.pol.hidden;          // (uniform; checked by the host: 512 / 256 / 128 -- the reference's hidden sizes are a config, drloco/config/hypers.py:98-99)
+            if (hid == 512) DL_RP_PAIR(512); else if (hid == 256) DL_RP_PAIR(256); else DL_RP_PAIR(128);
+#undef DL_RP_PAIR
         }
         // ---- E: one control step of the four walkers
         if (lane == 0 && role == 0) {
@@ -1443,18 +1449,19 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
 
     // ---- dl_collect_rollouts(DL_ROLLOUT_PERSISTENT): the whole rollout as one launch of k_rollout_persistent
     double* rp_partial = nullptr; double* rp_xpart = nullptr; unsigned* rp_sync = nullptr; long long* rp_prof = nullptr;
-    float* pol_packed = nullptr;      // pol_packed_floats(512): k-chunk-major copies of the policy's weights, refreshed by every rollout call
+    float* pol_packed = nullptr;      // pol_packed_floats(512) (room for any supported hidden size): k-chunk-major copies of the policy's weights, refreshed by every rollout call
     int n_cus = 0;
     int spin_grid = 1 << 22;      // polls of the grid exchange before a workgroup gives up (~2 s)
     int pack_policy(const dl_policy_params& pol, PolPacked* out, hipStream_t s) override {
         *out = PolPacked{nullptr, nullptr, nullptr};
-        if (pol.hidden != 512) return DL_OK;                  // the packed form is built for the eight-wave kernel
+        const int H = pol.hidden;
+        if (H != 512 && H != 256 && H != 128) return DL_OK;                  // the packed form is built for the eight-wave kernels
         int rc;
         if (!pol_packed && (rc = dalloc(&pol_packed, pol_packed_floats(512)))) return rc;
-        const int chunks = 512 * 128 + 12 * 512 + 128 * 16;
+        const int chunks = H * (H / 4) + 12 * H + (H / 4) * 16;
         hipLaunchKernelGGL(k_pack_policy, dim3((chunks + 255) / 256), dim3(256), 0, s, pol, pol_packed);
         HIPCHK(hipGetLastError());
-        out->w2p = pol_packed; out->w1p = pol_packed + (size_t)512 * 512; out->whp = out->w1p + (size_t)48 * 512;
+        out->w2p = pol_packed; out->w1p = pol_packed + (size_t)H * H; out->whp = out->w1p + (size_t)48 * H;
         return DL_OK;
     }
     int persistent_ok(int hidden, std::string* why) override {
@@ -1462,7 +1469,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if constexpr (!CAN_PERSIST) return no("the persistent rollout kernel exists for the 16-lane float32 kernels of the lane-only (straight) walker");
         else {
             if (!(variant == 1 && gmd)) return no("the persistent rollout kernel needs the 16-lane kernels (lanes_per_walker = 16)");
-            if (hidden != 512) return no("the persistent rollout kernel is built for hidden = 512 (eight waves per workgroup)");
+            if (hidden != 512 && hidden != 256 && hidden != 128) return no("the persistent rollout kernels are built for hidden = 512, 256 or 128 (eight waves per workgroup x 4 / 2 / 1 tiles)");
             if (inj_armed) return no("injected states are pending");
             if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cus = 0; }
             if (n_cus <= 0 || (n + 15) / 16 > n_cus * rp_kblocks<TP>()) return no(rp_kblocks<TP>() > 1 ? "more than 128 walkers per CU: a workgroup of the persistent rollout kernel takes at most eight blocks of sixteen walkers" : "more than 16 walkers per CU: this walker's workgroups take one block of sixteen walkers");
@@ -2040,26 +2047,30 @@ static int policy_launch(const dl_policy_params* p, const float* obs, int32_t n,
     if (!p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->wa || !p->ba || !p->wv || !p->bv || !p->log_std) return fail(DL_E_INVAL, "dl_policy_forward: NULL parameter array");
     if (p->hidden <= 0 || p->hidden % 64 || p->hidden > 64 * POL_MAXT || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15)
         return fail(DL_E_INVAL, "dl_policy_forward: hidden must be a multiple of 64 and <= 512, obs_dim <= 48, act_dim <= 15");
-    const int nw = p->hidden == 512 ? 8 : 4;                    // waves per workgroup
+    // hidden = 512 / 256 / 128 run as EIGHT waves x 4 / 2 / 1 tiles (the form the persistent rollout kernels call: the heads' eight partial sums, hence the bits, are the same
+    // in every form); hidden = 64 as four waves x 1 tile
+    const int nw = p->hidden >= 128 ? 8 : 4;                    // waves per workgroup
+    const int H = p->hidden;
     const size_t lds = pol_lds_bytes(nw);                       // 23 KB (8 waves): below the default limit, no attribute needed on any device
     const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(64 * nw);
 #define DL_POL_LAUNCH(NTW, NW) \
     hipLaunchKernelGGL((k_policy_forward<NTW, NW>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, PolPacked{nullptr, nullptr, nullptr});
+#define DL_POL_LAUNCH8(NTW) \
+            if (n <= POL_ROWS * 256 && pk.w2p) {   /* ... and with the hidden layer's weights packed by the caller of a whole rollout (same arithmetic: bit-identical) */ \
+                hipLaunchKernelGGL((k_policy_forward<NTW, 8, true, true>), grid, block, pol_lds_bytes_whole(8, H), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk); \
+            } else if (n <= POL_ROWS * 256) {   /* at most one workgroup per CU on an MI355X: the barrier-free form with the whole h1 block in LDS (51 KB for 512) */ \
+                hipLaunchKernelGGL((k_policy_forward<NTW, 8, true>), grid, block, pol_lds_bytes_whole(8, H), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, PolPacked{nullptr, nullptr, nullptr}); \
+            } else if (pk.w2p) {                /* more rows than one workgroup per CU: the lean (23 KB) form, packed weights */ \
+                hipLaunchKernelGGL((k_policy_forward<NTW, 8, false, true>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk); \
+            } else DL_POL_LAUNCH(NTW, 8)
     switch (p->hidden / 64) {
         case 1: DL_POL_LAUNCH(1, 4) break;
-        case 2: DL_POL_LAUNCH(2, 4) break;
-        case 4: DL_POL_LAUNCH(4, 4) break;
-        case 8:
-            if (n <= POL_ROWS * 256 && pk.w2p) {   // ... and with the hidden layer's weights packed by the caller of a whole rollout (same arithmetic: bit-identical)
-                hipLaunchKernelGGL((k_policy_forward<4, 8, true, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk);
-            } else if (n <= POL_ROWS * 256) {   // at most one workgroup per CU on an MI355X: the barrier-free form with the whole h1 block in LDS (51 KB)
-                hipLaunchKernelGGL((k_policy_forward<4, 8, true>), grid, block, pol_lds_bytes_whole(8, 512), (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, PolPacked{nullptr, nullptr, nullptr});
-            } else if (pk.w2p) {                // more rows than one workgroup per CU: the lean (23 KB) form, packed weights
-                hipLaunchKernelGGL((k_policy_forward<4, 8, false, true>), grid, block, lds, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, vf, pk);
-            } else DL_POL_LAUNCH(4, 8)
-            break;
+        case 2: DL_POL_LAUNCH8(1) break;
+        case 4: DL_POL_LAUNCH8(2) break;
+        case 8: DL_POL_LAUNCH8(4) break;
         default: return fail(DL_E_INVAL, "dl_policy_forward: hidden must be 64, 128, 256 or 512");
     }
+#undef DL_POL_LAUNCH8
 #undef DL_POL_LAUNCH
     HIPCHK(hipGetLastError());
     return DL_OK;
@@ -2072,8 +2083,9 @@ int dl_policy_forward(const dl_policy_params* p, const float* obs, int32_t n, co
 }
 int dl_policy_pack(const dl_policy_params* p, float* packed, void* stream) {
     if (!p || !packed || !p->w1 || !p->w2 || !p->wa || !p->wv) return fail(DL_E_INVAL, "dl_policy_pack: bad arguments");
-    if (p->hidden != 512 || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15) return fail(DL_E_INVAL, "dl_policy_pack: the packed layout exists for hidden = 512 (obs_dim <= 48, act_dim <= 15)");
-    const int chunks = 512 * 128 + 12 * 512 + 128 * 16;
+    const int H = p->hidden;
+    if ((H != 512 && H != 256 && H != 128) || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15) return fail(DL_E_INVAL, "dl_policy_pack: the packed layout exists for hidden = 512, 256, 128 (obs_dim <= 48, act_dim <= 15)");
+    const int chunks = H * (H / 4) + 12 * H + (H / 4) * 16;
     hipLaunchKernelGGL(k_pack_policy, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed);
     HIPCHK(hipGetLastError());
     return DL_OK;
@@ -2084,17 +2096,20 @@ int dl_policy_forward_packed(const dl_policy_params* p, const float* packed, con
     PolVnFuse none{};
     PolPacked pk{nullptr, nullptr, nullptr};
     if (packed) {
-        if (!p || p->hidden != 512) return fail(DL_E_INVAL, "dl_policy_forward_packed: the packed layout exists for hidden = 512");
-        pk.w2p = packed; pk.w1p = packed + (size_t)512 * 512; pk.whp = pk.w1p + (size_t)48 * 512;
+        if (!p || (p->hidden != 512 && p->hidden != 256 && p->hidden != 128)) return fail(DL_E_INVAL, "dl_policy_forward_packed: the packed layout exists for hidden = 512, 256, 128");
+        pk.w2p = packed; pk.w1p = packed + (size_t)p->hidden * p->hidden; pk.whp = pk.w1p + (size_t)48 * p->hidden;
     }
     return policy_launch(p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, none, stream, pk);
 }
 int dl_policy_forward_pair(const dl_policy_params* p, const float* packed, const float* obs, int32_t n, const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
                            int32_t deterministic, float* actions, float* values, float* log_probs, void* stream) {
     if (!p || !packed || !obs || !actions || !values || !log_probs || n <= 0) return fail(DL_E_INVAL, "dl_policy_forward_pair: bad arguments");
-    if (p->hidden != 512 || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15) return fail(DL_E_INVAL, "dl_policy_forward_pair: hidden = 512, obs_dim <= 48, act_dim <= 15");
-    PolPacked pk{packed, packed + (size_t)512 * 512, packed + (size_t)512 * 512 + (size_t)48 * 512};
-    hipLaunchKernelGGL(k_policy_forward_pair, dim3((n + 3) / 4), dim3(128), 0, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, pk);
+    const int H = p->hidden;
+    if ((H != 512 && H != 256 && H != 128) || p->obs_dim <= 0 || p->obs_dim > 48 || p->act_dim <= 0 || p->act_dim > 15) return fail(DL_E_INVAL, "dl_policy_forward_pair: hidden = 512, 256 or 128, obs_dim <= 48, act_dim <= 15");
+    PolPacked pk{packed, packed + (size_t)H * H, packed + (size_t)H * H + (size_t)48 * H};
+#define DL_PAIR_LAUNCH(HH) hipLaunchKernelGGL(k_policy_forward_pair<HH>, dim3((n + 3) / 4), dim3(128), 0, (hipStream_t)stream, *p, obs, n, eps, seed, counter, index_base, deterministic, actions, values, log_probs, pk)
+    if (H == 512) DL_PAIR_LAUNCH(512); else if (H == 256) DL_PAIR_LAUNCH(256); else DL_PAIR_LAUNCH(128);
+#undef DL_PAIR_LAUNCH
     HIPCHK(hipGetLastError());
     return DL_OK;
 }

@@ -84,7 +84,7 @@ def evaluate_walking(eval_env, policy, n_saved_models=0, chunk=None, persistent=
     """Play the first episode of every walker of `eval_env` (from make_eval_env) with the deterministic policy and return the statistics
     eval_walking computes (same names as the TrainingMonitor attributes, callback.py:322-345,367-378).
     ONE device call: dl_collect_rollouts over `ep_dur_max` control steps with DL_ROLLOUT_DETERMINISTIC (the persistent one-launch form
-    where it exists: straight walker, float32, hidden = 512; three launches per control step enqueued without a host round trip
+    where it exists: float32, 16 lanes per walker, hidden = 512 / 256 / 128; three launches per control step enqueued without a host round trip
     otherwise), then three dl_stats_snapshot reads.  chunk: control steps per call (default: the whole episode budget in one call); with a
     smaller chunk the host looks between calls whether every walker has finished and stops early.  `policy`: a HipPolicy."""
     import ctypes as C

@@ -35,10 +35,10 @@ class HipPolicy:
         self._packed, self._packed_key, self._packed_stream = None, None, None
 
     def _packed_weights(self):
-        """k-chunk-major copy of the weights for the stand-alone forward pass (hidden = 512), refreshed whenever a weight tensor was replaced
+        """k-chunk-major copy of the weights for the stand-alone forward pass (hidden = 512 / 256 / 128), refreshed whenever a weight tensor was replaced
         (load_state) or written to (torch bumps `tensor._version` on every in-place update, e.g. an optimiser step) or the caller moved to
         another stream (the copy is written and read in stream order: the key carries the stream, a repack waits for the last read)."""
-        if self.hidden != 512:
+        if self.hidden not in (512, 256, 128):
             return None
         ws = (self.w1, self.w2, self.wa, self.wv)
         stream = torch.cuda.current_stream()
@@ -47,8 +47,9 @@ class HipPolicy:
         except RuntimeError:          # inference-mode tensors have no version counter: repack every time
             key = None
         if key is None or key != self._packed_key:
-            if self._packed is None:
-                self._packed = torch.empty(512 * 512 + 48 * 512 + 16 * 512, device=self.w1.device)
+            h = self.hidden
+            if self._packed is None or self._packed.numel() != h * h + 48 * h + 16 * h:
+                self._packed = torch.empty(h * h + 48 * h + 16 * h, device=self.w1.device)
             if self._packed_stream is not None and self._packed_stream != stream:
                 stream.wait_stream(self._packed_stream)          # a forward pass on the other stream may still be reading the old copy
             p = self._params()

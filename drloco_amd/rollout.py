@@ -42,7 +42,7 @@ class HipRolloutBuffer:
         policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]: the normalised observation and episode-start flags that
         open this rollout -- overwritten with the ones that open the next (SB3's _last_obs / _last_episode_starts).
         persistent: True = ONE launch for the whole rollout (a persistent workgroup per sixteen walkers, one grid-wide exchange per control
-        step; float32, hidden = 512, <= 128 walkers per CU (19-dof walker: <= 16 per CU); needs the GPU to itself -- the call waits for the launch and raises DrlocoFault if
+        step; float32, hidden = 512 / 256 / 128, <= 128 walkers per CU (19-dof walker: <= 16 per CU); needs the GPU to itself -- the call waits for the launch and raises DrlocoFault if
         the exchange timed out), False = three launches per control step, None = persistent where it exists, falling back to the launch form
         (walkers reset, moments restored, a warning) if the exchange times out.
         moments: 'per_step' (SB3's semantics, default) or 'per_rollout' (opt-in relaxation, persistent form only: the whole rollout is

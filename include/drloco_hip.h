@@ -361,7 +361,7 @@ int dl_policy_forward(const dl_policy_params* params, const float* obs, int32_t 
                       uint64_t seed, uint64_t counter, int32_t index_base, int32_t deterministic,
                       float* actions, float* values, float* log_probs, void* stream);
 
-/* The same forward pass reading the weights from a k-chunk-major copy (hidden = 512): in torch's [out][in] layout the 16 lanes of a quarter-wave
+/* The same forward pass reading the weights from a k-chunk-major copy (hidden = 512, 256 or 128): in torch's [out][in] layout the 16 lanes of a quarter-wave
  * read 16 bytes from 16 different rows (64 cache lines per wave instruction), packed they read one contiguous 256-byte run -- 29 instead of 40 us for
  * 4096 rows, bit-identical results.  dl_policy_pack writes the copy (DL_POLICY_PACKED_FLOATS(512) floats, device memory; call it again whenever
  * the weights change -- dl_collect_rollouts / dl_rollout_policy do so themselves, once per call); packed == NULL = dl_policy_forward. */
@@ -371,7 +371,7 @@ int dl_policy_forward_packed(const dl_policy_params* params, const float* packed
                              const float* eps, uint64_t seed, uint64_t counter, int32_t index_base,
                              int32_t deterministic, float* actions, float* values, float* log_probs, void* stream);
 
-/* The same forward pass in its four-rows-per-wave-pair form (packed weights, hidden = 512): a workgroup of two waves per four rows on
+/* The same forward pass in its four-rows-per-wave-pair form (packed weights, hidden = 512, 256 or 128): a workgroup of two waves per four rows on
  * v_mfma_f32_4x4x1_16B_f32, every sum in the order of dl_policy_forward -- bit-identical outputs (tests/test_gpu_persistent.py::test_policy_pair_form_is_the_forward_pass_bit_for_bit).  It is the building
  * block that lets a wave pair of the persistent rollout kernel evaluate the policy of its own four walkers; stand-alone it is a reference for that. */
 int dl_policy_forward_pair(const dl_policy_params* params, const float* packed, const float* obs, int32_t n,
@@ -423,7 +423,7 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
  *       control step, the policy forward of its own rows (matrix cores), MimicEnv.step of its walkers (the split-workgroup step kernel's code)
  *       and VecNormalize's moment update through one grid-wide exchange.  Exact SB3 semantics (every step normalises with the moments of all
  *       walkers up to that step); bit-identical to mode 0 when `vn->flags` selects the blocked reduction order (bit 32) and dl_set_split is on.
- *       Needs: float32, 16 lanes per walker, hidden = 512, at most 128 walkers per CU for the straight walker (32768 on an MI355X; above 16 per CU a workgroup takes several blocks of sixteen walkers per control step) -- query with
+ *       Needs: float32, 16 lanes per walker, hidden = 512, 256 or 128 (eight waves x 4 / 2 / 1 tiles; the reference's sizes are a config, drloco/config/hypers.py:98-99), at most 128 walkers per CU for the straight walker (32768 on an MI355X; above 16 per CU a workgroup takes several blocks of sixteen walkers per control step) -- query with
  *       dl_rollout_persistent_ok (1 / 0); DL_E_INVAL otherwise.  The 19-dof walker (ABI 6): one block per workgroup, i.e. at most 16 walkers per CU (4096).  EXCLUSIVE GPU: the grid-wide exchange needs every workgroup of the launch resident at
  *       the same time (one per CU), so no other process, stream or handle may hold CUs while it runs -- dl_rollout_persistent_ok only checks the
  *       walker count, it cannot see other users of the device.  A grid exchange that does not complete within its (bounded, ~2 s) poll budget raises

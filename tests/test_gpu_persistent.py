@@ -19,7 +19,7 @@ def torch_cuda():
     return torch
 
 
-def _setup(torch, model, refs, n, T, seed=21, **vn_kw):
+def _setup(torch, model, refs, n, T, seed=21, hidden=512, **vn_kw):
     from drloco_amd.policy import HipPolicy
     from drloco_amd.rollout import HipRolloutBuffer
     from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
@@ -27,7 +27,7 @@ def _setup(torch, model, refs, n, T, seed=21, **vn_kw):
     venv.set_split(True)
     vn = HipVecNormalize(venv, **vn_kw)
     vn.blocked_reduce = True
-    pol = HipPolicy(hidden=512, seed=4)
+    pol = HipPolicy(hidden=hidden, seed=4)
     buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
     vn.reset()
     return venv, vn, pol, buf, vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
@@ -37,10 +37,21 @@ def _setup(torch, model, refs, n, T, seed=21, **vn_kw):
                          ids=['full-size', 'ragged-63-workgroups', 'one-workgroup', 'partly-filled-workgroup', 'two-blocks-per-workgroup', 'ragged-two-blocks',
                               'three-blocks-crossing-group-boundaries'])
 def test_persistent_rollout_is_the_launch_path_bit_for_bit(torch_cuda, model, refs, n, T):
-    torch = torch_cuda
+    _persistent_vs_launches(torch_cuda, model, refs, n, T, 512)
+
+
+@pytest.mark.parametrize('hidden', [256, 128])
+@pytest.mark.parametrize('n,T', [(1000, 33), (5, 9), (6000, 8)], ids=['ragged-63-workgroups', 'partly-filled-workgroup', 'two-blocks-per-workgroup'])
+def test_persistent_rollout_other_hidden_sizes(torch_cuda, model, refs, n, T, hidden):
+    """The reference's hidden sizes are a config (drloco/config/hypers.py:98-99; default [512, 512]): 256 and 128 run through the same persistent kernel as eight
+    waves x 2 / 1 tiles, bit-identical to the launch path (whose dl_policy_forward uses the same eight-wave form)."""
+    _persistent_vs_launches(torch_cuda, model, refs, n, T, hidden)
+
+
+def _persistent_vs_launches(torch, model, refs, n, T, hidden):
     res = []
     for persistent in (False, True):
-        venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
+        venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T, hidden=hidden)
         for rollout in range(2):                                # the second rollout starts from the first one's last observation and moments
             buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=persistent)
             assert buf.last_form == ('persistent' if persistent else 'launches')
@@ -79,12 +90,13 @@ def test_persistent_rollout_flag_combinations(torch_cuda, model, refs, kw, n):
         assert torch.equal(x, y), kw
 
 
-@pytest.mark.parametrize('n', [1000, 4096, 6000], ids=['one-block-per-workgroup', 'full-size', 'two-blocks-per-workgroup'])
-def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs, n):
+@pytest.mark.parametrize('n,hidden', [(1000, 512), (4096, 512), (6000, 512), (1000, 256), (4096, 128)],
+                         ids=['one-block-per-workgroup', 'full-size', 'two-blocks-per-workgroup', 'hidden-256', 'hidden-128-full-size'])
+def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs, n, hidden):
     torch = torch_cuda
     from drloco_amd.vec_env import HipVecEnv
     T = 48
-    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T)
+    venv, vn, pol, buf, last_obs, last_done = _setup(torch, model, refs, n, T, hidden=hidden)
     # give the moments a non-trivial start: one exact rollout first
     buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
     torch.cuda.synchronize()
@@ -119,7 +131,7 @@ def test_persistent_rollout_with_per_rollout_moments(torch_cuda, model, refs, n)
     np.testing.assert_allclose(buf.rewards.cpu().numpy(), exp_rew, rtol=0, atol=1e-6)
     # (3) the policy's outputs are those of dl_policy_forward on the recorded observations (same counter stream)
     from drloco_amd.policy import HipPolicy
-    p2 = HipPolicy(hidden=512, seed=4)
+    p2 = HipPolicy(hidden=hidden, seed=4)
     p2.counter = counter0
     for t in range(T):          # EVERY step (the 4x4x1 defect of round 4 showed in about one row in a thousand: dl_policy_pair.hpp)
         p2.counter = counter0 + t
@@ -287,7 +299,7 @@ def test_persistent_form_refusals(torch_cuda, model, refs):
         torch.cuda.synchronize()
         return buf.last_form
     # other hidden sizes, float64, one lane per walker, too many walkers: the automatic choice is the launch form, an explicit request raises
-    for venv, pol in ((HipVecEnv(num_envs=64, model=model, refs=refs), HipPolicy(hidden=128)), (HipVecEnv(num_envs=64, model=model, refs=refs, precision=64), HipPolicy(hidden=512)),
+    for venv, pol in ((HipVecEnv(num_envs=64, model=model, refs=refs), HipPolicy(hidden=64)), (HipVecEnv(num_envs=64, model=model, refs=refs, precision=64), HipPolicy(hidden=512)),
                       (HipVecEnv(num_envs=64, model=model, refs=refs, lanes_per_walker=1), HipPolicy(hidden=512)), (HipVecEnv(num_envs=32784, model=model, refs=refs), HipPolicy(hidden=512))):
         assert attempt(venv, pol) == 'launches'
         with pytest.raises(L.DrlocoError):
@@ -464,13 +476,14 @@ def test_grid_exchange_timeout_falls_back_in_auto_mode(torch_cuda, model, refs):
     venv.close()
 
 
-def test_policy_forms_agree_bit_for_bit(torch_cuda):
+@pytest.mark.parametrize('hidden', [512, 256, 128])
+def test_policy_forms_agree_bit_for_bit(torch_cuda, hidden):
     """dl_policy_forward picks its form by batch size (<= 4096 rows: the whole first-layer block staged in LDS, barrier-free hidden layer;
     above: the lean 23 KB form that fits next to env-step workgroups); rollouts add the packed weight layout.  Same order of arithmetic in
     all of them: the first 4096 rows of an 8192-row call (lean) equal a 4096-row call (whole) bit for bit."""
     torch = torch_cuda
     from drloco_amd.policy import HipPolicy
-    pol = HipPolicy(hidden=512, seed=11)
+    pol = HipPolicy(hidden=hidden, seed=11)
     g = torch.Generator(device='cuda'); g.manual_seed(2)
     obs = torch.randn(8192, 29, device='cuda', generator=g)
     eps = torch.randn(8192, 8, device='cuda', generator=g)
@@ -496,7 +509,8 @@ def test_policy_forms_agree_bit_for_bit(torch_cuda):
     torch.cuda.synchronize()
     assert not torch.equal(a9, a4[:64]) and torch.allclose(a9, ref, atol=2e-5)
 
-def test_policy_pair_form_is_the_forward_pass_bit_for_bit(torch_cuda):
+@pytest.mark.parametrize('hidden', [512, 256, 128])
+def test_policy_pair_form_is_the_forward_pass_bit_for_bit(torch_cuda, hidden):
     """dl_policy_forward_pair (four rows per wave pair on v_mfma_f32_4x4x1_16B_f32, single-k instructions issued in the order in which the 16x16x4 tiles of
     dl_policy_forward accumulate) gives the same bits: sampled actions with given draws and with the counter-based stream, deterministic actions, values,
     log-probabilities; ragged row counts."""
@@ -505,7 +519,7 @@ def test_policy_pair_form_is_the_forward_pass_bit_for_bit(torch_cuda):
     from drloco_amd import lib as L
     from drloco_amd.policy import HipPolicy
     from drloco_amd.vec_env import _ptr, _stream
-    pol = HipPolicy(hidden=512, seed=11)
+    pol = HipPolicy(hidden=hidden, seed=11)
     g = torch.Generator(device='cuda'); g.manual_seed(5)
     for n in (4096, 1001, 6, 3):
         obs = 3.0 * torch.randn(n, 29, device='cuda', generator=g)
