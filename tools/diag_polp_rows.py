@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Count the wrong policy rows of the per-rollout kernel (k_rollout_pairs) of whatever library DL_LIB_PATH names: every recorded action / value of R rollouts of
 T steps x 4096 walkers is recomputed from its recorded observation with dl_policy_forward and compared bit for bit.  The product library gives 0; the variants of
-tools/asm_bisect.py give the round-4 defect or not (EXPERIMENTS.md, "the 4x4x1 defect, found").  GPU box; POLP_R = number of rollouts (default 4 = 524 288 rows)."""
+tools/asm_bisect.py give the round-4 defect or not (EXPERIMENTS.md, "the 4x4x1 defect, found").  GPU box; POLP_R = number of rollouts (default 4 = 524 288 rows), POLP_HIDDEN = 512 / 256 / 128."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,15 +11,16 @@ from drloco_amd.rollout import HipRolloutBuffer
 from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
 
 n, T, R = 4096, 32, int(os.environ.get('POLP_R', '4'))
+HID = int(os.environ.get('POLP_HIDDEN', '512'))
 venv = HipVecEnv(num_envs=n, seed=21)
 venv.set_split(True)
 vn = HipVecNormalize(venv)
 vn.blocked_reduce = True
 vn.reset()
-pol = HipPolicy(hidden=512, seed=4)
+pol = HipPolicy(hidden=HID, seed=4)
 buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
 lo, ld = vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
-p2 = HipPolicy(hidden=512, seed=4)
+p2 = HipPolicy(hidden=HID, seed=4)
 bad = rows = 0
 byrow = [0, 0, 0, 0]
 for r in range(R):
@@ -39,4 +40,4 @@ for r in range(R):
         idx = w.nonzero()[:, 0]
         for k in range(4):
             byrow[k] += int((idx % 4 == k).sum())
-print(os.environ.get('DL_LIB_PATH', 'product').split('/')[-1], ': wrong rows', bad, 'of', rows, '; by row of the pair', byrow)
+print(os.environ.get('DL_LIB_PATH', 'product').split('/')[-1], 'hidden', HID, ': wrong rows', bad, 'of', rows, '; by row of the pair', byrow)
