@@ -42,7 +42,7 @@
 #define DL_SLEEP_N 1        // s_sleep argument of a poll (64 cycles per unit).  Round 5, A/B on one box against 16 (rounds 2-4) / 4 / 2 / 48: 1 is best on every line (+0.6 % headline, +1.4 % 19-dof walker, +0.8 / +1.1 % policy lines): the partner's reaction time is on the dynamics wave's critical path at every commit
 #endif
 #define DL_SLEEP() __builtin_amdgcn_s_sleep(DL_SLEEP_N)        // a waiting wave of a split workgroup: 64 x N cycles, cut short by the partner's s_wakeup
-#define DL_WAKE() asm volatile("s_wakeup")
+#define DL_WAKE() asm volatile("s_wakeup")          // NB (round 5, tools/ubench/snop_wakeup.hip): an s_wakeup also ENDS THE s_nop another wave of the workgroup is in, after one wait state.  The hand-written hazard padding of these kernels is the DPP one (g_dpp_ready, `s_nop 1`), for which one state is enough on gfx950 (measured beside a wave that loops over s_wakeup: 0 stale lanes with `s_nop 0`, 92 % with no wait); the policy kernels, whose MFMA results need 3 .. 10 states, wait with v_nop (dl_policy.hpp)
 // the hand-over between the two waves of a split pair is the one place where DIFFERENT waves exchange data through LDS: workgroup-scope
 // release before the flag store, acquire after the successful poll (g_sync's wavefront scope orders a wave against itself only)
 #ifdef DL_EXP_NO_WG_FENCE       // experiment switch: wavefront scope only (the round-2 form)
@@ -368,7 +368,7 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, floa
 template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) {
     asm("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
-__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
+__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }          // (two states by the ISA manual; one is what gfx950 needs, and one is what is left of an s_nop that a partner's s_wakeup ends: see DL_WAKE)
 // max(bcast_K(x), lo): the row broadcast folded into the v_max.  The two wait states between the VALU write of x and its DPP read are
 // part of the statement: the register allocator may place a copy of x right before an asm statement, behind a separate g_dpp_ready.
 template <int K> __device__ __forceinline__ float max_bcast(float x, float lo) {

@@ -30,20 +30,26 @@ namespace dl {
 typedef float pf4 __attribute__((ext_vector_type(4)));
 
 // EVERY MFMA of the policy kernels is inline asm with the accumulator TIED to the destination ("+v": source C and destination are the same
-// registers) and every wait state around it written by hand -- hipcc pads nothing around inline asm, which is the point: its own padding behind
-// a v_mfma_f32_4x4x1 (4 wait states before an LDS store of the result) is what let one row in a thousand go stale inside the per-rollout kernel
-// (dl_policy_pair.hpp; found by patching the assembly in round 5 -- the relocated accumulators round 4 blamed are innocent, but the tied form
-// stays: it keeps the register allocator out of the chains and lets tools/check_mfma_overlap.py prove the listing of every build, rules R1 .. R5).
-// Measured on gfx950 (tools/ubench/mfma_ds_store.hip, profiles/r05_mfma_ds_store.txt): a reader of a 16x16x4 result needs 9 (LDS store) / 10 (VALU)
-// wait states, hipcc emits 10; of a 4x4x1 result 3 / 4, hipcc emits 4 -- and the kernel showed an event worth 2 more that no micro test reproduces.
+// registers) and every wait state around it written by hand, AS v_nop, NEVER AS s_nop.  Why (EXPERIMENTS.md, round 5, "the 4x4x1 defect, found";
+// tools/ubench/snop_wakeup.hip, profiles/r05_snop_wakeup.txt): **an s_wakeup executed by another wave of the workgroup ends the s_nop this wave is
+// in** -- whatever its count, it is over after one wait state (27 % of the readers 8 states behind a 4x4x1 saw the stale accumulator beside a wave
+// that loops over s_wakeup; none beside s_sleep, s_load, VALU, LDS, MFMA or memory streams; none when the wait is v_nop or split over several
+// s_nop).  The split workgroups hand over with s_sleep / s_wakeup (dl_group.hpp), so inside the rollout kernels any single s_nop can shrink to one
+// state: hipcc's own `s_nop 3` between a v_mfma_f32_4x4x1 and the LDS store of its result did, about once in a thousand rows (the round-4 defect of
+// dl_policy_pair.hpp; the relocated accumulators round 4 blamed are innocent).  hipcc pads nothing around inline asm, so the asm form is what keeps
+// its s_nop out of these kernels; tools/check_mfma_overlap.py proves on the listing of every build that the waits are there, counting an s_nop as
+// ONE state (rules R1 .. R5).  The need, measured (tools/ubench/mfma_ds_store.hip): a reader of a 16x16x4 result 9 (LDS store) / 10 (VALU) wait
+// states, of a 4x4x1 result 3 / 4.
 //   DL_MFMA16       the chain form: back to back on one accumulator (the 8-pass shape interlocks on an exactly matching source C) or interleaved;
 //   DL_MFMA16_OPEN  the first instruction after a VALU write of an operand (the zero-initialised accumulator): two wait states in front;
-//   DL_MFMA16_SETTLE before any other reader or writer of the accumulator: 20 wait states (the measured 10 + the 2 of the event + 8 of margin;
-//                   three times per forward pass and tile: nothing against the ~2000 MFMAs in between).
+//   DL_MFMA16_SETTLE before any other reader or writer of the accumulator: 16 x v_nop (three times per forward pass and tile).
+#define DL_VNOP2 "v_nop\n\tv_nop"
+#define DL_VNOP4 DL_VNOP2 "\n\t" DL_VNOP2
+#define DL_VNOP16 DL_VNOP4 "\n\t" DL_VNOP4 "\n\t" DL_VNOP4 "\n\t" DL_VNOP4
 #define DL_MFMA16(ACC, AV, BV) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
-#define DL_MFMA16_OPEN(ACC, AV, BV) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
-#define DL_MFMA16_PAD(ACC) asm volatile("s_nop 1" : "+v"(ACC))          // behind a VALU write of an accumulator whose first MFMA is a plain DL_MFMA16
-#define DL_MFMA16_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(ACC))
+#define DL_MFMA16_OPEN(ACC, AV, BV) asm volatile(DL_VNOP2 "\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
+#define DL_MFMA16_PAD(ACC) asm volatile(DL_VNOP2 : "+v"(ACC))          // behind a VALU write of an accumulator whose first MFMA is a plain DL_MFMA16
+#define DL_MFMA16_SETTLE(ACC) asm volatile(DL_VNOP16 : "+v"(ACC))
 
 __device__ __forceinline__ float pol_tanh(float x) {
     // 1 - 2 / (exp(2x) + 1); |error| < 2e-7 absolute

@@ -63,15 +63,13 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
     sync();
     const int colb = h * (H / 2) + l;             // this lane's column of column group cb: colb + 64 cb
     // one block of sixteen k: A fragments a[j] (k = 4 j .. 4 j + 3 of the lane's row), B fragments b[cb][j] (the same k of the lane's column in group cb)
-    // The 4x4x1 instructions are inline asm with the accumulator tied to the destination ("+v") and EVERY wait state behind them is written by hand.  History: as builtins, inside the
-    // rollout kernel (not in the stand-alone one), about one row in a thousand -- always the third of the four -- came out wrong by ~1e-2 while other pairs of the workgroup ran.
-    // Round 4 blamed the relocated accumulators the listing showed (destination != source C over a dying B register) and tied them.  Round 5 bisected the builtin build by patching
-    // its assembly (EXPERIMENTS.md, "the 4x4x1 defect, found"): ONE site carries the defect -- the last MFMA of the heads' single-accumulator chain, `s_nop 3`, then
-    // `ds_write2_b32 v0, v8, v9` storing rows 2 and 3 of the heads' partial sums.  hipcc's 4 wait states are one more than the store needs in isolation (3; a VALU reader needs 4:
-    // tools/ubench/mfma_ds_store.hip, where too few states give exactly this signature -- a stale FIRST data register = row 2), yet inside the kernel 3 and 4 states fail equally
-    // (~7e-4 of the rows) and 5 never did (0 of 10.5 M rows): some event delays that MFMA by two states and the compiler's padding does not cover it.  Relocation is innocent; what the
-    // tied form changed was that hipcc pads nothing around inline asm and the hand-written 12 states replaced its 4.  Now 20 before any reader (DL_POLP_SETTLE; measured need 3 / 4,
-    // plus the 2 of the event, plus margin), dependent instructions on different accumulators four apart in a block, the heads' single-accumulator chain four states apart.
+    // The 4x4x1 instructions are inline asm with the accumulator tied to the destination ("+v") and EVERY wait state behind them is written by hand, as v_nop (dl_policy.hpp).
+    // History: as builtins, inside the rollout kernel (not in the stand-alone one), about one row in a thousand -- always the third of the four -- came out wrong by ~1e-2 while
+    // other pairs of the workgroup ran.  Round 4 blamed the relocated accumulators the listing showed and tied them.  Round 5 bisected the builtin build by patching its assembly
+    // (EXPERIMENTS.md, "the 4x4x1 defect, found"): ONE site carries the defect -- the last MFMA of the heads' single-accumulator chain, hipcc's `s_nop 3`, then
+    // `ds_write2_b32 v0, v8, v9` storing rows 2 and 3 of the heads' partial sums (row 2 = the first data register the store reads) -- and then found the mechanism
+    // (tools/ubench/snop_wakeup.hip): another pair's s_wakeup ends the s_nop this wave is in after one wait state; the store needs three.  `s_nop 2` and `s_nop 3` failed alike, a
+    // second s_nop instruction in front (of any length) never did.  What the tied form really changed: hipcc pads nothing around inline asm, so its s_nop left the kernel.
 #ifdef DL_EXP_POLP_BUILTIN          // the round-4 form, for tools/asm_bisect.sh only: builtins, hipcc's own padding -- reproduces the stale row
 #define DL_POLP_MFMA(ACC, AV, BV) ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(AV, BV, ACC, 0, 0, 0)
 #define DL_POLP_SETTLE(ACC) ((void)0)
@@ -79,17 +77,17 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
 #define DL_POLP_HEAD_SETTLE(ACC) ((void)0)
 #else
 #define DL_POLP_MFMA(ACC, AV, BV) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
-#define DL_POLP_SETTLE(ACC) do { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(ACC[0])); _Pragma("unroll") for (int cb_ = 1; cb_ < NCB; cb_++) asm volatile("" : "+v"(ACC[cb_])); } while (0)          // (volatile asm statements keep their order: every accumulator's readers come behind the wait)
-#define DL_POLP_HEAD_MFMA(ACC, AV, BV) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))          // one accumulator, back to back: the wait states a dependent instruction needs
-#define DL_POLP_HEAD_SETTLE(ACC) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(ACC))
+#define DL_POLP_SETTLE(ACC) do { asm volatile(DL_VNOP16 : "+v"(ACC[0])); _Pragma("unroll") for (int cb_ = 1; cb_ < NCB; cb_++) asm volatile("" : "+v"(ACC[cb_])); } while (0)          // (volatile asm statements keep their order: every accumulator's readers come behind the wait)
+#define DL_POLP_HEAD_MFMA(ACC, AV, BV) asm volatile(DL_VNOP4 "\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))          // one accumulator, back to back: the wait states a dependent instruction needs
+#define DL_POLP_HEAD_SETTLE(ACC) asm volatile(DL_VNOP16 : "+v"(ACC))
 #endif
-    // (dependent instructions three wait states apart: with four accumulators the other three stand between, with two / one an s_nop fills up -- rule R5 of the checker)
+    // (dependent instructions three wait states apart: with four accumulators the other three stand between, with two / one v_nop fill up -- rule R5 of the checker)
 #ifdef DL_EXP_POLP_BUILTIN
 #define DL_POLP_GAP() ((void)0)
 #else
-#define DL_POLP_GAP() do { if constexpr (NCB == 2) asm volatile("s_nop 1"); else if constexpr (NCB == 1) asm volatile("s_nop 2"); } while (0)
+#define DL_POLP_GAP() do { if constexpr (NCB == 2) asm volatile(DL_VNOP2); else if constexpr (NCB == 1) asm volatile(DL_VNOP2 "\n\tv_nop"); } while (0)
 #endif
-#define DL_POLP_PAD(ACC) asm volatile("s_nop 1" : "+v"(ACC))          // behind the VALU write that zeroes an accumulator: two wait states before its first MFMA (rule R3; hipcc pads nothing in front of inline asm)
+#define DL_POLP_PAD(ACC) asm volatile(DL_VNOP2 : "+v"(ACC))          // behind the VALU write that zeroes an accumulator: two wait states before its first MFMA (rule R3; hipcc pads nothing in front of inline asm)
 #define DL_POLP_BLOCK(ACC, AF, BF)                                                                                       \
     _Pragma("unroll") for (int c = 0; c < 4; c++) _Pragma("unroll") for (int j = 0; j < 4; j++) {                        \
         _Pragma("unroll") for (int cb = 0; cb < NCB; cb++) DL_POLP_MFMA(ACC[cb], AF[j][c], BF[cb][j][c]);                \
@@ -184,7 +182,7 @@ __device__ __forceinline__ void pol_forward_pair(const dl_policy_params& p, cons
 #pragma unroll
                 for (int j = 0; j < 4; j++) DL_POLP_HEAD_MFMA(ha, a[j][c], b[j][c]);
         }
-        DL_POLP_HEAD_SETTLE(ha);          // <- the site of the round-4 defect: hipcc put `s_nop 3` here
+        DL_POLP_HEAD_SETTLE(ha);          // <- the site of the round-4 defect: hipcc put ONE `s_nop 3` here, and an s_wakeup of another pair can end it after one state
 #pragma unroll
         for (int i = 0; i < 4; i++) part[(w * 4 + i) * 16 + jo] = ha[i];
     }

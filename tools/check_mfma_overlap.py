@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """Static check of a `hipcc -S` listing for the MFMA forms the policy kernels rely on.
 
-Background (drloco_amd/csrc/dl_policy_pair.hpp, EXPERIMENTS.md "the 4x4x1 defect, found"): written as builtins, the per-rollout kernel stored a stale row of a
-v_mfma_f32_4x4x1 result about once in a thousand rows.  Round 4 blamed the relocated accumulators the listing showed (destination != source C, laid over a dying
-A / B operand) and tied every MFMA as inline asm; round 5 bisected the builtin build by patching its assembly and found ONE site: hipcc's 4 wait states between the
-last MFMA of a chain and the `ds_write2_b32` of its rows 2, 3 -- one more than the store needs in a micro test (tools/ubench/mfma_ds_store.hip: 3 for an LDS
-store, 4 for a VALU reader; 9 / 10 behind a 16x16x4), two fewer than it needed inside the kernel.  Because hipcc pads nothing around inline asm, the tied form
-puts every wait state in the source, and this tool proves on the listing of the product build that they are there, with margin:
+Background (drloco_amd/csrc/dl_policy.hpp, EXPERIMENTS.md "the 4x4x1 defect, found"): written as builtins, the per-rollout kernel stored a stale row of a
+v_mfma_f32_4x4x1 result about once in a thousand rows.  Round 4 blamed the relocated accumulators the listing showed and tied every MFMA as inline asm; round 5
+bisected the builtin build by patching its assembly to ONE site -- hipcc's `s_nop 3` between the last MFMA of a chain and the `ds_write2_b32` of its rows -- and
+then found the mechanism in a micro test (tools/ubench/snop_wakeup.hip): an s_wakeup executed by another wave of the workgroup ENDS THE s_nop THIS WAVE IS IN
+after one wait state.  The split workgroups hand over with s_sleep / s_wakeup, so in the rollout kernels no software-managed hazard may rest on an s_nop.
+hipcc pads nothing around inline asm: the tied form keeps its s_nop out, the hand-written waits are v_nop, and this tool proves on the listing of the product
+build that they are there -- counting EVERY instruction, an `s_nop N` too, as one wait state.  Measured need of a reader (tools/ubench/mfma_ds_store.hip):
+3 (LDS store) / 4 (VALU) states behind a 4x4x1, 9 / 10 behind a 16x16x4.
 
   R1  vdst != srcC and vdst overlaps srcA or srcB                                   (what round 4 blamed; any MFMA shape)        
   R2  vdst != srcC for a 4x4x1                                                      (no relocation at all in the small shape)                 
   R3  a VALU write of an A / B / C register less than 2 wait states before an MFMA  (hipcc pads nothing in front of inline asm)
-  R4  an MFMA's D read or written by anything but an MFMA taking it whole as srcC less than passes + 10 wait states later
-                                                                                    (2-pass 4x4x1: 12, 8-pass 16x16x4: 18 = the measured need of a VALU
-                                                                                     reader, passes + 2, the 2 states of the event seen in the kernel, and
-                                                                                     6 of margin; asm MFMAs only)
+  R4  an MFMA's D read or written by anything but an MFMA taking it whole as srcC less than passes + 6 wait states later
+                                                                                    (2-pass 4x4x1: 8, 8-pass 16x16x4: 14 = the measured need of a VALU
+                                                                                     reader, passes + 2, and 4 of margin; asm MFMAs only)
   R5  dependent 4x4x1 on the same accumulator less than 2 wait states apart         (asm MFMAs only; the larger shapes interlock)
 
 usage: tools/check_mfma_overlap.py <listing.s> [substring of a kernel name]      exit code 1 if a rule is violated.
-A wait state = one issued instruction (s_nop N = N + 1).  R4 / R5 follow every path: the fall-through and the target of each branch inside the
+A wait state = one issued instruction (`s_nop N`: ONE, see above).  R4 / R5 follow every path: the fall-through and the target of each branch inside the
 window (the layer loops end with MFMAs right in front of their back edge); R3 looks back inside the basic block only."""
 import re
 import sys
@@ -88,8 +89,9 @@ def parse(lines):
 
 
 def states(l):
-    op, _, rest = l.partition(' ')
-    return int(rest.strip(), 0) + 1 if op == 's_nop' else 1
+    """wait states an instruction is worth: ONE, also for `s_nop N` -- an s_wakeup of another wave of the workgroup ends an s_nop after one state
+    (tools/ubench/snop_wakeup.hip), and the rollout kernels' split workgroups hand over with s_wakeup"""
+    return 1
 
 
 def valu_write(l):
@@ -145,7 +147,7 @@ def check(path, name, items, report):
         if not in_asm:
             continue
         # R4 / R5: look ahead along every path (fall-through and branch targets) until D has settled
-        need4, need5 = passes(op) + 10, 2
+        need4, need5 = passes(op) + 6, 2
         seen, work, hit = set(), [(i + 1, 0)], None
         while work and hit is None:
             j, gone = work.pop()

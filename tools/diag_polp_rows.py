@@ -23,6 +23,8 @@ lo, ld = vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
 p2 = HipPolicy(hidden=HID, seed=4)
 bad = rows = 0
 byrow = [0, 0, 0, 0]
+by_t = [0] * T          # where in the rollout (the pairs of a workgroup start their first policy phase together and drift apart afterwards)
+by_pair = [0, 0, 0, 0]          # which pair of its workgroup
 for r in range(R):
     c0 = pol.counter
     try:
@@ -40,4 +42,9 @@ for r in range(R):
         idx = w.nonzero()[:, 0]
         for k in range(4):
             byrow[k] += int((idx % 4 == k).sum())
+            by_pair[k] += int(((idx // 4) % 4 == k).sum())
+        by_t[t] += int(w.sum())
 print(os.environ.get('DL_LIB_PATH', 'product').split('/')[-1], 'hidden', HID, ': wrong rows', bad, 'of', rows, '; by row of the pair', byrow)
+if bad:
+    print('   by control step of the rollout:', by_t)
+    print('   by pair of the workgroup:', by_pair)
