@@ -13,6 +13,8 @@ modes (what is padded with 12 wait states unless said otherwise):
   ds_not_site          every LDS successor except the heads' store
   site<N>              N extra wait states in front of the heads' store only (`ds_write2_b32 v0, v8, v9` behind the single-accumulator chain)
   site-1               one wait state FEWER there (s_nop 3 -> s_nop 2)
+  site_nop7            hipcc's `s_nop 3` there made ONE `s_nop 7` (8 states in one instruction: what an s_wakeup can end)
+  site_vnop4           ... made four `v_nop` (the same 4 states, which nothing can end)
   list                 print every non-MFMA successor of a 4x4x1 with its class, change nothing
 Prints the number of sites touched."""
 import re
@@ -79,6 +81,10 @@ for i, l in enumerate(lines):
                 out += PAD12; n += 1
     elif mode == 'ds_not_site' and kd == 'ds' and not is_site(nx):
         out += PAD12; n += 1
+    elif mode in ('site_nop7', 'site_vnop4') and is_site(nx):
+        assert lines[i + 1].strip() == 's_nop 3', lines[i + 1]
+        lines[i + 1] = '\ts_nop 7' if mode == 'site_nop7' else '\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop'
+        n += 1
     elif mode.startswith('site') and is_site(nx):
         extra = int(mode[4:])
         if extra < 0:
