@@ -230,8 +230,8 @@ def test_per_step_sync_refusals(torch_cuda, model, refs):
     venv.close()
 
 
-@pytest.mark.parametrize('n,T', [(4096, 12), (1000, 17), (5, 9)], ids=['full-size', 'ragged', 'partly-filled-workgroup'])
-def test_persistent_rollout_19dof_walker(torch_cuda, n, T):
+@pytest.mark.parametrize('n,T,hidden', [(4096, 12, 512), (1000, 17, 512), (5, 9, 512), (1000, 17, 256), (600, 11, 128)], ids=['full-size', 'ragged', 'partly-filled-workgroup', 'hidden-256', 'hidden-128'])
+def test_persistent_rollout_19dof_walker(torch_cuda, n, T, hidden):
     """BASELINE config 4's walker with a policy in the loop as ONE launch per rollout (round 5: the look-ahead split workgroups exist for the 19-dof walker,
     sixteen of its regions + the moments fit a CU's LDS): k_rollout_persistent<TopoWalker165> in the exact mode is the launch-per-step form bit for bit (split step
     kernel, blocked reduction order), and the per-rollout relaxation gives the same buffers on both of its kernels (pair by pair on v_mfma_f32_4x4x1, workgroup
@@ -248,7 +248,7 @@ def test_persistent_rollout_19dof_walker(torch_cuda, n, T):
         venv = HipVecEnv(models.WALKER_165CM, num_envs=n, seed=21, refs=table, ep_dur_max=10)          # episodes end (time-out) and reset inside the window
         venv.set_split(True)
         vn = HipVecNormalize(venv); vn.blocked_reduce = True
-        pol = HipPolicy(obs_dim=47, act_dim=13, hidden=512, seed=4)
+        pol = HipPolicy(obs_dim=47, act_dim=13, hidden=hidden, seed=4)
         buf = HipRolloutBuffer(T, n, 47, 13, torch.device('cuda'))
         vn.reset()
         return venv, vn, pol, buf, vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
