@@ -42,7 +42,7 @@
 #define DL_SLEEP_N 1        // s_sleep argument of a poll (64 cycles per unit).  Round 5, A/B on one box against 16 (rounds 2-4) / 4 / 2 / 48: 1 is best on every line (+0.6 % headline, +1.4 % 19-dof walker, +0.8 / +1.1 % policy lines): the partner's reaction time is on the dynamics wave's critical path at every commit
 #endif
 #define DL_SLEEP() __builtin_amdgcn_s_sleep(DL_SLEEP_N)        // a waiting wave of a split workgroup: 64 x N cycles, cut short by the partner's s_wakeup
-#define DL_WAKE() asm volatile("s_wakeup")          // NB (round 5, tools/ubench/snop_wakeup.hip): an s_wakeup also ENDS THE s_nop another wave of the workgroup is in, after one wait state.  The hand-written hazard padding of these kernels is the DPP one (g_dpp_ready, `s_nop 1`), for which one state is enough on gfx950 (measured beside a wave that loops over s_wakeup: 0 stale lanes with `s_nop 0`, 92 % with no wait); the policy kernels, whose MFMA results need 3 .. 10 states, wait with v_nop (dl_policy.hpp)
+#define DL_WAKE() asm volatile("s_wakeup")          // NB (round 5, tools/ubench/snop_wakeup.hip): an s_wakeup also ENDS THE s_nop another wave of the workgroup is in, after one wait state.  The hand-written hazard padding of these kernels is the DPP one (DL_DPP_NOP below: one state, `s_nop 0`, which cannot be shortened); the policy kernels, whose MFMA results need 3 .. 10 states, wait with v_nop (dl_policy.hpp)
 // the hand-over between the two waves of a split pair is the one place where DIFFERENT waves exchange data through LDS: workgroup-scope
 // release before the flag store, acquire after the successful poll (g_sync's wavefront scope orders a wave against itself only)
 #ifdef DL_EXP_NO_WG_FENCE       // experiment switch: wavefront scope only (the round-2 form)
@@ -368,26 +368,40 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, floa
 template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) {
     asm("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
-__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile("s_nop 1" : "+v"(a)); }          // (two states by the ISA manual; one is what gfx950 needs, and one is what is left of an s_nop that a partner's s_wakeup ends: see DL_WAKE)
-// max(bcast_K(x), lo): the row broadcast folded into the v_max.  The two wait states between the VALU write of x and its DPP read are
+// Wait states between a VALU write of a register and its read through DPP in the hand-written statements.  The ISA manual asks for two and hipcc pads its own DPP
+// instructions with `s_nop 1`; measured on gfx950 (tools/ubench/dpp_wait.hip, profiles/r05_dpp_wait.txt: seven producers x six DPP forms, alone, beside s_wakeup, beside
+// VALU + DPP work): with NO wait the read is stale, with ONE state never (0 of 8.3 G lane-reads).  And two states cannot be had from `s_nop 1` in these kernels anyway: a
+// partner's s_wakeup ends an s_nop after one state (tools/ubench/snop_wakeup.hip) -- rounds 2-4 ran on one state whenever that happened, bit-identical launch after launch.
+// So the product says what it relies on: ONE state, as `s_nop 0`, which nothing can shorten (+2.5 % headline, +3.6 % 19-dof walker against `s_nop 1`).
+// -DDL_DPP_WAIT=2 is the manual's padding in its wakeup-proof form (`s_nop 0` twice).  tools/check_dpp_hazards.py checks the listing against DL_DPP_WAIT.
+#ifndef DL_DPP_WAIT
+#define DL_DPP_WAIT 1
+#endif
+#if DL_DPP_WAIT == 2
+#define DL_DPP_NOP "s_nop 0\n\ts_nop 0"
+#else
+#define DL_DPP_NOP "s_nop 0"
+#endif
+__device__ __forceinline__ void g_dpp_ready(float& a) { asm volatile(DL_DPP_NOP : "+v"(a)); }
+// max(bcast_K(x), lo): the row broadcast folded into the v_max.  The wait between the VALU write of x and its DPP read (DL_DPP_NOP) is
 // part of the statement: the register allocator may place a copy of x right before an asm statement, behind a separate g_dpp_ready.
 template <int K> __device__ __forceinline__ float max_bcast(float x, float lo) {
     float d;
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x), "v"(lo), "n"(K));
+    asm(DL_DPP_NOP "\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x), "v"(lo), "n"(K));
     return d;
 }
 // x += bcast_K(x) * b for a chain of such steps on one register (each reads what the previous one wrote: wait states included, see max_bcast)
 template <int K> __device__ __forceinline__ void fmac_bcast_chain(float& x, float b) {
-    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
+    asm(DL_DPP_NOP "\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
 // one wait for a whole group of values that are about to be read through DPP
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) {
-    if constexpr (NV == 2) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]));
-    else if constexpr (NV == 3) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
-    else if constexpr (NV == 4) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-    else if constexpr (NV == 6) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
-    else if constexpr (NV == 16) asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
-    else { for (int i = 0; i < NV; i++) asm volatile("s_nop 1" : "+v"(x[i])); }
+    if constexpr (NV == 2) asm volatile(DL_DPP_NOP : "+v"(x[0]), "+v"(x[1]));
+    else if constexpr (NV == 3) asm volatile(DL_DPP_NOP : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+    else if constexpr (NV == 4) asm volatile(DL_DPP_NOP : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else if constexpr (NV == 6) asm volatile(DL_DPP_NOP : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+    else if constexpr (NV == 16) asm volatile(DL_DPP_NOP : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+    else { for (int i = 0; i < NV; i++) asm volatile(DL_DPP_NOP : "+v"(x[i])); }
 }
 #else
 // host emulation: the generic forms (a DPP read followed by a multiply-add)

@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Static check of a `hipcc -S` listing for the gfx9 hazard the hand-written DPP statements have to respect themselves: a VGPR written by a VALU
-instruction may be read through DPP (src0 of a *_dpp instruction) only two wait states later.  Inline asm is opaque to the compiler's hazard
+instruction may be read through DPP (src0 of a *_dpp instruction) only NEED wait states later.  Inline asm is opaque to the compiler's hazard
 recogniser, and the register allocator may put a copy right in front of an asm statement -- behind the s_nop that was meant to cover it.
-usage: tools/check_dpp_hazards.py <listing.s> [substring of a kernel name]      (exit code 1 if a violation is found)
+NEED = 1: what gfx950 was measured to need (tools/ubench/dpp_wait.hip: stale with no wait, never with one state, 8.3 G lane-reads) and what the product
+pads with (dl_group.hpp, DL_DPP_WAIT); the ISA manual's figure is 2 (`--need 2`, for a -DDL_DPP_WAIT=2 build).  EVERY instruction counts as ONE wait state,
+an `s_nop N` too: an s_wakeup of another wave of the workgroup ends an s_nop after one state (tools/ubench/snop_wakeup.hip).
+usage: tools/check_dpp_hazards.py <listing.s> [substring of a kernel name] [--need N]      (exit code 1 if a violation is found)
 Paths: the straight-line window inside a basic block, carried over a label on the fall-through path and -- two passes -- from the tail of every
 block that branches to the label (s_branch / s_cbranch_* with a label operand).  Only the last instructions of a predecessor block are looked at
 (a predecessor shorter than the hazard window does not inherit from its own predecessors)."""
 import re
 import sys
 
-path = sys.argv[1]
-key = sys.argv[2] if len(sys.argv) > 2 else ''
+argv = list(sys.argv[1:])
+NEED = 1            # wait states between the VALU write and the DPP read
+if '--need' in argv:
+    i = argv.index('--need')
+    NEED = int(argv[i + 1])
+    del argv[i:i + 2]
+path = argv[0]
+key = argv[1] if len(argv) > 1 else ''
 REG = re.compile(r'^v(\d+)$|^v\[(\d+):(\d+)\]$')
-NEED = 2            # wait states between the VALU write and the DPP read
 
 
 def regs(tok):
@@ -54,7 +62,7 @@ def effect(l):
     op, _, rest = l.partition(' ')
     ops = [o.strip() for o in rest.split(',')] if rest else []
     if op == 's_nop':
-        return int(ops[0], 0) + 1, set()
+        return 1, set()          # (whatever its count: see the module docstring)
     if op.startswith('v_') and ops and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
         return 1, regs(ops[0].split(' ')[0])
     return 1, set()
