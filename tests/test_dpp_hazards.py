@@ -73,3 +73,15 @@ def test_checker_follows_branches(tmp_path):
     assert _run(ok, tmp_path, 'branch_ok.s', '--need', '2').returncode == 0
     direct = ACROSS_BRANCH.replace("\ts_cbranch_vccz .LBB0_2\n", "").replace("\tv_add_f32_e32 v7, v1, v2\n\tv_add_f32_e32 v8, v1, v2\n\tv_add_f32_e32 v9, v1, v2\n", "")
     assert _run(direct, tmp_path, 'direct.s').returncode == 1          # no instruction between the write and the DPP read: a hazard at any setting
+
+
+@pytest.mark.timeout(900)
+def test_no_multi_state_s_nop_in_the_kernels_that_use_s_wakeup():
+    """An s_wakeup of another wave of the workgroup ends an s_nop after ONE wait state (tools/ubench/snop_wakeup.hip), so hipcc's own padding may be trusted in the split /
+    rollout kernels only where one state is enough: `s_nop 0 / 1` (the DPP class).  Anything longer -- v_div_fmas behind a VCC write, an SGPR address behind a VALU write, a
+    builtin MFMA's reader -- must not appear, except in front of the fault word's global_atomic_or on the time-out paths."""
+    from drloco_amd import lib
+    lib.check_dpp_hazards()          # (builds the listing if needed)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'survey_snop.py'), lib.LISTING, '--check'], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip().splitlines()[-1].startswith('0 multi-state'), p.stdout[-2000:]
+    assert 'k_env_step_g16_split' in p.stdout and 'k_rollout_pairs' in p.stdout
