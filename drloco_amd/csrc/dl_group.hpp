@@ -370,7 +370,7 @@ template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float
 }
 // Wait states between a VALU write of a register and its read through DPP in the hand-written statements.  The ISA manual asks for two and hipcc pads its own DPP
 // instructions with `s_nop 1`; measured on gfx950 (tools/ubench/dpp_wait.hip, profiles/r05_dpp_wait.txt: seven producers x six DPP forms, alone, beside s_wakeup, beside
-// VALU + DPP work): with NO wait the read is stale, with ONE state never (0 of 8.3 G lane-reads).  And two states cannot be had from `s_nop 1` in these kernels anyway: a
+// VALU + DPP work, beside MFMAs): with NO wait the read is stale, with ONE state never (0 of 11 G lane-reads).  And two states cannot be had from `s_nop 1` in these kernels anyway: a
 // partner's s_wakeup ends an s_nop after one state (tools/ubench/snop_wakeup.hip) -- rounds 2-4 ran on one state whenever that happened, bit-identical launch after launch.
 // So the product says what it relies on: ONE state, as `s_nop 0`, which nothing can shorten (+2.5 % headline, +3.6 % 19-dof walker against `s_nop 1`).
 // -DDL_DPP_WAIT=2 is the manual's padding in its wakeup-proof form (`s_nop 0` twice).  tools/check_dpp_hazards.py checks the listing against DL_DPP_WAIT.

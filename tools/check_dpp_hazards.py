@@ -2,7 +2,7 @@
 """Static check of a `hipcc -S` listing for the gfx9 hazard the hand-written DPP statements have to respect themselves: a VGPR written by a VALU
 instruction may be read through DPP (src0 of a *_dpp instruction) only NEED wait states later.  Inline asm is opaque to the compiler's hazard
 recogniser, and the register allocator may put a copy right in front of an asm statement -- behind the s_nop that was meant to cover it.
-NEED = 1: what gfx950 was measured to need (tools/ubench/dpp_wait.hip: stale with no wait, never with one state, 8.3 G lane-reads) and what the product
+NEED = 1: what gfx950 was measured to need (tools/ubench/dpp_wait.hip: stale with no wait, never with one state, 11 G lane-reads) and what the product
 pads with (dl_group.hpp, DL_DPP_WAIT); the ISA manual's figure is 2 (`--need 2`, for a -DDL_DPP_WAIT=2 build).  EVERY instruction counts as ONE wait state,
 an `s_nop N` too: an s_wakeup of another wave of the workgroup ends an s_nop after one state (tools/ubench/snop_wakeup.hip).
 usage: tools/check_dpp_hazards.py <listing.s> [substring of a kernel name] [--need N]      (exit code 1 if a violation is found)

@@ -2,8 +2,8 @@
 // The split workgroups cannot have two from an `s_nop 1` anyway -- a partner's s_wakeup ends an s_nop after one state (snop_wakeup.hip) -- so the question decides
 // between `s_nop 0` (one state, which nothing can shorten) and two `v_nop` in the hand-written DPP statements of dl_group.hpp (DL_DPP_WAIT).
 // Every producer x consumer pair the kernels contain one state apart (tools/check_dpp_hazards.py on a -DDL_DPP_WAIT=1 listing: v_fma_f32 / v_mov_b32 ->
-// v_max_f32_dpp / v_fmac_f32_dpp row_newbcast) and the neighbouring forms, with 0 (control), 1 and 2 states, alone and beside a wave that loops over s_wakeup or
-// VALU work.  The register is overwritten with a marker first, so a stale read differs from a fresh one.
+// v_max_f32_dpp / v_fmac_f32_dpp row_newbcast) and the neighbouring forms, with 0 (control), 1 and 2 states, alone and beside a wave that loops over s_wakeup,
+// VALU + DPP work or MFMAs.  The register is overwritten with a marker first, so a stale read differs from a fresh one.
 // usage: dpp_wait [iters]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(512) void k(const float* A, const float* B, unsigne
         while (*(volatile int*)&done < 4) {
             for (int i = 0; i < 8; i++) {
                 if (neighbour == 1) asm volatile("s_wakeup\n\ts_nop 3\n\ts_wakeup\n\ts_nop 3\n\ts_wakeup\n\ts_nop 3\n\ts_wakeup\n\ts_nop 3");
+                else if (neighbour == 3) { typedef float f4 __attribute__((ext_vector_type(4))); f4 a0 = {x, y, x, y}, a1 = a0;
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %3, %2, %1\n\tv_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %3, %2, %1\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop\n\tv_nop" : "+v"(a0), "+v"(a1) : "v"(x), "v"(y));
+                    x = a0[0] * 1e-30f + 0.5f; y = a1[1] * 1e-30f + 0.25f; }
                 else asm volatile("v_add_f32 %0, %0, %1\n\tv_fma_f32 %1, %0, %1, %0\n\tv_mul_f32 %0, %0, %1\n\tv_add_f32_dpp %1, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_rcp_f32 %0, %0\n\tv_fma_f32 %1, %0, %1, %0" : "+v"(x), "+v"(y));
             }
         }
@@ -84,7 +87,7 @@ static void run(const float* A, const float* B, unsigned long long* bad, int ite
 template <int P, int C>
 static void row(const float* A, const float* B, unsigned long long* bad, int iters, unsigned long long* tot) {
     printf("%-36s -> %-36s", p_name[P], c_name[C]);
-    for (int nb = 0; nb < 3; nb++) run<P, C>(A, B, bad, iters, nb, tot);
+    for (int nb = 0; nb < 4; nb++) run<P, C>(A, B, bad, iters, nb, tot);
     printf("\n");
 }
 template <int P>
@@ -102,7 +105,7 @@ int main(int argc, char** argv) {
     hipMemcpy(A, h, n * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < n; i++) h[i] = (float)(i % 613) / 613.f + 0.1f;
     hipMemcpy(B, h, n * 4, hipMemcpyHostToDevice);
-    printf("stale DPP reads of %lld lane-reads per cell; columns: [alone | beside s_wakeup | beside VALU + DPP work] x [0 | 1 (s_nop 0) | 2 (2 x v_nop)] wait states, against 6 x v_nop\n", 256LL * 256 * iters);
+    printf("stale DPP reads of %lld lane-reads per cell; columns: [alone | beside s_wakeup | beside VALU + DPP work | beside MFMA 16x16x4 + 4x4x1] x [0 | 1 (s_nop 0) | 2 (2 x v_nop)] wait states, against 6 x v_nop\n", 256LL * 256 * iters);
     unsigned long long tot[3] = {0, 0, 0};
     rows<P_ADD>(A, B, bad, iters, tot); rows<P_FMA>(A, B, bad, iters, tot); rows<P_MOV>(A, B, bad, iters, tot); rows<P_MUL>(A, B, bad, iters, tot);
     rows<P_FMAC_DPP>(A, B, bad, iters, tot); rows<P_RCP>(A, B, bad, iters, tot); rows<P_CNDMASK>(A, B, bad, iters, tot);
