@@ -235,6 +235,9 @@ def main():
     ap.add_argument('--no-split', action='store_true', help='keep the one-wave-per-four-walkers launch form of the step kernel (dl_set_split 0); the default switches the split workgroup on where it exists (straight walker, float32, 16 lanes, one handle)')
     ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 128 walkers per CU)')
     ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="with --policy and the persistent form: 'per_rollout' is the opt-in relaxation (the rollout is normalised with its start-of-rollout moments, one exact merge at its end); not SB3's semantics")
+    ap.add_argument('--checkpoint', type=str, default='', help="with --policy: a TRAINED policy instead of the random-init one -- 'walking' = the packaged drloco_amd/data/walking_policy.npz (examples/train_ppo.py, 8 M steps: the walkers reach the 3000-step episode limit), or the path of such a file (tools/pack_walking_ckpt.py).  Its VecNormalize moments are loaded and the walkers get a training env's step counter (quirk Q2), so the rollouts are what training looks like once the walkers WALK: feet on the ground, contact-rich (not the benchmark configuration)")
+    ap.add_argument('--deterministic', action='store_true', help='with --policy: the mean action instead of a sample (DL_ROLLOUT_DETERMINISTIC; evaluation-style rollouts)')
+    ap.add_argument('--solver-stats', action='store_true', help="switch the step kernel's solver diagnostics on (dl_debug_counters: a few stores per walker and control step inside the timed region) and report Newton iterations / constraint rows per forward evaluation in self_check")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--vn-sync', choices=['per_rollout', 'per_step'], default='per_rollout', help="with --policy on several ranks: 'per_step' = VecNormalize's moments advance with the batch of ALL ranks every control step (SB3's semantics across ranks: one all-reduce of 2 (obs_dim + 1) doubles per control step, host loop); default: per rank, merged exactly between rollouts")
     ap.add_argument('--dump', type=str, default='', help='after the run every rank saves what its LAST rollout produced (episode starts, action tape, raw step outputs, moments) to <path>.rank<r>.npz (tests/test_gpu_distributed.py compares ranks with a single-process run)')
@@ -340,7 +343,16 @@ def main():
         # launches of dl_rollout_fixed need no host round trip per control step
         venv.set_push_schedule(np.stack([50 * np.cos(ang), 50 * np.sin(ang), 0 * ang], 1), (400 * u(4)).astype(np.int32), period=400, duration=20)
     policy = None
-    if args.policy:
+    ckpt_meta = None
+    if args.checkpoint and not (args.policy and args.walker == 'straight' and args.handles == 1):
+        raise SystemExit('--checkpoint needs --policy, the straight walker and one handle')
+    if args.policy and args.checkpoint:
+        from drloco_amd import checkpoint
+        policy, ckpt_meta = checkpoint.load_walking_policy(None if args.checkpoint == 'walking' else args.checkpoint, vec_normalize=vn, seed=99, index_base=rank * n)
+        args.hidden = policy.hidden
+        vn.norm_obs_t.copy_(venv.obs)          # the opening observation again, under the loaded moments
+        vn._normalize_obs_inplace(vn.norm_obs_t)
+    elif args.policy:
         from drloco_amd.policy import HipPolicy
         policy = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=args.hidden, seed=99, index_base=rank * n)
 
@@ -372,7 +384,7 @@ def main():
             T_loop = 0
         elif policy is not None:
             buf.collect_rollouts(vn, policy, last_obs, last_done, persistent={'auto': None, 'launches': False, 'persistent': True}[args.rollout_form],
-                                 moments=args.moments)     # dl_collect_rollouts: the whole loop in one C-ABI call (one launch in the persistent form)
+                                 moments=args.moments, deterministic=args.deterministic)     # dl_collect_rollouts: the whole loop in one C-ABI call (one launch in the persistent form)
             T_loop = 0
         else:
             buf.reset()
@@ -400,6 +412,8 @@ def main():
         rollout = rollout_group
     for _ in range(args.warmup):
         rollout()
+    if args.solver_stats:
+        venv.debug_counters()          # enables (and clears) the per-walker solver diagnostics
     lib.check(venv._lib.dl_profile(venv._h, args.profile_every))    # HIP events around every k-th launch of the step kernel
     barrier()
     t0 = time.perf_counter()
@@ -427,15 +441,37 @@ def main():
         fin = fin and bool(torch.isfinite(raw_obs).all().item() and torch.isfinite(raw_rew).all().item())
         # (random torques of +-300 N m make a walker's trunk spin up to 1e3 .. 1e7 rad/s now and then before it falls -- the float64 oracle shows the same
         #  events --, and one such observation stays in VecNormalize's never-forgetting variance: DESIGN.md 7.  Reported, not asserted.)
+        # what tells a physics blow-up from a kernel defect: walker-steps on the reference's exception path (MujocoException -> reward 0, done, double reset; the device
+        # counts them per walker since dl_create: warm-up included) and raw observations far outside any walking state
+        div = torch.zeros(n, dtype=torch.float64, device=dev)
+        lib.check(venv._lib.dl_stats_snapshot(venv._h, b'diverged_steps', C.c_void_p(div.data_ptr()), None))
+        torch.cuda.synchronize()
+        raw_abs = raw_obs.abs()
         checks = {'finite': fin, 'raw_reward_min': rmin, 'raw_reward_max': rmax, 'episodes_ended_last_rollout': n_done, 'normalised_obs_absmax': obs_absmax,
                   'obs_rms_var_max': float(vn.obs_rms.var.max()),
+                  'exception_path_steps': int(div.sum().item()), 'walker_steps_run': int(n * T * (args.warmup + args.steps)),
+                  'raw_obs_beyond_1e3': int((raw_abs > 1e3).sum().item()), 'raw_obs_beyond_1e10': int((raw_abs > 1e10).sum().item()),
+                  'raw_obs_sample': ('the last rollout: %d walker-steps' % (raw_obs.shape[0] * raw_obs.shape[1])) if raw_obs.dim() == 3 else 'the last control step only (a policy in the loop keeps no raw ring)',
                   'note': 'obs_rms_var_max >> 1 is the reference\'s VecNormalize fed with random +-300 N m torques: a trunk spinning up before a fall leaves one huge sample in the never-forgetting '
                           'variance of one or two velocity columns (the float64 oracle shows the same events, DESIGN.md 7), which are then normalised to ~0 for the rest of the run -- '
-                          'normalised_obs_absmax within the clip is therefore not a sign of healthy statistics'}
+                          'normalised_obs_absmax within the clip is therefore not a sign of healthy statistics; exception_path_steps / raw_obs_beyond_* count those events'}
+        if args.solver_stats:
+            cnt = venv.debug_counters(clear=False).astype('float64')          # [4, n]: sum of Newton iterations, max of the last step, sum of constraint rows, diverged steps -- over the timed rollouts
+            evals = T * args.steps * 4 * venv.model.frame_skip
+            it_last, rows_last = venv.debug_eval_iters(rows=True)               # [evals per step, n]: every evaluation of the last control step
+            import numpy as np
+            checks['solver'] = {'newton_iterations_per_evaluation': float(cnt[0].mean() / evals), 'p99_walker': float(np.quantile(cnt[0] / evals, 0.99)),
+                                'constraint_rows_per_evaluation': float(cnt[2].mean() / evals), 'p99_walker_rows': float(np.quantile(cnt[2] / evals, 0.99)),
+                                'last_step_iterations_p50_p99_max': [float(np.quantile(it_last, 0.5)), float(np.quantile(it_last, 0.99)), int(it_last.max())],
+                                'last_step_rows_p50_p99_max': [float(np.quantile(rows_last, 0.5)), float(np.quantile(rows_last, 0.99)), int(rows_last.max())]}
+        if ckpt_meta is not None:
+            ep = lambda name: float(torch.tensor(venv.get_attr(name)).double().mean().item())
+            checks['walking'] = {'ep_len_smoothed_mean': ep('ep_len_smoothed'), 'moved_distance_mean_m': ep('moved_distance'), 'mean_step_reward_smoothed': ep('mean_reward_smoothed'),
+                                 'checkpoint': args.checkpoint, 'actions': 'mean (deterministic)' if args.deterministic else 'sampled (as in training)'}
         # MimicEnv.step: reward = 0 on done, else imitation (<= 1) + 0.2 alive bonus (mimic_env.py:142-168); VecNormalize clips at 10
         assert fin, f'bench self-check: non-finite values in the rollout buffer {checks}'
         assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'
-        assert n_done < n * T and (n_done > 0 or T < 256), f'bench self-check: implausible number of episode ends {checks}'      # (random torques: walkers start falling after ~100 control steps)
+        assert n_done < n * T and (n_done > 0 or T < 256 or ckpt_meta is not None), f'bench self-check: implausible number of episode ends {checks}'      # (random torques: walkers start falling after ~100 control steps; a trained policy may keep every walker up for a whole rollout)
         assert obs_absmax <= 10.0 + 1e-5, f'bench self-check: normalised observations beyond the clip {checks}'
     if args.dump and group is None:
         import numpy as np
@@ -446,7 +482,17 @@ def main():
                  rewards=buf.rewards.cpu().numpy(), advantages=buf.advantages.cpu().numpy(), obs_mean=vn.obs_rms.mean, obs_var=vn.obs_rms.var, obs_count=vn.obs_rms.count,
                  ret_mean=vn.ret_rms.mean, ret_var=vn.ret_rms.var, ret_count=vn.ret_rms.count, cursor=venv.get_state()['cursor'], qpos=venv.get_state()['qpos'], **ring)
     ranks_seen = 1
+    per_rank = None
     if use_dist:
+        # one all-gather: every rank's wall time of the timed region and the summed duration of its bracketed step-kernel launches -- a SCALE line can then tell
+        # imbalance between ranks (kernel time min / max) from the cost of the collectives (wall time - kernel time)
+        mine = torch.tensor([dt * 1e3, tot_ms.value, float(launches.value)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ar = torch.stack(allr).cpu().numpy()
+        per_rank = {'wall_ms': [round(float(x), 3) for x in ar[:, 0]], 'step_kernel_ms': [round(float(x), 3) for x in ar[:, 1]], 'bracketed_launches': [int(x) for x in ar[:, 2]],
+                    'step_kernel_ms_min_max': [round(float(ar[:, 1].min()), 3), round(float(ar[:, 1].max()), 3)],
+                    'outside_step_kernel_ms_max': round(float((ar[:, 0] - ar[:, 1]).max()), 3)}
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -478,13 +524,18 @@ def main():
         if tfile and os.path.exists(tfile):
             try:
                 pj = json.load(open(tfile))
-                if pj.get('kernel_code_sha16') == kernel_code_sha16():
+                cfg_now = (C.c_int32 * 3)()
+                lib.check(venv._lib.dl_profile_launch_config(venv._h, cfg_now))
+                launch_now = {'grid': int(cfg_now[0]), 'workgroup': int(cfg_now[1]), 'lds_bytes': int(cfg_now[2])}
+                same_launch = pj.get('launch') in (None, launch_now)          # (passes stamped before round 6 carry no geometry)
+                if pj.get('kernel_code_sha16') == kernel_code_sha16() and same_launch:
                     two_waves = split or persistent_line          # two waves per SIMD of which one mostly sleeps: busy cycles against the SIMDs' time, not the waves'
                     traffic, valu_busy = pj.get('hbm_bytes_per_launch'), (pj.get('valu_busy_frac_simd') if two_waves else pj.get('valu_busy_frac'))
                     mfma_busy = pj.get('mfma_busy_frac_simd')
                     prof_origin = {'file': 'profiles/' + tname, 'tag': pj.get('tag'), 'kernel_code_sha16': pj.get('kernel_code_sha16')}
                 else:
-                    prof_origin = {'file': 'profiles/' + tname, 'stale': True, 'measured_sha16': pj.get('kernel_code_sha16') or pj.get('kernel_sources_sha16'), 'built_sha16': kernel_code_sha16()}
+                    prof_origin = {'file': 'profiles/' + tname, 'stale': True, 'measured_sha16': pj.get('kernel_code_sha16') or pj.get('kernel_sources_sha16'), 'built_sha16': kernel_code_sha16(),
+                                   'measured_launch': pj.get('launch'), 'launch': launch_now}
             except Exception:
                 traffic = None
         out = {
@@ -493,7 +544,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('loco3d 19-dof walker (synthetic mocap table), ' if args.walker == 'loco3d' else 'straight_walking 3D walker, ') + f'{n} parallel envs per GPU, fixed {T}-step synthetic rollout '
                                    '(env step + VecNormalize + rollout store + GAE + adv-norm)',
-                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': (f'device policy (dl_policy_forward, {venv.obs_dim}-{args.hidden}-{args.hidden}-{{{venv.nu},1}})' + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
+                       'envs_per_gpu': n, 'rollout_len': T, 'frame_skip': 10 if args.walker == 'loco3d' else 5, 'integrator': 'RK4', 'sharding': f'env-index ranges x{world}', 'actions': (f'device policy (dl_policy_forward, {venv.obs_dim}-{args.hidden}-{args.hidden}-{{{venv.nu},1}})' + (f', TRAINED weights ({args.checkpoint}): the walkers walk' if args.checkpoint else '') + (', mean actions' if args.deterministic else '') + (f', {args.handles} handles on {args.handles} streams' if group is not None else '')) if args.policy else 'pre-generated',
                        'vecnormalize': 'main stream' if (args.policy or args.no_overlap) else ('side stream, one dl_vecnormalize_steps call per run' if not args.vn_single_steps else 'side stream, under the following run of env steps'),
                        'step_kernel_form': 'split workgroups: 4 dynamics + 4 constraint waves per 16 walkers (dl_set_split 1)' if split else 'one wave per 4 walkers',
                        'env_launches': (('ONE persistent launch per rollout (k_rollout_pairs: every wave pair takes its four walkers through policy + env step, moments per rollout (relaxation))' if args.moments == 'per_rollout' else 'ONE persistent launch per rollout (k_rollout_persistent: policy + env step + moment exchange per control step), exact per-step moments')
@@ -507,9 +558,11 @@ def main():
                          'valu_busy_frac': valu_busy, 'mfma_busy_frac': mfma_busy, 'from_profile': prof_origin,
                          'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
         }
+        out['code_object'] = {k: v for k, v in (lib.SELECTED or {}).items() if k != 'probe'}          # which of the two builds ran (drloco_amd/lib.py: two wait states in front of a DPP read unless this device proved that one is enough)
         out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'ranks_seen': ranks_seen, 'backend': dist.get_backend() if use_dist else None, 'vn_sync': vn.sync,
                               'collectives_per_control_step': 'all-reduce of 2 x (obs_dim + 1) doubles (VecNormalize batch sums: exact per-step moments over all ranks)' if (use_dist and vn.sync == 'per_step') else None,
-                              'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None}
+                              'collectives_per_rollout': 'all-reduce of 3 doubles (adv-norm sums) + all-reduce of 2 x (obs_dim + 1) + 2 doubles (VecNormalize moment increments)' if use_dist else None,
+                              'per_rank': per_rank}
         out['self_check'] = checks
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_base

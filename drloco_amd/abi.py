@@ -5,7 +5,7 @@ library's own view (dl_abi_sizeof) and that every declared symbol is exported.
 """
 import ctypes as C
 
-DL_ABI_VERSION = 6
+DL_ABI_VERSION = 7
 DL_ADV_WORKSPACE_BYTES = (2 * 512 + 2) * 8
 
 
@@ -29,6 +29,8 @@ EVAL_N_TIMES = 20        # drloco/config/config.py:23
 DL_ROLLOUT_PERSISTENT, DL_ROLLOUT_MOMENTS_PER_ROLLOUT, DL_ROLLOUT_WORKGROUP_TILES, DL_ROLLOUT_DETERMINISTIC = 1, 2, 4, 8
 DL_OK, DL_E_INVAL, DL_E_NODEVICE, DL_E_HIP, DL_E_NOMEM, DL_E_FAULT = 0, -1, -2, -3, -4, -5
 DL_FAULT_DYN_TIMEOUT, DL_FAULT_SRV_TIMEOUT, DL_FAULT_GRID_TIMEOUT = 1, 2, 4          # bits of the fault word (dl_fault_check)
+DL_INTENDED_COUNT_PER_EPISODE, DL_INTENDED_EVAL_OWN_STEP, DL_INTENDED_COMZ_PER_EPISODE = 2, 4, 8          # bits of dl_config.intended_semantics (quirks Q2, Q3, Q4 off)
+DL_INTENDED_ALL = 2 | 4 | 8
 
 _d, _i = C.c_double, C.c_int32
 
@@ -71,6 +73,7 @@ class Config(C.Structure):
         ('rew_weights', _d * 3), ('rew_scale', _d), ('alive_bonus', _d), ('com_z_min', _d),
         ('ctrl_freq', _d), ('ep_dur_max', _i), ('mirror_policy', _i), ('precision', _i),
         ('env_index_base', _i), ('seed', C.c_uint64), ('env_kind', _i), ('lanes_per_walker', _i),
+        ('intended_semantics', _i), ('strict_solver', _i),
     ]
 
 
@@ -109,9 +112,13 @@ def default_config(**kw):
     c.seed = 1234
     c.env_kind = DL_ENV_STRAIGHT
     c.lanes_per_walker = 0          # auto
+    c.intended_semantics = 0        # strict_reference_quirks: the reference's behaviour incl. Q1-Q4
+    c.strict_solver = 0
     for k, v in kw.items():
         if k == 'rew_weights':
             c.rew_weights[:] = list(v)
+        elif k == 'strict_reference_quirks':          # True (default): as the reference; False: every switchable quirk (Q2, Q3, Q4) off
+            c.intended_semantics = 0 if v else DL_INTENDED_ALL
         else:
             setattr(c, k, v)
     return c

@@ -27,6 +27,7 @@ real SB3 1.0 exists to compare with.
 """
 import io
 import json
+import os
 import pickle
 import sys
 import types
@@ -34,6 +35,8 @@ import zipfile
 
 import numpy as np
 import torch
+
+from . import abi
 
 _VN_CLASS = ('stable_baselines3.common.vec_env.vec_normalize', 'VecNormalize')
 _RMS_CLASS = ('stable_baselines3.common.running_mean_std', 'RunningMeanStd')
@@ -287,3 +290,32 @@ def write_model_zip(policy, path, observation_space=None, action_space=None, opt
             _drop_placeholder_modules({'gym'})
         if fakes and len(fakes) > 1 and fakes[1]:
             _drop_placeholder_modules({'drloco'})
+
+
+# ---- the packaged walking policy (drloco_amd/data/walking_policy.npz) ----------------------------------------------------
+WALKING_POLICY = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'walking_policy.npz')
+# count_steps_same_vel of a walker that has been training for a while (quirk Q2: the counter never resets; 8 M steps / 128 walkers / ~132 control steps per
+# reference step): any value >= the number of steps makes the desired-velocity observation the constant step_velocities[0] the policy was trained on
+TRAINED_STEP_COUNT = 457
+
+
+def load_walking_policy(path=None, vec_normalize=None, **policy_kw):
+    """The packaged TRAINED policy (examples/train_ppo.py, the reference's 8 M-step budget: the walker reaches the 3000-step episode limit and walks ~22 m per
+    episode -- what "trained" means in drloco/common/callback.py:336-369) -> HipPolicy; with `vec_normalize` (a HipVecNormalize) also its moments and, for the walkers of
+    its env, the step counter of a training env (quirk Q2: see evaluation.make_eval_env(history='training')).  tools/pack_walking_ckpt.py writes the file from a
+    `train_ppo.py --save` checkpoint.  Returns (policy, meta dict)."""
+    import json
+    from .policy import HipPolicy
+    with np.load(path or WALKING_POLICY) as z:
+        g = {k: z[k] for k in z.files}
+    pol = HipPolicy(obs_dim=g['w1'].shape[1], act_dim=g['wa'].shape[0], hidden=g['w1'].shape[0], **policy_kw)
+    pol.load_state(**{k: torch.as_tensor(g[k]) for k in _KEYS})
+    meta = json.loads(str(g['meta']))
+    if vec_normalize is not None:
+        vn = vec_normalize
+        vn.obs_rms.load_state(dict(mean=g['obs_mean'], var=g['obs_var'], count=float(g['obs_count'])))
+        vn.ret_rms.load_state(dict(mean=g['ret_mean'], var=g['ret_var'], count=float(g['ret_count'])))
+        st = vn.venv.get_state()
+        st['cursor'][abi.DL_CUR_COUNT] = TRAINED_STEP_COUNT
+        vn.venv.set_state(cursor=st['cursor'])
+    return pol, meta

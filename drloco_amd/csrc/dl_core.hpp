@@ -219,6 +219,7 @@ template <typename T, typename TP> struct DevModel {
 template <typename T> struct DevCfg {
     T rew_w[3], rew_scale, alive_bonus, com_z_min, inv_ctrl_freq;
     int32_t ep_dur_max, mirror_policy, env_index_base;
+    int32_t intended;          // dl_config.intended_semantics (DL_INTENDED_*): 0 = the reference's behaviour incl. its quirks Q1-Q4
     uint64_t seed;
     int32_t n_steps, total_len, stride, n_rows;
     const T* table;            // sample-major [total_len][2*NV]: the 2*NV reference values of one mocap sample are contiguous

@@ -27,7 +27,12 @@ enum {
     // the FIRST episode a walker finished since the handle was created or all its walkers were reset (dl_reset without a mask), as
     // TrainingMonitor.eval_walking measures an episode (callback.py:300-317: duration incl. the terminal step, walked distance and reward sum
     // WITHOUT it): length, walked distance after the last non-terminal step, reward sum -- what a batched evaluation reads after ONE rollout call
-    MON_FIRST_LEN, MON_FIRST_MOVED, MON_FIRST_RET, MON_WALKED_LAST, MON_WORDS
+    MON_FIRST_LEN, MON_FIRST_MOVED, MON_FIRST_RET, MON_WALKED_LAST,
+    // ... counted by the record's OWN step / reward counters, which a reset of all walkers zeroes: MON_EP_LEN / MON_RET keep the reference Monitor's behaviour of carrying
+    // over a reset (monitor_wrapper.py has no reset hook), so on a handle that was stepped before its reset they still hold the episode in flight
+    MON_FIRST_CUR_LEN, MON_FIRST_CUR_RET,
+    // control steps of this walker that took the reference's exception path (MujocoException -> reward 0, done, double reset: mimic_env.py:86-91) since dl_create
+    MON_DIVERGED, MON_WORDS
 };
 
 constexpr int DL_DBG_EVALS = 40;      // evaluations per control step the diagnostics record (4 x frame_skip: 20 / 40)
@@ -53,7 +58,28 @@ template <typename T> struct DevState {
     // bounded poll by TIMEOUT ors its reason in (DL_FAULT_*); the host raises DL_E_FAULT at its next call (dl_fault_check)
     int32_t* fault;
     int32_t spin_dyn, spin_srv;   // polls before a dynamics wave / a constraint wave of a split workgroup gives up (dl_debug_set_spin_limit)
+    // quirk Q4 (adjust_COM_Z_pos mutates the data set in place, base_ref_trajecs.py:126-127): [n_steps][N], the COM-z offset step s of walker w's copy of the data set
+    // carries = the lowest-foot-site height of the last reset that landed on it (dl_get_ref_offsets); written at resets, read when a cursor rolls into another step
+    T* zacc;
 };
+
+// quirk Q4 is reproduced unless dl_config.intended_semantics says otherwise
+template <typename T> DL_HD bool q4_on(const DevCfg<T>& c) { return !(c.intended & DL_INTENDED_COMZ_PER_EPISODE); }
+// zacc is written by one lane and read, possibly much later in the same launch, by others: both sides go to the L2 (agent scope), never through a stale L1 line
+template <typename T> DL_HD T zacc_load(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+template <typename T> DL_HD void zacc_store(T* p, T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = x;
+#endif
+}
 
 DL_HD uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -82,7 +108,9 @@ DL_HD void ref_lookup(const DevCfg<T>& c, const int32_t (&cur)[DL_CUR_WORDS], T 
         vr[j] = ref_at(c, TP::NV + j, base);
     });
     if (cur[DL_CUR_HAS_DIST]) qr[0] += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1);   // quirk Q1
-    else qr[2] -= comz_off;
+    // quirk Q4: comz_off = the offset the step being read carries from the last reset onto it (the data set itself was re-anchored: whoever reads the step sees it);
+    // DL_INTENDED_COMZ_PER_EPISODE: the reset's own offset, on the reset step only
+    if (q4_on(c) || !cur[DL_CUR_HAS_DIST]) qr[2] -= comz_off;
 }
 
 template <typename T, typename TP> DL_HD void cursor_next(const DevCfg<T>& c, int32_t (&cur)[DL_CUR_WORDS]) {
@@ -162,8 +190,10 @@ DL_HD void mon_smooth(double* mon, int n, int i, int word, int bit, double x, do
 }
 
 // cur_pos: refs._pos after this step's refs.next() (before any reset), as Monitor.step reads it
-DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const double (&terms)[3], double tor, double walked, int cur_pos) {
+DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const double (&terms)[3], double tor, double walked, int cur_pos, bool exc = false) {
     auto W = [&](int w) -> double& { return mon[(size_t)w * n + i]; };
+    if (exc) W(MON_DIVERGED) += 1;
+    W(MON_FIRST_CUR_LEN) += 1; W(MON_FIRST_CUR_RET) += rew;
     if (W(MON_EP_LEN) == 0) W(MON_INIT_POS) = (double)cur_pos;      // monitor_wrapper.py:91-93
     W(MON_TOR_LAST) = tor;
     W(MON_EP_LEN) += 1; W(MON_NSTEPS) += 1; W(MON_RET) += rew; W(MON_LAST) = rew;
@@ -180,7 +210,8 @@ DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const 
         W(MON_DIFFICULT) = (len < W(MON_S_EP_LEN) * 0.75) ? 1.0 : 0.0;                    // :122-123 (after the smoothing update)
         mon_smooth(mon, n, i, MON_S_TOR, 6, W(MON_TOR) / len, 0.75);
         W(MON_MOVED) = walked;
-        if (W(MON_FIRST_LEN) == 0) { W(MON_FIRST_LEN) = len; W(MON_FIRST_MOVED) = W(MON_WALKED_LAST); W(MON_FIRST_RET) = W(MON_RET) - W(MON_LAST); }
+        if (W(MON_FIRST_LEN) == 0) { W(MON_FIRST_LEN) = W(MON_FIRST_CUR_LEN); W(MON_FIRST_MOVED) = W(MON_WALKED_LAST); W(MON_FIRST_RET) = W(MON_FIRST_CUR_RET) - rew; }
+        W(MON_FIRST_CUR_LEN) = 0; W(MON_FIRST_CUR_RET) = 0;
         W(MON_EP_LEN) = 0; W(MON_RET) = 0; W(MON_TOR) = 0;
     }
     W(MON_WALKED_LAST) = done ? 0.0 : walked;          // the walked distance after this step if the episode goes on (the next step may be terminal)
@@ -222,7 +253,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
     }
     // everything that is only needed after the physics is loaded here (nothing but q, v, warm, ctrl
     // and the cursor stays live across the forward evaluations)
-    const T comz = st.comz_off[i];
+    T comz = st.comz_off[i];
     double walked = st.walked[i];
     T tor = T(0);
     static_for<TP::NU>([&](auto ai) { constexpr int a = ai.value; tor += dl_abs(dl_clamp(ctrl[a], m.force_lo[a], m.force_hi[a])); });
@@ -237,6 +268,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
         st.need_reset[i] = 2;
     } else {
         cursor_next<T, TP>(c, cur);
+        if (q4_on(c)) comz = zacc_load(st.zacc + (size_t)cur[DL_CUR_READ_STEP] * n + i);          // the offset of the step the cursor reads NOW
         float o[TP::OBS];
         get_obs<T, TP>(c, cur, q, v, o);
         cur[DL_CUR_EP_DUR] += 1;
@@ -254,7 +286,7 @@ DL_HD void env_step_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c, 
         if (dst) static_for<TP::OBS>([&](auto ki) { dst[(size_t)i * TP::OBS + ki.value] = dl_sat_out(o[ki.value]); });
         if (dn) st.need_reset[i] = 1;
     }
-    monitor_step(st.mon, n, i, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS]);
+    monitor_step(st.mon, n, i, (double)r, dn, terms, tor_mean, walked, cur[DL_CUR_POS], exc);
     st.mon[(size_t)MON_POSREW * n + i] = terms[0]; st.mon[(size_t)MON_VELREW * n + i] = terms[1]; st.mon[(size_t)MON_COMREW * n + i] = terms[2];
     if (rew_terms) { rew_terms[3 * (size_t)i] = (float)terms[0]; rew_terms[3 * (size_t)i + 1] = (float)terms[1]; rew_terms[3 * (size_t)i + 2] = (float)terms[2]; }
     rew[i] = r == r ? r : 0.0f;
@@ -286,13 +318,14 @@ DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c,
             // _get_deterministic_init_state (straight_walk_trajecs.py:237-265) incl. quirk Q3
             s = cur[DL_CUR_EVAL_K];
             p = (int)(0.75 * (double)(c.step_off[s + 1] - c.step_off[s]));
-            read = 0;
+            read = (c.intended & DL_INTENDED_EVAL_OWN_STEP) ? s : 0;
             cur[DL_CUR_EVAL_K] = (s + 1 >= 20) ? 0 : s + 1;
         }
         else if (st.inj_rsi && st.inj_rsi[i] >= 0) { s = st.inj_rsi[i]; p = st.inj_rsi[(size_t)n + i]; }
         else rsi_draw(c, (uint32_t)(c.env_index_base + i), (uint32_t)cur[DL_CUR_EPISODE], s, p);
         cur[DL_CUR_EPISODE] += 1;
         cur[DL_CUR_EP_DUR] = 0;
+        if (c.intended & DL_INTENDED_COUNT_PER_EPISODE) cur[DL_CUR_COUNT] = 1;
         cur[DL_CUR_I_STEP] = s; cur[DL_CUR_RSI_STEP] = s; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s; cur[DL_CUR_POS] = p; cur[DL_CUR_HAS_DIST] = 0;
         ref_lookup<T, TP>(c, cur, T(0), q, v);
         // lowest foot-sole corner onto the floor (mimic_env.py:547-559)
@@ -307,6 +340,9 @@ DL_HD void env_reset_lane(const DL_CONST DevModel<T, TP>& m, const DevCfg<T>& c,
             });
             q[2] -= low;
             comz = low;
+            // quirk Q4 (adjust_COM_Z_pos): the step's row of this walker's data set is re-anchored in place.  The reference subtracts `low` measured at the ALREADY shifted
+            // row; the foot height follows the root's z one to one, so the row ends at (pristine - low measured at the pristine row): the offset is replaced, not summed
+            if (q4_on(c)) zacc_store(st.zacc + (size_t)cur[DL_CUR_READ_STEP] * n + i, low);
         }
         // set_state -> mj_forward: qacc of the initial state seeds the warmstart
         (void)forward_io<T, TP>(m, mem, q, v, zero_u, zero_w, warm);

@@ -368,14 +368,17 @@ template <int CTRL> __device__ __forceinline__ void fmac_dpp_self(float& x, floa
 template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float b) {
     asm("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
-// Wait states between a VALU write of a register and its read through DPP in the hand-written statements.  The ISA manual asks for two and hipcc pads its own DPP
-// instructions with `s_nop 1`; measured on gfx950 (tools/ubench/dpp_wait.hip, profiles/r05_dpp_wait.txt: seven producers x six DPP forms, alone, beside s_wakeup, beside
-// VALU + DPP work, beside MFMAs): with NO wait the read is stale, with ONE state never (0 of 11 G lane-reads).  And two states cannot be had from `s_nop 1` in these kernels anyway: a
-// partner's s_wakeup ends an s_nop after one state (tools/ubench/snop_wakeup.hip) -- rounds 2-4 ran on one state whenever that happened, bit-identical launch after launch.
-// So the product says what it relies on: ONE state, as `s_nop 0`, which nothing can shorten (+2.5 % headline, +3.6 % 19-dof walker against `s_nop 1`).
-// -DDL_DPP_WAIT=2 is the manual's padding in its wakeup-proof form (`s_nop 0` twice).  tools/check_dpp_hazards.py checks the listing against DL_DPP_WAIT.
+// Wait states between a VALU write of a register and its read through DPP in the hand-written statements.  The ISA manual asks for TWO and hipcc pads its own DPP
+// instructions with `s_nop 1`; measured on gfx950 (dl_hwprobe.hpp / tools/ubench/dpp_wait.hip, profiles/r05_dpp_wait.txt: seven producers x six DPP forms, alone, beside
+// s_wakeup, beside VALU + DPP work, beside MFMAs): with NO wait the read is stale, with ONE state never (0 of 11 G lane-reads).  Two code objects are built (drloco_amd/lib.py):
+//   libdrloco_hip.so       DL_DPP_WAIT = 2, the DEFAULT: the manual's two states in their wakeup-proof form, `s_nop 0` twice (an `s_nop 1` is worth ONE state once another
+//                          wave's s_wakeup ends it: tools/ubench/snop_wakeup.hip) -- spec-conformant on any gfx9 part;
+//   libdrloco_hip_dpp1.so  -DDL_DPP_WAIT=1: one state, `s_nop 0` (+2.5 % headline, +3.6 % 19-dof walker).  Used only on a device that has just PROVEN, in this process, that one
+//                          state is enough and that the test can fail (dl_hw_probe: stale reads with no wait, none with one): drloco_amd.lib.load() asks the conformant
+//                          library to run the probe and switches only on that evidence; dl_create of this build runs the probe itself and refuses otherwise (DL_E_HIP).
+// tools/check_dpp_hazards.py checks each listing against its DL_DPP_WAIT (--need).
 #ifndef DL_DPP_WAIT
-#define DL_DPP_WAIT 1
+#define DL_DPP_WAIT 2
 #endif
 #if DL_DPP_WAIT == 2
 #define DL_DPP_NOP "s_nop 0\n\ts_nop 0"

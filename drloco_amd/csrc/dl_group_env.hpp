@@ -312,7 +312,10 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     auto walked_put = [&](double x) { if (j == 0) { if constexpr (sizeof(T) == 8) walked_w[0] = x; else { const uint64_t b = __builtin_bit_cast(uint64_t, x); uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32); DL_VPIN(lo); DL_VPIN(hi); walked_w[0] = __builtin_bit_cast(T, lo); walked_w[1] = __builtin_bit_cast(T, hi); } } };      // (pinned: a constant 0.0 is otherwise a register pair hoisted out of the step loop)
     auto walked_get = [&]() -> double { if constexpr (sizeof(T) == 8) return walked_w[0]; else { const T w0 = walked_w[0], w1 = walked_w[1]; return __builtin_bit_cast(double, (uint64_t)__builtin_bit_cast(uint32_t, w0) | ((uint64_t)__builtin_bit_cast(uint32_t, w1) << 32)); } };
     walked_put(st.walked[w1]);
-    T comz = st.comz_off[w1];
+    // COM-z offset of the reference step the cursor reads: quirk Q4 (default) keeps one per step and walker in memory (st.zacc: the data set the reference mutates in place),
+    // a register holds the current step's; DL_INTENDED_COMZ_PER_EPISODE: the last reset's, valid on the reset step only
+    const bool q4 = q4_on(c);
+    T comz = q4 ? zacc_load(st.zacc + (size_t)cur[DL_CUR_READ_STEP] * n + w1) : st.comz_off[w1];
     // (the reward terms of the last step are values of type T held as doubles in the Monitor words: kept as T here, widened where they are used)
     T terms[3] = {(T)st.mon[(size_t)MON_POSREW * n + w1], (T)st.mon[(size_t)MON_VELREW * n + w1], (T)st.mon[(size_t)MON_COMREW * n + w1]};
     long long t_phys_end = 0;
@@ -545,10 +548,12 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
         r = 0.0f; dn = true; walked_put(0.0);
         terms[0] = terms[1] = terms[2] = T(1);
     } else {
+        const int rs_old = cur[DL_CUR_READ_STEP];
         if constexpr (PRE) {
 #pragma unroll
             for (int k = 0; k < DL_CUR_WORDS; k++) cur[k] = cur_n[k];
         } else cursor_next<T, TP>(c, cur);
+        if (q4 && cur[DL_CUR_READ_STEP] != rs_old) comz = zacc_load(st.zacc + (size_t)cur[DL_CUR_READ_STEP] * n + w);          // rolled into another step: the offset ITS row carries (quirk Q4)
         g_sync<T>();
         stage_qv();
         g_sync<T>();
@@ -566,8 +571,8 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             const int base = c.step_off[cur[DL_CUR_READ_STEP]] + cur[DL_CUR_POS];
             auto ref_q = [&](int d) -> T {
                 T qr = ref_at(c, d, base);
-                if (cur[DL_CUR_HAS_DIST]) { if (d == 0) qr += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1); }
-                else if (d == 2) qr -= comz;
+                if (cur[DL_CUR_HAS_DIST] && d == 0) qr += ref_at(c, 0, c.step_off[cur[DL_CUR_RSI_STEP] + 1] - 1);
+                if (d == 2 && (q4 || !cur[DL_CUR_HAS_DIST])) qr -= comz;
                 return qr;
             };
             T dp = T(0), dvv = T(0), dc = T(0);
@@ -575,8 +580,8 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
                 T d1, d2;
                 if constexpr (PRE) {
                     T qr = pre_qr;
-                    if (cur[DL_CUR_HAS_DIST]) { if (jd == 0) qr += pre_dist; }
-                    else if (jd == 2) qr -= comz;
+                    if (cur[DL_CUR_HAS_DIST] && jd == 0) qr += pre_dist;
+                    if (jd == 2 && (q4 || !cur[DL_CUR_HAS_DIST])) qr -= comz;
                     d1 = q - qr; d2 = v - pre_vr;
                 } else { d1 = q - ref_q(jd); d2 = v - ref_at(c, NV + jd, base); }
                 if (jd < 3) dc = d1 * d1; else { dp = d1 * d1; dvv = d2 * d2; }
@@ -601,7 +606,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     }
     if (valid && j == 0) {
         const double terms_d[3] = {(double)terms[0], (double)terms[1], (double)terms[2]};
-        monitor_step(st.mon, n, w, (double)r, dn, terms_d, tor_mean, walked_get(), cur[DL_CUR_POS]);
+        monitor_step(st.mon, n, w, (double)r, dn, terms_d, tor_mean, walked_get(), cur[DL_CUR_POS], exc);
         if (rew_terms) { rew_terms[3 * (size_t)w] = (float)terms[0]; rew_terms[3 * (size_t)w + 1] = (float)terms[1]; rew_terms[3 * (size_t)w + 2] = (float)terms[2]; }
         rew[w] = r == r ? r : 0.0f;          // (a NaN can only come out of a state beyond float32's range: see dl_sat_out)
         done[w] = dn ? 1 : 0;
@@ -619,13 +624,14 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             else if (eval_mode) {
                 s0 = cur[DL_CUR_EVAL_K];
                 p0 = (int)(0.75 * (double)(c.step_off[s0 + 1] - c.step_off[s0]));
-                read = 0;
+                read = (c.intended & DL_INTENDED_EVAL_OWN_STEP) ? s0 : 0;
                 cur[DL_CUR_EVAL_K] = (s0 + 1 >= 20) ? 0 : s0 + 1;
             }
             else if (st.inj_rsi && st.inj_rsi[w] >= 0) { s0 = st.inj_rsi[w]; p0 = st.inj_rsi[(size_t)n + w]; }
             else rsi_draw(c, (uint32_t)(c.env_index_base + w), (uint32_t)cur[DL_CUR_EPISODE], s0, p0);
             cur[DL_CUR_EPISODE] += 1;
             cur[DL_CUR_EP_DUR] = 0;
+            if (c.intended & DL_INTENDED_COUNT_PER_EPISODE) cur[DL_CUR_COUNT] = 1;
             cur[DL_CUR_I_STEP] = s0; cur[DL_CUR_RSI_STEP] = s0; cur[DL_CUR_READ_STEP] = read >= 0 ? read : s0; cur[DL_CUR_POS] = p0; cur[DL_CUR_HAS_DIST] = 0;
             const int base = c.step_off[cur[DL_CUR_READ_STEP]] + p0;
             if (isdof) { q = ref_at(c, jd, base); v = ref_at(c, NV + jd, base); }
@@ -633,11 +639,15 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
             { GKin<T> kin; g_fk<T, TP>(g, lt, q, qx, kin); }
             comz = g_lowest_site<T, TP>(g);
             if constexpr (NX > 0) qx.x[2] -= comz; else { if (j == 2) q -= comz; }
+            // quirk Q4 (adjust_COM_Z_pos): the row of the step just bound is re-anchored in this walker's data set (see env_reset_lane: replaced, not summed)
+            if (q4 && valid && j == 0) zacc_store(st.zacc + (size_t)cur[DL_CUR_READ_STEP] * n + w, comz);
             g_sync<T>();
             stage_qv();
             warm = T(0);
             static_for<NX>([&](auto ti) { warmx.x[ti.value] = T(0); });
+            const int rs_reset = cur[DL_CUR_READ_STEP];
             cursor_next<T, TP>(c, cur);
+            if (q4 && cur[DL_CUR_READ_STEP] != rs_reset) comz = zacc_load(st.zacc + (size_t)cur[DL_CUR_READ_STEP] * n + w);          // (a reset onto the last samples of a step: the first refs.next() rolls over)
             g_sync<T>();
             write_obs((nrep == 2 && rep == 0) ? term_obs : obs, false);
             g_sync<T>();

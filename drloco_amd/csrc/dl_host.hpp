@@ -85,6 +85,7 @@ template <typename T> inline void fill_dev_cfg(const dl_config& c, const dl_refs
     o.rew_scale = (T)c.rew_scale; o.alive_bonus = (T)c.alive_bonus; o.com_z_min = (T)c.com_z_min;
     o.inv_ctrl_freq = (T)(1.0 / c.ctrl_freq);
     o.ep_dur_max = c.ep_dur_max; o.mirror_policy = c.mirror_policy; o.env_index_base = c.env_index_base; o.seed = c.seed;
+    o.intended = c.intended_semantics;
     o.n_steps = r.n_steps; o.total_len = r.total_len; o.stride = r.stride; o.n_rows = r.n_rows;
 }
 

@@ -7,12 +7,14 @@
 // one coalesced 256-byte (f32) segment.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "dl_host.hpp"
+#include "dl_hwprobe.hpp"
 #include "dl_policy.hpp"
 #include "dl_policy_pair.hpp"
 
@@ -961,7 +963,7 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
     __syncthreads();
     int epoch = 0;
     int32_t* const fault_w = args()->st.fault;
-    const int pair_spin = args()->a.spin_grid;          // polls before a wave gives its partner up (dl_debug_set_grid_spin; 1 << 22 ~ seconds)
+    const int pair_spin = args()->a.spin_grid;          // polls before a wave gives its partner up: the budget of the persistent kernels' waits, shared with the grid exchange of k_rollout_persistent (dl_debug_set_grid_spin sets both: include/drloco_hip.h; 1 << 22 ~ seconds)
     // The two waves of the pair meet: everything either has written (LDS, memory) is visible to the other afterwards.  Bounded like every poll of the split form -- an
     // error, never a hung GPU -- and, like there, a wave never carries on with stale data: a wave whose partner did not arrive sets the handle's fault word
     // (DL_FAULT_SRV_TIMEOUT), the pair is dead from then on (every later pair_sync returns at once) and the wave LEAVES the kernel at the next phase boundary
@@ -976,7 +978,9 @@ void k_rollout_pairs(const RolloutArgs<TP> args_by_value) {
         if (lane == 0) ps[Sp::MB_PAIR0 + role] = epoch;
         int budget = pair_spin;
         while (DL_UNIFORM(ps[Sp::MB_PAIR1 - role]) < epoch && --budget > 0) __builtin_amdgcn_s_sleep(1);
-        if (budget <= 0) {
+        // the verdict comes from a LAST read of the partner's counter, not from the budget: a partner that arrives on the very last poll (or a budget of 0 with the
+        // partner already there) has arrived
+        if (DL_UNIFORM(ps[Sp::MB_PAIR1 - role]) < epoch) {
             pair_alive = false;
             if (fault_w && lane == 0) DL_FAULT_OR(fault_w, DL_FAULT_SRV_TIMEOUT);
         }
@@ -1116,6 +1120,7 @@ struct dl_env_s {
     int prof_steps = 0, prof_last_steps = 0;   // control steps covered by the bracketed launches (since / at the last dl_profile_read)
     virtual int get_state(void*, void*, void*, int32_t*, double*, hipStream_t) = 0;
     virtual int set_state(const void*, const void*, const void*, const int32_t*, const double*, hipStream_t) = 0;
+    virtual int ref_offsets(void* get, const void* set, hipStream_t) = 0;
     virtual int forward(const void*, void*, int32_t*, int32_t*, int32_t*, hipStream_t) = 0;
     virtual int snapshot(int word, double* out, hipStream_t) = 0;
     virtual int terminate_early(int32_t* flags, hipStream_t) = 0;
@@ -1141,6 +1146,10 @@ struct dl_env_s {
     bool prof_open = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
+    // launch geometry of the last bracketed launch of the dominant kernel: threads of the grid, threads per workgroup, dynamic LDS bytes (dl_profile_launch_config:
+    // what a committed PMC pass is compared with before its counters are replayed, next to the device code's hash)
+    int launch_cfg[3] = {0, 0, 0};
+    void note_launch(long long blocks, int block, size_t lds) { if (prof_open) { launch_cfg[0] = (int)(blocks * block); launch_cfg[1] = block; launch_cfg[2] = (int)lds; } }
     void prof_begin(hipStream_t s) {
         prof_open = false;
         if (!prof || (prof_tick++ % prof) != 0) return;
@@ -1238,6 +1247,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&st.qvel, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&st.warm, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&st.comz_off, n))) return rc;
+        if ((rc = dalloc(&st.zacc, (size_t)r.n_steps * n))) return rc;          // quirk Q4: zero = the pristine data set
         if ((rc = dalloc(&st.cur, (size_t)DL_CUR_WORDS * n))) return rc;
         if ((rc = dalloc(&st.walked, n))) return rc;
         if ((rc = dalloc(&st.mon, (size_t)MON_WORDS * n))) return rc;
@@ -1276,8 +1286,8 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int reset(const uint8_t* mask, const int32_t* is, const int32_t* ip, float* obs, hipStream_t s) override {
         if ((is == nullptr) != (ip == nullptr)) return fail(DL_E_INVAL, "init_step and init_pos must be given together");
-        if (!mask) HIPCHK(hipMemsetAsync(st.mon + (size_t)MON_FIRST_LEN * n, 0, (size_t)4 * n * sizeof(double), s));          // a reset of ALL walkers opens a new "first episode" record (MON_FIRST_*, MON_WALKED_LAST)
-        static_assert(MON_FIRST_MOVED == MON_FIRST_LEN + 1 && MON_FIRST_RET == MON_FIRST_LEN + 2 && MON_WALKED_LAST == MON_FIRST_LEN + 3, "cleared as one run");
+        if (!mask) HIPCHK(hipMemsetAsync(st.mon + (size_t)MON_FIRST_LEN * n, 0, (size_t)6 * n * sizeof(double), s));          // a reset of ALL walkers opens a new "first episode" record (MON_FIRST_*, MON_WALKED_LAST, and the record's own step / reward counters)
+        static_assert(MON_FIRST_MOVED == MON_FIRST_LEN + 1 && MON_FIRST_RET == MON_FIRST_LEN + 2 && MON_WALKED_LAST == MON_FIRST_LEN + 3 && MON_FIRST_CUR_LEN == MON_FIRST_LEN + 4 && MON_FIRST_CUR_RET == MON_FIRST_LEN + 5, "cleared as one run");
         hipLaunchKernelGGL((k_env_reset<T, TP, BLOCK>), dim3(grid()), dim3(BLOCK), LDS, s, (const DevModel<T, TP>*)md, c, st, 1, mask, is, ip, obs ? obs : scratch_obs, (float*)nullptr, eval_mode);
         HIPCHK(hipGetLastError());
         return DL_OK;
@@ -1290,6 +1300,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         const int k = nsteps < MULTI ? nsteps : MULTI;
         st.push_step0 = push_step; push_step += k;
         prof_begin(s);
+        if (split) note_launch(((n + GW - 1) / GW + 3) / 4, 512, CAN_SPLIT ? SLDS : 0); else note_launch((n + GW - 1) / GW, 64, GLDS);
         if constexpr (CAN_SPLIT) {
             if (split) hipLaunchKernelGGL((k_env_step_g16_split<T, TP>), dim3(((n + GW - 1) / GW + 3) / 4), dim3(512), SLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, (float*)nullptr,
                                           (float*)nullptr, (const T*)inj_q, (const T*)inj_v, (const int32_t*)nullptr, (float*)nullptr, eval_mode, k);
@@ -1307,6 +1318,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (variant == 1 && gmd) {
             st.push_step0 = push_step; push_step += 1;
             prof_begin(s);
+            if (split) note_launch(((n + GW - 1) / GW + 3) / 4, 512, CAN_SPLIT ? SLDS : 0); else note_launch((n + GW - 1) / GW, 64, GLDS);
             if constexpr (CAN_SPLIT) {
                 if (split) hipLaunchKernelGGL((k_env_step_g16_split<T, TP>), dim3(((n + GW - 1) / GW + 3) / 4), dim3(512), SLDS, s, (const GModel<T, TP>*)gmd, c, st, act, obs, rew, done, term, terms,
                                               (const T*)inj_q, (const T*)inj_v, (const int32_t*)(inj_armed ? inj_flags : nullptr), ctrl_dbg, eval_mode, 1);
@@ -1348,6 +1360,12 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if (w) HIPCHK(hipMemcpyAsync(st.warm, w, b, hipMemcpyDeviceToDevice, s));
         if (cur) HIPCHK(hipMemcpyAsync(st.cur, cur, (size_t)DL_CUR_WORDS * n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         if (walked) HIPCHK(hipMemcpyAsync(st.walked, walked, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return DL_OK;
+    }
+    int ref_offsets(void* get, const void* set, hipStream_t s) override {
+        const size_t b = (size_t)c.n_steps * n * sizeof(T);
+        if (get) HIPCHK(hipMemcpyAsync(get, st.zacc, b, hipMemcpyDeviceToDevice, s));
+        if (set) HIPCHK(hipMemcpyAsync(st.zacc, set, b, hipMemcpyDeviceToDevice, s));
         return DL_OK;
     }
     int forward(const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, hipStream_t s) override {
@@ -1466,7 +1484,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     }
     int persistent_ok(int hidden, std::string* why) override {
         auto no = [&](const char* w) { if (why) *why = w; return 0; };
-        if constexpr (!CAN_PERSIST) return no("the persistent rollout kernel exists for the 16-lane float32 kernels of the lane-only (straight) walker");
+        if constexpr (!CAN_PERSIST) return no("the persistent rollout kernels exist for the 16-lane float32 kernels of walkers whose split workgroup + moments block fit the LDS of a CU (both walkers of the reference do)");
         else {
             if (!(variant == 1 && gmd)) return no("the persistent rollout kernel needs the 16-lane kernels (lanes_per_walker = 16)");
             if (hidden != 512 && hidden != 256 && hidden != 128) return no("the persistent rollout kernels are built for hidden = 512, 256 or 128 (eight waves per workgroup x 4 / 2 / 1 tiles)");
@@ -1519,6 +1537,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             if (per_rollout == 1) HIPCHK(hipMemsetAsync(rp_partial, 0, (size_t)nblk * 4 * W * 2 * sizeof(double), s));          // the pairs' sums start at zero (the workgroup form writes every slot it owns)
             st.push_step0 = push_step; push_step += nT;
             prof_begin(s);
+            note_launch(nwg, 512, SLDS + rollout_lds_extra<TP>());
             RolloutArgs<TP> ra{};
             ra.gm = gmd; ra.c = c; ra.st = st; ra.a = a; ra.eval_mode = eval_mode;
             if (per_rollout == 1) hipLaunchKernelGGL((k_rollout_pairs<TP>), dim3(nwg), dim3(512), SLDS + rollout_lds_extra<TP>(), s, ra);
@@ -1585,12 +1604,64 @@ int dl_abi_sizeof(int which) {
     }
 }
 
+int dl_dpp_wait_states(void) { return DL_DPP_WAIT; }
+int dl_hw_probe(int32_t device, int32_t iters, uint64_t* out) {
+    if (!out) return fail(DL_E_INVAL, "dl_hw_probe: out must not be NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DL_E_NODEVICE, "dl_hw_probe: no HIP device");
+    if (device >= ndev) return fail(DL_E_INVAL, "dl_hw_probe: no such device");
+    int prev = 0;
+    HIPCHK(hipGetDevice(&prev));
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    unsigned long long o[8];
+    const int e = hwprobe::probe(iters > 0 ? iters : 64, o);
+    if (device >= 0) (void)hipSetDevice(prev);
+    if (e != 0) return fail(DL_E_HIP, std::string("dl_hw_probe: ") + hipGetErrorString((hipError_t)e));
+    for (int i = 0; i < 8; i++) out[i] = o[i];
+    return DL_OK;
+}
+#if DL_DPP_WAIT < 2
+// The one-wait-state build runs only on a device that has shown, in this process, that one state is enough (and that the test can tell): once per device.
+static int dpp_one_state_proven(int device) {
+    static std::mutex mu;
+    static int verdict[64] = {0};          // 0 unknown, 1 proven, -1 refuted
+    static unsigned long long seen[64][3];
+    std::lock_guard<std::mutex> lock(mu);
+    const int d = device < 0 || device >= 64 ? 0 : device;
+    if (!verdict[d]) {
+        uint64_t o[8];
+        const int rc = dl_hw_probe(device, 32, o);
+        if (rc != DL_OK) return rc;
+        seen[d][0] = o[0]; seen[d][1] = o[1]; seen[d][2] = o[2];
+        verdict[d] = (o[1] == 0 && o[2] == 0) ? 1 : -1;
+    }
+    if (verdict[d] < 0)
+        return fail(DL_E_HIP, "dl_create: this library (libdrloco_hip_dpp1.so) pads its hand-written DPP reads with ONE wait state, and device " + std::to_string(device) + " shows stale DPP reads with one state (" +
+                    std::to_string(seen[d][0]) + " / " + std::to_string(seen[d][1]) + " / " + std::to_string(seen[d][2]) + " with 0 / 1 / 2 states, dl_hw_probe): load libdrloco_hip.so, the build with the ISA manual's two states");
+    return DL_OK;
+}
+#endif
 int dl_create(const dl_model_desc* model, const dl_refs_desc* refs, const dl_config* cfg, int32_t n_envs, int32_t device, dl_handle* out) {
     if (!model || !refs || !cfg || !out || n_envs <= 0) return fail(DL_E_INVAL, "dl_create: bad arguments");
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DL_E_NODEVICE, "dl_create: no HIP device (this library has no CPU path)");
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        // the reference's train.py hides the GPUs from its own process before it builds the environments (use_cpu(): CUDA_VISIBLE_DEVICES = "", drloco/train.py:35,80, whenever
+        // drloco/config/config.py:10 USE_CPU = True, the default) and HIP honours that variable: say so instead of leaving the caller to guess
+        std::string why = "dl_create: no HIP device (this library has no CPU path)";
+        for (const char* var : {"CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"}) {
+            const char* v = getenv(var);
+            if (v && !*v) why += std::string("; ") + var + " is set to the empty string in this process, which hides every GPU -- the reference's train.py does that in use_cpu() "
+                                 "(drloco/train.py:35) when drloco/config/config.py:10 USE_CPU is True: set USE_CPU = False (INTEGRATION.md 1)";
+            else if (v) why += std::string("; ") + var + "=" + v;
+        }
+        return fail(DL_E_NODEVICE, why);
+    }
     if (device < 0 || device >= ndev) return fail(DL_E_INVAL, "dl_create: device ordinal out of range");
+#if DL_DPP_WAIT < 2
+    { const int rc = dpp_one_state_proven(device); if (rc != DL_OK) return rc; }
+#endif
+    if (cfg->intended_semantics & ~(DL_INTENDED_COUNT_PER_EPISODE | DL_INTENDED_EVAL_OWN_STEP | DL_INTENDED_COMZ_PER_EPISODE)) return fail(DL_E_INVAL, "dl_create: unknown bits in intended_semantics");
     std::string why;
     if (cfg->precision != 32 && cfg->precision != 64 && cfg->precision != 0) return fail(DL_E_INVAL, "dl_create: precision must be 32 or 64");
     const bool f64 = cfg->precision == 64;
@@ -1686,6 +1757,17 @@ int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qa
     NEED(h);
     return h->set_state(qpos, qvel, qacc_warm, cursor, walked, (hipStream_t)stream);
 }
+int dl_get_ref_offsets(dl_handle h, void* z_offsets, void* stream) {
+    NEED(h);
+    NOFAULT(h);
+    if (!z_offsets) return fail(DL_E_INVAL, "dl_get_ref_offsets: z_offsets must not be NULL");
+    return h->ref_offsets(z_offsets, nullptr, (hipStream_t)stream);
+}
+int dl_set_ref_offsets(dl_handle h, const void* z_offsets, void* stream) {
+    NEED(h);
+    if (!z_offsets) return fail(DL_E_INVAL, "dl_set_ref_offsets: z_offsets must not be NULL");
+    return h->ref_offsets(nullptr, z_offsets, (hipStream_t)stream);
+}
 int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream) {
     NEED(h);
     return h->forward(ctrl, qacc, ncon, nefc, niter, (hipStream_t)stream);
@@ -1769,7 +1851,7 @@ int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream) 
         {"ep_len_smoothed", MON_S_EP_LEN}, {"ep_ret_smoothed", MON_S_EP_RET}, {"mean_reward_smoothed", MON_S_MEAN_REW},
         {"moved_distance", MON_MOVED}, {"mean_ep_pos_rew_smoothed", MON_S_POS}, {"mean_ep_vel_rew_smoothed", MON_S_VEL},
         {"mean_ep_com_rew_smoothed", MON_S_COM}, {"mean_abs_ep_torque_smoothed", MON_S_TOR}, {"ep_len", MON_EP_LEN},
-        {"first_ep_len", MON_FIRST_LEN}, {"first_ep_moved", MON_FIRST_MOVED}, {"first_ep_ret", MON_FIRST_RET}, {"init_pos", MON_INIT_POS}, {"et_pos", MON_ET_POS}, {"last_abs_torque", MON_TOR_LAST}, {"difficult", MON_DIFFICULT}};
+        {"diverged_steps", MON_DIVERGED}, {"first_ep_len", MON_FIRST_LEN}, {"first_ep_moved", MON_FIRST_MOVED}, {"first_ep_ret", MON_FIRST_RET}, {"init_pos", MON_INIT_POS}, {"et_pos", MON_ET_POS}, {"last_abs_torque", MON_TOR_LAST}, {"difficult", MON_DIFFICULT}};
     for (const auto& t : tab)
         if (!strcmp(name, t.name)) return h->snapshot(t.word, out, (hipStream_t)stream);
     return fail(DL_E_INVAL, std::string("dl_stats_snapshot: unknown attribute ") + name);
@@ -1806,6 +1888,12 @@ int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches) {
 int dl_profile_steps(dl_handle h) {
     NEED(h);
     return h->prof_last_steps;
+}
+int dl_profile_launch_config(dl_handle h, int32_t* out3) {
+    NEED(h);
+    if (!out3) return fail(DL_E_INVAL, "dl_profile_launch_config: out must not be NULL");
+    for (int k = 0; k < 3; k++) out3[k] = h->launch_cfg[k];
+    return DL_OK;
 }
 
 int dl_moments_update(double* mean, double* var, double* count, const float* x, int32_t B, int32_t D, void* stream) {

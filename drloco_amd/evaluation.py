@@ -86,11 +86,18 @@ def evaluate_walking(eval_env, policy, n_saved_models=0, chunk=None, persistent=
     ONE device call: dl_collect_rollouts over `ep_dur_max` control steps with DL_ROLLOUT_DETERMINISTIC (the persistent one-launch form
     where it exists: float32, 16 lanes per walker, hidden = 512 / 256 / 128; three launches per control step enqueued without a host round trip
     otherwise), then three dl_stats_snapshot reads.  chunk: control steps per call (default: the whole episode budget in one call); with a
-    smaller chunk the host looks between calls whether every walker has finished and stops early.  `policy`: a HipPolicy."""
+    smaller chunk the host looks between calls whether every walker has finished and stops early.  `policy`: a HipPolicy; any other object with
+    `.forward(obs, deterministic=True)` is evaluated by the step-by-step host loop below.
+    A device fault of the persistent form (a hand-over or grid-exchange time-out: another process holding CUs) does not abort a training run that
+    evaluates inside its loop: with persistent=None the fault is cleared, the walkers are reset and the evaluation is redone in the launch form, with a
+    warning; persistent=True raises DrlocoFault."""
     import ctypes as C
+    if not hasattr(policy, '_params'):
+        return evaluate_walking_host_loop(eval_env, policy, n_saved_models)
     venv = eval_env.venv
     n, dev = venv.num_envs, venv.device
     eval_env.training = False
+    cursor0 = venv.get_state()['cursor'] if persistent is None else None          # (the evaluation counters k of the walkers: a redo after a fault starts from the same init states)
     eval_env.reset()                                                   # (a reset of all walkers also opens a new first-episode record)
     horizon = int(venv.cfg.ep_dur_max)
     T = horizon if chunk is None else max(1, min(int(chunk), horizon))
@@ -114,7 +121,15 @@ def evaluate_walking(eval_env, policy, n_saved_models=0, chunk=None, persistent=
         steps += T
         if use_persistent:
             torch.cuda.current_stream().synchronize()
-            lib.check(venv._lib.dl_fault_check(venv._h, None))             # a persistent launch is complete only with a clear fault word
+            rc = venv._lib.dl_fault_check(venv._h, None)                   # a persistent launch is complete only with a clear fault word
+            if rc == abi.DL_E_FAULT and persistent is None:
+                import warnings
+                warnings.warn('drloco_amd: the persistent evaluation launch reported a device fault (' + venv._lib.dl_last_error().decode() + '); fault cleared, walkers reset, '
+                              'evaluation redone with the launch form')
+                lib.check(venv._lib.dl_fault_clear(venv._h))
+                venv.set_state(cursor=cursor0)
+                return evaluate_walking(eval_env, policy, n_saved_models, chunk, persistent=False)
+            lib.check(rc)
         lib.check(venv._lib.dl_stats_snapshot(venv._h, b'first_ep_len', _ptr(first_len), _stream()))
         if steps < horizon and bool((first_len > 0).all()):
             break

@@ -33,41 +33,87 @@ class DrlocoFault(DrlocoError):
 
 LISTING_DIR = os.path.join(os.path.dirname(_HERE), 'build_dbg', 'listing')
 LISTING = os.path.join(LISTING_DIR, 'dl_kernels-hip-amdgcn-amd-amdhsa-gfx950.s')
+# The two code objects of the product (dl_group.hpp, DL_DPP_WAIT): 'w2' = libdrloco_hip.so, the DEFAULT -- the ISA manual's two wait states between a VALU write and its
+# DPP read in the hand-written statements; 'w1' = libdrloco_hip_dpp1.so, one state: what gfx950 was measured to need (+2.5 % headline), used only on a device that has
+# proven it in this process (load() below).  DL_LIB_PATH (experiment builds) bypasses the choice.
+VARIANTS = {
+    'w2': dict(path=os.path.join(CSRC, 'libdrloco_hip.so'), flags=[], need=2, listing=LISTING),
+    'w1': dict(path=os.path.join(CSRC, 'libdrloco_hip_dpp1.so'), flags=['-DDL_DPP_WAIT=1'], need=1,
+               listing=os.path.join(os.path.dirname(_HERE), 'build_dbg', 'listing_dpp1', 'dl_kernels-hip-amdgcn-amd-amdhsa-gfx950.s')),
+}
 
 
 def _sources():
     return [os.path.join(CSRC, s) for s in _SOURCES] + [os.path.join(INCLUDE, 'drloco_hip.h')]
 
 
-def build(force=False, verbose=False, listing=False):
-    """hipcc --offload-arch=gfx950 of the kernels + C-ABI into an in-tree shared library.  listing=True keeps the device assembly of the
-    same compilation (-save-temps, build_dbg/listing/) for tools/check_dpp_hazards.py -- the hand-written DPP statements carry their own
-    wait states, which the compiler's hazard recogniser does not check."""
-    srcs = _sources()
-    fresh = lambda path: os.path.exists(path) and all(os.path.getmtime(s) <= os.path.getmtime(path) for s in srcs)
-    if not force and fresh(LIB_PATH) and (not listing or fresh(LISTING)):
-        return LIB_PATH
+def _build_cmd(variant, listing):
+    v = VARIANTS[variant]
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I' + INCLUDE, '-I' + CSRC] + EXTRA_FLAGS + \
-          os.environ.get('DL_EXTRA_FLAGS', '').split() + (['-save-temps'] if listing else []) + [os.path.join(CSRC, 'dl_kernels.hip'), '-o', LIB_PATH]
+    # -ffile-prefix-map: no absolute path of the build directory inside the code object (line tables, __FILE__), so that the same sources hash to the same
+    # device code wherever they are built (device_code_sha16 is what profiles/*.json are stamped with)
+    return [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffile-prefix-map=' + os.path.dirname(_HERE) + '=.', '-I' + INCLUDE, '-I' + CSRC] + EXTRA_FLAGS + \
+        v['flags'] + os.environ.get('DL_EXTRA_FLAGS', '').split() + (['-save-temps'] if listing else []) + [os.path.join(CSRC, 'dl_kernels.hip'), '-o', v['path']]
+
+
+def _fresh(path):
+    return os.path.exists(path) and all(os.path.getmtime(s) <= os.path.getmtime(path) for s in _sources())
+
+
+def build(force=False, verbose=False, listing=False, variant='w2'):
+    """hipcc --offload-arch=gfx950 of the kernels + C-ABI into an in-tree shared library (one of VARIANTS).  listing=True keeps the device assembly of the
+    same compilation (-save-temps, build_dbg/listing*/) for tools/check_dpp_hazards.py -- the hand-written DPP statements carry their own
+    wait states, which the compiler's hazard recogniser does not check."""
+    v = VARIANTS[variant]
+    if variant == 'w2' and os.environ.get('DL_LIB_PATH'):
+        return LIB_PATH
+    if not force and _fresh(v['path']) and (not listing or _fresh(v['listing'])):
+        return v['path']
+    cmd = _build_cmd(variant, listing)
     if verbose:
         print(' '.join(cmd))
     if listing:
-        os.makedirs(LISTING_DIR, exist_ok=True)
-    subprocess.check_call(cmd, cwd=LISTING_DIR if listing else None)
+        os.makedirs(os.path.dirname(v['listing']), exist_ok=True)
+    subprocess.check_call(cmd, cwd=os.path.dirname(v['listing']) if listing else None)
+    return v['path']
+
+
+def build_all(force=False, verbose=False, listing=True):
+    """Both code objects, compiled side by side (two hipcc processes; a compilation is single-threaded and takes a few minutes)."""
+    todo = [k for k, v in VARIANTS.items() if force or not (_fresh(v['path']) and (not listing or _fresh(v['listing'])))]
+    procs = []
+    for k in todo:
+        cmd = _build_cmd(k, listing)
+        if verbose:
+            print(' '.join(cmd))
+        if listing:
+            os.makedirs(os.path.dirname(VARIANTS[k]['listing']), exist_ok=True)
+        procs.append((k, cmd, subprocess.Popen(cmd, cwd=os.path.dirname(VARIANTS[k]['listing']) if listing else None)))
+    for k, cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    return [VARIANTS[k]['path'] for k in VARIANTS]
+
+
+def loaded_path():
+    """The library load() chose (after a load), else the default one."""
+    if SELECTED and SELECTED.get('variant') in VARIANTS:
+        return VARIANTS[SELECTED['variant']]['path']
     return LIB_PATH
 
 
 def device_code_sha16(path=None):
     """Identity of the DEVICE code of a built library: sha256 over its `.hip_fatbin` section (the gfx950 code object hipcc embedded), first 16
-    hex digits.  Comments, host code and anything else that leaves the compiled kernels alone do not move it; profiles/*.json carry it so that
-    bench.py replays counter-derived figures only for the kernels they were measured on."""
+    hex digits.  Comments, host code and anything else that leaves the compiled kernels alone do not move it, nor does the directory the library was built
+    in (-ffile-prefix-map in the build command); profiles/*.json carry it so that bench.py replays counter-derived figures only for the kernels they were
+    measured on.  Default: the library load() selected."""
     import hashlib
     import struct
-    with open(path or LIB_PATH, 'rb') as f:
+    path = path or loaded_path()
+    with open(path, 'rb') as f:
         data = f.read()
     if data[:4] != b'\x7fELF' or data[4] != 2:
-        raise DrlocoError(f'{path or LIB_PATH}: not a 64-bit ELF file')
+        raise DrlocoError(f'{path}: not a 64-bit ELF file')
     shoff, = struct.unpack_from('<Q', data, 0x28)
     shentsize, shnum, shstrndx = struct.unpack_from('<HHH', data, 0x3A)
     sec = lambda i: struct.unpack_from('<IIQQQQIIQQ', data, shoff + i * shentsize)          # name, type, flags, addr, offset, size, ...
@@ -77,27 +123,28 @@ def device_code_sha16(path=None):
         name = data[str_off + name_off:data.index(b'\0', str_off + name_off)]
         if name == b'.hip_fatbin':
             return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
-    raise DrlocoError(f'{path or LIB_PATH}: no .hip_fatbin section (not a hipcc build?)')
+    raise DrlocoError(f'{path}: no .hip_fatbin section (not a hipcc build?)')
 
 
-def check_dpp_hazards():
-    """Run tools/check_dpp_hazards.py over the listing of the product build (building it if needed); raises on a violation."""
-    build(listing=True)
+def check_dpp_hazards(variant='w2'):
+    """Run tools/check_dpp_hazards.py over the listing of a product build (building it if needed) against ITS number of wait states; raises on a violation."""
+    build(listing=True, variant=variant)
+    v = VARIANTS[variant]
     tool = os.path.join(os.path.dirname(_HERE), 'tools', 'check_dpp_hazards.py')
-    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, LISTING], capture_output=True, text=True)
+    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, v['listing'], '--need', str(v['need'])], capture_output=True, text=True)
     if p.returncode != 0:
-        raise DrlocoError('DPP read-after-write hazard in the device code:\n' + p.stdout[-4000:] + p.stderr[-2000:])
+        raise DrlocoError(f'DPP read-after-write hazard in the device code ({variant}):\n' + p.stdout[-4000:] + p.stderr[-2000:])
     return p.stdout.strip().splitlines()[-1]
 
 
-def check_mfma_overlap():
-    """Run tools/check_mfma_overlap.py over the listing of the product build (building it if needed); raises on a violation: an MFMA whose
+def check_mfma_overlap(variant='w2'):
+    """Run tools/check_mfma_overlap.py over the listing of a product build (building it if needed); raises on a violation: an MFMA whose
     destination differs from its source C and lies over an A / B operand, a relocated 4x4x1 accumulator, or a missing hand-written wait state."""
-    build(listing=True)
+    build(listing=True, variant=variant)
     tool = os.path.join(os.path.dirname(_HERE), 'tools', 'check_mfma_overlap.py')
-    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, LISTING], capture_output=True, text=True)
+    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, VARIANTS[variant]['listing']], capture_output=True, text=True)
     if p.returncode != 0:
-        raise DrlocoError('MFMA operand overlap / wait-state violation in the device code:\n' + p.stdout[-4000:] + p.stderr[-2000:])
+        raise DrlocoError(f'MFMA operand overlap / wait-state violation in the device code ({variant}):\n' + p.stdout[-4000:] + p.stderr[-2000:])
     return p.stdout.strip().splitlines()[-1]
 
 
@@ -106,6 +153,8 @@ _SIGNATURES = {
     # name: (restype, argtypes)       -- every symbol include/drloco_hip.h declares
     'dl_last_error': (C.c_char_p, []),
     'dl_abi_version': (C.c_int, []),
+    'dl_dpp_wait_states': (C.c_int, []),
+    'dl_hw_probe': (C.c_int, [_I, _I, C.POINTER(C.c_uint64)]),
     'dl_create': (C.c_int, [C.POINTER(abi.ModelDesc), C.POINTER(abi.RefsDesc), C.POINTER(abi.Config), _I, _I, C.POINTER(_V)]),
     'dl_destroy': (C.c_int, [_V]),
     'dl_num_envs': (_I, [_V]),
@@ -118,6 +167,8 @@ _SIGNATURES = {
     'dl_rollout_fixed': (C.c_int, [_V, _I, _P, _P, _P, _P, _P]),
     'dl_get_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
     'dl_set_state': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
+    'dl_get_ref_offsets': (C.c_int, [_V, _P, _P]),
+    'dl_set_ref_offsets': (C.c_int, [_V, _P, _P]),
     'dl_forward': (C.c_int, [_V, _P, _P, _P, _P, _P, _P]),
     'dl_set_randomization': (C.c_int, [_V, _P, _P, _P]),
     'dl_set_push': (C.c_int, [_V, _P, _P]),
@@ -130,6 +181,7 @@ _SIGNATURES = {
     'dl_profile': (C.c_int, [_V, _I]),
     'dl_profile_read': (C.c_int, [_V, C.POINTER(C.c_double), C.POINTER(_I)]),
     'dl_profile_steps': (C.c_int, [_V]),
+    'dl_profile_launch_config': (C.c_int, [_V, C.POINTER(_I)]),
     'dl_moments_update': (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     'dl_normalize_obs': (C.c_int, [_P, _P, _P, _I, _I, C.c_double, C.c_double, _P]),
     'dl_normalize_reward': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, _P]),
@@ -164,23 +216,65 @@ _EXTRA = {
 }
 
 
+def _open(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in {**_SIGNATURES, **_EXTRA}.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.dl_abi_version() != abi.DL_ABI_VERSION:
+        raise DrlocoError(f'ABI version mismatch between drloco_amd/abi.py and {os.path.basename(path)}')
+    for which, struct in enumerate((abi.ModelDesc, abi.RefsDesc, abi.Config)):
+        if lib.dl_abi_sizeof(which) != C.sizeof(struct):
+            raise DrlocoError(f'struct size mismatch for {struct.__name__}')
+    return lib
+
+
+def hw_probe(lib=None, device=-1, iters=64):
+    """dl_hw_probe on `device` (-1: the current one): dict(stale_dpp=[0, 1, 2 wait states], stale_mfma=[single s_nop 7, 8 x v_nop, two s_nop], lane_reads_per_cell, cells)
+    -- or None without a HIP device."""
+    lib = lib or load()
+    out = (C.c_uint64 * 8)()
+    rc = lib.dl_hw_probe(device, iters, out)
+    if rc == abi.DL_E_NODEVICE:
+        return None
+    if rc != 0:
+        raise DrlocoError(f'dl_hw_probe failed: {lib.dl_last_error().decode()}')
+    return dict(stale_dpp=[int(out[0]), int(out[1]), int(out[2])], stale_mfma=[int(out[3]), int(out[4]), int(out[5])], lane_reads_per_cell=int(out[6]), cells=int(out[7]))
+
+
+SELECTED = None          # after load(): dict(variant, why, probe) -- what bench.py reports
+
+
 def load():
-    """Load the HIP library; raises DrlocoError if it has not been built."""
-    global _lib
+    """Load the HIP library; raises DrlocoError if it has not been built.  Which code object: DL_LIB_PATH (an experiment build) as it is; otherwise the default,
+    spec-conformant one (two wait states in front of the hand-written DPP reads) unless this process's device PROVES that one is enough -- dl_hw_probe shows stale reads
+    with no wait (the test can fail) and none with one state --, in which case the one-state build is used.  DL_DPP_WAIT=2 / 1 in the environment forces a choice
+    (1 still has to pass the probe: dl_create of that build runs it and refuses otherwise)."""
+    global _lib, SELECTED
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise DrlocoError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in {**_SIGNATURES, **_EXTRA}.items():
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
-    if lib.dl_abi_version() != abi.DL_ABI_VERSION:
-        raise DrlocoError('ABI version mismatch between drloco_amd/abi.py and libdrloco_hip.so')
-    for which, struct in enumerate((abi.ModelDesc, abi.RefsDesc, abi.Config)):
-        if lib.dl_abi_sizeof(which) != C.sizeof(struct):
-            raise DrlocoError(f'struct size mismatch for {struct.__name__}')
+    lib = _open(LIB_PATH)
+    SELECTED = dict(variant='experiment build (DL_LIB_PATH)' if os.environ.get('DL_LIB_PATH') else 'w2', dpp_wait_states=int(lib.dl_dpp_wait_states()), why='default', probe=None)
+    want = os.environ.get('DL_DPP_WAIT', 'auto')
+    fast = VARIANTS['w1']['path']
+    if not os.environ.get('DL_LIB_PATH') and want != '2' and os.path.exists(fast):
+        probe = None
+        try:
+            probe = hw_probe(lib)
+        except DrlocoError as e:
+            SELECTED['why'] = f'probe failed ({e}): spec-conformant build'
+        if probe is None:
+            if SELECTED['why'] == 'default':
+                SELECTED['why'] = 'no HIP device in this process: spec-conformant build'
+        elif probe['stale_dpp'][0] > 0 and probe['stale_dpp'][1] == 0 and probe['stale_dpp'][2] == 0:
+            lib = _open(fast)
+            SELECTED = dict(variant='w1', dpp_wait_states=int(lib.dl_dpp_wait_states()), probe=probe,
+                            why=f"this device needs ONE wait state in front of a DPP read: {probe['stale_dpp'][0]} stale reads with none, 0 with one, of {probe['cells']} x {probe['lane_reads_per_cell']} lane-reads (dl_hw_probe)")
+        else:
+            SELECTED.update(probe=probe, why=f"probe: stale DPP reads with 0 / 1 / 2 wait states = {probe['stale_dpp']}: the one-state build is not proven on this device, spec-conformant build kept")
     _lib = lib
     return lib
 

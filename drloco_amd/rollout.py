@@ -36,7 +36,7 @@ class HipRolloutBuffer:
         self.episode_starts[t].copy_(episode_start); self.values[t].copy_(value); self.log_probs[t].copy_(log_prob)
         self.pos += 1
 
-    def collect_rollouts(self, vn, policy, last_obs, last_done, persistent=None, moments='per_step', workgroup_tiles=False):
+    def collect_rollouts(self, vn, policy, last_obs, last_done, persistent=None, moments='per_step', workgroup_tiles=False, deterministic=False):
         """SB3 1.0 OnPolicyAlgorithm.collect_rollouts (the loop between two PPO updates) as ONE C-ABI call, dl_collect_rollouts:
         T x (policy forward -> env step -> VecNormalize), every result written straight into this buffer.  vn: HipVecNormalize;
         policy: HipPolicy; last_obs float32 [N, obs] / last_done uint8 [N]: the normalised observation and episode-start flags that
@@ -49,6 +49,7 @@ class HipRolloutBuffer:
         normalised with the moments at its start, which are advanced once, by all T x N samples, at its end -- include/drloco_hip.h).
         workgroup_tiles (with 'per_rollout'): run the relaxation on the exact form's kernel (sixteen-row policy tiles, the workgroup's pairs meet
         every step) instead of the pair-by-pair kernel: the selectable fallback, about 4 % slower (DL_ROLLOUT_WORKGROUP_TILES).
+        deterministic: the policy's mean action instead of a sample (DL_ROLLOUT_DETERMINISTIC, every form; not for the cross-rank per-step host loop).
 
         What the automatic mode (persistent=None) does when the exchange times out, so that nobody is surprised by it: (1) the fault is cleared
         and VecNormalize's moments are restored to their pre-launch snapshot; (2) ALL walkers are reset (vn.reset()): every episode in flight
@@ -63,6 +64,8 @@ class HipRolloutBuffer:
             # exact per-step moments ACROSS RANKS (HipVecNormalize(sync='per_step')): every control step's update needs the other ranks' sums, so
             # the loop runs on the host -- policy forward, env step, local sums, all-reduce, merge, normalise: six launches + one collective per
             # control step.  With one rank and blocked_reduce it is the launch form of dl_collect_rollouts bit for bit (tests/test_gpu_persistent.py).
+            if deterministic:
+                raise lib.DrlocoError("deterministic rollouts go through dl_collect_rollouts: not with HipVecNormalize(sync='per_step')")
             if persistent or moments == 'per_rollout':
                 raise lib.DrlocoError("HipVecNormalize(sync='per_step') exchanges moments between ranks every control step: the persistent / per-rollout forms do not apply")
             if vn._ov is not None:
@@ -89,7 +92,10 @@ class HipRolloutBuffer:
         if moments == 'per_rollout' and not persistent:
             raise lib.DrlocoError("moments='per_rollout' exists in the persistent form of collect_rollouts only")
 
+        det = abi.DL_ROLLOUT_DETERMINISTIC if deterministic else 0
+
         def launch(mode):
+            mode |= det
             lib.check(self._lib.dl_collect_rollouts(vn.venv._h, C.byref(p), policy.seed, policy.counter, policy.index_base, C.byref(st), self.T,
                                                     _ptr(self.observations), _ptr(self.actions), _ptr(self.values), _ptr(self.log_probs), _ptr(self.rewards),
                                                     _ptr(self.episode_starts), _ptr(last_obs), _ptr(last_done), _ptr(vn.venv.obs), _ptr(vn.venv.rew), mode, _stream()))

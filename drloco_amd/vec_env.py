@@ -84,6 +84,7 @@ class HipVecEnv(_VecEnvBase):
         self._ep_len = np.zeros(n, np.int64)
         self.ep_lens = [[] for _ in range(n)]
         self._mlists = None                        # track_monitor_lists()
+        self.reuse_infos, self._info_pool, self._info_dirty = True, None, []          # _infos()
         self.split = False
         if split:
             self.set_split(True)
@@ -120,13 +121,14 @@ class HipVecEnv(_VecEnvBase):
     def step_wait(self):
         obs, rew, done, term = self.step_tensors(self._actions)
         obs_h, rew_h, done_h = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool)
-        infos = [{} for _ in range(self.num_envs)]
+        infos = self._infos()
         self._ep_len += 1
         self._update_monitor_lists(done_h)
         if done_h.any():
             term_h = term.cpu().numpy()
             for i in np.nonzero(done_h)[0]:
                 infos[i]['terminal_observation'] = term_h[i]
+                self._info_dirty.append(int(i))
                 self.ep_lens[i].append(int(self._ep_len[i]))
                 self._ep_len[i] = 0
         return obs_h, rew_h, done_h, infos
@@ -134,6 +136,23 @@ class HipVecEnv(_VecEnvBase):
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
+
+    def _infos(self):
+        """The step's list of info dicts.  MimicEnv.step returns `{}` (mimic_env.py:126) and the vec-env worker adds 'terminal_observation' for a finished env, so all
+        but a few of a step's dicts are empty: every walker keeps ONE dict object across steps (building N fresh dicts per step costs more host time than the step's device work
+        at thousands of walkers, tools/bench_vecenv_api.py), and a walker whose dict carried a terminal observation gets a fresh one at its next step -- what a caller kept from
+        an earlier step is never changed under its feet.  (A caller that WRITES into the info of an unfinished walker sees its entry again at the next step; reuse_infos = False
+        restores N fresh dicts per step.)"""
+        n = self.num_envs
+        if not self.reuse_infos:
+            return [{} for _ in range(n)]
+        pool = self._info_pool
+        if pool is None:
+            pool = self._info_pool = [{} for _ in range(n)]
+        for i in self._info_dirty:
+            pool[i] = {}
+        self._info_dirty = []
+        return list(pool)
 
     def rollout_fixed(self, actions, obs_out=None, rew_out=None, done_out=None):
         """Synthetic fixed-length rollout: actions float32 cuda [T, N, nu] (no policy)."""
@@ -295,6 +314,20 @@ class HipVecEnv(_VecEnvBase):
         q, v, w = f(qpos, self.rdtype), f(qvel, self.rdtype), f(warm, self.rdtype)
         c, wk = f(cursor, torch.int32), f(walked, torch.float64)
         lib.check(self._lib.dl_set_state(self._h, _ptr(q), _ptr(v), _ptr(w), _ptr(c), _ptr(wk), _stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def get_ref_offsets(self):
+        """Quirk Q4's record (dl_get_ref_offsets): the COM-z offset every reference step of every walker's data set carries from the last reset that landed on it
+        (adjust_COM_Z_pos, base_ref_trajecs.py:126-127): numpy [n_steps, N]."""
+        z = torch.empty(self.refs.n_steps, self.num_envs, dtype=self.rdtype, device=self.device)
+        lib.check(self._lib.dl_get_ref_offsets(self._h, _ptr(z), _stream()))
+        return z.cpu().numpy()
+
+    def set_ref_offsets(self, z):
+        z = torch.as_tensor(np.ascontiguousarray(z), dtype=self.rdtype, device=self.device).contiguous()
+        if tuple(z.shape) != (self.refs.n_steps, self.num_envs):
+            raise ValueError(f'z_offsets must be [n_steps = {self.refs.n_steps}, N = {self.num_envs}]')
+        lib.check(self._lib.dl_set_ref_offsets(self._h, _ptr(z), _stream()))
         torch.cuda.current_stream().synchronize()
 
     def forward(self, ctrl=None):
@@ -678,7 +711,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
         obs, rew, done, term = self.step_tensors(self._actions)
         self.flush()
         done_h = done.cpu().numpy().astype(bool)
-        infos = [{} for _ in range(self.num_envs)]
+        infos = self.venv._infos()
         self.venv._ep_len += 1
         self.venv._update_monitor_lists(done_h)
         if done_h.any():
@@ -688,6 +721,7 @@ class HipVecNormalize(_VecEnvWrapperBase):
             term_h = t.cpu().numpy()
             for i in np.nonzero(done_h)[0]:
                 infos[i]['terminal_observation'] = term_h[i]
+                self.venv._info_dirty.append(int(i))
                 self.venv.ep_lens[i].append(int(self.venv._ep_len[i]))
                 self.venv._ep_len[i] = 0
         return obs.cpu().numpy(), rew.cpu().numpy(), done_h, infos

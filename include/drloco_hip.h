@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 6   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed, dl_vn_local_sums / dl_vn_merge_sums (flag 64).  6: dl_policy_forward_pair, DL_ROLLOUT_WORKGROUP_TILES, DL_ROLLOUT_DETERMINISTIC, dl_stats_snapshot first_ep_* */
+#define DL_ABI_VERSION 7   /* 2: dl_rollout_policy, dl_vecnorm_state, dl_profile_steps; dl_profile takes a sampling stride.  3: dl_adv_stats takes a caller-owned workspace; dl_vecnormalize_step flag 16.  4: dl_vecnormalize_steps, dl_set_split.  5: DL_E_FAULT, dl_fault_check / dl_fault_clear, dl_collect_rollouts, dl_vecnormalize_step flag 32, dl_policy_pack / dl_policy_forward_packed, dl_vn_local_sums / dl_vn_merge_sums (flag 64).  6: dl_policy_forward_pair, DL_ROLLOUT_WORKGROUP_TILES, DL_ROLLOUT_DETERMINISTIC, dl_stats_snapshot first_ep_*.  7: dl_config.intended_semantics (quirk Q4 reproduced by default; switches for Q2-Q4) and dl_config.strict_solver, dl_get_ref_offsets / dl_set_ref_offsets, dl_dpp_probe */
 
 /* static capacities of the POD descriptors */
 #define DL_MAX_BODY 12
@@ -161,12 +161,39 @@ typedef struct dl_config {
                                (drloco/mujoco/config.py:9-10) */
     int32_t lanes_per_walker; /* launch geometry of the dynamics kernels: 1 = one walker per lane, 16 = one walker per
                                16-lane DPP row (models with <= 16 dofs), 0 = auto (16 where supported, else 1) */
+    int32_t intended_semantics; /* 0 (default) = strict_reference_quirks: the reference's behaviour incl. its quirks Q1-Q4.  Bits select
+                               the obviously intended behaviour instead: DL_INTENDED_* below.  (Q1, the COM-x offset of the step bound at reset, has no switch.) */
+    int32_t strict_solver;    /* float32 16-lane kernels (one-wave form): 1 = the Newton solver takes the reference's ([3P] MuJoCo mj_solNewton) decisions -- start at the cheaper
+                               of warm start and qacc_smooth, every line search run to its derivative tolerance (no Armijo acceptance of the first trial), no early exit
+                               on an unchanged active set, IEEE division and square roots -- at the cost of speed: the mode real MuJoCo vectors (golden G12) are compared under.
+                               0 (default): the product's iteration path; the minimiser is the same.  Refused (DL_E_INVAL) for split workgroups. */
 } dl_config;
+/* bits of dl_config.intended_semantics */
+#define DL_INTENDED_COUNT_PER_EPISODE 2  /* Q2 off: count_steps_same_vel restarts at 1 with every reset (the reference never resets it, straight_walk_trajecs.py:124,336) */
+#define DL_INTENDED_EVAL_OWN_STEP 4      /* Q3 off: an evaluation init reads the kinematics of ITS step k (the reference reads step 0's table, straight_walk_trajecs.py:237-265) */
+#define DL_INTENDED_COMZ_PER_EPISODE 8   /* Q4 off: the COM-z re-anchoring of reset_model applies to the reset step for the current episode only (rounds 1-5 of this library);
+                                            default: adjust_COM_Z_pos mutates the walker's copy of the data set in place (base_ref_trajecs.py:126-127, mimic_env.py:555-557):
+                                            every step keeps the offset of the last reset that landed on it, and a cursor rolling into that step reads it */
 
 typedef struct dl_env_s* dl_handle;
 
 const char* dl_last_error(void);
 int dl_abi_version(void);
+
+/* Hardware facts this library's hand-written wait states rest on, checked ON the device (no reference counterpart: the reference has no device code).
+ *   dl_dpp_wait_states   how many wait states this build keeps between a VALU write of a VGPR and its read through DPP in its hand-written statements:
+ *                        2 = libdrloco_hip.so, the default -- the gfx9 / CDNA ISA manual's number, as `s_nop 0` twice (no s_wakeup of another wave can shorten it);
+ *                        1 = libdrloco_hip_dpp1.so (-DDL_DPP_WAIT=1) -- what gfx950 was measured to need (+2.5 % on the benchmark line).  dl_create of THAT build runs
+ *                        dl_hw_probe once per device and process and refuses (DL_E_HIP, text names the other library) unless one state is proven enough.
+ *   dl_hw_probe          ~0.1 s of micro kernels on `device` (-1: the current one), iters <= 0: 64.  out[8]:
+ *                        [0..2] stale DPP reads with 0 / 1 / 2 wait states behind the write, summed over 7 producers x 6 DPP forms, alone and beside a wave that loops over
+ *                               s_wakeup ([0] > 0 shows that the test can fail; the one-state build needs [1] == 0);
+ *                        [3..5] stale rows of a v_mfma_f32_4x4x1 result read 8 wait states later beside an s_wakeup loop, the wait written as ONE `s_nop 7` ([3] > 0: another
+ *                               wave's s_wakeup ends an s_nop after one state), as 8 x v_nop ([4] == 0: what the policy kernels wait with), as two s_nop ([5] == 0);
+ *                        [6] lane-reads per DPP cell, [7] DPP cells.
+ * The Python loader (drloco_amd/lib.py) loads the default build, asks it for the probe, and switches to the one-state build only on that evidence. */
+int dl_dpp_wait_states(void);
+int dl_hw_probe(int32_t device, int32_t iters, uint64_t* out);
 
 /* MimicWalker3dEnv.__init__ x N  (mimic_walker3d.py:33-40, mimic_env.py:19-57).
  * device: HIP device ordinal. */
@@ -217,6 +244,12 @@ int dl_get_state(dl_handle h, void* qpos, void* qvel, void* qacc_warm, int32_t* 
 int dl_set_state(dl_handle h, const void* qpos, const void* qvel, const void* qacc_warm,
                  const int32_t* cursor, const double* walked, void* stream);
 
+/* Quirk Q4's per-walker record: the COM-z offset each reference step carries from the last reset that landed on it (adjust_COM_Z_pos, base_ref_trajecs.py:126-127;
+ * every SubprocVecEnv worker owns a copy of the data set, so the record is per walker): real[n_steps, N] in the handle's real type, zero at dl_create.  The get / set pair
+ * completes dl_get_state / dl_set_state for parity tests and for carrying an environment over (a walker's current offset is re-read from the record by dl_set_ref_offsets). */
+int dl_get_ref_offsets(dl_handle h, void* z_offsets, void* stream);
+int dl_set_ref_offsets(dl_handle h, const void* z_offsets, void* stream);
+
 /* Forward dynamics only (mj_forward) at the current state with the given ctrl (real[nu,N],
  * already in torque units): writes qacc real[nv,N]; ncon/nefc/niter int32[N] may be NULL. */
 int dl_forward(dl_handle h, const void* ctrl, void* qacc, int32_t* ncon, int32_t* nefc,
@@ -266,7 +299,8 @@ int dl_terminate_early(dl_handle h, int32_t* flags, void* stream);
 /* Monitor attributes (drloco/mujoco/monitor_wrapper.py:88-133) kept per walker on device.
  * name: one of ep_len_smoothed, ep_ret_smoothed, mean_reward_smoothed, moved_distance,
  * mean_ep_pos_rew_smoothed, mean_ep_vel_rew_smoothed, mean_ep_com_rew_smoothed,
- * mean_abs_ep_torque_smoothed; first_ep_len, first_ep_moved, first_ep_ret: the FIRST episode a walker finished since dl_create or the last dl_reset of all
+ * mean_abs_ep_torque_smoothed; diverged_steps: control steps that took the exception path (MujocoException -> reward 0, done, double reset; mimic_env.py:86-91) since dl_create;
+ * first_ep_len, first_ep_moved, first_ep_ret: the FIRST episode a walker finished since dl_create or the last dl_reset of all
  * walkers (mask NULL), measured as TrainingMonitor.eval_walking measures an episode (drloco/common/callback.py:300-317: length incl. the terminal step;
  * walked distance and reward sum without it; 0 = no episode finished yet).  out: double[N] device. */
 int dl_stats_snapshot(dl_handle h, const char* name, double* out, void* stream);
@@ -281,6 +315,10 @@ int dl_profile_read(dl_handle h, double* total_ms, int32_t* launches);
 /* control steps covered by the launches the last dl_profile_read reported (dl_rollout_fixed takes up to 512 control steps per
  * launch of the 16-lane kernel, dl_step one) */
 int dl_profile_steps(dl_handle h);
+/* launch geometry of the last bracketed launch: out[3] = {threads of the grid, threads per workgroup, dynamic LDS bytes} -- what rocprofv3's kernel trace calls Grid_Size,
+ * Workgroup_Size, LDS_Block_Size.  A committed counter pass (profiles/traffic_*.json) records them; bench.py replays its figures only while the device code AND this geometry
+ * are the ones that pass measured. */
+int dl_profile_launch_config(dl_handle h, int32_t* out);
 
 /* ---- reductions of the SB3 layer (stable-baselines3==1.0, docs/conda_env.yml:30) ---- */
 
@@ -436,7 +474,9 @@ int dl_rollout_policy(dl_handle h, const dl_policy_params* policy, uint64_t seed
  *       Not SB3's per-step update; the same relaxation the cross-rank merge C3 applies.
  *       Kernel: every wave PAIR takes its own four walkers through the rollout (k_rollout_pairs: the policy on v_mfma_f32_4x4x1 chains, no meeting of the
  *       workgroup's pairs per step).  A pair whose two waves fail to meet within the poll budget raises DL_FAULT_SRV_TIMEOUT and stops; its rows of the
- *       buffers stay incomplete -- same rule as above: fault check before reading.
+ *       buffers stay incomplete -- same rule as above: fault check before reading.  (ONE poll budget serves both persistent kernels' waits -- the grid exchange of the
+ *       exact form and this pair meeting: ~seconds by default; the test hook dl_debug_set_grid_spin sets both.  A wave decides "my partner did not come" from a last
+ *       read of the partner's counter after the budget has run out, never from the budget alone.)
  *   ... | DL_ROLLOUT_WORKGROUP_TILES   the same relaxation on the exact form's kernel (k_rollout_persistent: sixteen-row policy tiles on v_mfma_f32_16x16x4, the
  *       workgroup's four pairs meet at every control step): the selectable fallback for the pair kernel, about 4 % slower; same buffers, the same moments after
  *       the merge up to the grouping of the float64 sums. */

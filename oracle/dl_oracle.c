@@ -763,6 +763,7 @@ struct dlo_env_s {
     int32_t *step_off, *step_is_left;
     double* step_vel;
     walker_t* w;
+    double* zacc; /* [n][n_steps]: quirk Q4, the COM-z offset every step of walker i's copy of the data set has accumulated (adjust_COM_Z_pos) */
     data_t d;
     int eval_mode;
 };
@@ -783,6 +784,7 @@ dlo_env* dlo_create(const dl_model_desc* model, const dl_refs_desc* refs, const 
     e->step_vel = (double*)malloc(refs->n_steps * sizeof(double));
     memcpy(e->step_vel, refs->step_vel, refs->n_steps * sizeof(double));
     e->w = (walker_t*)calloc(n, sizeof(walker_t));
+    e->zacc = (double*)calloc((size_t)n * refs->n_steps, sizeof(double));
     for (int i = 0; i < n; i++) {
         e->w[i].cur[DL_CUR_COUNT] = 1; /* straight_walk_trajecs.py:124 */
         for (int j = 0; j < model->nv; j++) e->w[i].q[j] = model->jnt_qpos0[j];
@@ -791,7 +793,7 @@ dlo_env* dlo_create(const dl_model_desc* model, const dl_refs_desc* refs, const 
 }
 void dlo_destroy(dlo_env* e) {
     if (!e) return;
-    free(e->table); free(e->step_off); free(e->step_is_left); free(e->step_vel); free(e->w); free(e);
+    free(e->table); free(e->step_off); free(e->step_is_left); free(e->step_vel); free(e->w); free(e->zacc); free(e);
 }
 
 static int step_len(const dlo_env* e, int s) { return e->step_off[s + 1] - e->step_off[s]; }
@@ -799,7 +801,13 @@ static int obs_dim(const dlo_env* e) { return e->cfg.env_kind == DL_ENV_LOCO3D ?
 
 /* refs.get_qpos()/get_qvel() at the cursor (base_ref_trajecs.py:44-56) incl. the COM-x offset of
  * _get_next_step (straight_walk_trajecs.py:338-347, quirk Q1) and the COM-z re-anchoring of
- * reset_model (mimic_env.py:555-557; applied to the reset step only) */
+ * reset_model (mimic_env.py:555-557 -> adjust_COM_Z_pos, base_ref_trajecs.py:126-127).  Quirk Q4 (default): the
+ * re-anchoring subtracts the offset from the COM-z row of the data set IN PLACE -- `_qpos_full` is `data[i_step]` itself after
+ * an RSI reset (straight_walk_trajecs.py:466-468) and `data[0]` after an evaluation init (:242, quirk Q3) --, and the copy
+ * `_get_next_step` makes at a rollover (:342) is a copy of the mutated row: whatever step the cursor reads carries the offsets of
+ * all earlier resets of THIS environment that landed on it (every SubprocVecEnv worker has its own data set).  zacc[i][step] is
+ * that sum.  With DL_INTENDED_COMZ_PER_EPISODE the offset applies to the reset step for the current episode only. */
+static int q4_on(const dlo_env* e) { return !(e->cfg.intended_semantics & DL_INTENDED_COMZ_PER_EPISODE); }
 static void ref_lookup(const dlo_env* e, const walker_t* w, double* qr, double* vr) {
     int nv = e->mm.m.nv;
     int base = e->step_off[w->cur[DL_CUR_READ_STEP]] + w->cur[DL_CUR_POS];
@@ -807,10 +815,11 @@ static void ref_lookup(const dlo_env* e, const walker_t* w, double* qr, double* 
         qr[j] = e->table[(size_t)j * e->total_len + base];
         vr[j] = e->table[(size_t)(nv + j) * e->total_len + base];
     }
+    if (q4_on(e)) qr[2] -= e->zacc[(size_t)(w - e->w) * e->n_steps + w->cur[DL_CUR_READ_STEP]];
     if (w->cur[DL_CUR_HAS_DIST]) {
         int rs = w->cur[DL_CUR_RSI_STEP];
         qr[0] += e->table[e->step_off[rs + 1] - 1];
-    } else {
+    } else if (!q4_on(e)) {
         qr[2] -= w->comz_off;
     }
 }
@@ -966,7 +975,7 @@ static void reset_walker(dlo_env* e, int i, int inj_step, int inj_pos, double* o
          * but the kinematics are read from step 0's table (quirk Q3) */
         s = c[DL_CUR_EVAL_K];
         p = (int32_t)(0.75 * step_len(e, s));
-        read = 0;
+        read = (e->cfg.intended_semantics & DL_INTENDED_EVAL_OWN_STEP) ? s : 0;
         c[DL_CUR_EVAL_K] = (s + 1 >= 20) ? 0 : s + 1;
     }
     else if (w->inject_rsi) { s = w->inj_rsi_step; p = w->inj_rsi_pos; }
@@ -975,11 +984,13 @@ static void reset_walker(dlo_env* e, int i, int inj_step, int inj_pos, double* o
     c[DL_CUR_EP_DUR] = 0;
     w->walked = 0;
     c[DL_CUR_I_STEP] = s; c[DL_CUR_RSI_STEP] = s; c[DL_CUR_READ_STEP] = read >= 0 ? read : s; c[DL_CUR_POS] = p; c[DL_CUR_HAS_DIST] = 0;
+    if (e->cfg.intended_semantics & DL_INTENDED_COUNT_PER_EPISODE) c[DL_CUR_COUNT] = 1;
     w->comz_off = 0;
-    ref_lookup(e, w, w->q, w->v);
+    ref_lookup(e, w, w->q, w->v);          /* Q4: the state is read from the row as earlier resets left it ... */
     double low = lowest_site(e, w->q);
-    w->q[2] -= low;
+    w->q[2] -= low;                        /* ... so the initial state itself does not depend on the history (the foot height follows the root's z) */
     w->comz_off = low;
+    if (q4_on(e)) e->zacc[(size_t)i * e->n_steps + c[DL_CUR_READ_STEP]] += low;          /* adjust_COM_Z_pos: `row -= low`, in place */
     /* set_state -> mj_forward: qacc of the initial state becomes the warmstart */
     { model_t tmp; forward(walker_model(e, w, &tmp), w->q, w->v, NULL, NULL, 0, &e->d); }
     memcpy(w->warm, e->d.qacc, m->nv * sizeof(double));
@@ -1124,6 +1135,13 @@ void dlo_set_state(dlo_env* e, const double* qpos, const double* qvel, const dou
         if (cursor) for (int k = 0; k < DL_CUR_WORDS; k++) e->w[i].cur[k] = cursor[(size_t)k * n + i];
         if (walked) e->w[i].walked = walked[i];
     }
+}
+/* quirk Q4's record in the layout of dl_get_ref_offsets: double[n_steps, N] */
+void dlo_get_ref_offsets(dlo_env* e, double* z) {
+    for (int i = 0; i < e->n; i++) for (int s = 0; s < e->n_steps; s++) z[(size_t)s * e->n + i] = e->zacc[(size_t)i * e->n_steps + s];
+}
+void dlo_set_ref_offsets(dlo_env* e, const double* z) {
+    for (int i = 0; i < e->n; i++) for (int s = 0; s < e->n_steps; s++) e->zacc[(size_t)i * e->n_steps + s] = z[(size_t)s * e->n + i];
 }
 void dlo_forward(dlo_env* e, const double* ctrl, double* qacc, int32_t* ncon, int32_t* nefc, int32_t* niter) {
     int nv = e->mm.m.nv, nu = e->mm.m.nu, n = e->n;

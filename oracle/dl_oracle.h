@@ -12,7 +12,7 @@
  *
  * PARITY STATUS
  *   env logic (cursor, reward, observation, termination, action mapping, monitor smoothing):
- *     pinned against the golden vectors tests/golden/G1..G7 generated from the reference itself.
+ *     pinned against the golden vectors tests/golden/G1..G11, G13..G15 generated from the reference itself.
  *   dynamics (mj_step): PARITY UNPINNED -- MuJoCo is a third-party binary that is not in
  *     /root/reference and not installable here; pinned only by physics known-answer tests
  *     (tests/test_oracle_physics.py).
@@ -49,6 +49,9 @@ void dlo_get_state(dlo_env* e, double* qpos, double* qvel, double* qacc_warm, in
                    double* walked);
 void dlo_set_state(dlo_env* e, const double* qpos, const double* qvel, const double* qacc_warm,
                    const int32_t* cursor, const double* walked);
+/* quirk Q4: the COM-z offsets the steps of every walker's data set carry (adjust_COM_Z_pos), double[n_steps, N] */
+void dlo_get_ref_offsets(dlo_env* e, double* z);
+void dlo_set_ref_offsets(dlo_env* e, const double* z);
 void dlo_forward(dlo_env* e, const double* ctrl, double* qacc, int32_t* ncon, int32_t* nefc,
                  int32_t* niter);
 /* MimicEnv.activate_evaluation for all walkers */

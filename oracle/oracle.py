@@ -154,6 +154,16 @@ class OracleEnv:
         c = None if cursor is None else np.ascontiguousarray(cursor, np.int32)
         lib().dlo_set_state(self.h, _p(q), _p(v), _p(w), _p(c, C.c_int32), _p(wk))
 
+    def get_ref_offsets(self):
+        z = np.zeros((self.refs.n_steps, self.n))
+        lib().dlo_get_ref_offsets(self.h, _p(z))
+        return z
+
+    def set_ref_offsets(self, z):
+        z = np.ascontiguousarray(z, np.float64)
+        assert z.shape == (self.refs.n_steps, self.n)
+        lib().dlo_set_ref_offsets(self.h, _p(z))
+
     def forward(self, ctrl=None):
         u = np.zeros((self.nu, self.n)) if ctrl is None else np.ascontiguousarray(ctrl, np.float64)
         qacc = np.zeros((self.nv, self.n))

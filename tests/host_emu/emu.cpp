@@ -15,7 +15,7 @@ template <typename T, typename TP> struct Emu {
     DevModel<T, TP> m;
     DevCfg<T> c;
     DevState<T> st;
-    std::vector<T> qpos, qvel, warm, comz, table, step_vel, lane, work;
+    std::vector<T> qpos, qvel, warm, comz, zacc, table, step_vel, lane, work;
     std::vector<int32_t> cur, need, inj, step_off, is_left, inj_flags;
     std::vector<double> walked, mon;
     std::vector<T> inj_q, inj_v;
@@ -59,6 +59,7 @@ template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_
     e->lane.assign(MemLayout<TP>::TOTAL, 0);
     e->work.assign((size_t)4 * TP::NV * n, 0);
     e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), e->work.data(), n};
+    e->zacc.assign((size_t)r->n_steps * n, 0); e->st.zacc = e->zacc.data();          // quirk Q4's record
     e->st.rnd = nullptr; e->st.dbgf = nullptr; e->st.dbg = nullptr; e->st.dbg_cap = 1 << 30;
     e->st.push_phase = nullptr; e->st.push_period = 1; e->st.push_dur = 0; e->st.push_step0 = 0;
     e->gm_ok = fill_group_model<T, TP>(*d, e->gm, why);
@@ -187,6 +188,7 @@ template <typename T, typename TP> static void emu_set_push_schedule(Emu<T, TP>*
         auto* e = (Emu<T, TP>*)h; e->inj_flags[i] = flag;                                                                     \
         if (q) for (int j = 0; j < TP::NV; j++) { e->inj_q[(size_t)j * e->n + i] = q[j]; e->inj_v[(size_t)j * e->n + i] = v[j]; } } \
     extern "C" void dle_inject_rsi_##SUF(void* h, int i, int s, int p) { auto* e = (Emu<T, TP>*)h; e->inj[i] = s; e->inj[(size_t)e->n + i] = p; } \
+    extern "C" void dle_get_zacc_##SUF(void* h, T* out) { auto* e = (Emu<T, TP>*)h; memcpy(out, e->zacc.data(), e->zacc.size() * sizeof(T)); }  \
     extern "C" void dle_set_eval_##SUF(void* h, int on) { ((Emu<T, TP>*)h)->eval_mode = on; }                                \
     extern "C" void dle_mon_##SUF(void* h, int word, double* out) { auto* e = (Emu<T, TP>*)h; memcpy(out, e->mon.data() + (size_t)word * e->n, e->n * 8); }
 

@@ -147,6 +147,12 @@ class EmuEnv:
         q = np.ascontiguousarray(qpos, self.rt); v = np.ascontiguousarray(qvel, self.rt)
         self._f('inject')(self.h, C.c_int(i), C.c_int(1), _p(q, self.ct), _p(v, self.ct))
 
+    def get_ref_offsets(self):
+        """quirk Q4's record (DevState::zacc): [n_steps, N]"""
+        z = np.zeros((self._desc.n_steps, self.n), self.rt)
+        self._f('get_zacc')(self.h, _p(z, self.ct))
+        return z
+
     def set_eval(self, on=True):
         self._f('set_eval')(self.h, C.c_int(int(on)))
 

@@ -55,6 +55,26 @@ def test_no_cpu_fallback(L, model, refs):
         HipVecEnv(num_envs=4)
 
 
+def test_nodevice_text_names_the_hidden_gpus(model, refs):
+    """The reference's train.py hides the GPUs from its own process (use_cpu(): CUDA_VISIBLE_DEVICES = "", drloco/train.py:35,80, whenever config.py:10 USE_CPU is True --
+    the default) before it builds the environments, and HIP honours the variable: dl_create's DL_E_NODEVICE then says which variable hides the devices and what to change.
+    (Runs in a child process so that the variable is in place before the HIP runtime initialises; on a GPU box this is the only way to see DL_E_NODEVICE at all.)"""
+    import subprocess
+    import sys
+    code = (
+        "import os, ctypes as C\n"
+        "os.environ['CUDA_VISIBLE_DEVICES'] = ''          # drloco/train.py:35\n"
+        "from drloco_amd import abi, lib, mocap, models\n"
+        "L = lib.load(); h = C.c_void_p(); m = models.make_model(); r = mocap.RefTable.load(); d = r.as_desc(); c = abi.default_config()\n"
+        "rc = L.dl_create(C.byref(m), C.byref(d), C.byref(c), 4, 0, C.byref(h))\n"
+        "print(rc, L.dl_last_error().decode())\n")
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert p.returncode == 0, p.stderr
+    rc, text = p.stdout.strip().split(' ', 1)
+    assert int(rc) == abi.DL_E_NODEVICE
+    assert 'CUDA_VISIBLE_DEVICES is set to the empty string' in text and 'USE_CPU' in text and 'train.py:35' in text
+
+
 def test_null_handle_is_rejected(L):
     assert L.dl_step(None, None, None, None, None, None, None, None) == abi.DL_E_INVAL
     assert L.dl_num_envs(None) == 0

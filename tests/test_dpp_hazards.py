@@ -18,8 +18,8 @@ BAD = """_Z3kerPf: ; @_Z3kerPf
 \tv_fmac_f32_dpp v5, v5, v4 row_newbcast:3 row_mask:0xf bank_mask:0xf
 \ts_endpgm
 """
-GOOD = BAD.replace("\tv_fmac_f32_dpp", "\ts_nop 0\n\tv_fmac_f32_dpp")          # one wait state: what gfx950 needs and the product pads with (DL_DPP_WAIT = 1)
-ONE_NOP1 = BAD.replace("\tv_fmac_f32_dpp", "\ts_nop 1\n\tv_fmac_f32_dpp")          # "two states" that an s_wakeup can cut to one
+GOOD = BAD.replace("\tv_fmac_f32_dpp", "\ts_nop 0\n\tv_fmac_f32_dpp")          # one wait state: what gfx950 was measured to need -- the opt-in code object (-DDL_DPP_WAIT=1), NOT the default
+ONE_NOP1 = BAD.replace("\tv_fmac_f32_dpp", "\ts_nop 1\n\tv_fmac_f32_dpp")          # two states by the manual's count (hipcc's own padding); an s_wakeup can cut it to one
 TWO = BAD.replace("\tv_fmac_f32_dpp", "\ts_nop 0\n\ts_nop 0\n\tv_fmac_f32_dpp")
 OTHER_REG = BAD.replace("v_mov_b32_e32 v5, v3", "v_mov_b32_e32 v6, v3")
 
@@ -33,19 +33,30 @@ def _run(text, tmp_path, name, *extra):
 def test_checker_on_synthetic_listings(tmp_path):
     p = _run(BAD, tmp_path, 'bad.s')
     assert p.returncode == 1 and '1 DPP read-after-write hazard(s)' in p.stdout and 'v_mov_b32_e32 v5, v3' in p.stdout
-    for text, name in ((GOOD, 'good.s'), (OTHER_REG, 'other.s'), (ONE_NOP1, 'nop1.s')):
+    # the DEFAULT is the ISA manual's two wait states (the default library, DL_DPP_WAIT = 2): one state is a violation at the default setting ...
+    p = _run(GOOD, tmp_path, 'one_state.s')
+    assert p.returncode == 1 and '1 DPP read-after-write hazard(s)' in p.stdout
+    # ... two `s_nop 0`, hipcc's own `s_nop 1` (two states by the manual's count) and an unrelated register are fine
+    for text, name in ((TWO, 'two.s'), (OTHER_REG, 'other.s'), (ONE_NOP1, 'nop1.s')):
         p = _run(text, tmp_path, name)
         assert p.returncode == 0 and '0 DPP read-after-write hazard(s)' in p.stdout, p.stdout
-    # the ISA manual's two states (a -DDL_DPP_WAIT=2 build): a single s_nop of any count is ONE state beside an s_wakeup
-    assert _run(GOOD, tmp_path, 'good2.s', '--need', '2').returncode == 1 and _run(ONE_NOP1, tmp_path, 'nop1_2.s', '--need', '2').returncode == 1
-    assert _run(TWO, tmp_path, 'two.s', '--need', '2').returncode == 0
+    # counted as what it is worth beside an s_wakeup (--snop one), a single s_nop of any count is ONE state
+    assert _run(ONE_NOP1, tmp_path, 'nop1_one.s', '--need', '2', '--snop', 'one').returncode == 1
+    assert _run(TWO, tmp_path, 'two_one.s', '--need', '2', '--snop', 'one').returncode == 0
+    # the opt-in one-state code object is checked with --need 1 (every s_nop one state): one `s_nop 0` passes, none fails
+    assert _run(GOOD, tmp_path, 'good1.s', '--need', '1').returncode == 0 and _run(ONE_NOP1, tmp_path, 'nop1_1.s', '--need', '1').returncode == 0
+    assert _run(BAD, tmp_path, 'bad1.s', '--need', '1').returncode == 1
 
 
 @pytest.mark.timeout(900)
-def test_product_listing_has_no_dpp_hazard():
+@pytest.mark.parametrize('variant', ['w2', 'w1'])
+def test_product_listing_has_no_dpp_hazard(variant):
+    """Both code objects of the product: the default (two wait states, the manual's figure) and the one-state build a device has to earn (drloco_amd/lib.py)."""
     from drloco_amd import lib
-    assert lib.check_dpp_hazards().startswith('0 DPP')
-    text = open(lib.LISTING).read()
+    assert lib.check_dpp_hazards(variant).startswith('0 DPP')
+    text = open(lib.VARIANTS[variant]['listing']).read()
+    # the two builds differ where they should: the hand-written wait in front of a DPP chain step
+    assert ('s_nop 0\n\ts_nop 0\n\tv_fmac_f32_dpp' in text) == (variant == 'w2')
     # the listing is the product's: the step kernels and their hand-written DPP forms are in it
     assert 'k_env_step_g16_split' in text and 'k_rollout_persistent' in text and text.count('v_fmac_f32_dpp') > 1000 and 'v_max_f32_dpp' in text
 
@@ -65,10 +76,10 @@ ACROSS_BRANCH = """_Z3kerPf: ; @_Z3kerPf
 
 def test_checker_follows_branches(tmp_path):
     # the write is two instructions (one wait state: the branch) in front of the read on the TAKEN path, four on the fall-through path
-    # (checked against the manual's two states, --need 2: with the product's one state the branch itself is the wait)
+    # (the default, the manual's two states; with --need 1 the branch itself is the wait)
     p = _run(ACROSS_BRANCH, tmp_path, 'branch.s', '--need', '2')
     assert p.returncode == 1 and 'v_mov_b32_e32 v5, v3' in p.stdout, p.stdout
-    assert _run(ACROSS_BRANCH, tmp_path, 'branch1.s').returncode == 0
+    assert _run(ACROSS_BRANCH, tmp_path, 'branch1.s', '--need', '1').returncode == 0
     ok = ACROSS_BRANCH.replace("\ts_cbranch_vccz", "\ts_nop 0\n\ts_cbranch_vccz")
     assert _run(ok, tmp_path, 'branch_ok.s', '--need', '2').returncode == 0
     direct = ACROSS_BRANCH.replace("\ts_cbranch_vccz .LBB0_2\n", "").replace("\tv_add_f32_e32 v7, v1, v2\n\tv_add_f32_e32 v8, v1, v2\n\tv_add_f32_e32 v9, v1, v2\n", "")

@@ -106,3 +106,43 @@ def test_plain_bench_gpus_2_starts_its_own_ranks():
     assert out['n_gpus'] == 2 and out['distributed']['world_size'] == 2 and out['distributed']['ranks_seen'] == 2
     assert out['value'] > 0 and out['self_check']['finite'] and out['scaling'] == 'weak'
     assert 'cpu_baseline' not in out          # rank 0 at N = 1 only
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()          # (counting devices does not initialise the GPU on this image)
+    except Exception:
+        return 0
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.skipif(_gpu_count() < 2, reason='RCCL needs one GPU per rank: this box has fewer than two (the test enables itself on a multi-GPU node)')
+@pytest.mark.parametrize('extra', [[], ['--policy']], ids=['fixed-actions', 'policy-in-the-loop'])
+def test_rccl_two_ranks_match_one_process(tmp_path, extra):
+    """The same comparison over RCCL (backend nccl, one GPU per rank, xGMI): costs nothing on a one-GPU box (skipped) and turns the first -m gpu run on a multi-GPU node into
+    evidence that the collectives (C1 adv-norm sums, C3 moment merge) work over RCCL with more than one rank.  `python bench.py --gpus 2` starts its own ranks."""
+    n, T = 512, 128
+    common = ['--rollout-len', str(T), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'DL_BENCH_BACKEND')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    two = _run([sys.executable, 'bench.py', '--gpus', '2', '--envs-per-gpu', str(n), '--dump', str(tmp_path / 'two')] + common, env)
+    one = _run([sys.executable, 'bench.py', '--gpus', '1', '--envs-per-gpu', str(2 * n), '--dump', str(tmp_path / 'one')] + common, env)
+    d2 = two['distributed']
+    assert d2['backend'] == 'nccl' and d2['world_size'] == 2 and d2['ranks_seen'] == 2 and two['n_gpus'] == 2
+    assert len(d2['per_rank']['step_kernel_ms']) == 2 and min(d2['per_rank']['step_kernel_ms']) > 0
+    ref = np.load(str(tmp_path / 'one') + '.rank0.npz')
+    ranks = [np.load(str(tmp_path / 'two') + f'.rank{r}.npz') for r in range(2)]
+    for r, d in enumerate(ranks):
+        cols = slice(r * n, (r + 1) * n)
+        if not extra:
+            for k in ('starts', 'actions', 'values', 'raw_obs', 'raw_rew'):
+                assert np.array_equal(d[k], ref[k][:, cols]), (r, k)
+            assert np.array_equal(d['cursor'], ref['cursor'][:, cols]) and np.array_equal(d['qpos'], ref['qpos'][:, cols])
+        else:
+            assert np.array_equal(d['observations'][0], ref['observations'][0][cols]) and np.array_equal(d['actions'][0], ref['actions'][0][cols])
+    for k in ('obs_mean', 'obs_var', 'obs_count', 'ret_mean', 'ret_var', 'ret_count'):
+        assert np.array_equal(ranks[0][k], ranks[1][k]), k
+    if not extra:
+        np.testing.assert_allclose(ranks[0]['obs_mean'], ref['obs_mean'], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ranks[0]['obs_var'], ref['obs_var'], rtol=1e-10)

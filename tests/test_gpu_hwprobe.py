@@ -1,0 +1,66 @@
+"""The two hardware facts the hand-written wait states of the library rest on, re-verified on every box the -m gpu suite runs on (drloco_amd/csrc/dl_hwprobe.hpp through
+dl_hw_probe; the long forms are tools/ubench/dpp_wait.hip and snop_wakeup.hip, profiles/r05_dpp_wait.txt / r05_snop_wakeup.txt):
+
+  (1) a VGPR written by a VALU instruction can be read through DPP ONE wait state later on gfx950 (the ISA manual says two): the one-state code object
+      (libdrloco_hip_dpp1.so) is used only where this holds, and the test can fail -- with NO wait the read IS stale;
+  (2) an s_wakeup executed by another wave of the workgroup ends the s_nop a wave is in after one state: a reader of an MFMA result behind ONE `s_nop 7` sees stale rows beside
+      a wave that loops over s_wakeup, never behind v_nop's (what the policy kernels wait with) or behind two s_nop instructions.
+
+The reference has no device code: there is nothing to cite; these are properties of the hardware this port runs on."""
+import ctypes as C
+
+import pytest
+
+from drloco_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def probe():
+    import torch
+    assert torch.cuda.is_available()
+    L = lib.load()
+    p = lib.hw_probe(L, iters=256)          # 4 x the loader's sample
+    assert p is not None
+    return p
+
+
+def test_a_dpp_read_needs_one_wait_state_on_this_device(probe):
+    s0, s1, s2 = probe['stale_dpp']
+    assert probe['cells'] == 84 and probe['lane_reads_per_cell'] >= 64 * 256 * 256
+    assert s0 > 1000, f'no stale DPP read WITHOUT a wait state ({probe}): the probe cannot fail on this device, so its verdict on one state means nothing'
+    assert s2 == 0, f'stale DPP reads with the ISA manual\'s TWO wait states: {probe}'
+    assert s1 == 0, (f'stale DPP reads with ONE wait state on this device ({probe}): the one-state code object must not be used here -- '
+                     'drloco_amd.lib.load() keeps the two-state build in this case, and dl_create of libdrloco_hip_dpp1.so refuses')
+
+
+def test_an_s_wakeup_ends_another_waves_s_nop(probe):
+    single, vnops, two = probe['stale_mfma']
+    assert single > 0, f'a single s_nop 7 beside an s_wakeup loop was never cut short ({probe}): the mechanism the policy kernels\' v_nop waits guard against did not show'
+    assert vnops == 0 and two == 0, f'stale MFMA rows behind v_nop / two s_nop waits: {probe}'
+
+
+def test_the_loader_chose_by_the_probe():
+    """drloco_amd.lib.load(): the one-state build only with the probe's evidence (or an experiment build named by DL_LIB_PATH); both builds say what they pad with."""
+    import os
+    L = lib.load()
+    sel = lib.SELECTED
+    assert sel is not None and sel['dpp_wait_states'] == L.dl_dpp_wait_states()
+    if os.environ.get('DL_LIB_PATH'):
+        return
+    if sel['variant'] == 'w1':
+        assert sel['dpp_wait_states'] == 1 and sel['probe']['stale_dpp'][0] > 0 and sel['probe']['stale_dpp'][1] == 0
+    else:
+        assert sel['dpp_wait_states'] == 2
+    # the one-state build's own guard: dl_create runs the probe and would refuse a device that fails it (here it passes: see the first test)
+    path = lib.VARIANTS['w1']['path']
+    if os.path.exists(path):
+        fast = lib._open(path)
+        assert fast.dl_dpp_wait_states() == 1
+        from drloco_amd import mocap, models
+        m, r = models.make_model(), mocap.RefTable.load()
+        d, c, h = r.as_desc(), abi.default_config(), C.c_void_p()
+        rc = fast.dl_create(C.byref(m), C.byref(d), C.byref(c), 16, 0, C.byref(h))
+        assert rc == 0, fast.dl_last_error()
+        fast.dl_destroy(h)

@@ -380,3 +380,34 @@ def test_bench_gpus_n_self_launch(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert not seen and 'disagree' in str(e.value.code)
+
+
+@pytest.mark.parametrize('source', ['lane', 'group'])
+def test_kernel_sources_on_host_follow_G15_quirk_Q4(emu, oracle, model, refs, source):
+    """Quirk Q4 (adjust_COM_Z_pos re-anchors the data set in place; golden G15, generated by the reference) through BOTH kernel sources on the host, float64:
+    the reference's COM-z values show up in the COM reward term of every step of all nine episodes, the per-step record (DevState::zacc) holds the offsets the
+    reference left in its data set, and the Monitor's smoothed COM term follows."""
+    from test_oracle_golden import g15_walk, load
+    g = load('G15_q4_com_z.npz')
+    cfg = abi.default_config(rew_weights=list(g['weights']))
+    e = emu.EmuEnv(model, refs, cfg, 1, 64)
+    if source == 'group':
+        e.step = e.gstep
+    zrow = lambda s: refs.table[2, refs.step_off[s]:refs.step_off[s + 1]]
+    worst = dict(terms=0.0, rew=0.0)
+
+    def per_reset(ep, obs0):
+        st = e.get_state()
+        np.testing.assert_allclose(st['qpos'][:, 0], g['ep_qpos0'][ep], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(obs0, g['ep_obs0'][ep], rtol=0, atol=2e-6)
+        s = int(g['ep_read_step'][ep]); L = refs.step_len[s]
+        assert st['cursor'][abi.DL_CUR_READ_STEP, 0] == s
+        np.testing.assert_allclose(zrow(s)[[0, 1, L // 2, L - 1]] - e.get_ref_offsets()[s, 0], g['ep_zrow'][ep], rtol=0, atol=1e-12)
+
+    def per_step(t, ep, obs, rew, done, term, terms):
+        assert done == bool(g['done'][t]), t
+        if not done:
+            worst['terms'] = max(worst['terms'], np.abs(terms - g['terms'][t]).max()); worst['rew'] = max(worst['rew'], abs(rew - g['rew'][t]))
+            np.testing.assert_allclose(obs, g['obs'][t], rtol=0, atol=2e-6)
+    g15_walk(e, g, refs, per_step, per_reset)
+    assert worst['terms'] < 2e-7 and worst['rew'] < 2e-7, worst          # float32 outputs of float64 arithmetic

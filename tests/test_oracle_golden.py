@@ -537,3 +537,100 @@ def test_G7_monitor_lists():
             ep_len = 0
     assert ml.rsi_positions[0] == list(g['rsi_positions']) and ml.et_positions[0] == list(g['et_positions'])
     assert ml.difficult_rsi_phases[0] == list(g['difficult_rsi_phases']) and len(g['difficult_rsi_phases']) > 0
+
+
+def g15_walk(env, g, refs, per_step, per_reset, to_f64=lambda x: x):
+    """Drive `env` (oracle or device wrapper with the oracle's method names) through golden G15's episodes: the injected RSI draws / evaluation inits, the injected
+    end states of every control step, the falls that end the episodes; calls per_reset(e, obs0, state) after every reset and per_step(t, e, obs, rew, done, term, terms)."""
+    ep_len, mode, draw = g['ep_len'], g['ep_mode'], g['ep_draw']
+
+    def arm(e):          # what the next reset will do
+        env.set_eval(bool(mode[e]))
+        if not mode[e]:
+            env.inject_rsi(0, int(draw[e, 0]), int(draw[e, 1]))
+    arm(0)
+    obs0 = env.reset()
+    t = 0
+    for e in range(len(ep_len)):
+        per_reset(e, obs0[0])
+        for k in range(int(ep_len[e])):
+            if k == ep_len[e] - 1 and e + 1 < len(ep_len):
+                arm(e + 1)
+            env.inject_state(0, g['inj_q'][t], g['inj_v'][t])
+            obs, rew, done, term, terms = env.step(g['actions'][t][None])
+            per_step(t, e, obs[0], rew[0], bool(done[0]), term[0], terms[0])
+            t += 1
+        obs0 = obs          # the auto-reset's observation opens the next episode
+
+
+def test_G15_quirk_Q4_com_z_offsets_persist_in_the_data_set(oracle, model, refs):
+    """Quirk Q4 (base_ref_trajecs.py:126-127 via mimic_env.py:555-557): golden G15 is ONE reference environment living through nine episodes -- two more resets onto
+    a step an earlier episode started on, one onto a step an earlier episode rolled through, two evaluation inits (which mutate step 0's row, quirk Q3), a reset
+    onto step 0 afterwards, a wrap 29 -> 0.  The oracle follows every reference COM-z value, reward term, the reward under a weight vector with a COM weight,
+    the initial states and the Monitor's smoothed COM term."""
+    g = load('G15_q4_com_z.npz')
+    env = make_env(oracle, model, refs, n=1, rew_weights=list(g['weights']))
+    zrow_pristine = lambda s: refs.table[2, refs.step_off[s]:refs.step_off[s + 1]]
+
+    def per_reset(e, obs0):
+        st = env.get_state()
+        np.testing.assert_allclose(st['qpos'][:, 0], g['ep_qpos0'][e], rtol=0, atol=1e-14)
+        assert np.array_equal(st['qvel'][:, 0], g['ep_qvel0'][e])
+        np.testing.assert_allclose(obs0, g['ep_obs0'][e], rtol=0, atol=1e-14)
+        cur = st['cursor'][:, 0]
+        assert (cur[abi.DL_CUR_I_STEP], cur[abi.DL_CUR_POS]) == tuple(g['ep_cursor0'][e][:2]) and cur[abi.DL_CUR_READ_STEP] == g['ep_read_step'][e]
+        # the row adjust_COM_Z_pos mutated, as the reference left it: pristine - accumulated offset
+        s = int(g['ep_read_step'][e]); L = refs.step_len[s]
+        z = zrow_pristine(s)[[0, 1, L // 2, L - 1]] - env.get_ref_offsets()[s, 0]
+        np.testing.assert_allclose(z, g['ep_zrow'][e], rtol=0, atol=1e-14)
+
+    seen = dict(com_min=1.0)
+
+    def per_step(t, e, obs, rew, done, term, terms):
+        assert done == bool(g['done'][t]), t
+        if done:
+            assert rew == 0 and np.signbit(rew)          # a fall: -0.0
+            np.testing.assert_allclose(term, g['obs'][t], rtol=0, atol=1e-14)
+        else:
+            np.testing.assert_allclose(obs, g['obs'][t], rtol=0, atol=1e-14)
+            qr, vr = env.ref_lookup(0)
+            np.testing.assert_allclose(qr, g['ref_q'][t], rtol=0, atol=1e-14, err_msg=f'step {t} episode {e}')          # COM-z with the offsets of Q4, COM-x with the offset of Q1
+            assert np.array_equal(vr, g['ref_v'][t])
+            np.testing.assert_allclose(terms, g['terms'][t], rtol=1e-12)
+            assert abs(rew - g['rew'][t]) <= 1e-12
+            seen['com_min'] = min(seen['com_min'], terms[2])
+        assert abs(env.stats('mean_ep_com_rew_smoothed')[0] - g['mean_ep_com_rew_smoothed'][t]) <= 1e-12, t
+        assert abs(env.stats('mean_ep_pos_rew_smoothed')[0] - g['mean_ep_pos_rew_smoothed'][t]) <= 1e-12, t
+
+    g15_walk(env, g, refs, per_step, per_reset)
+    assert seen['com_min'] < 0.9          # the COM term is not trivially 1 in the fixture
+    # ... and the fixture really tells the two behaviours apart: with the per-episode offset of rounds 1-5 the COM reference differs after the first rollover
+    env2 = make_env(oracle, model, refs, n=1, rew_weights=list(g['weights']), intended_semantics=abi.DL_INTENDED_COMZ_PER_EPISODE)
+    worst = [0.0]
+
+    def per_step2(t, e, obs, rew, done, term, terms):
+        if not done:
+            worst[0] = max(worst[0], abs(env2.ref_lookup(0)[0][2] - g['ref_q'][t][2]))
+    g15_walk(env2, g, refs, per_step2, lambda e, o: None)
+    assert worst[0] > 5e-3
+
+
+def test_intended_semantics_switches(oracle, model, refs):
+    """dl_config.intended_semantics: Q2 off restarts count_steps_same_vel with every reset, Q3 off lets an evaluation init read its own step's table."""
+    env = make_env(oracle, model, refs, n=1, intended_semantics=abi.DL_INTENDED_COUNT_PER_EPISODE | abi.DL_INTENDED_EVAL_OWN_STEP)
+    c = cursor(3, 10, count=17)
+    env.set_state(cursor=c)
+    env.inject_rsi(0, 8, 20)
+    env.reset()
+    cur = env.get_state()['cursor'][:, 0]
+    assert cur[abi.DL_CUR_COUNT] == 1 and cur[abi.DL_CUR_I_STEP] == 8
+    env.inject_rsi(0, -1, 0)
+    env.set_eval(True)
+    env.set_state(cursor=cursor(0, 0) + np.eye(abi.DL_CUR_WORDS, 1, -abi.DL_CUR_EVAL_K, dtype=np.int32) * 4)          # next evaluation init: k = 4
+    env.reset()
+    st = env.get_state()
+    cur = st['cursor'][:, 0]
+    assert cur[abi.DL_CUR_I_STEP] == 4 and cur[abi.DL_CUR_READ_STEP] == 4
+    p = int(0.75 * refs.step_len[4])
+    want = refs.table[:14, refs.step_off[4] + p]
+    assert np.array_equal(np.delete(st['qpos'][:, 0], 2), np.delete(want, 2))

@@ -2,10 +2,13 @@
 """Static check of a `hipcc -S` listing for the gfx9 hazard the hand-written DPP statements have to respect themselves: a VGPR written by a VALU
 instruction may be read through DPP (src0 of a *_dpp instruction) only NEED wait states later.  Inline asm is opaque to the compiler's hazard
 recogniser, and the register allocator may put a copy right in front of an asm statement -- behind the s_nop that was meant to cover it.
-NEED = 1: what gfx950 was measured to need (tools/ubench/dpp_wait.hip: stale with no wait, never with one state, 11 G lane-reads) and what the product
-pads with (dl_group.hpp, DL_DPP_WAIT); the ISA manual's figure is 2 (`--need 2`, for a -DDL_DPP_WAIT=2 build).  EVERY instruction counts as ONE wait state,
-an `s_nop N` too: an s_wakeup of another wave of the workgroup ends an s_nop after one state (tools/ubench/snop_wakeup.hip).
-usage: tools/check_dpp_hazards.py <listing.s> [substring of a kernel name] [--need N]      (exit code 1 if a violation is found)
+NEED = 2 (default): the ISA manual's figure and what the default library pads with (dl_group.hpp, DL_DPP_WAIT = 2: `s_nop 0` twice); `--need 1` for the
+-DDL_DPP_WAIT=1 code object (libdrloco_hip_dpp1.so: what gfx950 was measured to need -- stale with no wait, never with one state, 11 G lane-reads,
+tools/ubench/dpp_wait.hip -- selected at run time only on a device that passes dl_hw_probe).  Every instruction is one wait state; an `s_nop N` counts
+  --snop spec   N + 1 states, the manual's definition (default with --need 2: hipcc's own `s_nop 1` in front of its DPP instructions is conformant), or
+  --snop one    ONE state whatever N: an s_wakeup of another wave of the workgroup ends an s_nop after one state (tools/ubench/snop_wakeup.hip) -- the default with
+                --need 1, where it is what makes the check meaningful: one state is then what every path really has.
+usage: tools/check_dpp_hazards.py <listing.s> [substring of a kernel name] [--need N] [--snop spec|one]      (exit code 1 if a violation is found)
 Paths: the straight-line window inside a basic block, carried over a label on the fall-through path and -- two passes -- from the tail of every
 block that branches to the label (s_branch / s_cbranch_* with a label operand).  Only the last instructions of a predecessor block are looked at
 (a predecessor shorter than the hazard window does not inherit from its own predecessors)."""
@@ -13,10 +16,15 @@ import re
 import sys
 
 argv = list(sys.argv[1:])
-NEED = 1            # wait states between the VALU write and the DPP read
+NEED = 2            # wait states between the VALU write and the DPP read
 if '--need' in argv:
     i = argv.index('--need')
     NEED = int(argv[i + 1])
+    del argv[i:i + 2]
+SNOP_SPEC = NEED >= 2
+if '--snop' in argv:
+    i = argv.index('--snop')
+    SNOP_SPEC = argv[i + 1] == 'spec'
     del argv[i:i + 2]
 path = argv[0]
 key = argv[1] if len(argv) > 1 else ''
@@ -62,7 +70,7 @@ def effect(l):
     op, _, rest = l.partition(' ')
     ops = [o.strip() for o in rest.split(',')] if rest else []
     if op == 's_nop':
-        return 1, set()          # (whatever its count: see the module docstring)
+        return (int(ops[0], 0) + 1 if SNOP_SPEC else 1), set()          # (see the module docstring)
     if op.startswith('v_') and ops and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
         return 1, regs(ops[0].split(' ')[0])
     return 1, set()
@@ -123,6 +131,8 @@ def check(name, items, report):
 kernels = parse(open(path).read().split('\n'))
 total = 0
 for name, items in kernels.items():
+    if 'hwprobe' in name:          # dl::hwprobe::k_dpp / k_snop (dl_hwprobe.hpp) violate the rule ON PURPOSE: they are the kernels that measure what a violation does
+        continue
     if key in name:
         total += check(name, items, print)
 print(f'{total} DPP read-after-write hazard(s)')

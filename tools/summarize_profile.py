@@ -78,7 +78,11 @@ if 'hbm_bytes_per_launch' in out:
                 extra['mfma_insts_per_launch'] = pmc.get('SQ_INSTS_MFMA')
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_code_sha16          # the device code these counters belong to: bench.py reports them only while it matches
-    json.dump({**extra, 'tag': tag, 'kernel_code_sha16': kernel_code_sha16(), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
+    # ... and the launch geometry they belong to (host-side changes -- grid, workgroup, LDS, which kernel a mode dispatches to -- move what a pass measured without moving the code object)
+    launch = {'grid': int(out['grid']), 'workgroup': int(out['workgroup']), 'lds_bytes': int(out['lds_bytes'])} if out.get('grid') else None
+    from drloco_amd import lib as _lib
+    _lib.load()
+    json.dump({**extra, 'tag': tag, 'kernel_code_sha16': kernel_code_sha16(), 'launch': launch, 'code_object': (_lib.SELECTED or {}).get('variant'), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
                'source': f'profiles/{tag}_summary.txt', 'correction': 'FETCH_SIZE doubled (gfx950: 128 B requests tallied at 64 B), WRITE_SIZE as reported'},
               open(os.path.join(dst, 'traffic_env_step.json' if walker == 'straight' else f'traffic_env_step_{walker}.json'), 'w'))
 print('\n'.join(lines))
