@@ -1102,7 +1102,8 @@ def test_one_call_evaluation_is_the_host_loop(torch_cuda, model, refs, hidden, k
     for e in envs:
         e.venv.set_split(True)
     one = evaluate_walking(envs[0], pol, **kw)
-    loop = evaluate_walking_host_loop(envs[1], pol, check_every=100)          # (stops at the same multiple of 100 control steps as the chunked / whole-budget device calls: the two handles keep the same history)
+    every = kw.get('chunk', 400)          # the host loop looks whether everybody has finished where the device form does (after every chunk / after the whole 400-step budget): the two handles keep the same history
+    loop = evaluate_walking_host_loop(envs[1], pol, check_every=every)
     assert one['form'] == ('persistent' if hidden >= 128 and kw.get('persistent', True) else 'launches')
     assert one['device_calls'] == (1 if 'chunk' not in kw else -(-max(one['ep_durs']) // 100))
     assert one['ep_durs'] == loop['ep_durs'] and len(one['ep_durs']) == 20 and min(one['ep_durs']) >= 2
@@ -1112,10 +1113,9 @@ def test_one_call_evaluation_is_the_host_loop(torch_cuda, model, refs, hidden, k
     # a SECOND evaluation on the same handles, which have been stepped since their last reset (episodes in flight, Monitor counters running): the reset of all walkers opens a
     # new first-episode record with its OWN step / reward counters (taken from MON_EP_LEN / MON_RET, which carry over a reset as the reference Monitor's do, the record
     # included the steps and rewards of the episode in flight before the reset) -- the host loop, which counts from the reset itself (callback.py:300-317), must see the same episodes
-    if 'chunk' not in kw:
-        st0, st1 = envs[0].venv.get_state(), envs[1].venv.get_state()
-        assert np.array_equal(st0['cursor'], st1['cursor'])          # same history on both handles: same evaluation counters k, same episodes in flight
-    again, loop2 = evaluate_walking(envs[0], pol, **kw), evaluate_walking_host_loop(envs[1], pol, check_every=100)
+    st0, st1 = envs[0].venv.get_state(), envs[1].venv.get_state()
+    assert np.array_equal(st0['cursor'], st1['cursor'])          # same history on both handles: same evaluation counters k, same episodes in flight
+    again, loop2 = evaluate_walking(envs[0], pol, **kw), evaluate_walking_host_loop(envs[1], pol, check_every=every)
     assert len(again['ep_durs']) == 20 and min(again['ep_durs']) >= 2 and again['ep_durs'] != one['ep_durs']
     assert again['ep_durs'] == loop2['ep_durs'] and again['moved_distances'] == loop2['moved_distances'] and again['mean_rewards'] == loop2['mean_rewards']
     for e in envs:
@@ -2042,7 +2042,9 @@ def test_ref_offsets_round_trip_and_launch_forms(torch_cuda, oracle, model, refs
 
 
 
-def test_nodevice_text_on_a_gpu_box(torch_cuda, model, refs):
-    """dl_create's DL_E_NODEVICE names CUDA_VISIBLE_DEVICES = "" (what the reference's train.py sets with USE_CPU = True) -- here where a GPU exists and the variable alone hides it."""
+@pytest.mark.parametrize('var', ['CUDA_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES'])
+def test_nodevice_text_on_a_gpu_box(torch_cuda, model, refs, var):
+    """dl_create's DL_E_NODEVICE names the variable that hides the GPUs (the reference's train.py sets CUDA_VISIBLE_DEVICES = "" with USE_CPU = True) -- here where a GPU exists and the
+    variable alone decides; an empty CUDA_VISIBLE_DEVICES was measured NOT to hide the device from HIP on these boxes (accepted), an empty HIP_VISIBLE_DEVICES does."""
     from test_abi import test_nodevice_text_names_the_hidden_gpus
-    test_nodevice_text_names_the_hidden_gpus(model, refs)
+    test_nodevice_text_names_the_hidden_gpus(model, refs, var)
