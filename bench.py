@@ -510,13 +510,15 @@ def main():
         achieved = algo_bytes * n_prof * steps_per_launch / avg_launch_s / 1e9
         # counter-derived figures come from a committed rocprofv3 PMC pass (profiles/traffic_env_step.json, tools/gpu_round_profile.sh): they are
         # reported only for the configuration that pass measured AND only while the kernel sources are the ones it measured
-        traffic = valu_busy = mfma_busy = prof_origin = None
+        traffic = valu_busy = mfma_busy = prof_origin = valu_mix = None
         base_cfg = args.walker == 'straight' and args.lanes in (0, 16) and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs and not args.no_split and not args.vn_single_steps
         persistent_line = args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent' and args.handles == 1 and args.hidden == 512
         tname = None          # which committed pass belongs to this command line (profiles/, written by tools/summarize_profile.py)
         if base_cfg and not args.policy:
             tname = 'traffic_env_step.json'
-        elif base_cfg and persistent_line:
+        elif base_cfg and persistent_line and args.checkpoint == 'walking' and not args.deterministic:
+            tname = 'traffic_env_step_policy_walking_per_rollout.json' if args.moments == 'per_rollout' else 'traffic_env_step_policy_walking.json'
+        elif base_cfg and persistent_line and not args.checkpoint and not args.deterministic:
             tname = 'traffic_env_step_policy_per_rollout.json' if args.moments == 'per_rollout' else 'traffic_env_step_policy.json'
         elif args.walker == 'loco3d' and args.lanes in (0, 16) and not args.policy and not args.randomize and not args.no_overlap and n == 4096 and T == 512 and not args.runs:
             tname = 'traffic_env_step_loco3d.json'
@@ -527,11 +529,13 @@ def main():
                 cfg_now = (C.c_int32 * 3)()
                 lib.check(venv._lib.dl_profile_launch_config(venv._h, cfg_now))
                 launch_now = {'grid': int(cfg_now[0]), 'workgroup': int(cfg_now[1]), 'lds_bytes': int(cfg_now[2])}
-                same_launch = pj.get('launch') in (None, launch_now)          # (passes stamped before round 6 carry no geometry)
+                ml = pj.get('launch')          # (passes stamped before round 6 carry no geometry; rocprofv3's counter csv reports LDS_Block_Size 0 for dynamic LDS: compared only when it is there)
+                same_launch = ml is None or (ml.get('grid') == launch_now['grid'] and ml.get('workgroup') == launch_now['workgroup'] and ml.get('lds_bytes') in (0, None, launch_now['lds_bytes']))
                 if pj.get('kernel_code_sha16') == kernel_code_sha16() and same_launch:
                     two_waves = split or persistent_line          # two waves per SIMD of which one mostly sleeps: busy cycles against the SIMDs' time, not the waves'
                     traffic, valu_busy = pj.get('hbm_bytes_per_launch'), (pj.get('valu_busy_frac_simd') if two_waves else pj.get('valu_busy_frac'))
                     mfma_busy = pj.get('mfma_busy_frac_simd')
+                    valu_mix = pj.get('valu_mix')
                     prof_origin = {'file': 'profiles/' + tname, 'tag': pj.get('tag'), 'kernel_code_sha16': pj.get('kernel_code_sha16')}
                 else:
                     prof_origin = {'file': 'profiles/' + tname, 'stale': True, 'measured_sha16': pj.get('kernel_code_sha16') or pj.get('kernel_sources_sha16'), 'built_sha16': kernel_code_sha16(),
@@ -555,8 +559,8 @@ def main():
                          'traffic': traffic, 'kernel': ('k_env_step<float,TopoWalker165,32>' if args.walker == 'loco3d' else 'k_env_step<float,TopoStraight,64>') if args.lanes == 1 else
                                    ((('k_rollout_pairs<%s>' if args.moments == 'per_rollout' else 'k_rollout_persistent<%s>') % ('TopoWalker165' if args.walker == 'loco3d' else 'TopoStraight')) if (args.policy and group is None and getattr(buf, 'last_form', '') == 'persistent') else (('k_env_step_g16_split<float,TopoWalker165>' if split else 'k_env_step_g16<float,TopoWalker165>') if args.walker == 'loco3d' else ('k_env_step_g16_split<float,TopoStraight>' if split else 'k_env_step_g16<float,TopoStraight>'))), 'avg_launch_us': avg_launch_s * 1e6,
                          'launches': launches.value, 'sampled_every': args.profile_every, 'control_steps_per_launch': steps_per_launch, 'algorithmic_bytes_per_launch': algo_bytes * n_prof * steps_per_launch,
-                         'valu_busy_frac': valu_busy, 'mfma_busy_frac': mfma_busy, 'from_profile': prof_origin,
-                         'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of its real roof; the HBM fraction is reported as the contract asks'},
+                         'valu_busy_frac': valu_busy, 'mfma_busy_frac': mfma_busy, 'valu_mix': valu_mix, 'from_profile': prof_origin,
+                         'note': 'the fused dynamics kernel is FP32-VALU issue / latency bound (SURVEY.md 8d): valu_busy_frac = SQ_ACTIVE_INST_VALU / ' + ('the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 32; two waves per SIMD)' if split else 'SQ_WAVE_CYCLES') + ' of the committed rocprofv3 PMC pass (profiles/) is the fraction of ISSUE slots used -- not of arithmetic: valu_mix (the same pass: SQ_INSTS_VALU_ADD/MUL/FMA/TRANS_F32, SQ_THREAD_CYCLES_VALU) says how many of the issued instructions are FP32 arithmetic and what that is of the 157.3 TFLOP/s FP32 vector peak (fp32_frac_of_157_3_tf_vector_peak); the HBM fraction is reported as the contract asks'},
         }
         out['code_object'] = {k: v for k, v in (lib.SELECTED or {}).items() if k != 'probe'}          # which of the two builds ran (drloco_amd/lib.py: two wait states in front of a DPP read unless this device proved that one is enough)
         out['distributed'] = {'world_size': dist.get_world_size() if use_dist else 1, 'ranks_seen': ranks_seen, 'backend': dist.get_backend() if use_dist else None, 'vn_sync': vn.sync,

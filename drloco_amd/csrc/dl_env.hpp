@@ -61,6 +61,7 @@ template <typename T> struct DevState {
     // quirk Q4 (adjust_COM_Z_pos mutates the data set in place, base_ref_trajecs.py:126-127): [n_steps][N], the COM-z offset step s of walker w's copy of the data set
     // carries = the lowest-foot-site height of the last reset that landed on it (dl_get_ref_offsets); written at resets, read when a cursor rolls into another step
     T* zacc;
+    int32_t strict_solver;   // dl_config.strict_solver (g_forward, one-wave form)
 };
 
 // quirk Q4 is reproduced unless dl_config.intended_semantics says otherwise

@@ -406,6 +406,23 @@ template <int K> __device__ __forceinline__ float max_bcast(float x, float lo) {
 template <int K> __device__ __forceinline__ void fmac_bcast_chain(float& x, float b) {
     asm(DL_DPP_NOP "\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b), "n"(K));
 }
+// x in the lanes whose dof index (lane & 15) has its bit set in the COMPILE-TIME pattern M16, zero in the others.  Written as `(j < k) ? x : 0` the thirteen lane
+// predicates of the factorisation were computed once per launch and kept as thirteen 64-bit lane masks -- 26 SGPRs of a kernel that has none to spare: every use
+// reloaded its pair from a VGPR lane (two v_readlane per select: 26 VALU instructions per Newton iteration, profiles/r06_asm_mix.txt).  As a literal the mask is two s_mov_b32
+// on the scalar pipe, rematerialised where it is used.
+#ifndef DL_OPT_LITERAL_MASKS
+#define DL_OPT_LITERAL_MASKS 0          // round 6, measured: 1 is bit-identical and 3.3 % SLOWER (the masks stay live as SGPRs and push other values out: more lane spills in the evaluation body, EXPERIMENTS.md)
+#endif
+template <uint32_t M16> __device__ __forceinline__ float lane_keep(float x, int j) {
+#if DL_OPT_LITERAL_MASKS
+    constexpr uint64_t M = 0x0001000100010001ull * (uint64_t)(M16 & 0xffffu);
+    float d;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(d) : "v"(x), "s"(M));
+    return d;
+#else
+    return ((M16 >> j) & 1u) ? x : 0.0f;
+#endif
+}
 // one wait for a whole group of values that are about to be read through DPP
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&x)[NV]) {
     if constexpr (NV == 2) asm volatile(DL_DPP_NOP : "+v"(x[0]), "+v"(x[1]));
@@ -424,6 +441,7 @@ template <int K> __device__ __forceinline__ void fmac_bcast_self(float& x, float
 __device__ __forceinline__ void g_dpp_ready(float&) {}
 template <int K> __device__ __forceinline__ float max_bcast(float x, float lo) { const float b = rbcast<K>(x); return b > lo ? b : lo; }
 template <int K> __device__ __forceinline__ void fmac_bcast_chain(float& x, float b) { x += rbcast<K>(x) * b; }
+template <uint32_t M16> __device__ __forceinline__ float lane_keep(float x, int j) { return ((M16 >> j) & 1u) ? x : 0.0f; }
 template <int NV> __device__ __forceinline__ void g_dpp_ready_n(float (&)[NV]) {}
 #endif
 template <int K, int SIGN> __device__ __forceinline__ void fmac_bcast(double& d, double a, double b) {
@@ -436,6 +454,7 @@ template <int NV> __device__ __forceinline__ void g_dpp_ready_n(double (&)[NV]) 
 __device__ __forceinline__ void g_dpp_ready(double&) {}
 template <int K> __device__ __forceinline__ double max_bcast(double x, double lo) { const double b = rbcast<K>(x); return b > lo ? b : lo; }
 template <int K> __device__ __forceinline__ void fmac_bcast_chain(double& x, double b) { x += rbcast<K>(x) * b; }
+template <uint32_t M16> __device__ __forceinline__ double lane_keep(double x, int j) { return ((M16 >> j) & 1u) ? x : 0.0; }
 
 // ------------------------------------------------------------------------------------------
 // Uniform model scalars of the hot path, read ONCE per kernel and pinned in VGPRs (the empty asm makes the values
@@ -488,6 +507,7 @@ template <typename T, typename TP> struct GCtx {
     int spin_limit;
     DL_LDS T* bfr;                               // body frames [MAXB][BFR_W] and root height as g_fk publishes them / the collision stage reads them: GLds::BFR and
     DL_LDS T* rz;                                //   GLds::MISC inside the walker's region, or (partner wave of a split workgroup) GSplit::BFRX / RZX, its own space
+    int strict = 0;                              // dl_config.strict_solver (one-wave form): the Newton solver takes [3P] mj_solNewton's decisions instead of the product's shortcuts
 };
 // Split workgroup: a second wave builds the constraints of the same four walkers while the first runs the smooth dynamics.
 // Per walker, behind the regular region: the mirror block of M (which may no longer share the rows' space) and the mailbox.
@@ -1184,7 +1204,7 @@ template <typename T, typename TP> __device__ __forceinline__ void g_chol_rev(T 
         constexpr int k = TPL::order.at[ss.value];
         if constexpr (k > 0) {
             const T inv = dl_rsqrt_pivot(max_bcast<k>(hd, floor_));
-            const T hk = (j < k) ? h[k] : T(0);               // ancestors of k (unrelated lanes hold an exact zero; descendants their frozen column)
+            const T hk = lane_keep<(1u << k) - 1u>(h[k], j);   // (j < k) ? h[k] : 0 -- ancestors of k (unrelated lanes hold an exact zero; descendants their frozen column)
             T lik = hk * inv;
             lo[k] = -lik * inv;
             hd -= lik * lik;
@@ -1233,7 +1253,7 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
     // only the lanes below k take part in step k: the slot up[k] of lane k itself is not a matrix entry and those of the lanes above k are
     // stale rows (lanes of the other branch hold an exact zero) -- masked here, off the chain, so that u is x when the loop ends
     T up2[GL];
-    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = (j > k) ? s2 * up[k] : T(0); });
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = lane_keep<0xffffu & ~((2u << k) - 1u)>(s2 * up[k], j); });          // (j > k) ? s2 * up[k] : 0
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[N - 1 - ss.value];
         if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
@@ -1385,7 +1405,7 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
     const T s2 = -invd * invd;
     T u = yl * invd;
     T up2[GL];
-    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = (j > k) ? s2 * up[k] : T(0); });
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = lane_keep<0xffffu & ~((2u << k) - 1u)>(s2 * up[k], j); });          // (j > k) ? s2 * up[k] : 0
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[N - 1 - ss.value];
         if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
@@ -1448,9 +1468,12 @@ __device__ __forceinline__ void g_contact_jacobians(const GCtx<T, TP>& g, const 
         wb = (DL_LDS T*)(uintptr_t)wbo;
     }
 #endif
-    const int j = g.j;
+    int j = g.j;
     const auto& ln = *g.ln;
-    const int jdepth = g_lane_depth(lt);
+    int jdepth = g_lane_depth(lt);
+#if !defined(DL_GROUP_EMU)
+    if constexpr (!GD<TP>::PIN_ALL) { DL_VPIN(j); DL_VPIN(jdepth); }          // (opaque as well, round 6: the loop's three per-lane LDS bases -- wb + f(j), wb + f(depth) -- were still formed once per launch and reloaded from scratch in every evaluation)
+#endif
     // ---- contact-frame Jacobians, dof-lane major: lane a writes its own column (normal, tangent 1, tangent 2) of
     // every contact from its joint axis / anchor in registers (dofs that do not move the contact's body write zeros),
     // two contacts per trip; the same trip adds J x0 to the contacts' rows (six interleaved row sums, expanded to the
@@ -1912,6 +1935,66 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
     int iter = 0;
     g_sync<T>();
     tick(1);
+    // dl_config.strict_solver (one-wave form; wave-uniform): the decisions of [3P] mj_solNewton instead of the product's path: start at the cheaper of the warm start and
+    // qacc_smooth, every line search run to its derivative tolerance (no Armijo acceptance of the first trial), no early exit on an unchanged active set, IEEE division /
+    // square root in the line search and the gradient test.  The minimiser is the same; the iterates -- and the iteration count the diagnostics report -- follow the reference's.
+    bool strict_ = false;
+    if constexpr (!SPLIT) strict_ = g.strict != 0;
+    // the Newton direction -H^-1 grad for the Hessian as it stands (h, hd, hxx, hxl); used by the loop and, in strict mode, once before it with H = M
+    auto newton_dir = [&](T grad, const T (&gradx)[NXA], T& dir, T (&dirx)[NXA]) {
+        T up[GL], lo[GL], invd = T(1), hdk = hd;
+#pragma unroll
+        for (int a = 0; a < GL; a++) { up[a] = h[a]; lo[a] = T(0); }
+        GCholX<T, NXA> cx;
+        constexpr bool X_LAST = NX > 0 && DL_CHOL_X_LAST && DL_CHOL_LEAF_FIRST && DL_CHOL_SHORT_CHAIN;
+        if constexpr (NX > 0 && !X_LAST) {
+            T wxx[NXA][NXA], wxl[NXA];
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; wxl[t] = hxl[t]; static_for<NX>([&](auto ui) { wxx[t][ui.value] = hxx[t][ui.value]; }); });
+            g_chol_x<T, NX, N>(wxx, wxl, up, hdk, cx, T(1e-10));
+        }
+        T sx[NXA];
+        if constexpr (X_LAST) {
+            GCholXL<T, NXA> cl;
+            g_chol_rev<T, TP>(up, lo, hdk, invd, j, T(1e-10));
+            g_chol_x_last<T, TP>(lo, invd, hxl, hxx, cl, T(1e-10));
+            dir = -g_chol_solve_rev_x<T, TP>(lo, up, invd, cl, grad, gradx, sx, j);
+        } else
+        if constexpr (NX == 0 && DL_CHOL_LEAF_FIRST) {
+            g_chol_rev<T, TP>(up, lo, hdk, invd, j, T(1e-10));
+            dir = -g_chol_solve_rev<T, TP>(lo, up, invd, grad, j);
+        } else {
+            g_chol<T, N>(up, lo, hdk, invd, j, T(1e-10));
+            dir = -g_chol_solve_x<T, NX, N>(cx, lo, up, invd, grad, gradx, sx, j);
+        }
+        static_for<NX>([&](auto ti) { dirx[ti.value] = -sx[ti.value]; });
+    };
+    if constexpr (!SPLIT) {
+        if (strict_ && nefc > 0) {
+            // [3P] mj_solNewton: "if the cost at qacc_smooth is lower than at the warm start, start there".  H = M before any row is active, so qacc_smooth - warm = -M^-1 (M warm - smooth):
+            // the loop's own direction code with the gradient of the unconstrained problem; then J d (rows JV) and M d by the loop's own g_apply
+            T g0x[NXA], d0, d0x[NXA], Md0x[NXA];
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; g0x[t] = Max[t] - sm.smoothx[t]; });
+            newton_dir(Ma - smooth, g0x, d0, d0x);
+            const T Md0 = g_apply<T, TP>(g, ncon, my_lim, lim_sign, d0, d0x, sm, Md0x, jdepth);
+            g_sync<T>();
+            // cost(warm) = 1/2 d^T M d + sum 1/2 D min(0, jar)^2,  cost(qacc_smooth) = sum 1/2 D min(0, jar + jv)^2
+            T cw = T(0), cs0 = T(0);
+            for (int r = j; r < nefc; r += GL) {
+                const T a_ = rJA[r], b_ = a_ + rJV[r], D = rD[r];
+                if (a_ < T(0)) cw += T(0.5) * D * a_ * a_;
+                if (b_ < T(0)) cs0 += T(0.5) * D * b_ * b_;
+            }
+            T r3s[3] = {cw, cs0, (j < N) ? T(0.5) * d0 * Md0 : T(0)};
+            gsum_n<3>(r3s);
+            static_for<NX>([&](auto ti) { constexpr int t = ti.value; r3s[2] += T(0.5) * d0x[t] * Md0x[t]; });
+            if (r3s[1] < r3s[0] + r3s[2]) {          // (identical in the 16 lanes of the row: row sums)
+                qacc += d0; Ma += Md0;
+                static_for<NX>([&](auto ti) { constexpr int t = ti.value; qax[t] += d0x[t]; Max[t] += Md0x[t]; });
+                for (int r = j; r < nefc; r += GL) rJA[r] += rJV[r];
+            }
+            g_sync<T>();
+        }
+    }
     for (;;) {
         // ---- rows are processed by their owners: force, cost and active-set flips of a limit row by the lane of its
         // dof, of the four pyramid rows of contact c by lane c, which leaves the contact-frame force and the weights of
@@ -2017,6 +2100,8 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             // (both sides are >= 0): the correctly rounded square root was a dozen dependent instructions in front of the loop's exit branch
             const T bound = cs.tolerance + cs.tol_rel * scale * gmag;
 #if DL_OPT_GRADSQ
+            if (strict_) { if (!(scale * dl_sqrt(gn) >= bound) || iter >= cs.iterations) alive = false; }
+            else
             if (!(scale * scale * gn >= bound * bound) || iter >= cs.iterations) alive = false;   // also stops on NaN
 #else
             if (!(scale * dl_sqrt(gn) >= bound) || iter >= cs.iterations) alive = false;
@@ -2027,33 +2112,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
         if constexpr (TIMED) tacc[6] += 1;
         // ---- Newton direction
         T dir, dirx[NXA];
-        {
-            T up[GL], lo[GL], invd = T(1), hdk = hd;
-#pragma unroll
-            for (int a = 0; a < GL; a++) { up[a] = h[a]; lo[a] = T(0); }
-            GCholX<T, NXA> cx;
-            constexpr bool X_LAST = NX > 0 && DL_CHOL_X_LAST && DL_CHOL_LEAF_FIRST && DL_CHOL_SHORT_CHAIN;
-            if constexpr (NX > 0 && !X_LAST) {
-                T wxx[NXA][NXA], wxl[NXA];
-                static_for<NX>([&](auto ti) { constexpr int t = ti.value; wxl[t] = hxl[t]; static_for<NX>([&](auto ui) { wxx[t][ui.value] = hxx[t][ui.value]; }); });
-                g_chol_x<T, NX, N>(wxx, wxl, up, hdk, cx, T(1e-10));
-            }
-            T sx[NXA];
-            if constexpr (X_LAST) {
-                GCholXL<T, NXA> cl;
-                g_chol_rev<T, TP>(up, lo, hdk, invd, j, T(1e-10));
-                g_chol_x_last<T, TP>(lo, invd, hxl, hxx, cl, T(1e-10));
-                dir = -g_chol_solve_rev_x<T, TP>(lo, up, invd, cl, grad, gradx, sx, j);
-            } else
-            if constexpr (NX == 0 && DL_CHOL_LEAF_FIRST) {
-                g_chol_rev<T, TP>(up, lo, hdk, invd, j, T(1e-10));
-                dir = -g_chol_solve_rev<T, TP>(lo, up, invd, grad, j);
-            } else {
-                g_chol<T, N>(up, lo, hdk, invd, j, T(1e-10));
-                dir = -g_chol_solve_x<T, NX, N>(cx, lo, up, invd, grad, gradx, sx, j);
-            }
-            static_for<NX>([&](auto ti) { dirx[ti.value] = -sx[ti.value]; });
-        }
+        newton_dir(grad, gradx, dir, dirx);
         tick(3);
         T Mdx[NXA];
         const T Md = g_apply<T, TP>(g, ncon, my_lim, lim_sign, dir, dirx, sm, Mdx, jdepth);      // rows JV = J dir
@@ -2078,7 +2137,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
                 flips = flips || (ok && ((a_ + v_ < T(0)) != (t_ != T(0))));
             }
             for (int r = j + GL * NS; r < nefc; r += GL) flips = flips || ((rJA[r] + rJV[r] < T(0)) != (rTM[r] != T(0)));
-            if (alive && !gany(flips)) {
+            if (alive && !strict_ && !gany(flips)) {
                 qacc += dir; iter++; alive = false;
                 static_for<NX>([&](auto ti) { qax[ti.value] += dirx[ti.value]; });
             }
@@ -2091,7 +2150,7 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
             constexpr int t = ti.value;
             r4[0] += dirx[t] * (Max[t] - sm.smoothx[t]); r4[1] += T(0.5) * dirx[t] * Mdx[t]; r4[2] += dirx[t] * gradx[t]; r4[3] += dirx[t] * dirx[t];
         });
-        const T g1s = r4[0], g2 = r4[1], d0 = r4[2], snorm = DL_OPT_FSQRT ? dl_sqrt_fast(r4[3]) : dl_sqrt(r4[3]);     // (scales a tolerance: 1 ulp is plenty)
+        const T g1s = r4[0], g2 = r4[1], d0 = r4[2], snorm = (DL_OPT_FSQRT && !strict_) ? dl_sqrt_fast(r4[3]) : dl_sqrt(r4[3]);     // (scales a tolerance: 1 ulp is plenty)
         const T gtol = cs.tolerance * cs.ls_tolerance * snorm * cs.meaninertia * nvf + cs.ls_reltol * dl_abs(d0);
         T alpha = T(1), lo = T(0), hi = T(1e30), best_a = T(0), best_dc = T(0), best_mag = T(0), res_a = T(0), res_dc = T(0), res_mag = T(0);
         bool done = !alive || !(snorm >= T(1e-15));
@@ -2117,11 +2176,11 @@ __device__ __forceinline__ T g_forward(const GCtx<T, TP>& g, const GLaneTopo<T>&
 #if DL_OPT_ARMIJO
             // the full Newton step is taken as it is when it already brings a fair part of the decrease the quadratic model promises (d0 / 2 on
             // an unchanged active set): the exact minimiser along dir is worth two or three more trials only when it does not
-            if (!done && it == 1 && dc <= T(DL_OPT_ARMIJO_C) * d0) { res_a = alpha; res_dc = dc; res_mag = mag; done = true; }
+            if (!done && it == 1 && !strict_ && dc <= T(DL_OPT_ARMIJO_C) * d0) { res_a = alpha; res_dc = dc; res_mag = mag; done = true; }
 #endif
             if (!done) {
                 if (d1 < T(0)) lo = alpha; else hi = alpha;
-                const T cand = alpha - d1 * dl_rcp(d2);
+                const T cand = strict_ ? alpha - d1 / d2 : alpha - d1 * dl_rcp(d2);
                 const T mid = hi < T(1e29) ? T(0.5) * (lo + hi) : T(2) * alpha;
                 const T next = (cand > lo && cand < hi) ? cand : mid;
                 // converged: derivative below tolerance, or the iterate no longer moves at working precision

@@ -71,6 +71,7 @@ __device__ __forceinline__ void g_wave_forward(int lane, int wblock, int wg, int
     g_load_walk<T, TP>(m, st, wi, wk);
     GCtx<T, TP> g{smem + (size_t)grp * GLds<TP>::TOTAL, m, j, &ln, &cst, &wk, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MM, nullptr, nullptr, nullptr, 0,
                   smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::BFR, smem + (size_t)grp * GLds<TP>::TOTAL + GLds<TP>::MISC};
+    g.strict = st.strict_solver;
     T q = T(0), v = T(0), wm = T(0), force = T(0);
     if (j < NL) {
         const size_t o = (size_t)(j + NX) * n + wi;
@@ -293,6 +294,7 @@ __device__ __forceinline__ void g_wave_env_step(int lane, int wblock, int wg, in
     GCtx<T, TP> g{smem + (size_t)grp * WSTRIDE, m, j, &ln, &cst, &wk,
                   smem + (size_t)grp * WSTRIDE + (SPLIT ? GSplit<TP>::MMX : Ld::MM), SPLIT ? smem + (size_t)grp * WSTRIDE + GSplit<TP>::MB : nullptr, SPLIT ? smem + GSplit<TP>::MB : nullptr,
                   st.fault, st.spin_dyn, smem + (size_t)grp * WSTRIDE + Ld::BFR, smem + (size_t)grp * WSTRIDE + Ld::MISC};
+    if constexpr (!SPLIT) g.strict = st.strict_solver;
     int split_seq[4] = {0, 0, 0, 0};         // [0] command counter of the wave pair, [1], [2] cycle counters of the profiling build, [3] the hand-over has failed
     T q_ann = __builtin_bit_cast(T, (std::conditional_t<sizeof(T) == 4, uint32_t, uint64_t>)(~0ull));      // split workgroup: the configuration announced to the partner wave with the last request (none yet: a NaN pattern no state carries)
     DL_LDS T* wb = g.wb;

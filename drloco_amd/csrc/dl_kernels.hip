@@ -1248,6 +1248,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         if ((rc = dalloc(&st.warm, (size_t)TP::NV * n))) return rc;
         if ((rc = dalloc(&st.comz_off, n))) return rc;
         if ((rc = dalloc(&st.zacc, (size_t)r.n_steps * n))) return rc;          // quirk Q4: zero = the pristine data set
+        st.strict_solver = cfg.strict_solver ? 1 : 0;
         if ((rc = dalloc(&st.cur, (size_t)DL_CUR_WORDS * n))) return rc;
         if ((rc = dalloc(&st.walked, n))) return rc;
         if ((rc = dalloc(&st.mon, (size_t)MON_WORDS * n))) return rc;
@@ -1461,6 +1462,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
     void set_spin_limits(int dyn, int srv) override { st.spin_dyn = dyn >= 0 ? dyn : GSplit<TP>::SPIN_LIMIT; st.spin_srv = srv >= 0 ? srv : GSplit<TP>::SPIN_LIMIT; }
     int set_split(int on) override {
         if (on && !(CAN_SPLIT && variant == 1 && gmd)) return fail(DL_E_INVAL, "dl_set_split: the split workgroup exists for the 16-lane float32 kernels");
+        if (on && st.strict_solver) return fail(DL_E_INVAL, "dl_set_split: dl_config.strict_solver selects the one-wave form (the split workgroups run the product's solver path only)");
         split = on != 0;
         return DL_OK;
     }
@@ -1489,6 +1491,7 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
             if (!(variant == 1 && gmd)) return no("the persistent rollout kernel needs the 16-lane kernels (lanes_per_walker = 16)");
             if (hidden != 512 && hidden != 256 && hidden != 128) return no("the persistent rollout kernels are built for hidden = 512, 256 or 128 (eight waves per workgroup x 4 / 2 / 1 tiles)");
             if (inj_armed) return no("injected states are pending");
+            if (st.strict_solver) return no("dl_config.strict_solver selects the one-wave step kernel (the persistent kernels run the split workgroups' solver path)");
             if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cus = 0; }
             if (n_cus <= 0 || (n + 15) / 16 > n_cus * rp_kblocks<TP>()) return no(rp_kblocks<TP>() > 1 ? "more than 128 walkers per CU: a workgroup of the persistent rollout kernel takes at most eight blocks of sixteen walkers" : "more than 16 walkers per CU: this walker's workgroups take one block of sixteen walkers");
             return 1;

@@ -60,6 +60,7 @@ template <typename T, typename TP> static Emu<T, TP>* emu_create(const dl_model_
     e->work.assign((size_t)4 * TP::NV * n, 0);
     e->st = DevState<T>{e->qpos.data(), e->qvel.data(), e->warm.data(), e->comz.data(), e->cur.data(), e->walked.data(), e->mon.data(), e->need.data(), e->inj.data(), e->work.data(), n};
     e->zacc.assign((size_t)r->n_steps * n, 0); e->st.zacc = e->zacc.data();          // quirk Q4's record
+    e->st.strict_solver = cfg->strict_solver ? 1 : 0;
     e->st.rnd = nullptr; e->st.dbgf = nullptr; e->st.dbg = nullptr; e->st.dbg_cap = 1 << 30;
     e->st.push_phase = nullptr; e->st.push_period = 1; e->st.push_dur = 0; e->st.push_step0 = 0;
     e->gm_ok = fill_group_model<T, TP>(*d, e->gm, why);

@@ -73,7 +73,8 @@ def test_nodevice_text_names_the_hidden_gpus(model, refs, var):
         "print(rc, '|', L.dl_last_error().decode())\n")
     p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert p.returncode == 0, p.stderr
-    rc, text = p.stdout.strip().split(' | ', 1) if ' | ' in p.stdout else (p.stdout.strip().rstrip(' |'), '')
+    rc, _, text = p.stdout.strip().partition('|')
+    rc, text = rc.strip(), text.strip()
     if int(rc) == 0:
         assert var == 'CUDA_VISIBLE_DEVICES', f'{var} = "" left a device visible: {p.stdout}'          # (measured on ROCm 7.2: only the CUDA_ spelling is ignored when empty)
         return

@@ -411,3 +411,33 @@ def test_kernel_sources_on_host_follow_G15_quirk_Q4(emu, oracle, model, refs, so
             np.testing.assert_allclose(obs, g['obs'][t], rtol=0, atol=2e-6)
     g15_walk(e, g, refs, per_step, per_reset)
     assert worst['terms'] < 2e-7 and worst['rew'] < 2e-7, worst          # float32 outputs of float64 arithmetic
+
+
+@pytest.mark.parametrize('which', ['straight', 'loco3d'])
+def test_strict_solver_follows_the_reference_solvers_decisions(emu, oracle, which):
+    """dl_config.strict_solver: the 16-lane Newton solver takes [3P] mj_solNewton's decisions (start at the cheaper of warm start and qacc_smooth, exact line search every
+    iteration, no early exit on an unchanged active set) -- the kernel source on the host, float64, against the oracle, which restates that solver: the SAME iteration count on
+    (nearly) every random state, where the product's path (start at the warm start, full Newton step accepted when the active set stands) counts differently; the same minimiser
+    either way."""
+    m, table, cfg = _walker(which)
+    n = 96
+    q, v, w, u = _states(m, n, 4, 0.85 if which == 'straight' else 0.75)
+    o = oracle.OracleEnv(m, table, cfg, n)
+    o.set_state(qpos=q, qvel=v, warm=w)
+    qa, nc, ne, ni = o.forward(u)
+    import copy
+    out = {}
+    for strict in (0, 1):
+        c2 = copy.copy(cfg); c2.strict_solver = strict
+        e = emu.EmuEnv(m, table, c2, n, 64)
+        e.set_state(qpos=q, qvel=v, warm=w)
+        qb, nc2, ne2, ni2 = e.gforward(u)
+        assert np.array_equal(nc, nc2) and np.array_equal(ne, ne2)
+        assert (np.abs(qa - qb) / (1 + np.abs(qa))).max() < 1e-9          # the same minimiser
+        out[strict] = ni2
+        e.close()
+    con = ne > 0
+    assert con.sum() > n // 3
+    same_strict, same_default = (out[1][con] == ni[con]).mean(), (out[0][con] == ni[con]).mean()
+    assert same_strict >= 0.9, (same_strict, same_default, out[1][con][:20], ni[con][:20])
+    assert same_strict > same_default + 0.2, (same_strict, same_default)

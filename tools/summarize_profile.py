@@ -17,7 +17,8 @@ lines = []
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     flags = {'straight': '', 'randomize': ' --randomize', 'policy': ' --policy', 'policy_per_rollout': ' --policy --moments per_rollout', 'policy_launches': ' --policy --rollout-form launches',
-             'policy_32768_h2': ' --policy --envs-per-gpu 32768 --handles 2 --steps 2'}.get(walker, f' --walker {walker}')
+             'policy_32768_h2': ' --policy --envs-per-gpu 32768 --handles 2 --steps 2', 'policy_walking': ' --policy --checkpoint walking --warmup 8',
+             'policy_walking_per_rollout': ' --policy --checkpoint walking --warmup 8 --moments per_rollout'}.get(walker, f' --walker {walker}')
     lines.append('rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' + flags + '   (kernel_stats.csv, top rows)')
     lines.append(f'{"kernel":70s} {"calls":>7s} {"avg_us":>12s} {"min_us":>10s} {"max_us":>10s} {"pct":>7s}')
     for r in rows[:14]:
@@ -56,6 +57,34 @@ if 'SQ_ACTIVE_INST_VALU' in pmc and 'GRBM_GUI_ACTIVE' in pmc:
         lines.append('  MFMA busy / SIMD time (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)): %.3f' % (pmc['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * pmc['GRBM_GUI_ACTIVE'] / 8)))
     if 'TCP_TCC_READ_REQ_sum' in pmc and 'k_env_step_avg_us' in out:
         lines.append('  L2 -> CU read requests: %.3g per launch = %.2f TB/s at 64 B per request over the %.1f ms of the launch' % (pmc['TCP_TCC_READ_REQ_sum'], pmc['TCP_TCC_READ_REQ_sum'] * 64 / out['k_env_step_avg_us'] / 1e6, out['k_env_step_avg_us'] / 1e3))
+mix = None
+if all(k in pmc for k in ('SQ_INSTS_VALU', 'SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_TRANS_F32', 'SQ_INSTS_VALU_INT32')):
+    # the DYNAMIC mix of the dominant kernel: what the hardware's per-class VALU counters say, the rest by difference.  "other" = v_mov / v_cndmask / v_readlane / v_writelane
+    # / compares / max-min / DPP moves: instructions that occupy an issue slot and compute no float result (the static listing splits them further: tools/asm_mix2.py)
+    tot = pmc['SQ_INSTS_VALU']
+    cls = {'add_f32': pmc['SQ_INSTS_VALU_ADD_F32'], 'mul_f32': pmc['SQ_INSTS_VALU_MUL_F32'], 'fma_f32': pmc['SQ_INSTS_VALU_FMA_F32'], 'trans_f32': pmc['SQ_INSTS_VALU_TRANS_F32'],
+           'int32': pmc['SQ_INSTS_VALU_INT32'], 'int64': pmc.get('SQ_INSTS_VALU_INT64', 0.0), 'cvt': pmc['SQ_INSTS_VALU_CVT'], 'f64': pmc.get('SQ_INSTS_VALU_ADD_F64', 0.0)}
+    cls['other (moves, selects, lane reads / writes, compares, min / max)'] = tot - sum(cls.values())
+    lines.append('')
+    lines.append('DYNAMIC VALU instruction mix of the dominant kernel (per launch, wave instructions; SQ_INSTS_VALU_* classes, "other" by difference from SQ_INSTS_VALU):')
+    for k, v in cls.items():
+        lines.append(f'  {k:70s} {v:16.0f}  {v / tot:7.3f}')
+    flop_insts = cls['add_f32'] + cls['mul_f32'] + cls['trans_f32'] + 2 * cls['fma_f32']
+    mix = {'valu_insts': tot, **{k.split(' ')[0]: v for k, v in cls.items()}, 'fp32_arith_frac_of_valu': (cls['add_f32'] + cls['mul_f32'] + cls['trans_f32'] + cls['fma_f32']) / tot}
+    lanes = 64.0
+    cyc = pmc.get('SQ_INST_CYCLES_VALU') or pmc.get('SQ_ACTIVE_INST_VALU')          # (gfx950 has no SQ_INST_CYCLES_VALU; SQ_ACTIVE_INST_VALU counts the same quad-cycles: 1.014 per VALU instruction here)
+    if 'SQ_THREAD_CYCLES_VALU' in pmc and cyc:
+        # SQ_THREAD_CYCLES_VALU = VALU cycles x active threads (counter_defs.yaml, AvgNumActiveThreads): the mean number of lanes EXEC left on
+        lanes = pmc['SQ_THREAD_CYCLES_VALU'] / cyc
+        mix['active_lanes_mean'] = lanes
+        lines.append(f'  active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU): {lanes:.1f} of 64')
+    if 'k_env_step_avg_us' in out:
+        us = out['k_env_step_avg_us']
+        # (the mean lane count is over ALL VALU instructions; 14 of a row's 16 lanes carry a dof of the straight walker and the two idle ones are mostly left on: an upper bound of the useful arithmetic)
+        tf = flop_insts * lanes / (us * 1e-6) / 1e12
+        mix.update({'fp32_tflops_on_active_lanes': tf, 'fp32_frac_of_157_3_tf_vector_peak': tf / 157.3})
+        lines.append(f'  FP32 arithmetic: {flop_insts:.4g} flop-instructions (FMA = 2) x {lanes:.1f} active lanes / {us / 1e3:.2f} ms = {tf:.2f} TFLOP/s'
+                     f' = {tf / 157.3:.3f} of the 157.3 TFLOP/s FP32 vector peak (issue slots: VALU busy above; {100 * mix["fp32_arith_frac_of_valu"]:.1f} % of the issued VALU instructions are FP32 arithmetic)')
 lines.append('')
 lines.append(json.dumps({k: v for k, v in out.items() if k != 'pmc_per_launch'}))
 b = os.path.join(src, 'bench.json')
@@ -82,6 +111,8 @@ if 'hbm_bytes_per_launch' in out:
     launch = {'grid': int(out['grid']), 'workgroup': int(out['workgroup']), 'lds_bytes': int(out['lds_bytes'])} if out.get('grid') else None
     from drloco_amd import lib as _lib
     _lib.load()
+    if mix:
+        extra['valu_mix'] = mix
     json.dump({**extra, 'tag': tag, 'kernel_code_sha16': kernel_code_sha16(), 'launch': launch, 'code_object': (_lib.SELECTED or {}).get('variant'), 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'], 'raw_fetch_kib': pmc['FETCH_SIZE'], 'raw_write_kib': pmc['WRITE_SIZE'],
                'source': f'profiles/{tag}_summary.txt', 'correction': 'FETCH_SIZE doubled (gfx950: 128 B requests tallied at 64 B), WRITE_SIZE as reported'},
               open(os.path.join(dst, 'traffic_env_step.json' if walker == 'straight' else f'traffic_env_step_{walker}.json'), 'w'))
