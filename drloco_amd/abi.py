@@ -112,7 +112,7 @@ def default_config(**kw):
     c.seed = 1234
     c.env_kind = DL_ENV_STRAIGHT
     c.lanes_per_walker = 0          # auto
-    c.intended_semantics = int(__import__('os').environ.get('DL_DEBUG_INTENDED', '0'))        # strict_reference_quirks: the reference's behaviour incl. Q1-Q4
+    c.intended_semantics = 0        # strict_reference_quirks: the reference's behaviour incl. Q1-Q4
     c.strict_solver = 0
     for k, v in kw.items():
         if k == 'rew_weights':

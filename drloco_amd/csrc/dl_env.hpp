@@ -65,11 +65,7 @@ template <typename T> struct DevState {
 };
 
 // quirk Q4 is reproduced unless dl_config.intended_semantics says otherwise
-#ifdef DL_EXP_NO_Q4          // (bisecting aid)
-template <typename T> DL_HD bool q4_on(const DevCfg<T>&) { return false; }
-#else
 template <typename T> DL_HD bool q4_on(const DevCfg<T>& c) { return !(c.intended & DL_INTENDED_COMZ_PER_EPISODE); }
-#endif
 // zacc is written by one lane and read, possibly much later in the same launch, by others: both sides go to the L2 (agent scope), never through a stale L1 line
 template <typename T> DL_HD T zacc_load(const T* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -197,10 +193,8 @@ DL_HD void mon_smooth(double* mon, int n, int i, int word, int bit, double x, do
 // cur_pos: refs._pos after this step's refs.next() (before any reset), as Monitor.step reads it
 DL_HD void monitor_step(double* mon, int n, int i, double rew, bool done, const double (&terms)[3], double tor, double walked, int cur_pos, bool exc = false) {
     auto W = [&](int w) -> double& { return mon[(size_t)w * n + i]; };
-#ifndef DL_EXP_R5_MON          // (bisecting aid)
     if (exc) W(MON_DIVERGED) += 1;
     W(MON_FIRST_CUR_LEN) += 1; W(MON_FIRST_CUR_RET) += rew;
-#endif
     if (W(MON_EP_LEN) == 0) W(MON_INIT_POS) = (double)cur_pos;      // monitor_wrapper.py:91-93
     W(MON_TOR_LAST) = tor;
     W(MON_EP_LEN) += 1; W(MON_NSTEPS) += 1; W(MON_RET) += rew; W(MON_LAST) = rew;

@@ -22,9 +22,6 @@
 #define DL_EXP_EXTRAP_W 1.0
 #endif
 
-#ifndef DL_EXP_NO_SRV_FAULT
-#define DL_EXP_NO_SRV_FAULT 0          // (bisecting aid)
-#endif
 namespace dl {
 
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.  The SoA
@@ -171,7 +168,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
                 DL_SLEEP(); it++;
             }
             if (cur == seq) {         // timeout: the partner never asked and never released -- say so (the partner's next request then times out as well)
-                if (lane == 0 && g.fault && !DL_EXP_NO_SRV_FAULT) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
+                if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
                 break;
             }
             if (cmd == 0) break;          // released
@@ -222,7 +219,7 @@ __device__ __forceinline__ void g_constraint_server(int lane, int wblock, DL_LDS
                 int freed = 0;
                 for (int k2 = 0; !(freed = DL_UNIFORM((int)(flags[Sp::MB_MFREE] == seq))) && k2 < g.spin_limit; k2++) DL_SLEEP();
                 if (!freed) {
-                    if (lane == 0 && g.fault && !DL_EXP_NO_SRV_FAULT) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
+                    if (lane == 0 && g.fault) DL_FAULT_OR(g.fault, DL_FAULT_SRV_TIMEOUT);
                     break;
                 }
                 DL_WG_ACQUIRE();

@@ -102,28 +102,55 @@ def loaded_path():
     return LIB_PATH
 
 
-def device_code_sha16(path=None):
-    """Identity of the DEVICE code of a built library: sha256 over its `.hip_fatbin` section (the gfx950 code object hipcc embedded), first 16
-    hex digits.  Comments, host code and anything else that leaves the compiled kernels alone do not move it, nor does the directory the library was built
-    in (-ffile-prefix-map in the build command); profiles/*.json carry it so that bench.py replays counter-derived figures only for the kernels they were
-    measured on.  Default: the library load() selected."""
-    import hashlib
+def _elf_sections(data):
+    """{name: bytes} of a 64-bit little-endian ELF image"""
     import struct
-    path = path or loaded_path()
-    with open(path, 'rb') as f:
-        data = f.read()
     if data[:4] != b'\x7fELF' or data[4] != 2:
-        raise DrlocoError(f'{path}: not a 64-bit ELF file')
+        raise DrlocoError('not a 64-bit ELF image')
     shoff, = struct.unpack_from('<Q', data, 0x28)
     shentsize, shnum, shstrndx = struct.unpack_from('<HHH', data, 0x3A)
     sec = lambda i: struct.unpack_from('<IIQQQQIIQQ', data, shoff + i * shentsize)          # name, type, flags, addr, offset, size, ...
     str_off = sec(shstrndx)[4]
+    out = {}
     for i in range(shnum):
-        name_off, _, _, _, off, size = sec(i)[:6]
-        name = data[str_off + name_off:data.index(b'\0', str_off + name_off)]
-        if name == b'.hip_fatbin':
-            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
-    raise DrlocoError(f'{path}: no .hip_fatbin section (not a hipcc build?)')
+        name_off, typ, _, _, off, size = sec(i)[:6]
+        name = data[str_off + name_off:data.index(b'\0', str_off + name_off)].decode()
+        out[name] = b'' if typ == 8 else data[off:off + size]          # (SHT_NOBITS occupies no file space)
+    return out
+
+
+def device_code_sha16(path=None):
+    """Identity of the DEVICE code of a built library: sha256 over the INSTRUCTIONS and constants (`.text` + `.rodata`) of the gfx950 code object inside the library's
+    `.hip_fatbin` (an uncompressed clang offload bundle), first 16 hex digits.  Comments, host code, the directory the library was built in and how it was built (with or
+    without -save-temps: the code object's symbol / note sections differ, its instructions do not) leave it alone; profiles/*.json carry it so that bench.py replays
+    counter-derived figures only for the kernels they were measured on.  Default: the library load() selected."""
+    import hashlib
+    import struct
+    path = path or loaded_path()
+    with open(path, 'rb') as f:
+        host = _elf_sections(f.read())
+    fb = host.get('.hip_fatbin')
+    if fb is None:
+        raise DrlocoError(f'{path}: no .hip_fatbin section (not a hipcc build?)')
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    if not fb.startswith(magic):
+        raise DrlocoError(f'{path}: .hip_fatbin is not an uncompressed clang offload bundle')
+    n, = struct.unpack_from('<Q', fb, len(magic))
+    pos = len(magic) + 8
+    h = hashlib.sha256()
+    found = False
+    for _ in range(n):
+        off, size, tlen = struct.unpack_from('<QQQ', fb, pos)
+        triple = fb[pos + 24:pos + 24 + tlen].decode()
+        pos += 24 + tlen
+        if 'gfx950' in triple and size:
+            dev = _elf_sections(fb[off:off + size])
+            for name in ('.text', '.rodata'):
+                h.update(name.encode()); h.update(dev.get(name, b''))
+            found = True
+    if not found:
+        raise DrlocoError(f'{path}: no gfx950 code object in the offload bundle')
+    return h.hexdigest()[:16]
 
 
 def check_dpp_hazards(variant='w2'):

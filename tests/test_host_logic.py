@@ -441,3 +441,16 @@ def test_strict_solver_follows_the_reference_solvers_decisions(emu, oracle, whic
     same_strict, same_default = (out[1][con] == ni[con]).mean(), (out[0][con] == ni[con]).mean()
     assert same_strict >= 0.9, (same_strict, same_default, out[1][con][:20], ni[con][:20])
     assert same_strict > same_default + 0.2, (same_strict, same_default)
+
+
+def test_device_code_hash_is_of_the_instructions():
+    """lib.device_code_sha16: sha256 over .text + .rodata of the gfx950 code object in the library's offload bundle -- what profiles/*.json are stamped with.  Independent of the
+    build directory and of -save-temps (checked in round 6 against a build of the same sources under /tmp: identical; over the whole .hip_fatbin it was not); the two code objects
+    of the product differ (their hand-written DPP waits do)."""
+    import os
+    from drloco_amd import lib
+    paths = [v['path'] for v in lib.VARIANTS.values() if os.path.exists(v['path'])]
+    if len(paths) < 2:
+        pytest.skip('both code objects are built by __graft_entry__.build()')
+    a, b = (lib.device_code_sha16(p) for p in paths)
+    assert len(a) == 16 and int(a, 16) >= 0 and a != b and a == lib.device_code_sha16(paths[0])

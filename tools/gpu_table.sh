@@ -20,3 +20,16 @@ run policy_8192 --policy --envs-per-gpu 8192
 run policy_16384 --policy --envs-per-gpu 16384
 run policy_32768 --policy --envs-per-gpu 32768
 run policy_32768_per_rollout --policy --envs-per-gpu 32768 --moments per_rollout
+# round 6: the trained (walking) policy, the spec-conformant code object, the 19-dof walker with a policy
+run walking --policy --checkpoint walking --warmup 8 --steps 10
+run walking_per_rollout --policy --checkpoint walking --warmup 8 --steps 10 --moments per_rollout
+run walking_launches --policy --checkpoint walking --warmup 8 --steps 6 --rollout-form launches
+run walking_deterministic --policy --checkpoint walking --warmup 8 --steps 10 --deterministic
+run walking_32768 --policy --checkpoint walking --warmup 2 --steps 4 --envs-per-gpu 32768
+run loco3d_policy --walker loco3d --policy
+run loco3d_policy_per_rollout --walker loco3d --policy --moments per_rollout
+run policy_h256 --policy --hidden 256
+run policy_h128 --policy --hidden 128
+DL_DPP_WAIT=2 run default_two_wait_states
+DL_DPP_WAIT=2 run loco3d_two_wait_states --walker loco3d
+DL_DPP_WAIT=2 run policy_two_wait_states --policy
