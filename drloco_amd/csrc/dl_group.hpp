@@ -411,10 +411,14 @@ template <int K> __device__ __forceinline__ void fmac_bcast_chain(float& x, floa
 // reloaded its pair from a VGPR lane (two v_readlane per select: 26 VALU instructions per Newton iteration, profiles/r06_asm_mix.txt).  As a literal the mask is two s_mov_b32
 // on the scalar pipe, rematerialised where it is used.
 #ifndef DL_OPT_LITERAL_MASKS
-#define DL_OPT_LITERAL_MASKS 0          // round 6, measured: 1 is bit-identical and 3.3 % SLOWER (the masks stay live as SGPRs and push other values out: more lane spills in the evaluation body, EXPERIMENTS.md)
+// The thirteen (j < k) lane predicates of the leaf-first factorisation, round 6 (profiles/r06_asm_mix.txt, EXPERIMENTS.md): written plainly they are computed once per launch, kept as 64-bit
+// lane masks and reloaded from VGPR lanes -- two v_readlane per use, the 26 lane spills of the Newton loop.  0: that form.  1: literal SGPR masks in an inline-asm v_cndmask (lane_keep):
+// bit-identical, 3.3 % SLOWER (the masks stay live and push other values out).  2 (default): the predicates are formed per factorisation from a lane index made opaque at the top of
+// g_chol_rev / the solve: one v_cmp per use, no spill in the Newton loop, 65 fewer in the control-step body; bit-identical, +0.1 % headline, +0.4 % 19-dof walker, +1.0 % --policy.
+#define DL_OPT_LITERAL_MASKS 2
 #endif
 template <uint32_t M16> __device__ __forceinline__ float lane_keep(float x, int j) {
-#if DL_OPT_LITERAL_MASKS
+#if DL_OPT_LITERAL_MASKS == 1
     constexpr uint64_t M = 0x0001000100010001ull * (uint64_t)(M16 & 0xffffu);
     float d;
     asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(d) : "v"(x), "s"(M));
@@ -1195,6 +1199,11 @@ template <typename T, int N> __device__ __forceinline__ T g_chol_solve(const T (
 template <typename T, typename TP> __device__ __forceinline__ void g_chol_rev(T (&h)[GL], T (&lo)[GL], T hd, T& invd, int j, T floor_) {
     using TPL = GTopo<TP>;
     constexpr int N = GD<TP>::NL;
+#if DL_OPT_LITERAL_MASKS == 2 && !defined(DL_GROUP_EMU)
+    // the lane predicates (j < k) are formed HERE, per factorisation, from a lane index the compiler cannot trace back to the launch: one v_cmp into VCC per step instead of two
+    // v_readlane of a 64-bit mask computed once per launch and spilled (thirteen masks = 26 SGPRs of a kernel that has none to spare)
+    DL_VPIN(j);
+#endif
 #if DL_CHOL_SHORT_CHAIN
     // The pivots are one dependent chain through the whole factorisation (a dependent VALU instruction issues ~7 cycles after its producer
     // where independent ones issue every ~2.6): per step it is  max(bcast(hd), floor) [one DPP instruction] -> v_rsq -> multiply -> hd update;
@@ -1204,7 +1213,11 @@ template <typename T, typename TP> __device__ __forceinline__ void g_chol_rev(T 
         constexpr int k = TPL::order.at[ss.value];
         if constexpr (k > 0) {
             const T inv = dl_rsqrt_pivot(max_bcast<k>(hd, floor_));
-            const T hk = lane_keep<(1u << k) - 1u>(h[k], j);   // (j < k) ? h[k] : 0 -- ancestors of k (unrelated lanes hold an exact zero; descendants their frozen column)
+#if DL_OPT_LITERAL_MASKS == 1
+            const T hk = lane_keep<(1u << k) - 1u>(h[k], j);
+#else
+            const T hk = (j < k) ? h[k] : T(0);               // ancestors of k (unrelated lanes hold an exact zero; descendants their frozen column)
+#endif
             T lik = hk * inv;
             lo[k] = -lik * inv;
             hd -= lik * lik;
@@ -1253,7 +1266,14 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
     // only the lanes below k take part in step k: the slot up[k] of lane k itself is not a matrix entry and those of the lanes above k are
     // stale rows (lanes of the other branch hold an exact zero) -- masked here, off the chain, so that u is x when the loop ends
     T up2[GL];
-    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = lane_keep<0xffffu & ~((2u << k) - 1u)>(s2 * up[k], j); });          // (j > k) ? s2 * up[k] : 0
+#if DL_OPT_LITERAL_MASKS == 1
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = lane_keep<0xffffu & ~((2u << k) - 1u)>(s2 * up[k], j); });
+#else
+#if DL_OPT_LITERAL_MASKS == 2 && !defined(DL_GROUP_EMU)
+    DL_VPIN(j);
+#endif
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = (j > k) ? s2 * up[k] : T(0); });
+#endif
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[N - 1 - ss.value];
         if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
@@ -1405,7 +1425,14 @@ template <typename T, typename TP> __device__ __forceinline__ T g_chol_solve_rev
     const T s2 = -invd * invd;
     T u = yl * invd;
     T up2[GL];
-    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = lane_keep<0xffffu & ~((2u << k) - 1u)>(s2 * up[k], j); });          // (j > k) ? s2 * up[k] : 0
+#if DL_OPT_LITERAL_MASKS == 1
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = lane_keep<0xffffu & ~((2u << k) - 1u)>(s2 * up[k], j); });
+#else
+#if DL_OPT_LITERAL_MASKS == 2 && !defined(DL_GROUP_EMU)
+    DL_VPIN(j);
+#endif
+    static_for<N>([&](auto kk) { constexpr int k = kk.value; if constexpr (!TPL::is_leaf(k)) up2[k] = (j > k) ? s2 * up[k] : T(0); });
+#endif
     static_for<N>([&](auto ss) {
         constexpr int k = TPL::order.at[N - 1 - ss.value];
         if constexpr (!TPL::is_leaf(k)) fmac_bcast_chain<k>(u, up2[k]);
