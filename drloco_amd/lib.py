@@ -175,6 +175,18 @@ def check_mfma_overlap(variant='w2'):
     return p.stdout.strip().splitlines()[-1]
 
 
+def check_snop(variant='w2'):
+    """Run tools/survey_snop.py --check over the listing of a product build: raises if a kernel whose workgroups hand over with s_wakeup rests a software-managed hazard on ONE
+    `s_nop N`, N >= 2, of the compiler's (another wave's s_wakeup ends an s_nop after one wait state: tools/ubench/snop_wakeup.hip; round 6's crash on the time-out path)."""
+    build(listing=True, variant=variant)
+    tool = os.path.join(os.path.dirname(_HERE), 'tools', 'survey_snop.py')
+    p = subprocess.run([os.environ.get('PYTHON', 'python3'), tool, VARIANTS[variant]['listing'], '--check'], capture_output=True, text=True)
+    if p.returncode != 0:
+        bad = [l for l in p.stdout.splitlines() if '<--' in l]
+        raise DrlocoError(f'multi-state s_nop in a kernel that uses s_wakeup ({variant}):\n' + '\n'.join(bad[-20:]) + p.stderr[-2000:])
+    return p.stdout.strip().splitlines()[-1]
+
+
 _V, _I, _P = C.c_void_p, C.c_int32, C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)       -- every symbol include/drloco_hip.h declares
