@@ -187,10 +187,12 @@ int dl_abi_version(void);
  *                        dl_hw_probe once per device and process and refuses (DL_E_HIP, text names the other library) unless one state is proven enough.
  *   dl_hw_probe          ~0.1 s of micro kernels on `device` (-1: the current one), iters <= 0: 64.  out[8]:
  *                        [0..2] stale DPP reads with 0 / 1 / 2 wait states behind the write, summed over 7 producers x 6 DPP forms, alone and beside a wave that loops over
- *                               s_wakeup ([0] > 0 shows that the test can fail; the one-state build needs [1] == 0);
+ *                               s_wakeup ([0] > 0 shows that the test can fail; the one-state build needs [1] == 0).  [1] and [2] also take six VALU-writes-an-SGPR ->
+ *                               VALU-reads-it pairs (v_cmp -> v_cndmask, v_readlane -> v_writelane ...) beside s_wakeup: gfx940+ asks for two states there, hipcc pads with ONE
+ *                               `s_nop 1`, worth one state beside an s_wakeup (gfx950 measured: no stale read even without a wait, profiles/r06_sgpr_wait.txt);
  *                        [3..5] stale rows of a v_mfma_f32_4x4x1 result read 8 wait states later beside an s_wakeup loop, the wait written as ONE `s_nop 7` ([3] > 0: another
  *                               wave's s_wakeup ends an s_nop after one state), as 8 x v_nop ([4] == 0: what the policy kernels wait with), as two s_nop ([5] == 0);
- *                        [6] lane-reads per DPP cell, [7] DPP cells.
+ *                        [6] lane-reads per cell, [7] cells (84 DPP + 6 SGPR).
  * The Python loader (drloco_amd/lib.py) loads the default build, asks it for the probe, and switches to the one-state build only on that evidence. */
 int dl_dpp_wait_states(void);
 int dl_hw_probe(int32_t device, int32_t iters, uint64_t* out);
