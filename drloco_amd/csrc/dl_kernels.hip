@@ -1192,6 +1192,10 @@ template <typename T, typename TP> struct EnvImpl final : dl_env_s {
         HIPCHK(hipMalloc((void**)p, count * sizeof(U)));
         allocs.push_back(*p);
         HIPCHK(hipMemset(*p, 0, count * sizeof(U)));
+        // hipMemset of device memory returns before the fill has run, and the fill sits on the NULL stream: a caller's non-blocking stream (torch's side streams) does not wait for
+        // it, so the first kernel that WRITES a lazily allocated buffer could be overtaken by its zeroing (round 6: the packed policy weights of a HipEnvGroup handle's first
+        // chunk -- wrong actions at step 0 in one of thirteen runs of test_env_group_handles_are_shards).  Allocation is rare: wait for the fill here.
+        HIPCHK(hipStreamSynchronize(nullptr));
         return DL_OK;
     }
     int grid() const { return (n + BLOCK - 1) / BLOCK; }

@@ -1572,6 +1572,31 @@ def test_batched_vecnormalize_steps_match_single_steps(torch_cuda, model, refs, 
         assert a['starts'].sum() > 100
 
 
+def test_first_use_on_a_side_stream_is_repeatable(torch_cuda, model, refs):
+    """The first rollout chunk of FRESH handles on torch's non-blocking side streams, ten times over with the same seeds: identical every time.  (Round 6: the library zeroed its
+    lazily allocated buffers with a hipMemset whose fill runs on the NULL stream after the call has returned; a side stream does not wait for it, so the packed policy weights of a
+    group handle's first chunk were now and then zeroed AFTER they had been written -- wrong actions at step 0 in 38 of 119 repetitions of tools/diag_group_flake.py, one failure of
+    test_env_group_handles_are_shards in thirteen runs.  dalloc waits for its fill since.)"""
+    import torch
+    from drloco_amd.group import HipEnvGroup
+    from drloco_amd.policy import HipPolicy
+    first = None
+    for rep in range(10):
+        pol = HipPolicy(hidden=128, seed=6)
+        grp = HipEnvGroup(8, num_envs=2 * 192, handles=2, seed=77, index_base=1000, model=model, refs=refs)
+        grp.collect_rollouts(pol, chunk=8)
+        grp.join()
+        torch.cuda.synchronize()
+        got = [{k: getattr(b, k).clone() for k in ('observations', 'actions', 'values', 'rewards')} for b in grp.bufs]
+        grp.close()
+        if first is None:
+            first = got
+            continue
+        for h in range(2):
+            for k, v in got[h].items():
+                assert torch.equal(v, first[h][k]), (rep, h, k)
+
+
 def test_env_group_handles_are_shards(torch_cuda, model, refs):
     """HipEnvGroup (several handles, each with its policy -> step -> normalise chain on its own stream): every handle's
     rollout is exactly what that shard produces when run on its own, the moment merge is the exact Chan merge of the
