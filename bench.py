@@ -352,6 +352,8 @@ def main():
         args.hidden = policy.hidden
         vn.norm_obs_t.copy_(venv.obs)          # the opening observation again, under the loaded moments
         vn._normalize_obs_inplace(vn.norm_obs_t)
+        # a fixed policy under free-running VecNormalize statistics drifts out of its input distribution (checkpoint.moment_seat): every rollout starts from the checkpoint's moments
+        ckpt_restore = checkpoint.moment_seat(vn)
     elif args.policy:
         from drloco_amd.policy import HipPolicy
         policy = HipPolicy(obs_dim=venv.obs_dim, act_dim=venv.nu, hidden=args.hidden, seed=99, index_base=rank * n)
@@ -383,6 +385,8 @@ def main():
                                buf._starts[t0 + 1:ts[-1] + 2])
             T_loop = 0
         elif policy is not None:
+            if ckpt_meta is not None:
+                ckpt_restore()
             buf.collect_rollouts(vn, policy, last_obs, last_done, persistent={'auto': None, 'launches': False, 'persistent': True}[args.rollout_form],
                                  moments=args.moments, deterministic=args.deterministic)     # dl_collect_rollouts: the whole loop in one C-ABI call (one launch in the persistent form)
             T_loop = 0
@@ -467,7 +471,8 @@ def main():
         if ckpt_meta is not None:
             ep = lambda name: float(torch.tensor(venv.get_attr(name)).double().mean().item())
             checks['walking'] = {'ep_len_smoothed_mean': ep('ep_len_smoothed'), 'moved_distance_mean_m': ep('moved_distance'), 'mean_step_reward_smoothed': ep('mean_reward_smoothed'),
-                                 'checkpoint': args.checkpoint, 'actions': 'mean (deterministic)' if args.deterministic else 'sampled (as in training)'}
+                                 'checkpoint': args.checkpoint, 'actions': 'mean (deterministic)' if args.deterministic else 'sampled (as in training)',
+                                 'vecnormalize': "every rollout starts from the checkpoint's moments and advances them by its own samples (a fixed policy under free-running statistics drifts out of its input distribution)"}
         # MimicEnv.step: reward = 0 on done, else imitation (<= 1) + 0.2 alive bonus (mimic_env.py:142-168); VecNormalize clips at 10
         assert fin, f'bench self-check: non-finite values in the rollout buffer {checks}'
         assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'

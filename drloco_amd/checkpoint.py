@@ -319,3 +319,19 @@ def load_walking_policy(path=None, vec_normalize=None, **policy_kw):
         st['cursor'][abi.DL_CUR_COUNT] = TRAINED_STEP_COUNT
         vn.venv.set_state(cursor=st['cursor'])
     return pol, meta
+
+
+def moment_seat(vec_normalize):
+    """restore() = put a HipVecNormalize's observation / return moments back to what they are NOW (call right after load_walking_policy).  Why: a FIXED policy under
+    VecNormalize statistics that keep training leaves its own input distribution -- the checkpoint's variances hold the whole training history (falls included); fed with
+    walking-only data they shrink, the normalised observations grow, and after ~100 rollouts the walkers fall as often as under random torques (measured in bench.py:
+    episode length 1610 after 18 rollouts, 179 after 150).  In training the policy moves with its statistics; a benchmark or diagnostic that repeats rollouts with a fixed
+    policy calls restore() before each one: every rollout then starts from the checkpoint's moments and advances them by its own samples (no work of the path is skipped)."""
+    seat = [(r, r._mean.clone(), r._var.clone(), r._count.clone()) for r in (vec_normalize.obs_rms, vec_normalize.ret_rms)]
+
+    def restore():
+        for r, m, v, c in seat:
+            r._mean.copy_(m); r._var.copy_(v); r._count.copy_(c)
+            for dst, src in zip(r._sync, (m, v, c)):
+                dst.copy_(src)
+    return restore

@@ -31,12 +31,15 @@ def run(label, trained, form, moments):
     if trained:
         pol, _ = checkpoint.load_walking_policy(vec_normalize=vn, seed=99)
         vn.norm_obs_t.copy_(venv.obs); vn._normalize_obs_inplace(vn.norm_obs_t)
+        restore = checkpoint.moment_seat(vn)          # every rollout from the checkpoint's moments: a fixed policy under free-running statistics drifts out of its input distribution
     else:
+        restore = lambda: None
         pol = HipPolicy(hidden=512, seed=99)
     buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
     last_obs, last_done = vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
     persistent = form == 'persistent'
     for _ in range(WARM):
+        restore()
         buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=persistent, moments=moments)
     venv.debug_counters()
     ncon_hist, rows_hist, it_hist = np.zeros(19, np.int64), np.zeros(130, np.int64), np.zeros(128, np.int64)
@@ -45,6 +48,7 @@ def run(label, trained, form, moments):
     prof = torch.zeros((n // 16) * 4 * 11 + 512 * (n // 16) * 4, dtype=torch.int64, device='cuda') if prof_build else None
     tails = []
     for r in range(R):
+        restore()
         ev0.record()
         buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=persistent, moments=moments)
         ev1.record(); torch.cuda.synchronize()
