@@ -285,6 +285,42 @@ def test_persistent_rollout_19dof_walker(torch_cuda, n, T, hidden):
             assert torch.equal(rel[0][k], rel[1][k]), k
 
 
+def test_packaged_walking_policy_walks(torch_cuda):
+    """drloco_amd/data/walking_policy.npz (examples/train_ppo.py, 8 M steps; what `bench.py --policy --checkpoint walking` runs): with its VecNormalize moments and sampled actions
+    the walkers reach the 3000-step episode limit and walk > 15 m per episode (the reference's "stable walk": drloco/common/callback.py:336-369) -- on the persistent kernel.
+    checkpoint.moment_seat: restore() puts the moments back bit for bit (every rollout of a FIXED policy starts from the checkpoint's statistics: free-running ones drift away
+    from what the policy was trained on, EXPERIMENTS.md round 6)."""
+    torch = torch_cuda
+    from drloco_amd import checkpoint
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    n, T = 256, 512
+    venv = HipVecEnv(num_envs=n, seed=7)
+    venv.set_split(True)
+    vn = HipVecNormalize(venv); vn.reset()
+    pol, meta = checkpoint.load_walking_policy(vec_normalize=vn, seed=3)
+    vn.norm_obs_t.copy_(venv.obs); vn._normalize_obs_inplace(vn.norm_obs_t)
+    restore = checkpoint.moment_seat(vn)
+    seat = [(r._mean.clone(), r._var.clone(), r._count.clone()) for r in (vn.obs_rms, vn.ret_rms)]
+    buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+    last_obs, last_done = vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
+    ends = 0
+    for r in range(7):          # 3584 control steps: every walker past its first 3000-step episode
+        restore()
+        for (m, v, c), rms in zip(seat, (vn.obs_rms, vn.ret_rms)):
+            assert torch.equal(rms._mean, m) and torch.equal(rms._var, v) and torch.equal(rms._count, c)
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=True)
+        assert buf.last_form == 'persistent'
+        assert not torch.equal(vn.obs_rms._count, seat[0][2])          # the rollout advanced them
+        ends += int(buf._starts[1:T + 1].sum().item())
+    torch.cuda.synchronize()
+    ep_len = np.asarray(venv.get_attr('ep_len_smoothed'), np.float64)
+    moved = np.asarray(venv.get_attr('moved_distance'), np.float64)
+    assert ep_len.mean() > 2500 and moved.mean() > 15.0, (ep_len.mean(), moved.mean(), ends)
+    assert n <= ends < 2 * n, ends          # one time-limit end per walker and a few falls
+    venv.close()
+
+
 def test_persistent_form_refusals(torch_cuda, model, refs):
     torch = torch_cuda
     from drloco_amd import lib as L, mocap, models
