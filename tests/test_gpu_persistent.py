@@ -321,6 +321,29 @@ def test_packaged_walking_policy_walks(torch_cuda):
     venv.close()
 
 
+@pytest.mark.timeout(600)
+def test_bench_checkpoint_line_keeps_walking(torch_cuda):
+    """`bench.py --policy --checkpoint walking` (the contact-rich line of README / profiles/r06_table.txt) in a small shape: the line carries the walking self-check, hardly a walker
+    falls in the last rollout, and VecNormalize's largest variance at the end is the checkpoint's advanced by ONE rollout (every rollout starts from the checkpoint's moments)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, 'bench.py', '--no-cpu-baseline', '--policy', '--checkpoint', 'walking', '--envs-per-gpu', '512', '--rollout-len', '256', '--steps', '6', '--warmup', '2'],
+                       cwd=root, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    sc = d['self_check']
+    assert sc['finite'] and 'walking' in sc and 'checkpoint' in sc['walking']['vecnormalize']
+    assert sc['episodes_ended_last_rollout'] < 0.05 * 512, sc          # 2048 control steps: nobody at the 3000-step limit yet; a policy outside its input distribution falls within ~150
+    assert sc['exception_path_steps'] == 0
+    from drloco_amd import checkpoint
+    with np.load(checkpoint.WALKING_POLICY) as z:
+        v0 = float(z['obs_var'].max())
+    assert 0.8 * v0 < sc['obs_rms_var_max'] < 1.2 * v0, (v0, sc['obs_rms_var_max'])
+
+
 def test_persistent_form_refusals(torch_cuda, model, refs):
     torch = torch_cuda
     from drloco_amd import lib as L, mocap, models
