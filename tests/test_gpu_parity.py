@@ -155,6 +155,64 @@ def test_single_step_f32(torch_cuda, oracle, model, refs, lanes):
     assert rel.max() < 1e-4, rel.max()         # north_star: reward parity within 1e-4 relative
 
 
+@pytest.mark.parametrize('lanes', [16, 'split'], ids=['16-lanes-per-walker', '16-lanes-split-workgroups'])
+def test_f32_step_parity_in_the_walking_regime(torch_cuda, oracle, model, refs, lanes):
+    """The step parity above starts from states a dozen random steps behind a reset.  Here the states are those of WALKING: the packaged trained policy drives 512 walkers for
+    1536 control steps on the device (every phase of the gait, one or two feet on the ground in > 99 % of the states), then -- five times, with a re-sync each time -- the oracle
+    takes the device's state (qpos, qvel, warm start, cursor, quirk Q4's offsets), both take the policy's action, and the results are compared: done flags identical, reward
+    within north_star's 1e-4 (relative) on every walker that kept the oracle's constraint-row counts through the 20 evaluations of the step, the loose bound on the few that did
+    not (another contact set is another trajectory, not a rounding error: __graft_entry__.smoke)."""
+    import torch
+    from drloco_amd import checkpoint
+    from drloco_amd.rollout import HipRolloutBuffer
+    from drloco_amd.vec_env import HipVecEnv, HipVecNormalize
+    n, T = 512, 512
+    dev, orc = make_pair(oracle, model, refs, n, 32, lanes_per_walker=lanes, seed=11)
+    e64 = HipVecEnv(num_envs=n, precision=64, model=model, refs=refs, seed=11)
+    vn = HipVecNormalize(dev); vn.reset()
+    pol, _ = checkpoint.load_walking_policy(vec_normalize=vn, seed=5)
+    vn.norm_obs_t.copy_(dev.obs); vn._normalize_obs_inplace(vn.norm_obs_t)
+    restore = checkpoint.moment_seat(vn)
+    buf = HipRolloutBuffer(T, n, 29, 8, torch.device('cuda'))
+    last_obs, last_done = vn.norm_obs_t.clone(), torch.ones(n, dtype=torch.uint8, device='cuda')
+    for r in range(3):
+        restore()
+        buf.collect_rollouts(vn, pol, last_obs, last_done, persistent=False)
+    torch.cuda.synchronize()
+    assert int(buf._starts[1:T + 1].sum().item()) < 0.02 * n          # they walk
+    orc.reset(); e64.reset()
+    dev.debug_counters(); e64.debug_counters()
+    flipped, worst_same, ncon_seen = [], 0.0, []
+    for t in range(5):
+        restore()
+        a = pol.forward(last_obs)[0].cpu().numpy().astype(np.float32)
+        st = dev.get_state()
+        z = dev.get_ref_offsets()
+        for e in (orc, e64):
+            e.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=st['warm'], cursor=st['cursor'], walked=st['walked'])
+            e.set_ref_offsets(z)
+        ncon_seen.append(np.asarray(orc.forward()[1]))
+        obs_r, rew_r, done_r, _, _ = orc.step(a.astype(np.float64))
+        obs64, rew64, done64, _ = e64.step(a)
+        obs32, rew32, done32, _ = dev.step(a)
+        assert np.array_equal(done32, done_r.astype(bool)) and np.array_equal(done64, done_r.astype(bool))
+        live = ~done32
+        assert np.abs(rew64 - rew_r)[live].max() < 1e-6 and np.abs(obs64 - obs_r)[live].max() < 5e-5          # the float64 build IS the oracle's path
+        same = (e64.debug_eval_iters(rows=True)[1] == dev.debug_eval_iters(rows=True)[1]).all(axis=0)
+        rel = np.abs(rew32 - rew_r) / np.maximum(np.abs(rew_r), 1e-6)
+        flipped.append(int((~same & live).sum()))
+        worst_same = max(worst_same, float(rel[same & live].max()))
+        assert np.median(rel[live]) < 1e-5 and rel[same & live].max() < 1e-4, (t, float(np.median(rel[live])), float(rel[same & live].max()), flipped)
+        assert (~same & live).mean() <= 0.08 and rel[live].max() < 5e-2, (t, flipped, float(rel[live].max()))
+        # the device goes on from ITS state with the policy's next observation
+        o = torch.as_tensor(obs32, device='cuda'); vn._normalize_obs_inplace(o); last_obs.copy_(o)
+    ncon = np.concatenate(ncon_seen)
+    assert (ncon == 0).mean() < 0.02 and ncon.mean() > 1.5, (float((ncon == 0).mean()), float(ncon.mean()))          # the contact-rich regime, not the falls of the random-torque tests
+    print(f'walking regime ({lanes}): worst relative reward error on the oracle\'s contact set {worst_same:.2e}; walkers on another set per step {flipped} of {n}; contacts per state {ncon.mean():.2f}, none in {(ncon == 0).mean():.4f}')
+    for e in (dev, e64):
+        e.close()
+
+
 @LANES_S
 def test_rollout_f32_statistics(torch_cuda, oracle, model, refs, lanes):
     """Over a horizon the fp32 and fp64 trajectories of a contact-rich system separate (chaos), so
