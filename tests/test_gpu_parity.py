@@ -213,6 +213,47 @@ def test_f32_step_parity_in_the_walking_regime(torch_cuda, oracle, model, refs, 
         e.close()
 
 
+@pytest.mark.timeout(900)
+def test_policy_trained_on_the_device_walks_in_the_oracle(torch_cuda, oracle, model, refs):
+    """Closed loop over a horizon, walking regime: the packaged policy (trained on the float32 device kernels) drives 256 walkers of the float64 CPU oracle and 256 of the device
+    from the same reference-state initialisations, mean actions, frozen VecNormalize statistics, 600 control steps (4-5 m).  Trajectories of a contact-rich system separate
+    (chaos), so the horizon check is statistical: nobody falls on either side, mean step reward within 1 %, distance walked within 2 % -- the device's dynamics are the oracle's as
+    far as the learning problem can tell."""
+    import torch
+    from drloco_amd import checkpoint
+    from drloco_amd.vec_env import HipVecNormalize
+    n, T = 256, 600
+    dev, orc = make_pair(oracle, model, refs, n, 32, lanes_per_walker='split', seed=23)
+    vn = HipVecNormalize(dev); vn.reset()
+    pol, _ = checkpoint.load_walking_policy(vec_normalize=vn, seed=5)          # (also puts a training env's step counter into the cursors: quirk Q2)
+    mean, std = vn.obs_rms.mean.astype(np.float64), np.sqrt(vn.obs_rms.var.astype(np.float64) + vn.epsilon)
+    st = dev.get_state()
+    orc.reset()
+    orc.set_state(qpos=st['qpos'], qvel=st['qvel'], warm=st['warm'], cursor=st['cursor'], walked=st['walked'])
+    orc.set_ref_offsets(dev.get_ref_offsets())
+    obs_d, obs_o = dev.obs.cpu().numpy().astype(np.float64), orc.observe()[0]
+    assert np.abs(np.delete(obs_d - obs_o, 1, axis=1)).max() < 1e-4          # (column 1, the desired velocity, was written at the reset, before the loader put the training env's step counter in)
+    obs_d = obs_o.copy()
+
+    def act(obs):
+        o = torch.as_tensor(np.clip((obs - mean) / std, -vn.clip_obs, vn.clip_obs), dtype=torch.float32, device='cuda')
+        return pol.forward(o, deterministic=True)[0].cpu().numpy().astype(np.float32)
+    R = np.zeros((2, n)); falls = [0, 0]
+    x0 = [dev.get_state()['qpos'][0].copy(), orc.get_state()['qpos'][0].copy()]
+    for t in range(T):
+        o2, r2, d2, _ = dev.step(act(obs_d)); obs_d = o2.astype(np.float64)
+        o1, r1, d1, _, _ = orc.step(act(obs_o).astype(np.float64)); obs_o = o1
+        R[0] += r2; R[1] += r1
+        falls[0] += int(d2.sum()); falls[1] += int(d1.sum())
+    walked = [float(np.mean(dev.get_state()['qpos'][0] - x0[0])), float(np.mean(orc.get_state()['qpos'][0] - x0[1]))]
+    mr = R.mean(axis=1) / T
+    print(f'device / oracle: falls {falls}, mean step reward {mr[0]:.4f} / {mr[1]:.4f}, walked {walked[0]:.3f} / {walked[1]:.3f} m in {T} control steps')
+    assert falls == [0, 0], falls
+    assert abs(mr[0] - mr[1]) / mr[1] < 0.01 and mr[1] > 0.9, mr
+    assert abs(walked[0] - walked[1]) / walked[1] < 0.02 and walked[1] > 3.5, walked
+    dev.close()
+
+
 @LANES_S
 def test_rollout_f32_statistics(torch_cuda, oracle, model, refs, lanes):
     """Over a horizon the fp32 and fp64 trajectories of a contact-rich system separate (chaos), so
