@@ -478,6 +478,18 @@ def main():
         assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'
         assert n_done < n * T and (n_done > 0 or T < 256 or ckpt_meta is not None), f'bench self-check: implausible number of episode ends {checks}'      # (random torques: walkers start falling after ~100 control steps; a trained policy may keep every walker up for a whole rollout)
         assert obs_absmax <= 10.0 + 1e-5, f'bench self-check: normalised observations beyond the clip {checks}'
+    if group is not None:          # several handles (HipEnvGroup): the same refusal to print a number over broken output, on every handle's buffer
+        fin, n_done, obs_absmax = True, 0, 0.0
+        for v_, b_ in zip(group.venvs, group.bufs):
+            lib.check(v_._lib.dl_fault_check(v_._h, None))
+            fin = fin and all(bool(torch.isfinite(getattr(b_, k_)).all().item()) for k_ in ('observations', 'rewards', 'advantages', 'returns', 'values', 'log_probs'))
+            n_done += int(b_._starts[1:T + 1].sum().item())
+            obs_absmax = max(obs_absmax, float(b_.observations.abs().max().item()))
+        checks = {'finite': fin, 'episodes_ended_last_rollout': n_done, 'normalised_obs_absmax': obs_absmax, 'handles': len(group.bufs),
+                  'normalised_reward_absmax': max(float(b_.rewards.abs().max().item()) for b_ in group.bufs)}
+        assert fin, f'bench self-check: non-finite values in a handle\'s rollout buffer {checks}'
+        assert 0 < n_done < n * T, f'bench self-check: implausible number of episode ends {checks}'
+        assert obs_absmax <= 10.0 + 1e-5 and checks['normalised_reward_absmax'] <= 10.0 + 1e-5, f'bench self-check: normalised values beyond the clip {checks}'
     if args.dump and group is None:
         import numpy as np
         ring = {}
