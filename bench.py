@@ -235,6 +235,7 @@ def main():
     ap.add_argument('--no-split', action='store_true', help='keep the one-wave-per-four-walkers launch form of the step kernel (dl_set_split 0); the default switches the split workgroup on where it exists (straight walker, float32, 16 lanes, one handle)')
     ap.add_argument('--rollout-form', choices=['auto', 'launches', 'persistent'], default='auto', help='with --policy: dl_collect_rollouts as three launches per control step or as ONE persistent launch per rollout (auto: persistent where it exists -- straight walker, float32, <= 128 walkers per CU)')
     ap.add_argument('--moments', choices=['per_step', 'per_rollout'], default='per_step', help="with --policy and the persistent form: 'per_rollout' is the opt-in relaxation (the rollout is normalised with its start-of-rollout moments, one exact merge at its end); not SB3's semantics")
+    ap.add_argument('--checkpoint-moments', choices=['seat', 'free'], default='seat', help="with --checkpoint: 'seat' (default) = every rollout starts from the checkpoint's VecNormalize moments and advances them by its own samples; 'free' = the statistics run on from rollout to rollout as in training -- under a FIXED policy they drift and the walkers stop walking after ~100 rollouts (EXPERIMENTS.md round 6)")
     ap.add_argument('--checkpoint', type=str, default='', help="with --policy: a TRAINED policy instead of the random-init one -- 'walking' = the packaged drloco_amd/data/walking_policy.npz (examples/train_ppo.py, 8 M steps: the walkers reach the 3000-step episode limit), or the path of such a file (tools/pack_walking_ckpt.py).  Its VecNormalize moments are loaded and the walkers get a training env's step counter (quirk Q2), so the rollouts are what training looks like once the walkers WALK: feet on the ground, contact-rich (not the benchmark configuration)")
     ap.add_argument('--deterministic', action='store_true', help='with --policy: the mean action instead of a sample (DL_ROLLOUT_DETERMINISTIC; evaluation-style rollouts)')
     ap.add_argument('--solver-stats', action='store_true', help="switch the step kernel's solver diagnostics on (dl_debug_counters: a few stores per walker and control step inside the timed region) and report Newton iterations / constraint rows per forward evaluation in self_check")
@@ -385,7 +386,7 @@ def main():
                                buf._starts[t0 + 1:ts[-1] + 2])
             T_loop = 0
         elif policy is not None:
-            if ckpt_meta is not None:
+            if ckpt_meta is not None and args.checkpoint_moments == 'seat':
                 ckpt_restore()
             buf.collect_rollouts(vn, policy, last_obs, last_done, persistent={'auto': None, 'launches': False, 'persistent': True}[args.rollout_form],
                                  moments=args.moments, deterministic=args.deterministic)     # dl_collect_rollouts: the whole loop in one C-ABI call (one launch in the persistent form)
@@ -472,7 +473,7 @@ def main():
             ep = lambda name: float(torch.tensor(venv.get_attr(name)).double().mean().item())
             checks['walking'] = {'ep_len_smoothed_mean': ep('ep_len_smoothed'), 'moved_distance_mean_m': ep('moved_distance'), 'mean_step_reward_smoothed': ep('mean_reward_smoothed'),
                                  'checkpoint': args.checkpoint, 'actions': 'mean (deterministic)' if args.deterministic else 'sampled (as in training)',
-                                 'vecnormalize': "every rollout starts from the checkpoint's moments and advances them by its own samples (a fixed policy under free-running statistics drifts out of its input distribution)"}
+                                 'vecnormalize': "every rollout starts from the checkpoint's moments and advances them by its own samples (a fixed policy under free-running statistics drifts out of its input distribution)" if args.checkpoint_moments == 'seat' else 'free-running statistics under a fixed policy (--checkpoint-moments free): the workload drifts'}
         # MimicEnv.step: reward = 0 on done, else imitation (<= 1) + 0.2 alive bonus (mimic_env.py:142-168); VecNormalize clips at 10
         assert fin, f'bench self-check: non-finite values in the rollout buffer {checks}'
         assert 0.0 <= rmin and rmax <= 1.2 + 1e-5, f'bench self-check: raw rewards outside [0, 1.2] {checks}'
